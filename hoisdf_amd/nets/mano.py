@@ -1,0 +1,101 @@
+"""MANO hand model layer (linear blend skinning) in plain PyTorch.
+
+Scope: SURVEY.md section 8 row a16 / (f3) - "stays PyTorch": 4*B hands per step, negligible
+work.  It sits between the HIP hot path (which produces the 6D pose and shape parameters) and
+the reported vertex / joint coordinates.  The licensed MANO_RIGHT.pkl asset is not available
+offline, so ``synthetic_assets`` builds a MANO-*shaped* random asset with the same buffer names
+and shapes the reference registers (manopth/manopth/manolayer.py:72-101) - checkpoints that
+carry real ``mano_head.mano_layer.th_*`` buffers load over it with ``strict=True``.
+
+Semantics follow manopth/manopth/manolayer.py:111-276 for the configuration the reference uses
+(main/model.py:735-742: use_pca=False, flat_hand_mean=True, center_idx=0, side="right",
+axis-angle root and joints).  Units: inputs in MANO metres, outputs in millimetres.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+# kinematic tree of the 16 MANO joints (wrist + 5 fingers x 3)
+_PARENTS = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14]
+_TIP_VERTS = [745, 317, 444, 556, 673]
+_JOINT_ORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
+
+
+def synthetic_assets(seed: int = 0) -> Dict[str, torch.Tensor]:
+    r = np.random.default_rng(seed)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    w = r.random((778, 16)) ** 8
+    w = w / w.sum(1, keepdims=True)
+    jr = r.random((16, 778)) ** 6
+    jr = jr / jr.sum(1, keepdims=True)
+    return dict(
+        th_betas=torch.zeros(1, 10),
+        th_shapedirs=f32(0.004 * r.standard_normal((778, 3, 10))),
+        th_posedirs=f32(0.002 * r.standard_normal((778, 3, 135))),
+        th_v_template=f32(0.05 * r.standard_normal((1, 778, 3))),
+        th_J_regressor=f32(jr),
+        th_weights=f32(w),
+        th_faces=torch.from_numpy(r.integers(0, 778, (1538, 3))).long(),
+        th_hands_mean=torch.zeros(1, 45),
+        th_selected_comps=f32(r.standard_normal((45, 45)) / 6.0),
+    )
+
+
+def axis_angle_to_matrix(aa: torch.Tensor) -> torch.Tensor:
+    """(N,3) -> (N,3,3) through a unit quaternion with the reference's +1e-8 norm guard
+    (manopth/manopth/rodrigues_layer.py:43-54)."""
+    ang = (aa + 1e-8).norm(dim=1, keepdim=True)
+    axis = aa / ang
+    q = torch.cat([torch.cos(0.5 * ang), torch.sin(0.5 * ang) * axis], dim=1)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    rows = [w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+            2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
+            2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]
+    return torch.stack(rows, dim=1).view(-1, 3, 3)
+
+
+class ManoLayer(nn.Module):
+    def __init__(self, assets: Optional[Dict[str, torch.Tensor]] = None, center_idx: int = 0):
+        super().__init__()
+        assets = synthetic_assets() if assets is None else assets
+        for k, v in assets.items():
+            self.register_buffer(k, v.clone())
+        self.center_idx = center_idx
+
+    def forward(self, th_pose_coeffs: torch.Tensor, th_betas: torch.Tensor):
+        B = th_pose_coeffs.shape[0]
+        full = torch.cat([th_pose_coeffs[:, :3], self.th_hands_mean + th_pose_coeffs[:, 3:48]], 1)
+        R = axis_angle_to_matrix(full.reshape(-1, 3)).view(B, 16, 3, 3)
+        eye = torch.eye(3, dtype=R.dtype, device=R.device)
+        pose_map = (R[:, 1:] - eye).reshape(B, 135)
+
+        v_shaped = torch.einsum("vck,bk->bvc", self.th_shapedirs, th_betas) + self.th_v_template
+        J = torch.einsum("jv,bvc->bjc", self.th_J_regressor, v_shaped)
+        v_posed = v_shaped + torch.einsum("vck,bk->bvc", self.th_posedirs, pose_map)
+
+        # forward kinematics: world transform of every joint
+        bottom = torch.tensor([0.0, 0, 0, 1], dtype=R.dtype, device=R.device).expand(B, 1, 4)
+        G = []
+        for j, par in enumerate(_PARENTS):
+            t = J[:, j] if par < 0 else J[:, j] - J[:, par]
+            local = torch.cat([torch.cat([R[:, j], t.unsqueeze(2)], 2), bottom], 1)
+            G.append(local if par < 0 else torch.matmul(G[par], local))
+        G = torch.stack(G, 1)                                        # (B,16,4,4)
+        # skinning transforms: remove the rest-pose joint location
+        rest = torch.matmul(G[:, :, :3, :3], J.unsqueeze(3))        # (B,16,3,1)
+        A = G[:, :, :3, :].clone()
+        A[:, :, :, 3:] = A[:, :, :, 3:] - rest
+        T = torch.einsum("vj,bjrc->bvrc", self.th_weights, A)       # (B,778,3,4)
+        verts = torch.matmul(T[..., :3], v_posed.unsqueeze(3)).squeeze(3) + T[..., 3]
+
+        jtr = torch.cat([G[:, :, :3, 3], verts[:, _TIP_VERTS]], 1)[:, _JOINT_ORDER]
+        if self.center_idx is not None:
+            c = jtr[:, self.center_idx].unsqueeze(1)
+            jtr = jtr - c
+            verts = verts - c
+        return verts * 1000, jtr * 1000
