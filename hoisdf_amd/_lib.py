@@ -1,0 +1,100 @@
+"""ctypes binding of libhoisdf_hip.so (the C ABI declared in include/hoisdf.h).
+
+The HIP library is the product path: there is NO CPU / PyTorch fallback.  ``lib()`` raises
+``HoisdfLibraryError`` if the shared object is missing (run ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C hoisdf_amd/csrc``), and every call raises
+``HoisdfError`` with the library's message on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhoisdf_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hoisdf.h")
+MAX_LEVELS = 8
+
+
+class HoisdfLibraryError(RuntimeError):
+    pass
+
+
+class HoisdfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libhoisdf_hip status {code}: {msg}")
+        self.code = code
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("n_levels", C.c_int), ("B", C.c_int), ("data", C.c_void_p * MAX_LEVELS),
+                ("C", C.c_int * MAX_LEVELS), ("H", C.c_int * MAX_LEVELS), ("W", C.c_int * MAX_LEVELS)]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+_PYR = C.POINTER(Pyramid)
+
+# name -> argument ctypes (return type is int unless listed in _RET)
+SIGNATURES: Dict[str, List] = {
+    "hoisdf_project_gather_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P, _P, _P],
+    "hoisdf_project_gather_bwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P],
+    "hoisdf_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P],
+    "hoisdf_linear_bwd_input": [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P],
+    "hoisdf_linear_bwd_weight": [_P, _I, _P, _I, _P, _I, _P, _L, _I, _I, _P],
+    "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
+    "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
+    "hoisdf_weightnorm_fwd": [_P, _P, _P, _I, _P, _I, _I, _P],
+    "hoisdf_weightnorm_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "hoisdf_sdf_head_fwd": [_P, _I, _P, _P, _P, _P, _L, _I, _F, _P],
+    "hoisdf_sdf_head_bwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _I, _F, _P],
+    "hoisdf_lattice_count": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "hoisdf_lattice_fill": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
+    "hoisdf_select_smallest_abs": [_P, _P, _P, _I, _I, _P, _P],
+    "hoisdf_gather_rows": [_P, _I, _P, _L, _I, _P, _I, _P],
+    "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "hoisdf_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
+    "hoisdf_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                             _I, _F, _U64, _P],
+    "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
+                                   _U64, _P],
+    "hoisdf_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _U64, _P],
+    "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
+    "hoisdf_vote_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+}
+_RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HoisdfLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built (make -C hoisdf_amd/csrc). "
+                "There is no CPU fallback for the hot path.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        for name, ret in _RET.items():
+            fn = getattr(L, name)
+            fn.argtypes = []
+            fn.restype = ret
+        _lib = L
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HoisdfError(rc, lib().hoisdf_last_error().decode())
+
+
+def exported_symbols() -> List[str]:
+    return list(SIGNATURES) + list(_RET)

@@ -1,0 +1,114 @@
+"""Configuration surface, attribute-compatible with the reference's global ``cfg``
+(/root/reference/main/config.py:38-189) for everything the model reads.  Unlike the
+reference, importing this module has no side effects (no sys.path edits, no mkdir).
+"""
+from __future__ import annotations
+
+import os.path as osp
+
+
+class Config:
+    setting = "dexycb"  # ho3d, ho3d_render, dexycb, dexycb_full
+    dataset = "dexycb"
+
+    train_batch_size = 22
+    test_batch_size = 22
+    eval_batch_size = 22
+
+    num_samp_hand = 600
+    num_samp_obj = 200
+    points_filter_dist = 0.05
+    random_ratio = [0.3, 0.7]
+    random_move_dist = [0.03, 0.05, 0.07]
+    hand_sdf_scale = 3.1
+    obj_sdf_scale = 3.1
+    hand_cls_dist = 0.04
+    obj_cls_dist = 0.05
+
+    # SDF config
+    bins_n = 64
+    num_class = 6
+    PointFeatSize = 33
+    ClassifierBranch = False
+    ClampingDistance = 0.15
+
+    # model
+    use_big_decoder = False
+    use_inverse_kinematics = False
+    resnet_type = 50
+    mutliscale_layers = ["stride2", "stride4", "stride8", "stride16", "stride32"]
+    mutliscale_dim = 32 + 64 + 128 + 256 + 512
+
+    input_img_shape = (256, 256)
+    output_hm_shape = (128, 128, 128)
+    sigma = 2.5 / 2
+
+    hidden_dim = 256
+    dropout = 0.1
+    nheads = 4
+    dim_feedforward = 1024
+    enc_layers = 6
+    dec_layers = 4
+    pre_norm = False
+
+    mano_num_queries = 15 + 1 + 1
+    mano_shape_indx = 16
+
+    end_epoch = 70
+    point_sampling_epoch = 40
+    lr = 1e-4
+    lr_decay_gamma = 0.7
+    lr_drop = 9
+
+    sdf_hand_weight = 50
+    sdf_obj_weight = 25
+    sdf_cls_weight = 10
+    hm_weight = 100 / 100000
+    joint_weight = 1 / 10
+    cls_weight = 1 / 1
+    obj_hm_weight = 1
+    obj_rot_weight = 0.7
+    obj_trans_weight = 100 / 1
+
+    lambda_verts3d = 1e4
+    lambda_joints3d = 1e4
+    lambda_manopose = 10
+    lambda_manoshape = 0.1
+    mano_lambda_regulshape = 0.000001
+
+    eval_mesh = False
+    output_dir = "outputs"
+    num_thread = 15
+    gpu_ids = "0"
+    num_gpus = 1
+    continue_train = True
+
+    def apply_setting(self, setting: str) -> None:
+        """What editing ``setting`` in the reference's config.py does (config.py:39-44,96-97,154)."""
+        self.setting = setting
+        self.dataset = "ho3d" if "ho3d" in setting else "dexycb"
+        self.use_big_decoder = setting == "ho3d"
+        self.use_inverse_kinematics = setting == "ho3d_render"
+        self.eval_mesh = setting == "dexycb_full"
+        self.calc_mutliscale_dim(self.use_big_decoder, self.resnet_type)
+
+    def calc_mutliscale_dim(self, use_big_decoder_l, resnet_type_l):
+        if use_big_decoder_l:
+            self.mutliscale_dim = 128 + 256 + 512 + 1024 + 2048
+        else:
+            self.mutliscale_dim = 32 + 64 + 128 + 256 + 512
+
+    def setup_out_dirs(self, model_dir_name):
+        self.log_dir = osp.join(self.output_dir, "log", model_dir_name)
+        self.model_dir = osp.join(self.output_dir, "model_dump", model_dir_name)
+        self.tensorboard_dir = osp.join(self.output_dir, "tensorboard", model_dir_name)
+
+    def set_args(self, gpu_ids, model_dir_name, continue_train=False):
+        self.gpu_ids = gpu_ids
+        self.num_gpus = len(self.gpu_ids.split(","))
+        self.continue_train = continue_train
+        self.model_dir_name = model_dir_name
+        self.setup_out_dirs(model_dir_name)
+
+
+cfg = Config()

@@ -1,0 +1,354 @@
+// K1: pinhole projection + multi-level bilinear gather from an NHWC pyramid, its scatter-add
+// backward, and K5: dense-lattice generation with the strict bbox filter (stream compaction).
+//
+// Layout: the pyramid is channels-last, so the 4 taps of a point are 4 contiguous C_l-float
+// rows per level; a wave owns one point and its lanes sweep the concatenated channel axis in
+// float4 units -> every global access of the wave is a run of full 16-byte lanes.
+// HBM-bound by construction (15.9 KB read + 4 KB written per point at C = 992); the pyramid
+// (4 MB / sample) is L2 / Infinity-Cache resident across the ~2000-6000 points of a sample.
+#include "common.h"
+
+namespace hoisdf {
+
+struct PyrDev {
+  int n_levels;
+  int C4;                          // total channels / 4
+  const float* data[HOISDF_MAX_LEVELS];
+  float* grad[HOISDF_MAX_LEVELS];
+  int C[HOISDF_MAX_LEVELS], H[HOISDF_MAX_LEVELS], W[HOISDF_MAX_LEVELS];
+  int off4[HOISDF_MAX_LEVELS + 1]; // channel offset of each level, in float4 units
+};
+
+struct ProjArgs {
+  const float* points;
+  const int32_t* sample_idx;
+  long n_rows;
+  int rows_per_sample;
+  const float* center;
+  const float* cam_intr;
+  float scale, nx, ny;
+};
+
+// cam = p/scale + c ; q = K cam ; uv = q_xy / q_z ; g = (uv - n)/n      (main/model.py:148-157)
+__device__ __forceinline__ void project_row(const ProjArgs& a, long r, int& b, float (&cam)[3],
+                                            float (&uv)[2], float (&g)[2]) {
+  b = a.sample_idx ? a.sample_idx[r] : (int)(r / a.rows_per_sample);
+  const float* p = a.points + r * 3;
+  const float* c = a.center + (size_t)b * 3;
+  const float* K = a.cam_intr + (size_t)b * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cam[i] = __fadd_rn(__fdiv_rn(p[i], a.scale), c[i]);
+  float q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = cam[0] * K[i * 3 + 0] + cam[1] * K[i * 3 + 1] + cam[2] * K[i * 3 + 2];
+  uv[0] = __fdiv_rn(q[0], q[2]);
+  uv[1] = __fdiv_rn(q[1], q[2]);
+  g[0] = __fdiv_rn(uv[0] - a.nx, a.nx);
+  g[1] = __fdiv_rn(uv[1] - a.ny, a.ny);
+}
+
+struct Taps {
+  int o00, o01, o10, o11;   // pixel offsets (in pixels) of nw, ne, sw, se; -1 = out of range
+  float w00, w01, w10, w11;
+};
+
+// ATen grid_sampler_2d, bilinear / border / align_corners=True: unnormalise, clip, floor.
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int W, int H) {
+  float x = ((gx + 1.f) * 0.5f) * (float)(W - 1);
+  float y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+  x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+  y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+  float x0f = floorf(x), y0f = floorf(y);
+  int x0 = (int)x0f, y0 = (int)y0f;
+  float wx1 = x - x0f, wy1 = y - y0f;
+  float wx0 = (x0f + 1.f) - x, wy0 = (y0f + 1.f) - y;
+  Taps t;
+  bool xin = x0 + 1 <= W - 1, yin = y0 + 1 <= H - 1;
+  t.o00 = y0 * W + x0;
+  t.o01 = xin ? y0 * W + x0 + 1 : -1;
+  t.o10 = yin ? (y0 + 1) * W + x0 : -1;
+  t.o11 = (xin && yin) ? (y0 + 1) * W + x0 + 1 : -1;
+  t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+  return t;
+}
+
+__device__ __forceinline__ int level_of(const PyrDev& P, int u) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < HOISDF_MAX_LEVELS; ++i)
+    if (i < P.n_levels && u >= P.off4[i]) l = i;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, float* __restrict__ feat,
+                                                         int ldf, float* __restrict__ cam_out,
+                                                         float* __restrict__ uv_out) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long stride = (long)gridDim.x * 4;
+  for (; r < a.n_rows; r += stride) {
+    int b;
+    float cam[3], uv[2], g[2];
+    project_row(a, r, b, cam, uv, g);
+    if (lane < 3 && cam_out) cam_out[r * 3 + lane] = cam[lane];
+    if (lane < 2 && uv_out) uv_out[r * 2 + lane] = uv[lane];
+    float4* out = reinterpret_cast<float4*>(feat + (size_t)r * ldf);
+    for (int u = lane; u < P.C4; u += 64) {
+      const int l = level_of(P, u);
+      const int C = P.C[l], H = P.H[l], W = P.W[l];
+      const Taps t = make_taps(g[0], g[1], W, H);
+      const float* base = P.data[l] + (size_t)b * H * W * C + (size_t)(u - P.off4[l]) * 4;
+      float4 v = *reinterpret_cast<const float4*>(base + (size_t)t.o00 * C);
+      float4 acc = make_float4(v.x * t.w00, v.y * t.w00, v.z * t.w00, v.w * t.w00);
+      if (t.o01 >= 0) {
+        v = *reinterpret_cast<const float4*>(base + (size_t)t.o01 * C);
+        acc.x += v.x * t.w01; acc.y += v.y * t.w01; acc.z += v.z * t.w01; acc.w += v.w * t.w01;
+      }
+      if (t.o10 >= 0) {
+        v = *reinterpret_cast<const float4*>(base + (size_t)t.o10 * C);
+        acc.x += v.x * t.w10; acc.y += v.y * t.w10; acc.z += v.z * t.w10; acc.w += v.w * t.w10;
+      }
+      if (t.o11 >= 0) {
+        v = *reinterpret_cast<const float4*>(base + (size_t)t.o11 * C);
+        acc.x += v.x * t.w11; acc.y += v.y * t.w11; acc.z += v.z * t.w11; acc.w += v.w * t.w11;
+      }
+      out[u] = acc;
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 d, float w) {
+  atomicAdd(p + 0, d.x * w);
+  atomicAdd(p + 1, d.y * w);
+  atomicAdd(p + 2, d.z * w);
+  atomicAdd(p + 3, d.w * w);
+}
+
+__global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, const float* __restrict__ dfeat,
+                                                         int ldf) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long stride = (long)gridDim.x * 4;
+  for (; r < a.n_rows; r += stride) {
+    int b;
+    float cam[3], uv[2], g[2];
+    project_row(a, r, b, cam, uv, g);
+    const float4* din = reinterpret_cast<const float4*>(dfeat + (size_t)r * ldf);
+    for (int u = lane; u < P.C4; u += 64) {
+      const int l = level_of(P, u);
+      const int C = P.C[l], H = P.H[l], W = P.W[l];
+      const Taps t = make_taps(g[0], g[1], W, H);
+      float* base = P.grad[l] + (size_t)b * H * W * C + (size_t)(u - P.off4[l]) * 4;
+      const float4 d = din[u];
+      atomic_add4(base + (size_t)t.o00 * C, d, t.w00);
+      if (t.o01 >= 0) atomic_add4(base + (size_t)t.o01 * C, d, t.w01);
+      if (t.o10 >= 0) atomic_add4(base + (size_t)t.o10 * C, d, t.w10);
+      if (t.o11 >= 0) atomic_add4(base + (size_t)t.o11 * C, d, t.w11);
+    }
+  }
+}
+
+// ---- dense lattice (main/model.py:257-273): sheared, float32 index arithmetic --------------
+__device__ __forceinline__ void lattice_point(int idx, int n, float v32, float (&p)[3]) {
+  const float fn = (float)n;
+  const float a = (float)idx;                 // exact for idx < 2^24
+  const float zl = (float)(idx % n);
+  const float q = __fdiv_rn(a, fn);           // true (float) division, as int64 / int does in torch
+  const float yl = fmodf(q, fn);
+  const float xl = fmodf(__fdiv_rn(q, fn), fn);
+  p[0] = __fadd_rn(__fmul_rn(xl, v32), -1.f);
+  p[1] = __fadd_rn(__fmul_rn(yl, v32), -1.f);
+  p[2] = __fadd_rn(__fmul_rn(zl, v32), -1.f);
+}
+
+__device__ __forceinline__ bool lattice_keep(const float (&p)[3], const float* c, const float* K,
+                                             const float* bb, float scale) {
+  float cam[3], q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cam[i] = __fadd_rn(__fdiv_rn(p[i], scale), c[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = cam[0] * K[i * 3 + 0] + cam[1] * K[i * 3 + 1] + cam[2] * K[i * 3 + 2];
+  const float u = __fdiv_rn(q[0], q[2]), v = __fdiv_rn(q[1], q[2]);
+  return (u > bb[0]) && (u < bb[2]) && (v > bb[1]) && (v < bb[3]);      // strict (main/model.py:293-300)
+}
+
+__global__ __launch_bounds__(256) void lattice_count_kernel(const float* __restrict__ center,
+                                                            const float* __restrict__ cam_intr,
+                                                            const float* __restrict__ bbox, float scale,
+                                                            int n, float v32, int32_t* __restrict__ counts) {
+  const int b = blockIdx.y;
+  const int total = n * n * n;
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  bool keep = false;
+  if (idx < total) {
+    float p[3];
+    lattice_point(idx, n, v32, p);
+    keep = lattice_keep(p, center + b * 3, cam_intr + b * 9, bbox + b * 4, scale);
+  }
+  unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[b], __popcll(m));
+}
+
+// one 1024-thread workgroup per sample walks the lattice in order -> deterministic ascending
+// lattice order of the survivors (what boolean indexing yields in the reference).
+__global__ __launch_bounds__(1024) void lattice_fill_kernel(const float* __restrict__ center,
+                                                            const float* __restrict__ cam_intr,
+                                                            const float* __restrict__ bbox, float scale,
+                                                            int n, float v32,
+                                                            const int32_t* __restrict__ offsets,
+                                                            float* __restrict__ points,
+                                                            int32_t* __restrict__ sample_idx,
+                                                            int32_t* __restrict__ lattice_idx) {
+  __shared__ int wave_cnt[16];
+  __shared__ int running;
+  const int b = blockIdx.x;
+  const int total = n * n * n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = offsets[b];
+  __syncthreads();
+  for (int base = 0; base < total; base += 1024) {
+    const int idx = base + threadIdx.x;
+    float p[3] = {0.f, 0.f, 0.f};
+    bool keep = false;
+    if (idx < total) {
+      lattice_point(idx, n, v32, p);
+      keep = lattice_keep(p, center + b * 3, cam_intr + b * 9, bbox + b * 4, scale);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int pre = running;
+    for (int w = 0; w < wave; ++w) pre += wave_cnt[w];
+    if (keep) {
+      const int dst = pre + __popcll(m & ((1ULL << lane) - 1ULL));
+      points[(size_t)dst * 3 + 0] = p[0];
+      points[(size_t)dst * 3 + 1] = p[1];
+      points[(size_t)dst * 3 + 2] = p[2];
+      if (sample_idx) sample_idx[dst] = b;
+      if (lattice_idx) lattice_idx[dst] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int s = 0;
+      for (int w = 0; w < 16; ++w) s += wave_cnt[w];
+      running += s;
+    }
+    __syncthreads();
+  }
+}
+
+static int fill_pyr(PyrDev& P, int n_levels, const int* C, const int* H, const int* W) {
+  P.n_levels = n_levels;
+  int off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    if (C[l] <= 0 || (C[l] & 3) || H[l] <= 0 || W[l] <= 0) return -1;
+    P.C[l] = C[l]; P.H[l] = H[l]; P.W[l] = W[l];
+    P.off4[l] = off;
+    off += C[l] / 4;
+  }
+  for (int l = n_levels; l <= HOISDF_MAX_LEVELS; ++l) P.off4[l] = off;
+  P.C4 = off;
+  return 0;
+}
+
+static int grid_for_rows(long n_rows) {
+  long blocks = (n_rows + 3) / 4;
+  if (blocks > 256L * 16) blocks = 256L * 16;
+  return (int)blocks;
+}
+
+}  // namespace hoisdf
+
+using namespace hoisdf;
+
+static int check_proj(const float* points, long n_rows, int rows_per_sample, const int32_t* sample_idx,
+                      const float* center, const float* cam_intr, float scale, const char* who) {
+  HOISDF_REQUIRE(points && center && cam_intr, HOISDF_ERR_INVALID, "%s: null pointer", who);
+  HOISDF_REQUIRE(n_rows >= 0 && (sample_idx || rows_per_sample > 0) && scale != 0.f, HOISDF_ERR_INVALID,
+                 "%s: bad sizes", who);
+  return 0;
+}
+
+extern "C" int hoisdf_project_gather_fwd(const hoisdf_pyramid* pyr, const float* points,
+                                         const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                                         const float* center, const float* cam_intr, float scale, int img_h,
+                                         int img_w, float* feat, int ldf, float* cam_out, float* uv_out,
+                                         void* stream) {
+  HOISDF_REQUIRE(pyr && feat, HOISDF_ERR_INVALID, "project_gather_fwd: null pointer");
+  if (int rc = check_proj(points, n_rows, rows_per_sample, sample_idx, center, cam_intr, scale,
+                          "project_gather_fwd")) return rc;
+  HOISDF_REQUIRE(pyr->n_levels > 0 && pyr->n_levels <= HOISDF_MAX_LEVELS, HOISDF_ERR_INVALID,
+                 "project_gather_fwd: n_levels=%d", pyr->n_levels);
+  PyrDev P{};
+  HOISDF_REQUIRE(fill_pyr(P, pyr->n_levels, pyr->C, pyr->H, pyr->W) == 0, HOISDF_ERR_INVALID,
+                 "project_gather_fwd: level channels must be positive multiples of 4");
+  for (int l = 0; l < pyr->n_levels; ++l) {
+    HOISDF_REQUIRE(pyr->data[l] && ((uintptr_t)pyr->data[l] & 15) == 0, HOISDF_ERR_INVALID,
+                   "project_gather_fwd: level %d pointer null or not 16-byte aligned", l);
+    P.data[l] = pyr->data[l];
+  }
+  HOISDF_REQUIRE(ldf >= P.C4 * 4 && (ldf & 3) == 0 && ((uintptr_t)feat & 15) == 0, HOISDF_ERR_INVALID,
+                 "project_gather_fwd: feat must be 16-byte aligned with ldf %% 4 == 0 and ldf >= C");
+  if (n_rows == 0) return HOISDF_OK;
+  ProjArgs a{points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale,
+             (float)(img_w - 1) * 0.5f, (float)(img_h - 1) * 0.5f};
+  hipLaunchKernelGGL(gather_fwd_kernel, dim3(grid_for_rows(n_rows)), dim3(256), 0, as_stream(stream), P, a,
+                     feat, ldf, cam_out, uv_out);
+  return check_launch("gather_fwd");
+}
+
+extern "C" int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const float* points,
+                                         const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                                         const float* center, const float* cam_intr, float scale, int img_h,
+                                         int img_w, const float* dfeat, int ldf, void* stream) {
+  HOISDF_REQUIRE(dpyr && dfeat, HOISDF_ERR_INVALID, "project_gather_bwd: null pointer");
+  if (int rc = check_proj(points, n_rows, rows_per_sample, sample_idx, center, cam_intr, scale,
+                          "project_gather_bwd")) return rc;
+  HOISDF_REQUIRE(dpyr->n_levels > 0 && dpyr->n_levels <= HOISDF_MAX_LEVELS, HOISDF_ERR_INVALID,
+                 "project_gather_bwd: n_levels=%d", dpyr->n_levels);
+  PyrDev P{};
+  HOISDF_REQUIRE(fill_pyr(P, dpyr->n_levels, dpyr->C, dpyr->H, dpyr->W) == 0, HOISDF_ERR_INVALID,
+                 "project_gather_bwd: level channels must be positive multiples of 4");
+  for (int l = 0; l < dpyr->n_levels; ++l) {
+    HOISDF_REQUIRE(dpyr->data[l], HOISDF_ERR_INVALID, "project_gather_bwd: level %d pointer null", l);
+    P.grad[l] = dpyr->data[l];
+  }
+  HOISDF_REQUIRE(ldf >= P.C4 * 4 && (ldf & 3) == 0 && ((uintptr_t)dfeat & 15) == 0, HOISDF_ERR_INVALID,
+                 "project_gather_bwd: dfeat must be 16-byte aligned with ldf %% 4 == 0");
+  if (n_rows == 0) return HOISDF_OK;
+  ProjArgs a{points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale,
+             (float)(img_w - 1) * 0.5f, (float)(img_h - 1) * 0.5f};
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for_rows(n_rows)), dim3(256), 0, as_stream(stream), P, a,
+                     dfeat, ldf);
+  return check_launch("gather_bwd");
+}
+
+extern "C" int hoisdf_lattice_count(const float* center, const float* cam_intr, const float* bbox, float scale,
+                                    int bins_n, int B, int32_t* counts, void* stream) {
+  HOISDF_REQUIRE(center && cam_intr && bbox && counts, HOISDF_ERR_INVALID, "lattice_count: null pointer");
+  HOISDF_REQUIRE(bins_n >= 2 && bins_n <= 256 && B > 0, HOISDF_ERR_INVALID, "lattice_count: bins_n=%d B=%d",
+                 bins_n, B);
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(counts, 0, sizeof(int32_t) * B, st) != hipSuccess) {
+    set_error("lattice_count: memset failed");
+    return HOISDF_ERR_LAUNCH;
+  }
+  const int total = bins_n * bins_n * bins_n;
+  const float v32 = (float)(2.0 / (double)(bins_n - 1));
+  hipLaunchKernelGGL(lattice_count_kernel, dim3(cdiv(total, 256), B), dim3(256), 0, st, center, cam_intr, bbox,
+                     scale, bins_n, v32, counts);
+  return check_launch("lattice_count");
+}
+
+extern "C" int hoisdf_lattice_fill(const float* center, const float* cam_intr, const float* bbox, float scale,
+                                   int bins_n, int B, const int32_t* offsets, float* points,
+                                   int32_t* sample_idx, int32_t* lattice_idx, void* stream) {
+  HOISDF_REQUIRE(center && cam_intr && bbox && offsets && points, HOISDF_ERR_INVALID,
+                 "lattice_fill: null pointer");
+  HOISDF_REQUIRE(bins_n >= 2 && bins_n <= 256 && B > 0, HOISDF_ERR_INVALID, "lattice_fill: bins_n=%d B=%d",
+                 bins_n, B);
+  const float v32 = (float)(2.0 / (double)(bins_n - 1));
+  hipLaunchKernelGGL(lattice_fill_kernel, dim3(B), dim3(1024), 0, as_stream(stream), center, cam_intr, bbox,
+                     scale, bins_n, v32, offsets, points, sample_idx, lattice_idx);
+  return check_launch("lattice_fill");
+}

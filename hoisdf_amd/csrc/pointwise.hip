@@ -1,0 +1,475 @@
+// HBM-bound row kernels of the hot path: NeRF positional encoding (K3), weight-norm fold,
+// the 512->1 SDF head with tanh/clamp (tail of K4), sigma-gated token assembly (K8),
+// and residual+dropout+LayerNorm.
+// All are one-pass, coalesced (16-byte lanes where the row width allows), with wave-level
+// reductions; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace hoisdf {
+
+// ------------------------------------------------------------------------------------------
+// posenc: x0[r][col0 + 6k + {0,1,2}] = sin(2^k p), [.. + 3 + {0,1,2}] = cos(2^k p), k=0..4,
+// then xyz; common/utils/sdf_utils.py:113-126 (freq bands 2^linspace(0,4,5) = 1,2,4,8,16).
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ pts, long n_rows,
+                                                     float* __restrict__ x0, int ldx0, int col0,
+                                                     float* __restrict__ pe) {
+  long idx = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per (row, slot<36)
+  const long total = n_rows * 36;
+  for (; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / 36;
+    const int s = (int)(idx - r * 36);
+    float val = 0.f;
+    if (s < 30) {
+      const int k = s / 6, w = s - k * 6, d = w % 3;
+      const float f = (float)(1 << k);
+      const float arg = pts[r * 3 + d] * f;
+      val = (w < 3) ? sinf(arg) : cosf(arg);
+      if (pe) pe[r * 30 + s] = val;
+    } else if (s < 33) {
+      val = pts[r * 3 + (s - 30)];
+    }
+    if (x0 && col0 + s < ldx0) x0[(size_t)r * ldx0 + col0 + s] = val;   // s in [33,36) zero-fills the pad
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight norm: one wave per output row
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(const float* __restrict__ v,
+                                                             const float* __restrict__ g, float* __restrict__ W,
+                                                             int ldw, float* __restrict__ norms, int out, int in) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= out) return;
+  const float* vr = v + (size_t)r * in;
+  float s = 0.f;
+  for (int c = lane; c < in; c += 64) s += vr[c] * vr[c];
+  const float nrm = sqrtf(wave_sum(s));
+  const float sc = g[r] / nrm;
+  for (int c = lane; c < ldw; c += 64) W[(size_t)r * ldw + c] = c < in ? vr[c] * sc : 0.f;
+  if (norms && lane == 0) norms[r] = nrm;
+}
+
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ v,
+                                                             const float* __restrict__ g,
+                                                             const float* __restrict__ dW, int ldw,
+                                                             float* __restrict__ dv, float* __restrict__ dg,
+                                                             int out, int in) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= out) return;
+  const float* vr = v + (size_t)r * in;
+  const float* dr = dW + (size_t)r * ldw;
+  float s = 0.f, d = 0.f;
+  for (int c = lane; c < in; c += 64) { s += vr[c] * vr[c]; d += dr[c] * vr[c]; }
+  s = wave_sum(s); d = wave_sum(d);
+  const float nrm = sqrtf(s);
+  const float gn = g[r] / nrm;
+  const float coef = d / s;
+  for (int c = lane; c < in; c += 64) dv[(size_t)r * in + c] = gn * (dr[c] - vr[c] * coef);
+  if (lane == 0) dg[r] = d / nrm;
+}
+
+// ------------------------------------------------------------------------------------------
+// SDF head: one wave per row; K = 512
+__global__ __launch_bounds__(256) void sdf_head_fwd_kernel(const float* __restrict__ h, int ldh,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           float* __restrict__ sdf_raw, float* __restrict__ sdf,
+                                                           long n_rows, int K, float clampv) {
+  const int lane = threadIdx.x & 63;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (; r < n_rows; r += (long)gridDim.x * 4) {
+    const float* hr = h + (size_t)r * ldh;
+    float s = 0.f;
+    for (int c = lane * 4; c < K; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(hr + c);
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float t = tanhf(s + b[0]);
+      if (sdf_raw) sdf_raw[r] = t;
+      if (sdf) sdf[r] = fminf(fmaxf(t, -clampv), clampv);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restrict__ dsdf,
+                                                           const float* __restrict__ sdf_raw,
+                                                           const float* __restrict__ h, int ldh,
+                                                           const float* __restrict__ w, float* __restrict__ dh,
+                                                           int lddh, float* __restrict__ dw, float* __restrict__ db,
+                                                           long n_rows, int K, float clampv) {
+  // each wave walks rows with a grid stride and keeps a private dw accumulator per lane slot
+  const int lane = threadIdx.x & 63;
+  float4 dwa[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};   // K <= 512: 2 float4 per lane
+  float dba = 0.f;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (; r < n_rows; r += (long)gridDim.x * 4) {
+    const float t = sdf_raw[r];
+    // clamp passes gradient only strictly inside (torch.clamp: grad where min <= x <= max)
+    const float gpre = (t >= -clampv && t <= clampv) ? dsdf[r] * (1.f - t * t) : 0.f;
+    const float* hr = h + (size_t)r * ldh;
+    float* dr = dh + (size_t)r * lddh;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < K) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        *reinterpret_cast<float4*>(dr + c) = make_float4(gpre * ww.x, gpre * ww.y, gpre * ww.z, gpre * ww.w);
+        const float4 a = *reinterpret_cast<const float4*>(hr + c);
+        dwa[i].x += gpre * a.x; dwa[i].y += gpre * a.y; dwa[i].z += gpre * a.z; dwa[i].w += gpre * a.w;
+      }
+    }
+    dba += gpre;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < K) {
+      atomicAdd(dw + c + 0, dwa[i].x); atomicAdd(dw + c + 1, dwa[i].y);
+      atomicAdd(dw + c + 2, dwa[i].z); atomicAdd(dw + c + 3, dwa[i].w);
+    }
+  }
+  if (lane == 0) atomicAdd(db, dba);
+}
+
+// ------------------------------------------------------------------------------------------
+// token assembly: one wave per token row (D = 256 -> 64 float4 lanes)
+__global__ __launch_bounds__(256) void token_build_fwd_kernel(const float* __restrict__ cam,
+                                                              const float* __restrict__ center,
+                                                              const float* __restrict__ pe,
+                                                              const float* __restrict__ feat, int ldfeat,
+                                                              const float* __restrict__ sdf,
+                                                              const float* __restrict__ beta_ptr,
+                                                              float* __restrict__ tok, int B, int P, int S, int row0,
+                                                              int D) {
+  const int lane = threadIdx.x & 63;
+  const float beta = fmaxf(beta_ptr[0], 2e-3f);
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long n = (long)B * P;
+  for (; r < n; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / P), p = (int)(r - (long)b * P);
+    const float sig = (1.f / (1.f + expf(-sdf[r] / beta))) / beta;
+    float* o = tok + ((size_t)b * S + row0 + p) * D;
+    for (int c = lane; c < D; c += 64) {
+      float v;
+      if (c < 3) v = cam[r * 3 + c] - center[b * 3 + c];
+      else if (c < 33) v = pe[r * 30 + (c - 3)];
+      else v = feat[(size_t)r * ldfeat + (c - 33)] * sig;
+      o[c] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __restrict__ dtok,
+                                                              const float* __restrict__ feat, int ldfeat,
+                                                              const float* __restrict__ sdf,
+                                                              const float* __restrict__ beta_ptr,
+                                                              float* __restrict__ dfeat, int lddfeat,
+                                                              float* __restrict__ dbeta, int B, int P, int S,
+                                                              int row0, int D) {
+  const int lane = threadIdx.x & 63;
+  const float braw = beta_ptr[0];
+  const float beta = fmaxf(braw, 2e-3f);
+  float acc = 0.f;
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long n = (long)B * P;
+  for (; r < n; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / P), p = (int)(r - (long)b * P);
+    const float z = sdf[r] / beta;
+    const float sg = 1.f / (1.f + expf(-z));
+    const float sig = sg / beta;
+    // d sigma / d beta = -sg(1-sg) z / beta^2 - sg / beta^2
+    const float dsig = -(sg * (1.f - sg) * z + sg) / (beta * beta);
+    const float* d = dtok + ((size_t)b * S + row0 + p) * D;
+    for (int c = 33 + lane; c < D; c += 64) {
+      const float dv = d[c];
+      const float f = feat[(size_t)r * ldfeat + (c - 33)];
+      dfeat[(size_t)r * lddfeat + (c - 33)] = dv * sig;
+      acc += dv * f * dsig;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && dbeta) atomicAdd(dbeta, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// y = LN(x + dropout(r)); one wave per row, D <= 1024 (D/4 float4 units, <= 4 per lane)
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, long M,
+                                                         int D, float eps, float drop_p, float inv_keep,
+                                                         uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int nu = D >> 2;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (; row < M; row += (long)gridDim.x * 4) {
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = lane + 64 * i;
+      v[i] = make_float4(0, 0, 0, 0);
+      if (u < nu) {
+        float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * D + u * 4);
+        if (r) {
+          float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
+          if (drop_p > 0.f) {
+            const uint64_t e = (uint64_t)row * D + u * 4;
+            b.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
+            b.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
+            b.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
+            b.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+          }
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        v[i] = a;
+        s += a.x + a.y + a.z + a.w;
+      }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = lane + 64 * i;
+      if (u < nu) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        q += a * a + b * b + c * c + d * d;
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = lane + 64 * i;
+      if (u < nu) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + u * 4);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + u * 4);
+        float4 o;
+        o.x = (v[i].x - mu) * rs * g.x + bb.x;
+        o.y = (v[i].y - mu) * rs * g.y + bb.y;
+        o.z = (v[i].z - mu) * rs * g.z + bb.z;
+        o.w = (v[i].w - mu) * rs * g.w + bb.w;
+        *reinterpret_cast<float4*>(y + (size_t)row * D + u * 4) = o;
+      }
+    }
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+}
+
+// backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dr = dx * mask/(1-p).
+// dgamma/dbeta: per-wave register partials over a grid-stride of rows, then LDS + atomics.
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ r,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dx,
+                                                         float* __restrict__ dr, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, long M, int D, float drop_p,
+                                                         float inv_keep, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int nu = D >> 2;
+  float4 dg[4], db[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); }
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (; row < M; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[4], gd[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = lane + 64 * i;
+      xh[i] = make_float4(0, 0, 0, 0); gd[i] = make_float4(0, 0, 0, 0);
+      if (u < nu) {
+        float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * D + u * 4);
+        if (r) {
+          float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
+          if (drop_p > 0.f) {
+            const uint64_t e = (uint64_t)row * D + u * 4;
+            b.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
+            b.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
+            b.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
+            b.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+          }
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * D + u * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gamma + u * 4);
+        xh[i] = make_float4((a.x - mu) * rs, (a.y - mu) * rs, (a.z - mu) * rs, (a.w - mu) * rs);
+        gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        s1 += gd[i].x + gd[i].y + gd[i].z + gd[i].w;
+        s2 += gd[i].x * xh[i].x + gd[i].y * xh[i].y + gd[i].z * xh[i].z + gd[i].w * xh[i].w;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = lane + 64 * i;
+      if (u < nu) {
+        float4 o;
+        o.x = rs * (gd[i].x - s1 - xh[i].x * s2);
+        o.y = rs * (gd[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (gd[i].z - s1 - xh[i].z * s2);
+        o.w = rs * (gd[i].w - s1 - xh[i].w * s2);
+        *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = o;
+        if (dr) {
+          if (drop_p > 0.f) {
+            const uint64_t e = (uint64_t)row * D + u * 4;
+            o.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
+            o.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
+            o.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
+            o.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+          }
+          *reinterpret_cast<float4*>(dr + (size_t)row * D + u * 4) = o;
+        }
+      }
+    }
+  }
+  // reduce the 4 waves of the block through LDS, then one atomic per column per block
+  __shared__ float red[2][4][1024];
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = lane + 64 * i;
+    if (u < nu) {
+      *reinterpret_cast<float4*>(&red[0][w][u * 4]) = dg[i];
+      *reinterpret_cast<float4*>(&red[1][w][u * 4]) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+}  // namespace hoisdf
+
+using namespace hoisdf;
+
+static int row_grid(long n_rows) {
+  long blocks = (n_rows + 3) / 4;
+  if (blocks > 256L * 8) blocks = 256L * 8;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+extern "C" int hoisdf_posenc_fwd(const float* points, long n_rows, float* x0, int ldx0, int col0, float* pe,
+                                 void* stream) {
+  HOISDF_REQUIRE(points && (x0 || pe) && n_rows >= 0, HOISDF_ERR_INVALID, "posenc_fwd: bad arguments");
+  HOISDF_REQUIRE(!x0 || (col0 >= 0 && col0 + 33 <= ldx0), HOISDF_ERR_INVALID,
+                 "posenc_fwd: col0=%d + 33 exceeds ldx0=%d", col0, ldx0);
+  if (n_rows == 0) return HOISDF_OK;
+  long total = n_rows * 36;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, n_rows, x0,
+                     ldx0, col0, pe);
+  return check_launch("posenc");
+}
+
+extern "C" int hoisdf_weightnorm_fwd(const float* v, const float* g, float* W, int ldw, float* norms, int out,
+                                     int in, void* stream) {
+  HOISDF_REQUIRE(v && g && W && out > 0 && in > 0 && ldw >= in, HOISDF_ERR_INVALID, "weightnorm_fwd: bad arguments");
+  hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(cdiv(out, 4)), dim3(256), 0, as_stream(stream), v, g, W, ldw,
+                     norms, out, in);
+  return check_launch("weightnorm_fwd");
+}
+
+extern "C" int hoisdf_weightnorm_bwd(const float* v, const float* g, const float* dW, int ldw, float* dv,
+                                     float* dg, int out, int in, void* stream) {
+  HOISDF_REQUIRE(v && g && dW && dv && dg && out > 0 && in > 0 && ldw >= in, HOISDF_ERR_INVALID,
+                 "weightnorm_bwd: bad arguments");
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(out, 4)), dim3(256), 0, as_stream(stream), v, g, dW, ldw,
+                     dv, dg, out, in);
+  return check_launch("weightnorm_bwd");
+}
+
+extern "C" int hoisdf_sdf_head_fwd(const float* h, int ldh, const float* w, const float* b, float* sdf_raw,
+                                   float* sdf, long n_rows, int K, float clamp, void* stream) {
+  HOISDF_REQUIRE(h && w && b && (sdf_raw || sdf) && n_rows >= 0, HOISDF_ERR_INVALID, "sdf_head_fwd: null pointer");
+  HOISDF_REQUIRE(K > 0 && (K & 3) == 0 && (ldh & 3) == 0 && ldh >= K && ((uintptr_t)h & 15) == 0 &&
+                     ((uintptr_t)w & 15) == 0, HOISDF_ERR_INVALID, "sdf_head_fwd: K/ldh must be multiples of 4, 16-byte aligned");
+  if (n_rows == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(sdf_head_fwd_kernel, dim3(row_grid(n_rows)), dim3(256), 0, as_stream(stream), h, ldh, w, b,
+                     sdf_raw, sdf, n_rows, K, clamp);
+  return check_launch("sdf_head_fwd");
+}
+
+extern "C" int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, const float* h, int ldh,
+                                   const float* w, float* dh, int lddh, float* dw, float* db, long n_rows, int K,
+                                   float clamp, void* stream) {
+  HOISDF_REQUIRE(dsdf && sdf_raw && h && w && dh && dw && db && n_rows >= 0, HOISDF_ERR_INVALID,
+                 "sdf_head_bwd: null pointer");
+  HOISDF_REQUIRE(K > 0 && K <= 512 && (K & 3) == 0 && (ldh & 3) == 0 && (lddh & 3) == 0 && ldh >= K && lddh >= K,
+                 HOISDF_ERR_INVALID, "sdf_head_bwd: K must be a multiple of 4 and <= 512");
+  if (n_rows == 0) return HOISDF_OK;
+  int blocks = row_grid(n_rows);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dsdf, sdf_raw, h, ldh, w,
+                     dh, lddh, dw, db, n_rows, K, clamp);
+  return check_launch("sdf_head_bwd");
+}
+
+extern "C" int hoisdf_token_build_fwd(const float* cam, const float* center, const float* pe, const float* feat,
+                                      int ldfeat, const float* sdf, const float* beta_ptr, float* tok, int B, int P,
+                                      int S, int row0, int D, void* stream) {
+  HOISDF_REQUIRE(cam && center && pe && feat && sdf && beta_ptr && tok, HOISDF_ERR_INVALID,
+                 "token_build_fwd: null pointer");
+  HOISDF_REQUIRE(B > 0 && P >= 0 && row0 >= 0 && row0 + P <= S && D > 33 && ldfeat >= D - 33, HOISDF_ERR_INVALID,
+                 "token_build_fwd: bad sizes B=%d P=%d S=%d row0=%d D=%d", B, P, S, row0, D);
+  if (P == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(token_build_fwd_kernel, dim3(row_grid((long)B * P)), dim3(256), 0, as_stream(stream), cam,
+                     center, pe, feat, ldfeat, sdf, beta_ptr, tok, B, P, S, row0, D);
+  return check_launch("token_build_fwd");
+}
+
+extern "C" int hoisdf_token_build_bwd(const float* dtok, const float* feat, int ldfeat, const float* sdf,
+                                      const float* beta_ptr, float* dfeat, int lddfeat, float* dbeta, int B, int P,
+                                      int S, int row0, int D, void* stream) {
+  HOISDF_REQUIRE(dtok && feat && sdf && beta_ptr && dfeat, HOISDF_ERR_INVALID, "token_build_bwd: null pointer");
+  HOISDF_REQUIRE(B > 0 && P >= 0 && row0 >= 0 && row0 + P <= S && D > 33 && ldfeat >= D - 33 && lddfeat >= D - 33,
+                 HOISDF_ERR_INVALID, "token_build_bwd: bad sizes");
+  if (P == 0) return HOISDF_OK;
+  int blocks = row_grid((long)B * P);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(token_build_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dtok, feat, ldfeat,
+                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D);
+  return check_launch("token_build_bwd");
+}
+
+extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
+                                        float* y, float* mean, float* rstd, long M, int D, float eps, float drop_p,
+                                        uint64_t seed, void* stream) {
+  HOISDF_REQUIRE(x && gamma && beta && y && M >= 0, HOISDF_ERR_INVALID, "add_layernorm_fwd: null pointer");
+  HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
+                 "add_layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
+  if (M == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
+                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed);
+  return check_launch("add_layernorm_fwd");
+}
+
+extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
+                                        const float* mean, const float* rstd, float* dx, float* dr, float* dgamma,
+                                        float* dbeta, long M, int D, float drop_p, uint64_t seed, void* stream) {
+  HOISDF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && M >= 0, HOISDF_ERR_INVALID,
+                 "add_layernorm_bwd: null pointer");
+  HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
+                 "add_layernorm_bwd: D=%d must be a multiple of 4 and <= 1024", D);
+  if (M == 0) return HOISDF_OK;
+  int blocks = row_grid(M);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
+                     dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed);
+  return check_launch("add_layernorm_bwd");
+}

@@ -1,0 +1,341 @@
+"""``Model`` / ``get_model``: drop-in for the reference's main/model.py surface with the hot path
+(everything after the CNN encoder/decoder) running on hand-written gfx950 kernels.
+
+Same constructor-level module names (state-dict schema of SURVEY.md Appendix D), same
+``forward(inputs, targets, meta_info, mode, epoch_cnt, batch_ratio)`` signature and the
+``*_out`` key convention (main/train.py:111-112).  Differences, all internal:
+  * tokens are batch-first (B,S,256) and the pyramid is consumed channels-last;
+  * ``sdf_infer`` is batched on the device (lattice -> bbox compaction -> SDF -> exact top-K),
+    one host read of B survivor counts per field instead of 2*B CPU<->GPU hops
+    (reference main/model.py:285-352);
+  * the dense-grid selection returns the same *set* in the same ascending-|sdf| order.
+Reference line numbers are cited per method.
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .config import cfg as _global_cfg
+from .nets.blocks import MLP, SDFDecoder, Transformer, VoteTransformer
+from .nets.encoder import BackboneNet, DecoderNet
+from .nets.heads import JointvoteLoss, ManoHead, ManoLoss, ManoShapeLoss, SepSDFLoss
+from .nets.mano import ManoLayer
+
+
+def get_mano_tgt_mask(cfg=_global_cfg):
+    """common/utils/misc.py:11-31 - True = masked."""
+    n = cfg.mano_num_queries
+    m = torch.ones(n, n, dtype=torch.bool)
+    m[0, 0] = False
+    for i in range(5):
+        m[3 * i + 1:3 * i + 4, 3 * i + 1:3 * i + 4] = False
+    m[cfg.mano_shape_indx, cfg.mano_shape_indx] = False
+    return m
+
+
+def get_mano_memory_mask(cfg=_global_cfg):
+    """common/utils/misc.py:42-47."""
+    m = torch.zeros(cfg.mano_num_queries, cfg.num_samp_hand + cfg.num_samp_obj, dtype=torch.bool)
+    m[:, cfg.num_samp_hand:] = True
+    return m
+
+
+def get_manoshape_memory_mask(cfg=_global_cfg):
+    """common/utils/misc.py:34-39."""
+    m = torch.zeros(1, cfg.num_samp_hand + cfg.num_samp_obj, dtype=torch.bool)
+    m[:, cfg.num_samp_hand:] = True
+    return m
+
+
+class Model(nn.Module):
+    def __init__(self, backbone_net, decoder_net, hand_sdf_decoder, obj_sdf_decoder, hand_transformer,
+                 obj_transformer, mano_layer, cfg=_global_cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone_net = backbone_net
+        self.decoder_net = decoder_net
+        self.hand_sdf_decoder = hand_sdf_decoder
+        self.obj_sdf_decoder = obj_sdf_decoder
+        self.hand_transformer = hand_transformer
+        self.obj_transformer = obj_transformer
+        self.hand_sigmoid_beta = nn.Parameter(0.1 * torch.ones(1))
+        self.obj_sigmoid_beta = nn.Parameter(0.1 * torch.ones(1))
+        D, C = cfg.hidden_dim, cfg.mutliscale_dim
+        self.norm1 = nn.LayerNorm(C)                       # defined, never applied (reference :55)
+        self.linear_transformerin = MLP(C, [1024, 512, 256], D - cfg.PointFeatSize, 4, True)
+        self.linear_sdfin = MLP(C, [512], D, 2, True)
+        coord_change_mat = torch.tensor([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])
+        if cfg.use_inverse_kinematics:
+            self.mano_query_embed = nn.Embedding(1, D)
+        else:
+            self.mano_query_embed = nn.Embedding(cfg.mano_num_queries, D)
+            self.mano_head = ManoHead(mano_layer, coord_change_mat=coord_change_mat)
+            self.linear_pose = MLP(D, D, 6, 3)
+        self.linear_shape = MLP(D, D, 10, 3)
+        self.linear_handvote = MLP(D, D, 20 * 3, 4)
+        self.linear_handcls = MLP(D, D, 20, 3)
+        self.linear_objvote = MLP(D, D, 8 * 3, 4)          # unused in forward (reference :86-87)
+        self.linear_objcls = MLP(D, D, 8, 3)
+        self.linear_obj_rel_trans = MLP(D, D, 3, 3)
+        self.linear_obj_rot = MLP(D, D, 3, 3)
+        self.joints_vote_loss = JointvoteLoss(cfg.hand_cls_dist)
+        self.sdf_loss = SepSDFLoss()
+        if cfg.use_inverse_kinematics:
+            self.mano_shape_loss = ManoShapeLoss(cfg.lambda_manoshape, cfg.mano_lambda_regulshape)
+        else:
+            self.mano_loss = ManoLoss(cfg.lambda_verts3d, cfg.lambda_joints3d, cfg.lambda_manopose,
+                                      cfg.lambda_manoshape)
+        self.freeze_stages()
+        self._py_random = random            # the p < 0.4 branch draw (reference :426); injectable for tests
+        self._jitter = None                 # test hook: callable(like, d) -> jitter tensor
+
+    def freeze_stages(self):
+        if self.backbone_net is None:
+            return
+        for name, p in self.backbone_net.named_parameters():
+            if "bn" in name:
+                p.requires_grad = False
+
+    # ---- pieces ---------------------------------------------------------------------------
+    def _pyramid(self, feature_pyramid) -> ops.PyramidNHWC:
+        if isinstance(feature_pyramid, ops.PyramidNHWC):
+            return feature_pyramid
+        return ops.PyramidNHWC.from_nchw([feature_pyramid[k] for k in self.cfg.mutliscale_layers])
+
+    def sdf_activation(self, input, beta):
+        """reference :123-126 (sigma = sigmoid(sdf/beta)/beta, beta floored in place)."""
+        beta.data.clamp_(min=2e-3)
+        return torch.sigmoid(input / beta) / beta
+
+    def _sdf_rows(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None):
+        """K1-K4 on a flat list of points: returns (sdf clamped (n,), sdf_raw (n,), pe (n,30), cam (n,3))."""
+        c = self.cfg
+        feat, cam = ops.project_gather(pyr, points, center, cam_intr, scale, c.input_img_shape, sample_idx)
+        fea = self.linear_sdfin(feat)
+        pts = points.reshape(-1, 3)
+        pe = ops.posenc(pts)
+        # decoder input rows [feat256 | pe30 | xyz3] in a 292-wide (16-byte aligned) buffer
+        n = pts.shape[0]
+        x0 = torch.cat([fea, pe, pts, pts.new_zeros(n, 3)], dim=1)[:, :c.hidden_dim + c.PointFeatSize]
+        dec = self.hand_sdf_decoder if kind == "hand" else self.obj_sdf_decoder
+        sdf, raw = dec.forward_clamped(x0, c.ClampingDistance)
+        return sdf, raw, pe, cam
+
+    def sdf_forward(self, feature_pyramid, sdf_points, center_joint, cam_intr, sdf_scale, type="hand"):
+        """reference :181-244 -> (pred_sdf (B,P,1), None, pos_enc3d (B,P,30))."""
+        B, P, _ = sdf_points.shape
+        sdf, _, pe, _ = self._sdf_rows(self._pyramid(feature_pyramid), sdf_points, center_joint, cam_intr,
+                                       sdf_scale, type)
+        return sdf.view(B, P, 1), None, pe.view(B, P, -1)
+
+    def get_input_transformer(self, feature_pyramid, sdf_points, center_joint, cam_intr, sdf_scale):
+        """reference :145-179 -> (transformer_latent (B,P,223), cam_sdf_points (B,P,3))."""
+        B, P, _ = sdf_points.shape
+        feat, cam = ops.project_gather(self._pyramid(feature_pyramid), sdf_points, center_joint, cam_intr, sdf_scale,
+                                       self.cfg.input_img_shape)
+        return self.linear_transformerin(feat).view(B, P, -1), cam.view(B, P, 3)
+
+    @torch.no_grad()
+    def sdf_infer(self, feature_pyramid, center_joint, cam_intr, bbox, sdf_scale, num_points, type="hand"):
+        """reference :246-355, batched on the device -> (points (B,K,3), sdf (B,K,1), posenc (B,K,30), None)."""
+        c = self.cfg
+        pyr = self._pyramid(feature_pyramid)
+        B = center_joint.shape[0]
+        pts, sidx, _lidx, counts, offsets, counts_dev = ops.lattice_candidates(center_joint, cam_intr, bbox,
+                                                                              sdf_scale, c.bins_n)
+        short = [b for b, n in enumerate(counts) if n < num_points]
+        if short:
+            raise ValueError(
+                f"sdf_infer({type}): sample {short[0]} has only {counts[short[0]]} lattice points inside its "
+                f"bbox, fewer than num_points={num_points} (the reference fails at main/model.py:348)")
+        sdf, raw, pe, _ = self._sdf_rows(pyr, pts, center_joint, cam_intr, sdf_scale, type, sample_idx=sidx)
+        sel = ops.select_smallest_abs(raw, offsets, counts_dev, num_points)
+        pose_points = ops.gather_rows(pts, sel).view(B, num_points, 3)
+        pose_sdf = ops.gather_rows(sdf, sel).view(B, num_points, 1)
+        pose_pe = ops.gather_rows(pe, sel).view(B, num_points, -1)
+        return pose_points, pose_sdf, pose_pe, None
+
+    def render_gaussian_heatmap(self, joint_coord):
+        """reference :128-143 (encoder-side auxiliary target; plain torch)."""
+        c = self.cfg
+        x = torch.arange(c.output_hm_shape[2], device=joint_coord.device).float()
+        y = torch.arange(c.output_hm_shape[1], device=joint_coord.device).float()
+        yy, xx = torch.meshgrid(y, x, indexing="ij")
+        jx, jy = joint_coord[:, :, 0, None, None], joint_coord[:, :, 1, None, None]
+        hm = torch.exp(-(((xx[None, None] - jx) / c.sigma) ** 2) / 2 - (((yy[None, None] - jy) / c.sigma) ** 2) / 2)
+        return hm.sum(1) * 255
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def hot_path(self, pyr: ops.PyramidNHWC, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0):
+        """reference :370-402 and :424-662: everything after decoder_net except the aux image losses."""
+        c = self.cfg
+        training = mode == "train"
+        loss: Dict[str, torch.Tensor] = {}
+        out: Dict[str, torch.Tensor] = {}
+        root, ocen, K = meta_info["mano_root"], meta_info["obj_center_cam"], meta_info["cam_intr"]
+        hs_, os_ = c.hand_sdf_scale, c.obj_sdf_scale
+        nh, no = c.num_samp_hand, c.num_samp_obj
+        B = root.shape[0]
+
+        if training or c.dataset == "dexycb":                                         # :370-402
+            sh, _, _ = self.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, hs_, "hand")
+            so, _, _ = self.sdf_forward(pyr, inputs["obj_sdf_points"], ocen, K, os_, "obj")
+            cd = c.ClampingDistance
+            loss["sdfhand_loss"], loss["sdfobj_loss"] = self.sdf_loss(
+                sh, so, targets["hand_sdf"].clamp(-cd, cd), targets["obj_sdf"].clamp(-cd, cd))
+
+        p = self._py_random.uniform(0, 1)                                              # :426
+        if (p < 0.4 or epoch_cnt < c.point_sampling_epoch) and training:               # :427-460
+            d = c.random_move_dist[len([a for a in c.random_ratio if batch_ratio > a])]
+            jit = self._jitter or (lambda like, dd: torch.empty_like(like).uniform_(-dd, dd))
+            hand_points = inputs["hand_pre_points"] + jit(inputs["hand_pre_points"], d)
+            obj_points = inputs["obj_pre_points"] + jit(inputs["obj_pre_points"], d)
+            with torch.no_grad():   # the reference tracks these two calls but only ever uses them detached
+                hand_sdf, _, hand_pe = self.sdf_forward(pyr, hand_points, root, K, hs_, "hand")
+                obj_sdf, _, obj_pe = self.sdf_forward(pyr, obj_points, ocen, K, os_, "obj")
+        else:                                                                          # :462-481
+            hand_points, hand_sdf, hand_pe, _ = self.sdf_infer(pyr, root, K, meta_info["bbox_hand"], hs_, nh, "hand")
+            obj_points, obj_sdf, obj_pe, _ = self.sdf_infer(pyr, ocen, K, meta_info["bbox_obj"], os_, no, "obj")
+
+        self.hand_sigmoid_beta.data.clamp_(min=2e-3)                                   # :124
+        self.obj_sigmoid_beta.data.clamp_(min=2e-3)
+        hand_fea, hand_cam = self.get_input_transformer(pyr, hand_points, root, K, hs_)            # :486-493
+        obj_fea, obj_cam = self.get_input_transformer(pyr, obj_points, ocen, K, os_)
+        hand_rel = hand_cam - root[:, None, :]
+
+        with torch.no_grad():                                                          # :495-518 (outputs detached)
+            hand_o_pts = (hand_cam - ocen[:, None, :]) * os_
+            obj_h_pts = (obj_cam - root[:, None, :]) * hs_
+            hand_o_sdf, _, hand_o_pe = self.sdf_forward(pyr, hand_o_pts, ocen, K, os_, "obj")
+            obj_h_sdf, _, obj_h_pe = self.sdf_forward(pyr, obj_h_pts, root, K, hs_, "hand")
+
+        # token streams (batch-first).  The appended cross-field tokens are detached (:540,:558) and use
+        # the *other* centre for xyz ("# bug" lines :498,:508 replicated).
+        S, D = nh + no, c.hidden_dim
+        dev = root.device
+        hand_tok = torch.empty(B, S, D, device=dev)
+        obj_tok = torch.empty(B, S, D, device=dev)
+        with torch.no_grad():
+            ops.token_build(hand_tok, obj_cam.reshape(-1, 3), root, obj_h_pe, obj_fea.detach(), obj_h_sdf,
+                            self.hand_sigmoid_beta.detach(), nh)
+            ops.token_build(obj_tok, hand_cam.reshape(-1, 3), ocen, hand_o_pe, hand_fea.detach(), hand_o_sdf,
+                            self.obj_sigmoid_beta.detach(), no)
+        hand_tok = ops.token_build(hand_tok, hand_cam.reshape(-1, 3), root, hand_pe, hand_fea, hand_sdf.detach(),
+                                   self.hand_sigmoid_beta, 0)
+        obj_tok = ops.token_build(obj_tok, obj_cam.reshape(-1, 3), ocen, obj_pe, obj_fea, obj_sdf.detach(),
+                                  self.obj_sigmoid_beta, 0)
+
+        tgt_mask = None if c.use_inverse_kinematics else get_mano_tgt_mask(c)         # :564-569
+        hs, memory, hand_enc = self.hand_transformer.forward_batch_first(
+            hand_tok, self.mano_query_embed.weight, tgt_mask, nh)                      # :571-581
+        _, obj_enc = self.obj_transformer.forward_batch_first(obj_tok)                 # :582-584
+
+        hand_off = self.linear_handvote(hand_enc[:, :, :nh])                           # :587-593 (L,B,nh,60)
+        hand_cls = self.linear_handcls(hand_enc[:, :, :nh])
+        obj_rot = self.linear_obj_rot(obj_enc[:, :, :no])                              # (L,B,no,3)
+        obj_trans = self.linear_obj_rel_trans(obj_enc[:, :, :no])
+
+        pred_m = gt_m = None
+        if c.use_inverse_kinematics:                                                   # :595-597
+            mano_shape = self.linear_shape(hs[:, :, 0])
+            out["mano_shape_out"] = mano_shape[-1]
+        else:                                                                          # :599-620
+            pose6d = self.linear_pose(hs[:, :, :c.mano_shape_indx])                    # (L,B,16,6)
+            mano_shape = self.linear_shape(hs[:, :, c.mano_shape_indx])                # (L,B,10)
+            mp = targets["mano_param"] if (training or c.dataset == "dexycb") else None
+            pred_m, gt_m = self.mano_head.forward_batch_first(pose6d, mano_shape, mp)
+            out["mano_mesh_out"] = pred_m["verts3d"][-1]
+            out["mano_joints_out"] = pred_m["joints3d"][-1]
+            if c.dataset == "dexycb":
+                out["mano_joints_gt_out"] = gt_m["joints3d"]
+                out["mano_mesh_gt_out"] = gt_m["verts3d"]
+
+        if not training:                                                               # :622-624
+            out["obj_rot_out"] = obj_rot[-1].contiguous()
+            out["obj_trans_out"] = obj_trans[-1].contiguous()
+
+        if training or c.dataset == "dexycb":                                          # :626-638
+            joints_gt = targets["joint_cam_no_trans"][:, 1:]
+        else:
+            joints_gt = torch.zeros(B, 20, 3, device=dev)
+        (loss["loss_joint_3d"], loss["loss_joint_cls"], loss["loss_all_joint_3d"],
+         joints) = self.joints_vote_loss(hand_rel, hand_off, hand_cls, joints_gt, batch_first=True)
+        out["hand_joints_out"] = joints[-1]
+
+        if training or c.dataset == "dexycb":                                          # :640-654
+            if c.use_inverse_kinematics:
+                loss["shape_param_loss"], loss["shape_reg_loss"] = self.mano_shape_loss(
+                    mano_shape, targets["mano_param"][:, -10:])
+            else:
+                (loss["mano_mesh_loss"], loss["mano_joint_loss"], loss["pose_param_loss"],
+                 loss["shape_param_loss"], _, _) = self.mano_loss(pred_m, gt_m)
+        loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))    # :656-662
+        loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
+        return loss, out
+
+    def forward(self, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0):
+        """reference :357-665."""
+        c = self.cfg
+        img_feat, skips = self.backbone_net(inputs["img"])                            # :367-368 (PyTorch / MIOpen)
+        feature_pyramid, decoder_out = self.decoder_net(img_feat, skips)
+        pyr = self._pyramid(feature_pyramid)
+        loss, out = self.hot_path(pyr, inputs, targets, meta_info, mode, epoch_cnt, batch_ratio)
+        if mode == "train" or c.dataset == "dexycb":                                   # :404-422 aux image losses
+            out["joint_heatmap_out"] = decoder_out[:, 0]
+            out["hand_seg_gt_out"] = targets["hand_seg"]
+            out["hand_seg_pred_out"] = decoder_out[:, 1]
+            out["obj_seg_gt_out"] = targets["obj_seg"]
+            out["obj_seg_pred_out"] = decoder_out[:, 2]
+            loss["joint_heatmap"] = (decoder_out[:, 0] - self.render_gaussian_heatmap(targets["joint_coord"])) ** 2
+            loss["obj_seg"] = F.binary_cross_entropy(decoder_out[:, 2], targets["obj_seg"], reduction="none")
+            loss["hand_seg"] = F.binary_cross_entropy(decoder_out[:, 1], targets["hand_seg"], reduction="none")
+        return {**loss, **out}
+
+
+def init_weights(m):
+    """reference :668-679."""
+    if isinstance(m, (nn.ConvTranspose2d,)):
+        nn.init.normal_(m.weight, std=0.001)
+    elif isinstance(m, nn.Conv2d):
+        nn.init.normal_(m.weight, std=0.001)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.BatchNorm2d):
+        nn.init.constant_(m.weight, 1)
+        nn.init.constant_(m.bias, 0)
+    elif type(m) is nn.Linear:
+        nn.init.normal_(m.weight, std=0.01)
+        nn.init.constant_(m.bias, 0)
+
+
+def get_model(mode, cfg=_global_cfg, mano_layer=None, with_encoder=True):
+    """reference :682-766.  ``mano_layer``: a module with manopth's ManoLayer interface; defaults to
+    the synthetic MANO-shaped asset (the licensed MANO_RIGHT.pkl is not redistributable)."""
+    backbone = BackboneNet(cfg.resnet_type) if with_encoder else None
+    decoder = DecoderNet(cfg.resnet_type, big=cfg.use_big_decoder) if with_encoder else None
+    mk = lambda: SDFDecoder(cfg.hidden_dim, cfg.PointFeatSize, use_classifier=cfg.ClassifierBranch)
+    hand_dec, obj_dec = mk(), mk()
+    hand_tr = Transformer(d_model=cfg.hidden_dim, dropout=cfg.dropout, nhead=cfg.nheads,
+                          dim_feedforward=cfg.dim_feedforward, num_encoder_layers=cfg.enc_layers,
+                          num_decoder_layers=cfg.dec_layers, normalize_before=cfg.pre_norm,
+                          return_intermediate_dec=True)
+    obj_tr = VoteTransformer(d_model=cfg.hidden_dim, dropout=cfg.dropout, nhead=cfg.nheads,
+                             dim_feedforward=cfg.dim_feedforward, num_encoder_layers=cfg.enc_layers // 2,
+                             normalize_before=cfg.pre_norm, return_intermediate_dec=True)
+    if mano_layer is None:
+        mano_layer = ManoLayer()
+    if mode == "train":
+        if decoder is not None:
+            decoder.apply(init_weights)
+        for m in (hand_tr, obj_tr, hand_dec, obj_dec):
+            m.apply(init_weights)
+        for dec in (hand_dec, obj_dec):      # weight-normed layers: only the bias is re-initialised
+            for i in range(4):
+                nn.init.constant_(getattr(dec, f"linh{i}").bias, 0)
+    return Model(backbone, decoder, hand_dec, obj_dec, hand_tr, obj_tr, mano_layer, cfg=cfg)

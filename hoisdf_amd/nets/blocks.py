@@ -1,0 +1,276 @@
+"""Network blocks of the hot path as thin ``nn.Module`` parameter holders whose ``forward``
+runs on the HIP kernels (hoisdf_amd.ops).  Parameter names and shapes equal the reference's
+state dict so checkpoints are drop-in:
+  MLP              common/nets/layer.py:168-201      -> ``layers.{i}.weight/bias``
+  SDFDecoder       common/nets/sdf_net.py:12-122     -> ``linh{0..3}.weight_g/weight_v/bias``, ``linh4.*``
+  Transformer /    common/nets/transformer.py:15-459 -> ``encoder.layers.{i}.self_attn.in_proj_*`` ...
+  VoteTransformer
+Internally tokens are batch-first (B, S, 256); the seq-first public ``forward`` of the
+transformers keeps the reference's call signature and return layout.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class MLP(nn.Module):
+    """Linear(+ReLU) chain; last ReLU iff ``is_activation_last``."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers, is_activation_last=False):
+        super().__init__()
+        h = hidden_dim if isinstance(hidden_dim, list) else [hidden_dim] * (num_layers - 1)
+        assert len(h) == num_layers - 1, "len(hidden_dim) != num_layers-1"
+        dims = [input_dim] + h + [output_dim]
+        self.num_layers = num_layers
+        self.is_activation_last = is_activation_last
+        self.layers = nn.ModuleList(nn.Linear(dims[i], dims[i + 1]) for i in range(num_layers))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            act = i < self.num_layers - 1 or self.is_activation_last
+            x = ops.linear(x, layer.weight, layer.bias, act=act)
+        return x
+
+
+class _WNLinear(nn.Module):
+    """Parameters of a weight-normed nn.Linear in the legacy ``weight_g / weight_v`` naming the
+    reference's checkpoints use (torch.nn.utils.weight_norm, dim=0)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        lin = nn.Linear(in_f, out_f)
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        self.weight_g = nn.Parameter(lin.weight.detach().norm(dim=1, keepdim=True))
+        self.weight_v = nn.Parameter(lin.weight.detach().clone())
+
+    def effective_weight(self):
+        return ops.weight_norm(self.weight_v, self.weight_g)
+
+
+class SDFDecoder(nn.Module):
+    """x0 = [feat256 | posenc30 | xyz3] -> 512 -> 223 (+x0) -> 512 -> 512 -> 1, tanh.
+    Layers 0-3 weight-normed, ReLU + dropout(0.2) in training; skip-concat before layer 2."""
+
+    def __init__(self, latent_size, point_feat_size, dims=(512, 512, 512, 512), dropout_prob=0.2,
+                 use_classifier=False):
+        super().__init__()
+        assert not use_classifier, "ClassifierBranch=False in every released configuration"
+        d0 = latent_size + point_feat_size
+        self.in_dim = d0
+        self.linh0 = _WNLinear(d0, dims[0])
+        self.linh1 = _WNLinear(dims[0], dims[1] - d0)
+        self.linh2 = _WNLinear(dims[1], dims[2])
+        self.linh3 = _WNLinear(dims[2], dims[3])
+        self.linh4 = nn.Linear(dims[3], 1)
+        self.dropout_prob = dropout_prob
+
+    def hidden(self, x0):
+        """all layers up to the 512-wide h3 (input of the scalar head)"""
+        p = self.dropout_prob if self.training else 0.0
+        h0 = ops.linear(x0, self.linh0.effective_weight(), self.linh0.bias, act=True, drop_p=p)
+        h1 = ops.linear(h0, self.linh1.effective_weight(), self.linh1.bias, act=True, drop_p=p)
+        h2 = ops.linear(torch.cat([h1, x0], dim=1), self.linh2.effective_weight(), self.linh2.bias, act=True,
+                        drop_p=p)
+        return ops.linear(h2, self.linh3.effective_weight(), self.linh3.bias, act=True, drop_p=p)
+
+    def forward(self, input):
+        """(P, 289) -> (tanh sdf (P,1), None): the reference's call signature
+        (it returns a dummy tensor as second element when the classifier is off)."""
+        h3 = self.hidden(input)
+        _, raw = ops.sdf_head(h3, self.linh4.weight, self.linh4.bias, 1e30)
+        return raw.unsqueeze(1), None
+
+    def forward_clamped(self, x0, clamp):
+        h3 = self.hidden(x0)
+        return ops.sdf_head(h3, self.linh4.weight, self.linh4.bias, clamp)
+
+
+# -------------------------------------------------------------------------------------------------
+class _OutProj(nn.Linear):
+    """distinct type, like torch's NonDynamicallyQuantizableLinear: ``init_weights`` (type(m) is
+    nn.Linear) skips it, as in the reference."""
+
+
+class _MHA(nn.Module):
+    """nn.MultiheadAttention's parameter layout (packed in-projection)."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d_model, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = _OutProj(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = _MHA(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, x):
+        """post-norm layer on batch-first tokens (B,S,D); pos embedding is identically zero on
+        this path (main/model.py:542-562)."""
+        p = self.p if self.training else 0.0
+        a = self.self_attn
+        qkv = ops.linear(x, a.in_proj_weight, a.in_proj_bias)
+        o = ops.attention_self(qkv, a.num_heads, drop_p=p)
+        o = ops.linear(o, a.out_proj.weight, a.out_proj.bias)
+        x = ops.add_layernorm(x, o, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, act=True, drop_p=p)
+        h = ops.linear(h, self.linear2.weight, self.linear2.bias)
+        return ops.add_layernorm(x, h, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
+                                    for _ in range(num_layers))
+        self.inter_norm = nn.LayerNorm(d_model)
+        self.norm = None
+        self.num_layers = num_layers
+
+    def forward(self, x):
+        inter = []
+        n = self.inter_norm
+        for layer in self.layers:
+            x = layer(x)
+            inter.append(ops.add_layernorm(x, None, n.weight, n.bias, n.eps))
+        return x, torch.stack(inter)            # memory (B,S,D), intermediates (L,B,S,D)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = _MHA(d_model, nhead)
+        self.multihead_attn = _MHA(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, tgt, memory, query_pos, tgt_mask_u8, kv_len):
+        p = self.p if self.training else 0.0
+        E = tgt.shape[-1]
+        sa, ca = self.self_attn, self.multihead_attn
+        # masked self-attention over the queries: q = k = tgt + query_pos, v = tgt
+        qk = ops.linear(tgt + query_pos, sa.in_proj_weight[:2 * E], sa.in_proj_bias[:2 * E])
+        v = ops.linear(tgt, sa.in_proj_weight[2 * E:], sa.in_proj_bias[2 * E:])
+        o = ops.attention_small(qk[..., :E], qk[..., E:], v, tgt_mask_u8, sa.num_heads, p)
+        o = ops.linear(o, sa.out_proj.weight, sa.out_proj.bias)
+        tgt = ops.add_layernorm(tgt, o, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
+        # cross-attention to the encoder memory; only keys < kv_len (the hand points) are visible
+        q = ops.linear(tgt + query_pos, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
+        kv = ops.linear(memory, ca.in_proj_weight[E:], ca.in_proj_bias[E:])
+        o = ops.attention_cross(q, kv, ca.num_heads, kv_len, p)
+        o = ops.linear(o, ca.out_proj.weight, ca.out_proj.bias)
+        tgt = ops.add_layernorm(tgt, o, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
+        h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, act=True, drop_p=p)
+        h = ops.linear(h, self.linear2.weight, self.linear2.bias)
+        return ops.add_layernorm(tgt, h, self.norm3.weight, self.norm3.bias, self.norm3.eps, p)
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList(TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout)
+                                    for _ in range(num_layers))
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, memory, query_embed, tgt_mask_u8, kv_len):
+        B = memory.shape[0]
+        qpos = query_embed.unsqueeze(0).expand(B, -1, -1).contiguous()
+        x = torch.zeros_like(qpos)
+        outs = []
+        n = self.norm
+        for layer in self.layers:
+            x = layer(x, memory, qpos, tgt_mask_u8, kv_len)
+            outs.append(ops.add_layernorm(x, None, n.weight, n.bias, n.eps))
+        return torch.stack(outs)                 # (L,B,Q,D)
+
+
+def _mask_to_u8(mask: Optional[torch.Tensor], nq: int, device) -> torch.Tensor:
+    if mask is None:
+        return torch.zeros(nq, nq, dtype=torch.uint8, device=device)
+    return mask.to(device=device, dtype=torch.uint8).contiguous()
+
+
+def _kv_len_from_memory_mask(memory_mask: Optional[torch.Tensor], S: int) -> int:
+    """The reference's memory masks (common/utils/misc.py:34-47) hide a suffix of the keys for
+    every query; the kernels take that as a key-count.  Anything else is rejected loudly."""
+    if memory_mask is None:
+        return S
+    m = memory_mask.to(torch.bool).cpu()
+    kv = int((~m[0]).sum())
+    expect = torch.zeros_like(m)
+    expect[:, kv:] = True
+    if not torch.equal(m, expect) or kv == 0:
+        raise ValueError("memory_mask must mask exactly a suffix of the keys, identically for all queries")
+    return kv
+
+
+class Transformer(nn.Module):
+    """Encoder + decoder (hand stream).  ``forward`` keeps the reference signature (seq-first)."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
+                 return_intermediate_dec=False):
+        super().__init__()
+        assert activation == "relu" and not normalize_before, "reference config: post-norm, relu"
+        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout)
+        self.decoder = TransformerDecoder(d_model, nhead, num_decoder_layers, dim_feedforward, dropout)
+        self.d_model, self.nhead = d_model, nhead
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward_batch_first(self, tokens, query_embed, tgt_mask, kv_len):
+        memory, inter = self.encoder(tokens)
+        hs = self.decoder(memory, query_embed, _mask_to_u8(tgt_mask, query_embed.shape[0], tokens.device), kv_len)
+        return hs, memory, inter
+
+    def forward(self, src, mask, query_embed, pos_embed, tgt_mask=None, src_mask=None, memory_mask=None):
+        assert mask is None and src_mask is None, "padding / source masks are unused on this path"
+        x = src if pos_embed is None else src + pos_embed
+        kv_len = _kv_len_from_memory_mask(memory_mask, src.shape[0])
+        hs, memory, inter = self.forward_batch_first(x.permute(1, 0, 2).contiguous(), query_embed, tgt_mask,
+                                                     kv_len)
+        return hs.permute(0, 2, 1, 3), memory.permute(1, 0, 2), inter.permute(0, 2, 1, 3), None
+
+
+class VoteTransformer(nn.Module):
+    """Encoder only (object stream)."""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                 activation="relu", normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        assert activation == "relu" and not normalize_before
+        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout)
+        self.d_model, self.nhead = d_model, nhead
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward_batch_first(self, tokens):
+        return self.encoder(tokens)
+
+    def forward(self, src, mask, pos_embed, src_mask=None):
+        assert mask is None and src_mask is None
+        x = src if pos_embed is None else src + pos_embed
+        memory, inter = self.encoder(x.permute(1, 0, 2).contiguous())
+        return memory.permute(1, 0, 2), inter.permute(0, 2, 1, 3)

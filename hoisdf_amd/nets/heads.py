@@ -1,0 +1,147 @@
+"""Vote aggregation + losses (reference common/nets/loss.py:23-171) and the MANO head
+(common/nets/mano_head.py:185-278).
+
+``JointvoteLoss`` produces ``hand_joints_out`` through the HIP vote kernel (K12).  The three
+scalar losses around it and the MANO head are a16 / a15 rows of SURVEY.md section 8 - negligible
+work that stays in PyTorch (runs on the GPU through ATen).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class JointvoteLoss(nn.Module):
+    def __init__(self, hand_cls_dist: float = 0.04):
+        super().__init__()
+        self.hand_cls_dist = hand_cls_dist
+
+    def forward(self, hand_points, hand_off, hand_cls, joint_gt, batch_first: bool = False):
+        """hand_points (B,P,3) metres; hand_off (L,P,B,60) / hand_cls (L,P,B,20) as in the reference,
+        or (L,B,P,*) with batch_first=True; joint_gt (B,20,3) millimetres.
+        Returns loss_joint_3d, loss_joint_cls, loss_all_joint_3d, joints (L,B,20,3)."""
+        if not batch_first:
+            hand_off = hand_off.permute(0, 2, 1, 3)
+            hand_cls = hand_cls.permute(0, 2, 1, 3)
+        L, B, P, J = hand_cls.shape
+        joints = ops.vote_aggregate(hand_off, hand_cls, hand_points)                     # HIP, K12
+        vote = hand_points[None, :, :, None, :] + hand_off.reshape(L, B, P, J, 3)
+        near = ((hand_points[:, :, None, :] - joint_gt[:, None] / 1000).norm(dim=-1) < self.hand_cls_dist).float()
+        l3d = F.smooth_l1_loss(vote * 1000, joint_gt[None, :, None].expand(L, B, P, J, 3), reduction="none")
+        l3d = (l3d * near[None, ..., None]).sum((1, 2, 3)) / near.sum()
+        lcls = F.binary_cross_entropy_with_logits(hand_cls, near[None].expand(L, B, P, J))
+        lall = F.smooth_l1_loss(joints * 1000, joint_gt[None].expand(L, B, J, 3))
+        return l3d.mean(), lcls, lall, joints
+
+
+class SepSDFLoss(nn.Module):
+    def forward(self, hand_sdf, obj_sdf, hand_sdf_gt, obj_sdf_gt):
+        return (F.l1_loss(hand_sdf, hand_sdf_gt.unsqueeze(-1)), F.l1_loss(obj_sdf, obj_sdf_gt.unsqueeze(-1)))
+
+
+class ManoLoss(nn.Module):
+    def __init__(self, lambda_verts3d, lambda_joints3d, lambda_manopose, lambda_manoshape):
+        super().__init__()
+        self.lv, self.lj, self.lp, self.ls = lambda_verts3d, lambda_joints3d, lambda_manopose, lambda_manoshape
+
+    def forward(self, preds, gts):
+        def mse(a, b):
+            return F.mse_loss(a, b.unsqueeze(0).expand(a.shape))
+        return (self.lv * mse(preds["verts3d"], gts["verts3d"]), self.lj * mse(preds["joints3d"], gts["joints3d"]),
+                self.lp * mse(preds["mano_pose"], gts["mano_pose"]),
+                self.ls * mse(preds["mano_shape"], gts["mano_shape"]), None, None)
+
+
+class ManoShapeLoss(nn.Module):
+    def __init__(self, lambda_manoshape, lambda_regulshape):
+        super().__init__()
+        self.ls, self.lr = lambda_manoshape, lambda_regulshape
+
+    def forward(self, pred_shape, gt_shape):
+        return (self.ls * F.mse_loss(pred_shape, gt_shape.unsqueeze(0).expand(pred_shape.shape)),
+                self.lr * F.mse_loss(pred_shape, torch.zeros_like(pred_shape)))
+
+
+# ---- rotation conversions ---------------------------------------------------------------------
+def rot6d_to_matrix(x):
+    a1, a2 = x[:, :3], x[:, 3:6]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1)
+    return torch.stack((b1, b2, torch.cross(b1, b2, dim=1)), dim=-1)
+
+
+def matrix_to_quaternion(R, eps=1e-6):
+    """(N,3,3) -> (N,4) [w,x,y,z]; four-branch form on R^T selected by the diagonal, unnormalised
+    sign convention of the reference (mano_head.py:90-182)."""
+    T = R.transpose(1, 2)
+    d0, d1, d2 = T[:, 0, 0], T[:, 1, 1], T[:, 2, 2]
+    neg_z = d2 < eps
+    x_big = d0 > d1
+    x_small = d0 < -d1
+    cands = [
+        (1 + d0 - d1 - d2, [T[:, 1, 2] - T[:, 2, 1], None, T[:, 0, 1] + T[:, 1, 0], T[:, 2, 0] + T[:, 0, 2]], 1),
+        (1 - d0 + d1 - d2, [T[:, 2, 0] - T[:, 0, 2], T[:, 0, 1] + T[:, 1, 0], None, T[:, 1, 2] + T[:, 2, 1]], 2),
+        (1 - d0 - d1 + d2, [T[:, 0, 1] - T[:, 1, 0], T[:, 2, 0] + T[:, 0, 2], T[:, 1, 2] + T[:, 2, 1], None], 3),
+        (1 + d0 + d1 + d2, [None, T[:, 1, 2] - T[:, 2, 1], T[:, 2, 0] - T[:, 0, 2], T[:, 0, 1] - T[:, 1, 0]], 0),
+    ]
+    sel = [neg_z & x_big, neg_z & ~x_big, ~neg_z & x_small, ~neg_z & ~x_small]
+    q = torch.zeros(R.shape[0], 4, dtype=R.dtype, device=R.device)
+    den = torch.zeros(R.shape[0], dtype=R.dtype, device=R.device)
+    for (t, comps, slot), m in zip(cands, sel):
+        comps = [t if c is None else c for c in comps]
+        mf = m.to(R.dtype)
+        q = q + torch.stack(comps, -1) * mf[:, None]
+        den = den + t * mf
+    return 0.5 * q / torch.sqrt(den)[:, None]
+
+
+def quaternion_to_axis_angle(q):
+    v = q[..., 1:]
+    s2 = (v * v).sum(-1)
+    s = torch.sqrt(s2)
+    c = q[..., 0]
+    two_theta = 2.0 * torch.where(c < 0.0, torch.atan2(-s, -c), torch.atan2(s, c))
+    k = torch.where(s2 > 0.0, two_theta / s, torch.full_like(s, 2.0))
+    return v * k[..., None]
+
+
+def matrix_to_axis_angle(R):
+    aa = quaternion_to_axis_angle(matrix_to_quaternion(R))
+    return torch.where(torch.isnan(aa), torch.zeros_like(aa), aa)
+
+
+class ManoHead(nn.Module):
+    def __init__(self, mano_layer, coord_change_mat=None):
+        super().__init__()
+        self.mano_layer = mano_layer
+        self.mano_pose_size = 48
+        if coord_change_mat is not None:
+            self.register_buffer("coord_change_mat", coord_change_mat)
+        else:
+            self.coord_change_mat = None
+
+    def forward(self, pose6d, shape, mano_params=None):
+        """pose6d (L,16,B,6) [or (L,B,16,6) via forward_batch_first], shape (L,B,10)."""
+        return self.forward_batch_first(pose6d.permute(0, 2, 1, 3), shape, mano_params)
+
+    def forward_batch_first(self, pose6d, shape, mano_params=None):
+        from .mano import axis_angle_to_matrix
+        L, B, N, C = pose6d.shape
+        R = rot6d_to_matrix(pose6d.reshape(L * B * N, C))
+        pose = matrix_to_axis_angle(R).reshape(-1, self.mano_pose_size)
+        betas = shape.reshape(-1, 10)
+        verts, joints = self.mano_layer(th_pose_coeffs=pose, th_betas=betas)
+        pred = {"verts3d": verts.view(L, B, -1, 3) / 1000, "joints3d": joints.view(L, B, -1, 3) / 1000,
+                "mano_pose": R.view(L, B, N, 3, 3), "mano_shape": betas.view(L, B, 10)}
+        gt = None
+        if mano_params is not None:
+            gt_shape = mano_params[:, self.mano_pose_size:]
+            gt_pose = mano_params[:, :self.mano_pose_size].clone()
+            gt_pose[:, 3:] = gt_pose[:, 3:] - self.mano_layer.th_hands_mean
+            gv, gj = self.mano_layer(th_pose_coeffs=gt_pose, th_betas=gt_shape)
+            gt = {"verts3d": gv / 1000, "joints3d": gj / 1000, "mano_shape": gt_shape,
+                  "mano_pose": axis_angle_to_matrix(gt_pose.reshape(-1, 3)).view(-1, 16, 3, 3)}
+        return pred, gt

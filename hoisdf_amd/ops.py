@@ -1,0 +1,522 @@
+"""torch.autograd bindings of the HIP hot path (include/hoisdf.h via hoisdf_amd._lib).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape.  All
+arithmetic of the hot path runs in libhoisdf_hip.so.  There is no CPU or eager fallback: a
+CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import Pyramid, call
+
+_SEED = [0x9E3779B97F4A7C15, 0]
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the counter-based dropout RNG (each dropout site draws one 64-bit stream id)."""
+    _SEED[0] = int(seed) & 0xFFFFFFFFFFFFFFFF
+    _SEED[1] = 0
+
+
+def next_seed() -> int:
+    _SEED[1] += 1
+    return (_SEED[0] * 6364136223846793005 + _SEED[1] * 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise RuntimeError("hoisdf_amd ops need float32 CUDA/HIP tensors (no CPU fallback)")
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """view as (M, K) with unit inner stride and a uniform row stride"""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < x2.shape[1]):
+        x2 = x2.contiguous()
+    return x2
+
+
+# ---------------------------------------------------------------------------------------------
+# pyramid handling
+# ---------------------------------------------------------------------------------------------
+class PyramidNHWC:
+    """The feature pyramid in the layout the kernels want: per level a contiguous
+    [B][H][W][C] float32 tensor (a zero-copy view when the encoder ran channels_last)."""
+
+    def __init__(self, levels: Sequence[torch.Tensor]):
+        self.levels = [l if l.is_contiguous() else l.contiguous() for l in levels]
+        _chk(*self.levels)
+        self.B = self.levels[0].shape[0]
+        self.C = sum(l.shape[3] for l in self.levels)
+
+    @staticmethod
+    def from_nchw(maps: Sequence[torch.Tensor]) -> "PyramidNHWC":
+        return PyramidNHWC([m.permute(0, 2, 3, 1) for m in maps])
+
+    def struct(self, tensors: Optional[Sequence[torch.Tensor]] = None) -> Pyramid:
+        ts = self.levels if tensors is None else tensors
+        s = Pyramid()
+        s.n_levels, s.B = len(ts), self.B
+        for i, t in enumerate(ts):
+            s.data[i] = t.data_ptr()
+            s.C[i], s.H[i], s.W[i] = t.shape[3], t.shape[1], t.shape[2]
+        return s
+
+
+class _ProjectGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, sample_idx, center, cam_intr, scale, img_hw, *levels):
+        pyr = PyramidNHWC(levels)
+        pts = points.reshape(-1, 3).contiguous()
+        _chk(pts, center, cam_intr)
+        n = pts.shape[0]
+        rps = points.shape[-2] if sample_idx is None else 1
+        feat = torch.empty(n, pyr.C, device=pts.device, dtype=torch.float32)
+        cam = torch.empty(n, 3, device=pts.device, dtype=torch.float32)
+        s = pyr.struct()
+        call("hoisdf_project_gather_fwd", C.byref(s), _p(pts), _p(sample_idx), n, rps, _p(center), _p(cam_intr),
+             float(scale), img_hw[0], img_hw[1], _p(feat), pyr.C, _p(cam), None, _st())
+        ctx.save_for_backward(pts, sample_idx, center, cam_intr)
+        ctx.meta = (float(scale), img_hw, rps, [tuple(l.shape) for l in pyr.levels], pyr.B)
+        ctx.mark_non_differentiable(cam)
+        return feat, cam
+
+    @staticmethod
+    def backward(ctx, dfeat, _dcam):
+        pts, sample_idx, center, cam_intr = ctx.saved_tensors
+        scale, img_hw, rps, shapes, B = ctx.meta
+        dfeat = dfeat.contiguous()
+        grads = [torch.zeros(sh, device=dfeat.device, dtype=torch.float32) for sh in shapes]
+        g = Pyramid()
+        g.n_levels, g.B = len(grads), B
+        for i, t in enumerate(grads):
+            g.data[i] = t.data_ptr()
+            g.C[i], g.H[i], g.W[i] = t.shape[3], t.shape[1], t.shape[2]
+        call("hoisdf_project_gather_bwd", C.byref(g), _p(pts), _p(sample_idx), pts.shape[0], rps, _p(center),
+             _p(cam_intr), scale, img_hw[0], img_hw[1], _p(dfeat), dfeat.shape[1], _st())
+        return (None, None, None, None, None, None, *grads)
+
+
+def project_gather(pyr: PyramidNHWC, points, center, cam_intr, scale, img_hw=(256, 256), sample_idx=None):
+    """K1. points (B,P,3) [or (n,3) with sample_idx] -> feat (n, C), cam (n, 3).
+    Differentiable w.r.t. the pyramid levels only (the grid is detached in the reference)."""
+    return _ProjectGather.apply(points, sample_idx, center.contiguous(), cam_intr.contiguous(), scale,
+                                tuple(img_hw), *pyr.levels)
+
+
+# ---------------------------------------------------------------------------------------------
+# linear
+# ---------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, act, drop_p, seed):
+        x2 = _rows(x)
+        W = W if W.stride(-1) == 1 else W.contiguous()
+        _chk(x2, W, b)
+        M, K = x2.shape
+        N = W.shape[0]
+        assert W.shape[1] == K, (W.shape, K)
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        call("hoisdf_linear_fwd", _p(x2), x2.stride(0) if M > 1 else K, _p(W), W.stride(0), _p(b), _p(y), N, M, N,
+             K, int(act), float(drop_p), seed, _st())
+        ctx.save_for_backward(x2, W, y if (act or drop_p > 0) else None)
+        ctx.meta = (int(act), float(drop_p), b is not None, x.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        act, drop_p, has_b, xshape = ctx.meta
+        M, K = x2.shape
+        N = W.shape[0]
+        dy2 = _rows(dy)
+        if y is not None:
+            if not act:
+                raise RuntimeError("dropout without relu is not supported by linear()")
+            dpre = torch.empty(M, N, device=dy.device, dtype=torch.float32)
+            call("hoisdf_relu_dropout_bwd", _p(y), N, _p(dy2), dy2.stride(0) if M > 1 else N, _p(dpre), N, M, N,
+                 drop_p, _st())
+            dy2 = dpre
+        lddy = dy2.stride(0) if M > 1 else N
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dW = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
+            db = torch.zeros(N, device=dy.device, dtype=torch.float32) if has_b else None
+            call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(x2), x2.stride(0) if M > 1 else K, _p(dW), K,
+                 _p(db), M, N, K, _st())
+        return dx, dW, db, None, None, None
+
+
+def linear(x, W, b=None, act: bool = False, drop_p: float = 0.0):
+    """K2/K7/K9/K11: y = dropout(relu?(x W^T + b)); fp32-exact MFMA GEMM with fused epilogue."""
+    seed = next_seed() if drop_p > 0 else 0
+    return _Linear.apply(x, W, b, act, drop_p, seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# SDF decoder pieces
+# ---------------------------------------------------------------------------------------------
+def posenc(points: torch.Tensor) -> torch.Tensor:
+    """K3 (no grad: query points are inputs). (..., 3) -> (..., 30)"""
+    pts = points.reshape(-1, 3).contiguous()
+    _chk(pts)
+    pe = torch.empty(pts.shape[0], 30, device=pts.device, dtype=torch.float32)
+    call("hoisdf_posenc_fwd", _p(pts), pts.shape[0], None, 0, 0, _p(pe), _st())
+    return pe.view(*points.shape[:-1], 30)
+
+
+class _WeightNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        v = v.contiguous()
+        g = g.contiguous()
+        _chk(v, g)
+        out, inn = v.shape
+        W = torch.empty_like(v)
+        call("hoisdf_weightnorm_fwd", _p(v), _p(g), _p(W), inn, None, out, inn, _st())
+        ctx.save_for_backward(v, g)
+        return W
+
+    @staticmethod
+    def backward(ctx, dW):
+        v, g = ctx.saved_tensors
+        dW = dW.contiguous()
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g)
+        call("hoisdf_weightnorm_bwd", _p(v), _p(g), _p(dW), v.shape[1], _p(dv), _p(dg), v.shape[0], v.shape[1],
+             _st())
+        return dv, dg
+
+
+def weight_norm(v, g):
+    """W = g * v / ||v||_row  (nn.utils.weight_norm, dim=0)."""
+    return _WeightNorm.apply(v, g)
+
+
+class _SdfHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w, b, clamp):
+        h2 = _rows(h)
+        w = w.reshape(-1).contiguous()
+        _chk(h2, w, b)
+        M, K = h2.shape
+        raw = torch.empty(M, device=h.device, dtype=torch.float32)
+        sdf = torch.empty(M, device=h.device, dtype=torch.float32)
+        call("hoisdf_sdf_head_fwd", _p(h2), h2.stride(0) if M > 1 else K, _p(w), _p(b), _p(raw), _p(sdf), M, K,
+             float(clamp), _st())
+        ctx.save_for_backward(h2, w, raw)
+        ctx.clamp = float(clamp)
+        ctx.mark_non_differentiable(raw)
+        return sdf, raw
+
+    @staticmethod
+    def backward(ctx, dsdf, _draw):
+        h2, w, raw = ctx.saved_tensors
+        M, K = h2.shape
+        dsdf = dsdf.reshape(-1).contiguous()
+        dh = torch.empty(M, K, device=dsdf.device, dtype=torch.float32)
+        dw = torch.zeros(K, device=dsdf.device, dtype=torch.float32)
+        db = torch.zeros(1, device=dsdf.device, dtype=torch.float32)
+        call("hoisdf_sdf_head_bwd", _p(dsdf), _p(raw), _p(h2), h2.stride(0) if M > 1 else K, _p(w), _p(dh), K,
+             _p(dw), _p(db), M, K, ctx.clamp, _st())
+        return dh, dw.view(1, K), db, None
+
+
+def sdf_head(h, w, b, clamp: float):
+    """tail of K4: (M,512) -> clamped sdf (M,), raw tanh (M,)"""
+    return _SdfHead.apply(h, w, b, clamp)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense lattice + selection (no grad)
+# ---------------------------------------------------------------------------------------------
+def lattice_candidates(center, cam_intr, bbox, scale: float, bins_n: int):
+    """K5: per-sample survivors of the strict bbox test, in ascending lattice order.
+    Returns points (n,3), sample_idx (n,), lattice_idx (n,), counts (B,) [host list],
+    offsets (B,) int32 device.  One device->host read of the B counts."""
+    B = center.shape[0]
+    dev = center.device
+    center, cam_intr, bbox = center.contiguous(), cam_intr.contiguous(), bbox.contiguous()
+    _chk(center, cam_intr, bbox)
+    counts = torch.empty(B, device=dev, dtype=torch.int32)
+    call("hoisdf_lattice_count", _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts), _st())
+    counts_h = counts.cpu()
+    offsets_h = torch.zeros(B, dtype=torch.int32)
+    offsets_h[1:] = torch.cumsum(counts_h, 0)[:-1].to(torch.int32)
+    n = int(counts_h.sum())
+    offsets = offsets_h.to(dev)
+    pts = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    sidx = torch.empty(n, device=dev, dtype=torch.int32)
+    lidx = torch.empty(n, device=dev, dtype=torch.int32)
+    if n > 0:
+        call("hoisdf_lattice_fill", _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(offsets),
+             _p(pts), _p(sidx), _p(lidx), _st())
+    return pts, sidx, lidx, counts_h.tolist(), offsets, counts
+
+
+def select_smallest_abs(sdf_raw, offsets, counts, k: int):
+    """K6: (B,k) int32 row indices of the k smallest |sdf_raw| per sample, ascending."""
+    B = offsets.shape[0]
+    sel = torch.empty(B, k, device=sdf_raw.device, dtype=torch.int32)
+    call("hoisdf_select_smallest_abs", _p(sdf_raw), _p(offsets), _p(counts), B, k, _p(sel), _st())
+    return sel
+
+
+def gather_rows(src, sel):
+    src2 = _rows(src) if src.dim() > 1 else src.reshape(-1, 1)
+    n = sel.numel()
+    out = torch.empty(n, src2.shape[1], device=src.device, dtype=torch.float32)
+    call("hoisdf_gather_rows", _p(src2), src2.stride(0), _p(sel.reshape(-1).contiguous()), n, src2.shape[1], _p(out),
+         src2.shape[1], _st())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# tokens
+# ---------------------------------------------------------------------------------------------
+class _TokenBuild(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, cam, center, pe, feat, sdf, beta, row0):
+        """writes rows [row0, row0+P) of every sample of the batch-first token buffer tok (B,S,D)"""
+        B, S, D = tok.shape
+        P = cam.shape[0] // B
+        feat2 = _rows(feat)
+        cam, pe, sdf = cam.contiguous(), pe.reshape(-1, 30).contiguous(), sdf.reshape(-1).contiguous()
+        _chk(tok, cam, center, pe, feat2, sdf, beta)
+        call("hoisdf_token_build_fwd", _p(cam), _p(center), _p(pe), _p(feat2), feat2.stride(0), _p(sdf), _p(beta),
+             _p(tok), B, P, S, row0, D, _st())
+        ctx.save_for_backward(feat2, sdf, beta)
+        ctx.meta = (B, P, S, row0, D, feat.shape)
+        ctx.mark_dirty(tok)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        feat2, sdf, beta = ctx.saved_tensors
+        B, P, S, row0, D, fshape = ctx.meta
+        dtok = dtok.contiguous()
+        dfeat = torch.empty(B * P, D - 33, device=dtok.device, dtype=torch.float32)
+        dbeta = torch.zeros(1, device=dtok.device, dtype=torch.float32)
+        call("hoisdf_token_build_bwd", _p(dtok), _p(feat2), feat2.stride(0), _p(sdf), _p(beta), _p(dfeat), D - 33,
+             _p(dbeta), B, P, S, row0, D, _st())
+        # the rows this op wrote do not depend on the incoming buffer contents
+        dtok_in = dtok.clone()
+        dtok_in[:, row0:row0 + P] = 0
+        return dtok_in, None, None, None, dfeat.view(fshape), None, dbeta, None
+
+
+def token_build(tok, cam, center, pe, feat, sdf, beta, row0: int):
+    """K8: tok[b, row0+p] = [cam-center | pe | feat * sigmoid(sdf/beta)/beta]."""
+    return _TokenBuild.apply(tok, cam, center.contiguous(), pe, feat, sdf, beta, row0)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention + layer norm
+# ---------------------------------------------------------------------------------------------
+def _attn_fwd(q, k, v, H, kv_len, drop_p, seed):
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    for t, L in ((q, Lq), (k, Lk), (v, Lk)):
+        assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
+    o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_fwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse),
+         B, H, Lq, Lk, kv_len, float(drop_p), seed, _st())
+    return o, lse
+
+
+def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_bwd", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E,
+         _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, drop_p, seed, _st())
+
+
+class _AttentionSelf(torch.autograd.Function):
+    """qkv (B,L,3E): the packed in-projection output [q | k | v]."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, kv_len, drop_p, seed):
+        qkv = qkv.contiguous()
+        _chk(qkv)
+        E = qkv.shape[2] // 3
+        o, lse = _attn_fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (H, kv_len, float(drop_p), seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        H, kv_len, drop_p, seed = ctx.meta
+        E = qkv.shape[2] // 3
+        d = torch.empty_like(qkv)
+        _attn_bwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do.contiguous(), d[:, :, :E],
+                  d[:, :, E:2 * E], d[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        return d, None, None, None, None
+
+
+class _AttentionCross(torch.autograd.Function):
+    """q (B,Lq,E) contiguous; kv (B,Lk,2E): the packed [k | v] projection of the memory."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, kv_len, drop_p, seed):
+        q, kv = q.contiguous(), kv.contiguous()
+        _chk(q, kv)
+        E = q.shape[2]
+        o, lse = _attn_fwd(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.meta = (H, kv_len, float(drop_p), seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        H, kv_len, drop_p, seed = ctx.meta
+        E = q.shape[2]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _attn_bwd(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), dq, dkv[:, :, :E], dkv[:, :, E:], H, kv_len,
+                  drop_p, seed)
+        return dq, dkv, None, None, None, None
+
+
+def attention_self(qkv, H: int, kv_len: Optional[int] = None, drop_p: float = 0.0):
+    """K9: streaming-softmax self-attention on a packed (B,L,3E) projection; q scaled by 1/8 inside."""
+    kv_len = qkv.shape[1] if kv_len is None else kv_len
+    seed = next_seed() if drop_p > 0 else 0
+    return _AttentionSelf.apply(qkv, H, kv_len, drop_p, seed)
+
+
+def attention_cross(q, kv, H: int, kv_len: Optional[int] = None, drop_p: float = 0.0):
+    """K10: cross-attention of q (B,Lq,E) over a packed (B,Lk,2E) memory projection; only keys
+    < kv_len are attended (memory_mask of common/utils/misc.py:34-47)."""
+    kv_len = kv.shape[1] if kv_len is None else kv_len
+    seed = next_seed() if drop_p > 0 else 0
+    return _AttentionCross.apply(q, kv, H, kv_len, drop_p, seed)
+
+
+class _AttentionSmall(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, H, drop_p, seed):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        _chk(q, k, v)
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
+        probs = torch.empty(B, H, Lq, Lk, device=q.device, dtype=torch.float32)
+        call("hoisdf_attention_small_fwd", _p(q), E, _p(k), E, _p(v), E, _p(mask_u8), _p(o), E, _p(probs), B, H, Lq,
+             Lk, float(drop_p), seed, _st())
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.meta = (H, float(drop_p), seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, probs = ctx.saved_tensors
+        H, drop_p, seed = ctx.meta
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        do = do.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.zeros_like(k)
+        dv = torch.zeros_like(v)
+        call("hoisdf_attention_small_bwd", _p(q), E, _p(k), E, _p(v), E, _p(probs), _p(do), E, _p(dq), _p(dk), _p(dv),
+             B, H, Lq, Lk, drop_p, seed, _st())
+        return dq, dk, dv, None, None, None, None
+
+
+def attention_small(q, k, v, mask_u8, H: int, drop_p: float = 0.0):
+    """masked attention for the 17 MANO queries (Lq, Lk <= 64); mask (Lq,Lk) uint8, 1 = masked."""
+    seed = next_seed() if drop_p > 0 else 0
+    return _AttentionSmall.apply(q, k, v, mask_u8, H, drop_p, seed)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, drop_p, seed):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        r2 = None if r is None else r.reshape(-1, x.shape[-1]).contiguous()
+        _chk(x2, r2, gamma, beta)
+        M, D = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        call("hoisdf_add_layernorm_fwd", _p(x2), _p(r2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D,
+             float(eps), float(drop_p), seed, _st())
+        ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+        ctx.meta = (float(drop_p), seed, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, gamma, mean, rstd = ctx.saved_tensors
+        drop_p, seed, shape = ctx.meta
+        M, D = x2.shape
+        dy2 = dy.reshape(M, D).contiguous()
+        dx = torch.empty_like(x2)
+        dr = None if r2 is None else torch.empty_like(x2)
+        dg = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        call("hoisdf_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dr),
+             _p(dg), _p(db), M, D, drop_p, seed, _st())
+        return dx.view(shape), (None if dr is None else dr.view(shape)), dg, db, None, None, None
+
+
+def add_layernorm(x, r, gamma, beta, eps: float = 1e-5, drop_p: float = 0.0):
+    """LN(x + dropout(r)); r=None -> plain LayerNorm."""
+    seed = next_seed() if (drop_p > 0 and r is not None) else 0
+    return _AddLayerNorm.apply(x, r, gamma, beta, eps, drop_p if r is not None else 0.0, seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# votes
+# ---------------------------------------------------------------------------------------------
+class _Vote(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, off, cls, pts):
+        """off (L,B,P,J*3), cls (L,B,P,J), pts (B,P,3) -> joints (L,B,J,3)"""
+        off, cls, pts = off.contiguous(), cls.contiguous(), pts.contiguous()
+        _chk(off, cls, pts)
+        L, B, P, J = cls.shape
+        joints = torch.empty(L, B, J, 3, device=off.device, dtype=torch.float32)
+        stats = torch.empty(L, B, J, 2, device=off.device, dtype=torch.float32)
+        call("hoisdf_vote_fwd", _p(off), _p(cls), _p(pts), _p(joints), _p(stats), L, B, P, J, _st())
+        ctx.save_for_backward(off, cls, pts, joints, stats)
+        return joints
+
+    @staticmethod
+    def backward(ctx, dj):
+        off, cls, pts, joints, stats = ctx.saved_tensors
+        L, B, P, J = cls.shape
+        dj = dj.contiguous()
+        doff = torch.empty_like(off)
+        dcls = torch.empty_like(cls)
+        call("hoisdf_vote_bwd", _p(off), _p(cls), _p(pts), _p(joints), _p(stats), _p(dj), _p(doff), _p(dcls), L, B, P,
+             J, _st())
+        return doff, dcls, None
+
+
+def vote_aggregate(off, cls, pts):
+    """K12: joints[l,b,j] = sum_p softmax_p(cls)[p] (pts[p] + off[p,j])."""
+    return _Vote.apply(off, cls, pts)

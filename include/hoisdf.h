@@ -1,0 +1,216 @@
+/* libhoisdf_hip - C ABI of the MI355X (gfx950) HOISDF hot path.
+ *
+ * The reference (amathislab/HOISDF) has no FFI layer: its boundary for this path is the
+ * Python surface Model.forward / sdf_forward / sdf_infer / get_input_transformer /
+ * SDFDecoder.forward / Transformer.forward.  This header is the
+ * C-ABI a binding for that surface calls into; every entry cites the reference lines it
+ * replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are caller-allocated DEVICE buffers of float32 unless stated otherwise;
+ *     the library never allocates, frees or retains caller memory;
+ *   - every entry takes a HIP stream (hipStream_t passed as void*), is asynchronous, does
+ *     no hidden synchronisation and keeps no mutable global state;
+ *   - return value: 0 = ok, negative = hoisdf_status; the message of the last failure on
+ *     the calling thread is available from hoisdf_last_error();
+ *   - "rows" are point/token rows; `ld*` are leading dimensions in floats;
+ *   - dropout: p in [0,1); the keep mask is a pure function of (seed, element index), the
+ *     backward entry regenerates it from the same (p, seed).
+ */
+#ifndef HOISDF_H_
+#define HOISDF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOISDF_VERSION_MAJOR 0
+#define HOISDF_VERSION_MINOR 1
+
+typedef enum hoisdf_status {
+  HOISDF_OK = 0,
+  HOISDF_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unsupported dim) */
+  HOISDF_ERR_LAUNCH = -2,    /* HIP launch / runtime error */
+  HOISDF_ERR_TOO_FEW = -3,   /* sdf_infer: fewer bbox survivors than requested points */
+  HOISDF_ERR_WORKSPACE = -4  /* workspace too small */
+} hoisdf_status;
+
+#define HOISDF_MAX_LEVELS 8
+
+/* Feature pyramid in NHWC (channels-last) layout: level l is [B][H[l]][W[l]][C[l]].
+ * Concatenation order = level order (reference: cfg.mutliscale_layers, main/config.py:99). */
+typedef struct hoisdf_pyramid {
+  int n_levels;
+  int B;
+  const float* data[HOISDF_MAX_LEVELS];
+  int C[HOISDF_MAX_LEVELS];
+  int H[HOISDF_MAX_LEVELS];
+  int W[HOISDF_MAX_LEVELS];
+} hoisdf_pyramid;
+
+typedef struct hoisdf_pyramid_grad {
+  int n_levels;
+  int B;
+  float* data[HOISDF_MAX_LEVELS];
+  int C[HOISDF_MAX_LEVELS];
+  int H[HOISDF_MAX_LEVELS];
+  int W[HOISDF_MAX_LEVELS];
+} hoisdf_pyramid_grad;
+
+const char* hoisdf_version(void);
+const char* hoisdf_last_error(void);
+
+/* ---- K1: pinhole projection + 5-level bilinear gather --------------------------------
+ * reference: main/model.py:148-175 (get_input_transformer), :190-214 (sdf_forward),
+ * :286-328 (sdf_infer); F.grid_sample(bilinear, border, align_corners=True).
+ * points [n_rows][3] in the scaled SDF frame; row r belongs to sample
+ * sample_idx[r] (int32) or r / rows_per_sample when sample_idx is NULL.
+ * cam = p/scale + center[b]; uv = (K[b] cam)_xy / (K[b] cam)_z; grid = (uv - n)/n with
+ * n = ((img_w-1)/2, (img_h-1)/2).  feat [n_rows][ldf] receives the concatenated levels;
+ * cam_out [n_rows][3] and uv_out [n_rows][2] are optional (may be NULL). */
+int hoisdf_project_gather_fwd(const hoisdf_pyramid* pyr, const float* points,
+                              const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                              const float* center, const float* cam_intr, float scale,
+                              int img_h, int img_w, float* feat, int ldf, float* cam_out,
+                              float* uv_out, void* stream);
+/* Scatter-add of dfeat into the (pre-zeroed or accumulating) pyramid gradient. */
+int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const float* points,
+                              const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                              const float* center, const float* cam_intr, float scale,
+                              int img_h, int img_w, const float* dfeat, int ldf, void* stream);
+
+/* ---- K2/K7/K9/K11: fused linear layers (exact fp32 on the f32 MFMA pipe) --------------
+ * reference: nn.Linear inside common/nets/layer.py:168-201 (MLP), common/nets/sdf_net.py
+ * :87-113 (SDFDecoder hidden layers), nn.MultiheadAttention in/out projections and FFN
+ * (common/nets/transformer.py:269-302).
+ * y[M][N] = dropout(act(x[M][K] . W[N][K]^T + bias)), act: 0 none, 1 relu.
+ * Element (m,n) of y uses dropout index m*N+n. */
+int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias,
+                      float* y, int ldy, long M, int N, int K, int act, float drop_p,
+                      uint64_t seed, void* stream);
+/* dx[M][K] = dy[M][N] . W[N][K] */
+int hoisdf_linear_bwd_input(const float* dy, int lddy, const float* W, int ldw, float* dx,
+                            int lddx, long M, int N, int K, void* stream);
+/* dW[N][K] = dy[M][N]^T . x[M][K] ; db[N] = column sums of dy (db may be NULL).
+ * dW and db must be zero-filled by the caller when the library picks a split-K > 1; the
+ * library always accumulates with atomics, so pass zeroed buffers (or gradients to add to). */
+int hoisdf_linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
+                             int lddw, float* db, long M, int N, int K, void* stream);
+/* dpre = dy * (y > 0) * 1/(1-p): backward of relu followed by dropout, given the
+ * post-dropout output y (an element is kept-and-positive iff y > 0).  In place allowed. */
+int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,
+                            int ldd, long M, int N, float drop_p, void* stream);
+
+/* ---- K3/K4: SDF decoder pieces ---------------------------------------------------------
+ * reference: common/utils/sdf_utils.py:96-141 (Embedder), main/model.py:218-228 (decoder
+ * input [feat | posenc | xyz]), common/nets/sdf_net.py:57-62 (weight norm).
+ * Writes columns [col0, col0+30) = posenc(points) and [col0+30, col0+33) = points of the
+ * decoder-input rows x0 (ld = ldx0, trailing pad columns up to ldx0 zeroed), and the
+ * stand-alone posenc rows pe [n_rows][30] (may be NULL). */
+int hoisdf_posenc_fwd(const float* points, long n_rows, float* x0, int ldx0, int col0,
+                      float* pe, void* stream);
+/* W[r][:] = g[r] * v[r][:] / ||v[r][:]||, written with leading dimension ldw (>= in);
+ * pad columns are zeroed.  norms[r] (optional) receives ||v[r]||. */
+int hoisdf_weightnorm_fwd(const float* v, const float* g, float* W, int ldw, float* norms,
+                          int out, int in, void* stream);
+/* dv, dg from dW (same ldw): dg[r] = <dW[r], v[r]>/||v[r]||,
+ * dv[r] = g[r]/||v[r]|| * (dW[r] - v[r] <dW[r], v[r]>/||v[r]||^2). */
+int hoisdf_weightnorm_bwd(const float* v, const float* g, const float* dW, int ldw, float* dv,
+                          float* dg, int out, int in, void* stream);
+/* Final 512 -> 1 layer + tanh + clamp (common/nets/sdf_net.py:115-122, main/model.py:241).
+ * sdf_raw = tanh(h . w + b) (unclamped, what sdf_infer sorts on); sdf = clamp(sdf_raw). */
+int hoisdf_sdf_head_fwd(const float* h, int ldh, const float* w, const float* b, float* sdf_raw,
+                        float* sdf, long n_rows, int K, float clamp, void* stream);
+int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, const float* h, int ldh,
+                        const float* w, float* dh, int lddh, float* dw, float* db, long n_rows,
+                        int K, float clamp, void* stream);
+
+/* ---- K5/K6: dense-grid candidate generation + selection (sdf_infer) -------------------
+ * reference: main/model.py:257-302 (sheared lattice + strict bbox filter, on CPU there) and
+ * :345-352 (sort by |sdf|, keep the first num_points).
+ * Pass 1 (count) + pass 2 (fill) stream compaction of the bins_n^3 lattice per sample:
+ *   counts [B] int32 survivors per sample;
+ *   with offsets [B] (exclusive prefix of counts) the fill pass writes, for each survivor in
+ *   ascending lattice order, points [n][3] (scaled frame), sample_idx [n] and lattice_idx [n].*/
+int hoisdf_lattice_count(const float* center, const float* cam_intr, const float* bbox, float scale,
+                         int bins_n, int B, int32_t* counts, void* stream);
+int hoisdf_lattice_fill(const float* center, const float* cam_intr, const float* bbox, float scale,
+                        int bins_n, int B, const int32_t* offsets, float* points,
+                        int32_t* sample_idx, int32_t* lattice_idx, void* stream);
+/* Per sample b, select the k rows with the smallest |sdf_raw| among rows
+ * [offsets[b], offsets[b]+counts[b]) (ties: lower row first) and emit them in ascending
+ * (|sdf|, row) order: sel [B][k] int32 global row indices.  Exact (radix select + rank). */
+int hoisdf_select_smallest_abs(const float* sdf_raw, const int32_t* offsets, const int32_t* counts,
+                               int B, int k, int32_t* sel, void* stream);
+/* out[r][0:width] = src[sel[r]][0:width] */
+int hoisdf_gather_rows(const float* src, int lds, const int32_t* sel, long n_sel, int width,
+                       float* out, int ldo, void* stream);
+
+/* ---- K8: sigma gate + token assembly ----------------------------------------------------
+ * reference: main/model.py:123-126 (sdf_activation), :520-562 (token concat).
+ * For sample b and point p:  tok[b][row0+p][:] = [cam[b][p]-center[b] (3) | pe (30) |
+ * feat[b][p][0:F] * sigmoid(sdf/beta)/beta],  beta = max(*beta_ptr, 2e-3), F = D - 33.
+ * tok is batch-first [B][S][D]. */
+int hoisdf_token_build_fwd(const float* cam, const float* center, const float* pe,
+                           const float* feat, int ldfeat, const float* sdf, const float* beta_ptr,
+                           float* tok, int B, int P, int S, int row0, int D, void* stream);
+/* dfeat = dtok[33:] * sigma; *dbeta += sum dtok[33:] * feat * dsigma/dbeta (atomic). */
+int hoisdf_token_build_bwd(const float* dtok, const float* feat, int ldfeat, const float* sdf,
+                           const float* beta_ptr, float* dfeat, int lddfeat, float* dbeta, int B,
+                           int P, int S, int row0, int D, void* stream);
+
+/* ---- K9/K10: attention -------------------------------------------------------------------
+ * reference: nn.MultiheadAttention as used by common/nets/transformer.py:286-302,366-395.
+ * q rows [B][Lq][.. ldq], k/v rows [B][Lk][.. ldk/ldv], head h occupies columns
+ * [h*64, h*64+64) of each.  Only the first kv_len keys are attended (memory_mask of
+ * common/utils/misc.py:34-47 keeps keys < num_samp_hand).  Streaming-softmax (never
+ * materialises Lq x Lk), exact fp32 on the f32 MFMA pipe; q is scaled by 1/sqrt(64).
+ * o [B][Lq][ldo]; lse [B][H][Lq] log-sum-exp of the scaled scores (saved for backward).
+ * Dropout on the probabilities uses index ((b*H+h)*Lq+i)*Lk+j. */
+int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
+                         float drop_p, uint64_t seed, void* stream);
+/* delta [B][H][Lq] is scratch. dq/dk/dv have the same layouts/ld as q/k/v. Rows of dk/dv at
+ * keys >= kv_len are written as zero. */
+int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                         const float* o, int ldo, const float* dout, int lddo, const float* lse,
+                         float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk,
+                         int kv_len, float drop_p, uint64_t seed, void* stream);
+/* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
+ * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
+int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,
+                               int ldv, const uint8_t* mask, float* o, int ldo, float* probs, int B,
+                               int H, int Lq, int Lk, float drop_p, uint64_t seed, void* stream);
+int hoisdf_attention_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v,
+                               int ldv, const float* probs, const float* dout, int lddo, float* dq,
+                               float* dk, float* dv, int B, int H, int Lq, int Lk, float drop_p,
+                               uint64_t seed, void* stream);
+
+/* ---- residual + dropout + LayerNorm (common/nets/transformer.py:290-301) -----------------
+ * y = LN(x + dropout(r)) * gamma + beta over rows of width D (D <= 1024, multiple of 4);
+ * r may be NULL (plain LN, e.g. encoder.inter_norm / decoder.norm).  mean/rstd [M] saved. */
+int hoisdf_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
+                             float* y, float* mean, float* rstd, long M, int D, float eps,
+                             float drop_p, uint64_t seed, void* stream);
+/* dx (gradient w.r.t. x), dr (w.r.t. r, may be NULL), dgamma/dbeta accumulated atomically. */
+int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
+                             const float* mean, const float* rstd, float* dx, float* dr,
+                             float* dgamma, float* dbeta, long M, int D, float drop_p, uint64_t seed,
+                             void* stream);
+
+/* ---- K12: vote aggregation ----------------------------------------------------------------
+ * reference: common/nets/loss.py:31-56.  off [L][B][P][J*3], cls [L][B][P][J] (batch-first
+ * rows), pts [B][P][3].  joints[l][b][j] = sum_p softmax_p(cls)[p] * (pts[p] + off[p][j]).
+ * stats [L][B][J][2] = (max, sum of exp) of each softmax column, saved for the backward. */
+int hoisdf_vote_fwd(const float* off, const float* cls, const float* pts, float* joints, float* stats,
+                    int L, int B, int P, int J, void* stream);
+int hoisdf_vote_bwd(const float* off, const float* cls, const float* pts, const float* joints,
+                    const float* stats, const float* djoints, float* doff, float* dcls, int L, int B,
+                    int P, int J, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOISDF_H_ */
