@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""HOISDF hot-path benchmark (driver contract: one JSON line on rank 0).
+
+Workload = BASELINE.json configs[1]: DexYCB-shaped synthetic batch, B = 32 per GPU, 2048 SDF
+query points (1536 hand + 512 object, the reference's 3:1 split), ResNet-50 encoder (the
+reference has no HRNet; the encoder is outside the HIP scope and stays PyTorch/MIOpen), one
+full training step = encoder fwd + HIP hot path fwd + losses + backward + gradient all-reduce
+(RCCL) + AdamW, train mode (dropout on), point branch A (reference main/model.py:427-460,
+what the first 40 epochs run).  `value` = samples/s of the whole job, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
+LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
+                    obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the current stream = the stream the kernels are launched on)
+    around selected C-ABI calls; accumulates algorithmic FLOPs per call family."""
+
+    FLOPS = {
+        # (x, ldx, W, ldw, bias, y, ldy, M, N, K, ...)
+        "hoisdf_linear_fwd": lambda a: 2.0 * a[7] * a[8] * a[9],
+        # (dy, lddy, W, ldw, dx, lddx, M, N, K)
+        "hoisdf_linear_bwd_input": lambda a: 2.0 * a[6] * a[7] * a[8],
+        # (dy, lddy, x, ldx, dW, lddw, db, M, N, K)
+        "hoisdf_linear_bwd_weight": lambda a: 2.0 * a[7] * a[8] * a[9],
+        # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...): QK^T + PV
+        "hoisdf_attention_fwd": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
+        # (q,ldq,k,ldk,v,ldv,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...): 5 GEMM-equivalents
+        "hoisdf_attention_bwd": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
+    }
+
+    def __init__(self):
+        self.names = set(self.FLOPS)
+        self.records = {n: [] for n in self.names}
+        self._open = None
+
+    def begin(self, name, args):
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        self._open = (s, self.FLOPS[name](args))
+
+    def end(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        s, fl = self._open
+        self.records[name].append((s, e, fl))
+
+    def summary(self):
+        out = {}
+        for n, recs in self.records.items():
+            if not recs:
+                continue
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[n] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), gflop=fl / 1e9,
+                          tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
+    ap.add_argument("--n-hand", type=int, default=1536)
+    ap.add_argument("--n-obj", type=int, default=512)
+    ap.add_argument("--resnet", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=32,
+                    help="host threads for the CPU baseline (32 was the best of 16/32/64/256 probed on the "
+                         "2x EPYC 9575F GPU-box host; 256 threads is >10x slower)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from hoisdf_amd import _lib, ops, testing as T
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.ddp import GradReducer, reducible_parameters
+    from hoisdf_amd.model import get_model
+
+    _lib.lib()                     # fail loudly if the extension is missing
+    cfg = Config()
+    cfg.resnet_type = args.resnet
+    cfg.apply_setting("dexycb")
+    cfg.num_samp_hand, cfg.num_samp_obj = args.n_hand, args.n_obj
+    torch.manual_seed(0)           # identical initial weights on every rank
+    model = get_model("train", cfg=cfg).to(dev).train()
+    reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
+    ops.manual_seed(1000 + rank)
+    inputs, targets, meta = (T.to_device(x, dev) for x in T.synthetic_batch(args.batch, args.n_hand, args.n_obj,
+                                                                           seed=1234 + rank))
+
+    def step():
+        reducer.zero_grad()
+        out = model(inputs, targets, meta, "train", 0, 0.1)
+        loss = {k: v.mean() for k, v in out.items() if "_out" not in k}
+        total = sum(v * LOSS_WEIGHTS.get(k, 1.0) for k, v in loss.items())     # main/train.py:113-127,138
+        total.backward()
+        reducer.finish()
+        opt.step()
+        return total
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None if args.no_kernel_timing else KernelTimer()
+    barrier()
+    _lib.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    assert torch.isfinite(last), "non-finite loss"
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * args.batch * args.steps / dt
+    res = {
+        "metric": "samples/sec (img + 2048 SDF queries) fwd+bwd at 1/2/4/8 MI355X",
+        "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: DexYCB-shape synthetic batch {args.batch}/GPU, "
+                               f"{args.n_hand}+{args.n_obj} SDF query points, ResNet-{args.resnet} encoder "
+                               "(PyTorch/MIOpen; the reference has no HRNet), train step = fwd+bwd+grad "
+                               "all-reduce+AdamW, dropout on, point branch A (pre-points)",
+                   "global_batch": world * args.batch, "points": args.n_hand + args.n_obj,
+                   "parallelism": f"dp{world}", "final_loss": float(last.detach())},
+    }
+    if timer is not None:
+        ks = timer.summary()
+        dom = max(ks, key=lambda n: ks[n]["total_ms"])
+        kname = {"hoisdf_linear_fwd": "gemm_f32_kernel<1,1> (linear fwd)",
+                 "hoisdf_linear_bwd_input": "gemm_f32_kernel<1,0> (linear grad-input)",
+                 "hoisdf_linear_bwd_weight": "gemm_f32_kernel<0,0> (linear grad-weight, incl. bias colsum)",
+                 "hoisdf_attention_fwd": "attn_fwd_kernel",
+                 "hoisdf_attention_bwd": "attn_delta + attn_bwd_dkv + attn_bwd_dq"}[dom]
+        res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ks[dom]["tflops"], 2),
+                           "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ks[dom]["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": None,
+                           "avg_launch_us": round(ks[dom]["avg_us"], 2),
+                           "launches_per_step": ks[dom]["launches"] / args.steps,
+                           "algorithmic_gflop_per_launch": round(ks[dom]["gflop"] / ks[dom]["launches"], 3)}
+        res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / args.steps, 3), "tflops": round(v["tflops"], 2),
+                              "launches_per_step": v["launches"] / args.steps, "avg_us": round(v["avg_us"], 2)}
+                          for n, v in ks.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_step import time_cpu_baseline
+        cb = time_cpu_baseline(args.n_hand, args.n_obj, args.cpu_batch, iters=3, warmup=1, resnet_type=args.resnet,
+                               threads=min(args.cpu_threads, os.cpu_count() or 1))
+        cb["value"] = round(cb["value"], 4)
+        cb.pop("seconds_per_step", None)
+        res["cpu_baseline"] = cb
+        res["speedup_vs_cpu"] = round(value / cb["value"], 1)
+    print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

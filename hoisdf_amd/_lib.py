@@ -90,8 +90,24 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_timer = None
+
+
+def set_timer(timer) -> None:
+    """bench.py hook: ``timer.begin(name, args)`` / ``timer.end(name)`` bracket every C-ABI call whose
+    name is in ``timer.names`` (HIP events on the launch stream).  None disables."""
+    global _timer
+    _timer = timer
+
+
 def call(name: str, *args) -> None:
+    t = _timer
+    timed = t is not None and name in t.names
+    if timed:
+        t.begin(name, args)
     rc = getattr(lib(), name)(*args)
+    if timed:
+        t.end(name)
     if rc != 0:
         raise HoisdfError(rc, lib().hoisdf_last_error().decode())
 
