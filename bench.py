@@ -35,10 +35,10 @@ class KernelTimer:
     FLOPS = {
         # (x, ldx, W, ldw, bias, y, ldy, M, N, K, ...)
         "hoisdf_linear_fwd": lambda a: 2.0 * a[7] * a[8] * a[9],
-        # (dy, lddy, W, ldw, dx, lddx, M, N, K)
-        "hoisdf_linear_bwd_input": lambda a: 2.0 * a[6] * a[7] * a[8],
-        # (dy, lddy, x, ldx, dW, lddw, db, M, N, K)
-        "hoisdf_linear_bwd_weight": lambda a: 2.0 * a[7] * a[8] * a[9],
+        # (dy, lddy, bits, p, W, ldw, dx, lddx, M, N, K)
+        "hoisdf_linear_bwd_input": lambda a: 2.0 * a[8] * a[9] * a[10],
+        # (dy, lddy, bits, p, x, ldx, dW, lddw, db, M, N, K, ws, nws)
+        "hoisdf_linear_bwd_weight": lambda a: 2.0 * a[9] * a[10] * a[11],
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...): QK^T + PV
         "hoisdf_attention_fwd": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...): 5 GEMM-equivalents
@@ -176,7 +176,7 @@ def main():
         dom = max(ks, key=lambda n: ks[n]["total_ms"])
         kname = {"hoisdf_linear_fwd": "gemm_f32_kernel<1,1> (linear fwd)",
                  "hoisdf_linear_bwd_input": "gemm_f32_kernel<1,0> (linear grad-input)",
-                 "hoisdf_linear_bwd_weight": "gemm_f32_kernel<0,0> (linear grad-weight, incl. bias colsum)",
+                 "hoisdf_linear_bwd_weight": "gemm_f32_kernel<0,0> (linear grad-weight + fused bias grad)",
                  "hoisdf_attention_fwd": "attn_fwd_kernel",
                  "hoisdf_attention_bwd": "attn_delta + attn_bwd_dkv + attn_bwd_dq"}[dom]
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ks[dom]["tflops"], 2),

@@ -39,9 +39,9 @@ _PYR = C.POINTER(Pyramid)
 SIGNATURES: Dict[str, List] = {
     "hoisdf_project_gather_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P, _P, _P],
     "hoisdf_project_gather_bwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P],
-    "hoisdf_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P],
-    "hoisdf_linear_bwd_input": [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P],
-    "hoisdf_linear_bwd_weight": [_P, _I, _P, _I, _P, _I, _P, _L, _I, _I, _P],
+    "hoisdf_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
+    "hoisdf_linear_bwd_input": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _P],
+    "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "hoisdf_weightnorm_fwd": [_P, _P, _P, _I, _P, _I, _I, _P],
@@ -66,6 +66,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
+_OTHER = {"hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long)}
 
 _lib = None
 
@@ -85,6 +86,10 @@ def lib() -> C.CDLL:
         for name, ret in _RET.items():
             fn = getattr(L, name)
             fn.argtypes = []
+            fn.restype = ret
+        for name, (args, ret) in _OTHER.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
             fn.restype = ret
         _lib = L
     return _lib
@@ -113,4 +118,4 @@ def call(name: str, *args) -> None:
 
 
 def exported_symbols() -> List[str]:
-    return list(SIGNATURES) + list(_RET)
+    return list(SIGNATURES) + list(_RET) + list(_OTHER)

@@ -33,6 +33,7 @@ struct AttnArgs {
   int ldq, ldk, ldv, ldo, lddo;
   int B, H, Lq, Lk, kv_len;
   float drop_p, inv_keep;
+  uint32_t thresh;
   uint64_t seed;
 };
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void tile_store(const float4 (&reg)[NV], float* __res
 // ============================================================================================
 // forward: block = 128 queries (4 waves x 32) of one (b, head); K/V tiles of 64 keys
 // ============================================================================================
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 64 * PITCH];   // [buf][K|V][64][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, c = lane & 31;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < 32; ++i) qf[i] = 0.f;
   }
 
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
   float m = -INFINITY, lsum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -150,12 +152,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
     if (a.drop_p > 0.f) {
-      const uint64_t rowbase = ((uint64_t)bh * a.Lq + (uint64_t)qrow) * (uint64_t)a.Lk;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          s[t][r] *= drop_scale(a.drop_p, a.inv_keep, a.seed, rowbase + kt * 64 + t * 32 + CROW(r, h));
+          s[t][r] *= drop_scale(rowkey, (uint32_t)(kt * 64 + t * 32 + CROW(r, h)), a.thresh, a.inv_keep);
     }
     // O^T += V^T . P^T : A = V[key][d] (d along lanes), B = P registers
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __re
 // ============================================================================================
 // backward, dK / dV: block = 128 keys (4 waves x 32) of one (b, head); loops over 32-query tiles
 // ============================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 32 * PITCH + 64];   // Q tile, dO tile, lse[32], delta[32]
   float* Qs = lds;
   float* Ds = lds + 32 * PITCH;
@@ -279,28 +280,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       s = MFMA(qq.z, kf[4 * c4 + 2], s);  dp = MFMA(dd.z, vf[4 * c4 + 2], dp);
       s = MFMA(qq.w, kf[4 * c4 + 3], s);  dp = MFMA(dd.w, vf[4 * c4 + 3], dp);
     }
-    // P (dropped) and dS in registers
-    f32x16 pd, ds;
+    // P (dropped) and dS, in place: s <- Pd, dp <- dS  (keeps the kernel at 2 waves / SIMD)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ql = CROW(r, h);
-      float p = kvalid ? expf(s[r] * 0.125f - Ls[ql]) : 0.f;
+      const float p = kvalid ? expf(s[r] * 0.125f - Ls[ql]) : 0.f;
       float dscale = 1.f;
       if (a.drop_p > 0.f)
-        dscale = drop_scale(a.drop_p, a.inv_keep, a.seed,
-                            ((uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)) * (uint64_t)a.Lk + key);
-      pd[r] = p * dscale;
-      ds[r] = p * (dp[r] * dscale - Es[ql]);
+        dscale = drop_scale(drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)), (uint32_t)key,
+                            a.thresh, a.inv_keep);
+      s[r] = p * dscale;
+      dp[r] = p * (dp[r] * dscale - Es[ql]);
     }
     // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (A from LDS with d along lanes, B from registers)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float* dr = &Ds[CROW(r, h) * PITCH + c];
       const float* qr = &Qs[CROW(r, h) * PITCH + c];
-      dv[0] = MFMA(dr[0], pd[r], dv[0]);
-      dv[1] = MFMA(dr[32], pd[r], dv[1]);
-      dk[0] = MFMA(qr[0], ds[r], dk[0]);
-      dk[1] = MFMA(qr[32], ds[r], dk[1]);
+      dv[0] = MFMA(dr[0], s[r], dv[0]);
+      dv[1] = MFMA(dr[32], s[r], dv[1]);
+      dk[0] = MFMA(qr[0], dp[r], dk[0]);
+      dk[1] = MFMA(qr[32], dp[r], dk[1]);
     }
   }
   if (key < a.Lk) {
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) { qf[i] = 0.f; df[i] = 0.f; }
   }
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
   f32x16 dq[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -387,9 +388,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       const int key = kt * 32 + CROW(r, h);
       const float p = (key < a.kv_len) ? expf(s[r] * 0.125f - lse) : 0.f;
       float dscale = 1.f;
-      if (a.drop_p > 0.f)
-        dscale = drop_scale(a.drop_p, a.inv_keep, a.seed,
-                            ((uint64_t)bh * a.Lq + (uint64_t)qrow) * (uint64_t)a.Lk + key);
+      if (a.drop_p > 0.f) dscale = drop_scale(rowkey, (uint32_t)key, a.thresh, a.inv_keep);
       ds[r] = p * (dp[r] * dscale - delta);
     }
     // dQ^T += K^T . dS^T
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a, const u
   const float p = e / wave_sum(e);
   if (lane < a.Lk) probs[(size_t)w * a.Lk + lane] = p;
   float pd = p;
-  if (a.drop_p > 0.f && lane < a.Lk) pd *= drop_scale(a.drop_p, a.inv_keep, a.seed, (uint64_t)w * a.Lk + lane);
+  if (a.drop_p > 0.f && lane < a.Lk) pd *= drop_scale(drop_rowkey(a.seed, (uint64_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
   // out[d = lane] = sum_j pd_j V[j][d]
   float acc = 0.f;
   for (int j = 0; j < a.Lk; ++j) {
@@ -458,7 +457,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a, const f
   const float* dop = a.dout + ((size_t)b * a.Lq + qi) * a.lddo + head * DH;
   const float p = lane < a.Lk ? probs[(size_t)w * a.Lk + lane] : 0.f;
   float dsc = 1.f;
-  if (a.drop_p > 0.f && lane < a.Lk) dsc = drop_scale(a.drop_p, a.inv_keep, a.seed, (uint64_t)w * a.Lk + lane);
+  if (a.drop_p > 0.f && lane < a.Lk) dsc = drop_scale(drop_rowkey(a.seed, (uint64_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
   // dP_j = sum_d dO[d] V[j][d]  (lane = key j)
   float dpj = 0.f;
   if (lane < a.Lk) {
@@ -509,7 +508,7 @@ extern "C" int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.kv_len = kv_len;
-  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   if (int rc = check_attn(a, "attention_fwd")) return rc;
   HOISDF_REQUIRE(o && ldo >= H * DH && (ldo & 3) == 0 && ((uintptr_t)o & 15) == 0, HOISDF_ERR_INVALID,
                  "attention_fwd: bad output");
@@ -526,7 +525,7 @@ extern "C" int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.kv_len = kv_len;
-  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   if (int rc = check_attn(a, "attention_bwd")) return rc;
   HOISDF_REQUIRE(o && dout && lse && delta && dq && dk && dv, HOISDF_ERR_INVALID, "attention_bwd: null pointer");
   HOISDF_REQUIRE(ldo >= H * DH && lddo >= H * DH && (ldo & 3) == 0 && (lddo & 3) == 0 &&
@@ -549,7 +548,7 @@ extern "C" int hoisdf_attention_small_fwd(const float* q, int ldq, const float* 
   a.q = q; a.k = k; a.v = v; a.out = o;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.kv_len = Lk;
-  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   if (int rc = check_attn(a, "attention_small_fwd")) return rc;
   HOISDF_REQUIRE(o && probs && Lq <= 64 && Lk <= 64, HOISDF_ERR_INVALID, "attention_small_fwd: Lq, Lk must be <= 64");
   const long nw = (long)B * H * Lq;
@@ -566,7 +565,7 @@ extern "C" int hoisdf_attention_small_bwd(const float* q, int ldq, const float* 
   a.q = q; a.k = k; a.v = v; a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.kv_len = Lk;
-  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.seed = seed;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   if (int rc = check_attn(a, "attention_small_bwd")) return rc;
   HOISDF_REQUIRE(probs && dout && dq && dk && dv && Lq <= 64 && Lk <= 64, HOISDF_ERR_INVALID,
                  "attention_small_bwd: bad arguments");

@@ -23,20 +23,26 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- counter-based RNG for dropout ----------------------------------------------------
-// keep(idx) is a pure function of (seed, idx) so the backward pass regenerates the mask.
+// keep(row, col) is a pure function of (seed, row, col) so the backward pass regenerates the
+// mask.  The row part is hashed once per row; per element it is one multiply-xor + one 32-bit
+// finaliser and an integer compare against thresh = p * 2^32 (no float conversion).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float rand01(uint64_t seed, uint64_t idx) {
-  uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + (uint32_t)seed) ^
-                     mix32((uint32_t)(seed >> 32) + 0x9E3779B9U));
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
+__device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint64_t row) {
+  return mix32((uint32_t)row ^ mix32((uint32_t)(row >> 32) ^ (uint32_t)(seed >> 32)) ^ (uint32_t)seed);
 }
-// multiplier applied to a kept element; 0 for a dropped one.  p == 0 -> exactly 1.
-__device__ __forceinline__ float drop_scale(float p, float inv_keep, uint64_t seed, uint64_t idx) {
-  if (p <= 0.f) return 1.f;
-  return rand01(seed, idx) >= p ? inv_keep : 0.f;
+__device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {
+  return mix32((col * 0x9E3779B1U) ^ rowkey) >= thresh;
+}
+// multiplier applied to a kept element; 0 for a dropped one.
+__device__ __forceinline__ float drop_scale(uint32_t rowkey, uint32_t col, uint32_t thresh, float inv_keep) {
+  return drop_keep(rowkey, col, thresh) ? inv_keep : 0.f;
+}
+static inline uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
 
 // ---- wave-level reductions (64 lanes) -------------------------------------------------

@@ -2,13 +2,21 @@
 // bit-for-bit an fmaf chain).  One template serves the three contractions a linear layer needs:
 //   forward      y  = x . W^T      A[m][k] k-contiguous, B[n][k] k-contiguous
 //   grad input   dx = dy . W       A[m][k] k-contiguous, B[k][n] n-contiguous
-//   grad weight  dW = dy^T . x     A[k][m] m-contiguous, B[k][n] n-contiguous   (split-K, atomics)
+//   grad weight  dW = dy^T . x     A[k][m] m-contiguous, B[k][n] n-contiguous   (split-K)
 // Block tile 128x128x32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
 // VGPRs).  LDS holds both operands k-major ([k][m]) so the MFMA fragment read is always one
 // conflict-free ds_read_b32 per operand per k-pair; only the global->LDS staging differs with
 // the operand's memory orientation.  Register-staged double buffering: the next tile's global
 // loads are in flight during the 64 MFMAs of the current one; one barrier per k-tile.
 // Block ids are remapped so that the tiles sharing an A row-panel sit on one XCD (shared L2).
+//
+// Fusions: bias + ReLU + dropout in the forward epilogue, which also emits a 1-bit/element sign map
+// (wave ballot); in both backward contractions the ReLU/dropout backward (dy * [y > 0] / (1-p)) is
+// applied from that bitmap while staging the dy operand (an L2-resident 1/32-size side input), so
+// the pre-activation gradient is never written to HBM; the bias gradient (column sums of dy) is
+// accumulated from the staged dy tiles of the grad-weight kernel.  Split-K partial tiles go to a
+// caller workspace and are summed by a second small kernel (device-scope float atomics bypass the
+// per-XCD L2 and cost ~25 % of the kernel; the atomic path remains for workspace-less calls).
 #include "common.h"
 
 namespace hoisdf {
@@ -24,12 +32,18 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;
+  const uint32_t* abits;   // optional 1-bit mask of A ([rows][ldbits] words along A's contiguous
+                           // "column" index of the ORIGINAL [M][N] dy): A is used as A * bit * ascale
+  uint32_t* bits_out;      // optional (forward): 1 bit per output element, set iff y > 0
+  float* colsum;           // optional (grad-weight only): column sums of (masked) A
   int M, N, K;
-  int lda, ldb, ldc;
+  int lda, ldb, ldc, ldbits;
   int act;
-  float drop_p, inv_keep;
+  float drop_p, inv_keep, ascale;
+  uint32_t thresh;
   uint64_t seed;
-  int splitk, k_per_split, atomic_out;
+  int splitk, k_per_split, atomic_out, partial;
+  long c_split_stride, colsum_split_stride;
   int tiles_m, tiles_n;
   int vecA, vecB;
 };
@@ -76,6 +90,36 @@ __device__ __forceinline__ void stage_load(float4 (&reg)[4], const float* __rest
   }
 }
 
+// 4 mask bits per staged float4, from the forward's ReLU/dropout sign bitmap.
+// KC (dy as [m][n], tile rows = m, k = n): word (row, k0/32), nibble at (tid&7)*4.
+// MC (dy as [k=m][i=n], tile "rows" r = n, k = m): word (m, n/32), nibble at (tid&7)*4.
+template <bool KC>
+__device__ __forceinline__ void load_bits(uint32_t (&w)[4], const uint32_t* __restrict__ bits, int ldbits, int r0,
+                                          int R, int k0, int kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t v = 0u;
+    if (KC) {
+      const int r = r0 + (tid >> 3) + 32 * i;
+      if (r < R && k0 < kend) v = bits[(size_t)r * ldbits + (k0 >> 5)];
+    } else {
+      const int k = k0 + (tid >> 5) + 8 * i;
+      const int r = r0 + (tid & 31) * 4;
+      if (k < kend && r < R) v = bits[(size_t)k * ldbits + (r >> 5)];
+    }
+    w[i] = (v >> ((tid & 7) * 4)) & 0xFu;
+  }
+}
+__device__ __forceinline__ void apply_bits(float4 (&a)[4], const uint32_t (&w)[4], float sc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i].x = (w[i] & 1u) ? a[i].x * sc : 0.f;
+    a[i].y = (w[i] & 2u) ? a[i].y * sc : 0.f;
+    a[i].z = (w[i] & 4u) ? a[i].z * sc : 0.f;
+    a[i].w = (w[i] & 8u) ? a[i].w * sc : 0.f;
+  }
+}
+
 template <bool KC>
 __device__ __forceinline__ void stage_store(const float4 (&reg)[4], float* __restrict__ lds, int tid) {
 #pragma unroll
@@ -95,13 +139,16 @@ __device__ __forceinline__ void stage_store(const float4 (&reg)[4], float* __res
   }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
+template <bool A_KC, bool B_KC, bool MASK, bool ATOMIC>
+__global__ __launch_bounds__(NT, 3) void gemm_f32_kernel(GemmArgs g) {
   constexpr int SA = A_KC ? LDS_KC : LDS_MC;
   constexpr int SB = B_KC ? LDS_KC : LDS_MC;
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * SA + 2 * BK * SB];
+  // one LDS stage (33 KB) + register staging: 3 workgroups per CU (3 waves / SIMD) hide the
+  // barrier + global-load latency better than a double-buffered 66 KB stage at 2 per CU
+  // (PMC: MFMA pipe 65 % busy, 22-57 % of wave cycles parked in s_waitcnt/barrier at 2 per CU).
+  __shared__ __attribute__((aligned(16))) float lds[BK * SA + BK * SB];
   float* As = lds;
-  float* Bs = lds + 2 * BK * SA;
+  float* Bs = lds + BK * SA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -110,13 +157,24 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
 
   const int ntile = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
-  const int split = bid / ntile;
-  int t = xcd_remap(bid - split * ntile, ntile);
+  int split, t;
+  if (g.splitk > 1) {
+    // split-K (grad-weight): every tile of one k-slice runs on the SAME XCD (block b -> XCD b % 8), so the
+    // dy / x row band the slice streams through is fetched once into that XCD's L2 and shared by all of
+    // the slice's output tiles (PMC before: 34 % L2 hit rate, 3.7x HBM over-fetch).
+    split = (bid & 7) + 8 * (bid / (8 * ntile));
+    t = (bid >> 3) % ntile;
+    if (split >= g.splitk) return;
+  } else {
+    split = 0;
+    t = xcd_remap(bid, ntile);
+  }
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
+  const bool do_colsum = (!A_KC) && g.colsum != nullptr && tn == 0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -127,9 +185,19 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[4], rb[4];
+  uint32_t rm[4];
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (nk > 0) {
     stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid);
+    if (MASK) {
+      load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg, kend, tid);
+      apply_bits(ra, rm, g.ascale);
+    }
     stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+    }
     stage_store<A_KC>(ra, As, tid);
     stage_store<B_KC>(rb, Bs, tid);
   }
@@ -140,13 +208,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
   const int khalf = lane >> 5;
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
     if (kt + 1 < nk) {
       stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.vecA, tid);
+      if (MASK) load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
       stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, tid);
     }
-    const float* as = As + cur * BK * SA;
-    const float* bs = Bs + cur * BK * SB;
+    const float* as = As;
+    const float* bs = Bs;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a0 = as[(kk + khalf) * SA + arow];
@@ -158,33 +226,100 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmArgs g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+    __syncthreads();                       // every wave is done reading this stage
     if (kt + 1 < nk) {
-      stage_store<A_KC>(ra, As + (cur ^ 1) * BK * SA, tid);
-      stage_store<B_KC>(rb, Bs + (cur ^ 1) * BK * SB, tid);
+      if (MASK) apply_bits(ra, rm, g.ascale);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+      }
+      stage_store<A_KC>(ra, As, tid);
+      stage_store<B_KC>(rb, Bs, tid);
+      __syncthreads();
     }
-    __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // bias gradient: this block column (tn == 0) has seen every dy element of its (m-tile, k-slice)
+  if (do_colsum) {
+    float* red = lds;                       // all LDS readers are past the final barrier
+    *reinterpret_cast<float4*>(&red[(tid >> 5) * 128 + (tid & 31) * 4]) = csum;
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += red[j * 128 + tid];
+      const int col = m0 + tid;
+      if (col < g.M) {
+        if (g.partial) g.colsum[(size_t)split * g.colsum_split_stride + col] = s;
+        else atomicAdd(&g.colsum[col], s);
+      }
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Three straight-line passes (value, store, sign bits) so the 64 stores of a lane issue back to back.
+  float* Cb = g.C + (size_t)split * g.c_split_stride;
+  const int rbase = m0 + wm * 64 + 4 * khalf;
+  const int cbase = n0 + wn * 64 + (lane & 31);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-    if (col >= g.N) continue;
-    const float bv = (g.bias != nullptr && split == 0) ? g.bias[col] : 0.f;
+    const int col = cbase + j * 32;
+    const float bv = (g.bias != nullptr && split == 0 && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (row >= g.M) continue;
         float v = acc[i][j][r] + bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.drop_p > 0.f)
-          v *= drop_scale(g.drop_p, g.inv_keep, g.seed, (uint64_t)row * (uint64_t)g.N + col);
-        float* dst = g.C + (size_t)row * g.ldc + col;
-        if (g.atomic_out) atomicAdd(dst, v);
-        else *dst = v;
+        acc[i][j][r] = v;
       }
+  }
+  if (g.drop_p > 0.f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const uint32_t rk = drop_rowkey(g.seed, (uint64_t)row);
+        acc[i][0][r] *= drop_scale(rk, (uint32_t)cbase, g.thresh, g.inv_keep);
+        acc[i][1][r] *= drop_scale(rk, (uint32_t)(cbase + 32), g.thresh, g.inv_keep);
+      }
+  }
+  const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+  if (ATOMIC) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+          if (full || (row < g.M && col < g.N)) atomicAdd(Cb + (size_t)row * g.ldc + col, acc[i][j][r]);
+        }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+          if (full || (row < g.M && col < g.N)) Cb[(size_t)row * g.ldc + col] = acc[i][j][r];
+        }
+    if (g.bits_out) {
+      // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+            const bool ok = row < g.M && col < g.N;
+            const unsigned long long m = __ballot(ok && acc[i][j][r] > 0.f);
+            if ((lane & 31) == 0 && ok)
+              g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(khalf ? (m >> 32) : m);
+          }
     }
   }
 }
@@ -199,29 +334,39 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   // (a k-chunk that crosses the end of the contraction range falls back to guarded scalars)
   g.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (A_KC ? (g.k_per_split % 4 == 0) : true);
   g.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (B_KC ? (g.k_per_split % 4 == 0) : true);
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splitk));
-  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(NT), 0, st, g);
+  const int ntile = g.tiles_m * g.tiles_n;
+  dim3 grid((unsigned)(g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile));
+  constexpr bool CAN_ATOMIC = !A_KC && !B_KC;      // only the grad-weight contraction accumulates with atomics
+  if (CAN_ATOMIC && g.atomic_out) {
+    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
+  } else {
+    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, false>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, false>), grid, dim3(NT), 0, st, g);
+  }
   return check_launch("gemm_f32");
 }
 
-// column sums of dy[M][N] -> db[N] (atomic accumulate); one block handles 256 rows x 64 cols
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int ld, long M, int N,
-                                                     float* __restrict__ db) {
-  __shared__ float part[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int w = threadIdx.x >> 6;
-  long r0 = (long)blockIdx.y * 256;
-  float s = 0.f;
-  if (col < N) {
-    for (int i = w; i < 256; i += 4) {
-      long r = r0 + i;
-      if (r < M) s += dy[(size_t)r * ld + col];
+// out[i] = sum_s part[s*stride + i]   (float4 lanes; n4 = number of float4 elements)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, long stride, int splits,
+                                                              float* __restrict__ out, long n) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  for (; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float4 s = *reinterpret_cast<const float4*>(part + i);
+      for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = s;
+    } else {
+      for (long j = i; j < n; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + j];
+        out[j] = s;
+      }
     }
   }
-  part[w][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (w == 0 && col < N) atomicAdd(&db[col], part[0][threadIdx.x] + part[1][threadIdx.x] +
-                                                  part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy,
@@ -237,13 +382,23 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, int ldy, co
   }
 }
 
+static void plan_splitk(long M, int N, int K, int& splitk, int& kper) {
+  int tiles = cdiv(N, BM) * cdiv(K, BN);
+  int ksteps = cdiv(M, BK);
+  int want = tiles >= 1024 ? 1 : cdiv(1024, tiles);
+  splitk = want < 1 ? 1 : want;
+  if (splitk > ksteps / 4) splitk = ksteps / 4 > 0 ? ksteps / 4 : 1;   // >= 4 k-tiles per split
+  kper = cdiv(ksteps, splitk) * BK;
+  splitk = cdiv(M, kper);
+}
+
 }  // namespace hoisdf
 
 using namespace hoisdf;
 
 extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias,
                                  float* y, int ldy, long M, int N, int K, int act, float drop_p,
-                                 uint64_t seed, void* stream) {
+                                 uint64_t seed, uint32_t* relu_bits, void* stream) {
   HOISDF_REQUIRE(x && W && y, HOISDF_ERR_INVALID, "linear_fwd: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, HOISDF_ERR_INVALID,
                  "linear_fwd: bad sizes M=%ld N=%d K=%d ldx=%d ldw=%d ldy=%d", M, N, K, ldx, ldw, ldy);
@@ -253,54 +408,81 @@ extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ld
   GemmArgs g{};
   g.A = x; g.B = W; g.C = y; g.bias = bias;
   g.M = (int)M; g.N = N; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldy;
-  g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.seed = seed;
+  g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.splitk = 1; g.k_per_split = ((K + BK - 1) / BK) * BK; g.atomic_out = 0;
+  g.bits_out = relu_bits; g.ldbits = (N + 31) / 32;
   return launch_gemm<true, true>(g, as_stream(stream));
 }
 
-extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const float* W, int ldw, float* dx,
-                                       int lddx, long M, int N, int K, void* stream) {
+extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                                       const float* W, int ldw, float* dx, int lddx, long M, int N, int K,
+                                       void* stream) {
   HOISDF_REQUIRE(dy && W && dx, HOISDF_ERR_INVALID, "linear_bwd_input: null pointer");
-  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && M < (1L << 31),
+  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && M < (1L << 31) &&
+                     drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_input: bad sizes");
   if (M == 0) return HOISDF_OK;
   GemmArgs g{};
   // dx[m][k] = sum_n dy[m][n] W[n][k]: contraction index n; "B" is W read as [n][k] = [contract][out]
-  g.A = dy; g.B = W; g.C = dx; g.bias = nullptr;
+  g.A = dy; g.B = W; g.C = dx; g.bias = nullptr; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
   g.M = (int)M; g.N = K; g.K = N; g.lda = lddy; g.ldb = ldw; g.ldc = lddx;
   g.act = 0; g.drop_p = 0.f; g.inv_keep = 1.f; g.seed = 0;
   g.splitk = 1; g.k_per_split = ((N + BK - 1) / BK) * BK; g.atomic_out = 0;
   return launch_gemm<true, false>(g, as_stream(stream));
 }
 
-extern "C" int hoisdf_linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
-                                        int lddw, float* db, long M, int N, int K, void* stream) {
+extern "C" long hoisdf_linear_bwd_weight_workspace(long M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int splitk, kper;
+  plan_splitk(M, N, K, splitk, kper);
+  if (splitk <= 1) return 0;
+  return (long)splitk * ((long)N * K + N);
+}
+
+extern "C" int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                                        const float* x, int ldx, float* dW, int lddw, float* db, long M, int N,
+                                        int K, float* workspace, long workspace_floats, void* stream) {
   HOISDF_REQUIRE(dy && x && dW, HOISDF_ERR_INVALID, "linear_bwd_weight: null pointer");
-  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K && M < (1L << 31),
+  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K && M < (1L << 31) &&
+                     drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_weight: bad sizes");
   if (M == 0) return HOISDF_OK;
   hipStream_t st = as_stream(stream);
   GemmArgs g{};
   // dW[n][k] = sum_m dy[m][n] x[m][k]: out rows n, out cols k, contraction m
-  g.A = dy; g.B = x; g.C = dW; g.bias = nullptr;
-  g.M = N; g.N = K; g.K = (int)M; g.lda = lddy; g.ldb = ldx; g.ldc = lddw;
+  g.A = dy; g.B = x; g.bias = nullptr; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
+  g.M = N; g.N = K; g.K = (int)M; g.lda = lddy; g.ldb = ldx;
   g.act = 0; g.drop_p = 0.f; g.inv_keep = 1.f; g.seed = 0;
-  int tiles = cdiv(N, BM) * cdiv(K, BN);
-  int ksteps = cdiv(M, BK);
-  int want = tiles >= 1024 ? 1 : cdiv(1024, tiles);
-  int splitk = want < 1 ? 1 : want;
-  if (splitk > ksteps / 4) splitk = ksteps / 4 > 0 ? ksteps / 4 : 1;   // >= 4 k-tiles per split
-  int kper = cdiv(ksteps, splitk) * BK;
-  splitk = cdiv(M, kper);
-  g.splitk = splitk; g.k_per_split = kper; g.atomic_out = 1;
-  int rc = launch_gemm<false, false>(g, st);
-  if (rc) return rc;
-  if (db) {
-    dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 256));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, dy, lddy, M, N, db);
-    return check_launch("colsum");
+  int splitk, kper;
+  plan_splitk(M, N, K, splitk, kper);
+  g.splitk = splitk; g.k_per_split = kper;
+  const long need = splitk > 1 ? (long)splitk * ((long)N * K + N) : 0;
+  if (splitk == 1) {
+    // one pass, direct stores (dW/db fully overwritten; db via atomics needs zero only if tiles_m... =1 split: plain)
+    g.C = dW; g.ldc = lddw; g.atomic_out = 0; g.partial = 1; g.c_split_stride = 0;
+    g.colsum = db; g.colsum_split_stride = 0;
+    return launch_gemm<false, false>(g, st);
   }
-  return HOISDF_OK;
+  if (workspace && workspace_floats >= need) {
+    HOISDF_REQUIRE(lddw == K, HOISDF_ERR_INVALID, "linear_bwd_weight: workspace mode needs a dense dW (lddw == K)");
+    g.C = workspace; g.ldc = K; g.atomic_out = 0; g.partial = 1; g.c_split_stride = (long)N * K;
+    g.colsum = db ? workspace + (size_t)splitk * N * K : nullptr; g.colsum_split_stride = N;
+    int rc = launch_gemm<false, false>(g, st);
+    if (rc) return rc;
+    const long n = (long)N * K;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, workspace, (long)N * K, splitk, dW, n);
+    if (db)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, workspace + (size_t)splitk * N * K, (long)N,
+                         splitk, db, (long)N);
+    return check_launch("linear_bwd_weight reduce");
+  }
+  // workspace-less: atomics into caller-zeroed dW / db
+  g.C = dW; g.ldc = lddw; g.atomic_out = 1; g.partial = 0; g.c_split_stride = 0;
+  g.colsum = db; g.colsum_split_stride = 0;
+  return launch_gemm<false, false>(g, st);
 }
 
 extern "C" int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, long M,
                                                          int D, float eps, float drop_p, float inv_keep,
-                                                         uint64_t seed) {
+                                                         uint64_t seed, uint32_t thresh) {
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -218,11 +218,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
         if (r) {
           float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
           if (drop_p > 0.f) {
-            const uint64_t e = (uint64_t)row * D + u * 4;
-            b.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
-            b.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
-            b.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
-            b.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
+            b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
+            b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
+            b.w *= drop_scale(rk, e + 3, thresh, inv_keep);
           }
           a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ dx,
                                                          float* __restrict__ dr, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, long M, int D, float drop_p,
-                                                         float inv_keep, uint64_t seed) {
+                                                         float inv_keep, uint64_t seed, uint32_t thresh) {
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   float4 dg[4], db[4];
@@ -291,11 +291,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         if (r) {
           float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
           if (drop_p > 0.f) {
-            const uint64_t e = (uint64_t)row * D + u * 4;
-            b.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
-            b.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
-            b.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
-            b.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
+            b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
+            b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
+            b.w *= drop_scale(rk, e + 3, thresh, inv_keep);
           }
           a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
@@ -323,11 +323,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = o;
         if (dr) {
           if (drop_p > 0.f) {
-            const uint64_t e = (uint64_t)row * D + u * 4;
-            o.x *= drop_scale(drop_p, inv_keep, seed, e + 0);
-            o.y *= drop_scale(drop_p, inv_keep, seed, e + 1);
-            o.z *= drop_scale(drop_p, inv_keep, seed, e + 2);
-            o.w *= drop_scale(drop_p, inv_keep, seed, e + 3);
+            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            o.x *= drop_scale(rk, e + 0, thresh, inv_keep);
+            o.y *= drop_scale(rk, e + 1, thresh, inv_keep);
+            o.z *= drop_scale(rk, e + 2, thresh, inv_keep);
+            o.w *= drop_scale(rk, e + 3, thresh, inv_keep);
           }
           *reinterpret_cast<float4*>(dr + (size_t)row * D + u * 4) = o;
         }
@@ -455,7 +455,7 @@ extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const fl
                  "add_layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
   if (M == 0) return HOISDF_OK;
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
-                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed);
+                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p));
   return check_launch("add_layernorm_fwd");
 }
 
@@ -470,6 +470,6 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
   int blocks = row_grid(M);
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
-                     dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed);
+                     dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p));
   return check_launch("add_layernorm_bwd");
 }

@@ -38,7 +38,7 @@ def _st():
 
 def _chk(*ts):
     for t in ts:
-        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+        if t is not None and (not t.is_cuda or t.dtype not in (torch.float32,)):
             raise RuntimeError("hoisdf_amd ops need float32 CUDA/HIP tensors (no CPU fallback)")
 
 
@@ -130,38 +130,37 @@ class _Linear(torch.autograd.Function):
         M, K = x2.shape
         N = W.shape[0]
         assert W.shape[1] == K, (W.shape, K)
+        if drop_p > 0 and not act:
+            raise RuntimeError("dropout without relu is not supported by linear()")
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        need_bits = bool(act) and (x.requires_grad or W.requires_grad or (b is not None and b.requires_grad))
+        bits = torch.empty(M, (N + 31) // 32, device=x.device, dtype=torch.int32) if need_bits else None
         call("hoisdf_linear_fwd", _p(x2), x2.stride(0) if M > 1 else K, _p(W), W.stride(0), _p(b), _p(y), N, M, N,
-             K, int(act), float(drop_p), seed, _st())
-        ctx.save_for_backward(x2, W, y if (act or drop_p > 0) else None)
+             K, int(act), float(drop_p), seed, _p(bits), _st())
+        ctx.save_for_backward(x2, W, bits)
         ctx.meta = (int(act), float(drop_p), b is not None, x.shape)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W, y = ctx.saved_tensors
+        x2, W, bits = ctx.saved_tensors
         act, drop_p, has_b, xshape = ctx.meta
         M, K = x2.shape
         N = W.shape[0]
         dy2 = _rows(dy)
-        if y is not None:
-            if not act:
-                raise RuntimeError("dropout without relu is not supported by linear()")
-            dpre = torch.empty(M, N, device=dy.device, dtype=torch.float32)
-            call("hoisdf_relu_dropout_bwd", _p(y), N, _p(dy2), dy2.stride(0) if M > 1 else N, _p(dpre), N, M, N,
-                 drop_p, _st())
-            dy2 = dpre
         lddy = dy2.stride(0) if M > 1 else N
+        # relu/dropout backward is fused into the staging of dy inside both contractions (1-bit sign map)
+        p = drop_p if bits is not None else 0.0
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
+            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             dW = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
             db = torch.zeros(N, device=dy.device, dtype=torch.float32) if has_b else None
-            call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(x2), x2.stride(0) if M > 1 else K, _p(dW), K,
-                 _p(db), M, N, K, _st())
+            call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), p, _p(x2), x2.stride(0) if M > 1 else K, _p(dW),
+                 K, _p(db), M, N, K, None, 0, _st())
         return dx, dW, db, None, None, None
 
 

@@ -86,18 +86,27 @@ int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const float* poin
  * :87-113 (SDFDecoder hidden layers), nn.MultiheadAttention in/out projections and FFN
  * (common/nets/transformer.py:269-302).
  * y[M][N] = dropout(act(x[M][K] . W[N][K]^T + bias)), act: 0 none, 1 relu.
- * Element (m,n) of y uses dropout index m*N+n. */
+ * The dropout mask of element (m,n) is a hash of (seed, m, n).
+ * relu_bits (optional, [M][ceil(N/32)] uint32): bit n%32 of word [m][n/32] is set iff
+ * y[m][n] > 0, i.e. the element survived ReLU and dropout - all the backward needs. */
 int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias,
                       float* y, int ldy, long M, int N, int K, int act, float drop_p,
-                      uint64_t seed, void* stream);
-/* dx[M][K] = dy[M][N] . W[N][K] */
-int hoisdf_linear_bwd_input(const float* dy, int lddy, const float* W, int ldw, float* dx,
-                            int lddx, long M, int N, int K, void* stream);
-/* dW[N][K] = dy[M][N]^T . x[M][K] ; db[N] = column sums of dy (db may be NULL).
- * dW and db must be zero-filled by the caller when the library picks a split-K > 1; the
- * library always accumulates with atomics, so pass zeroed buffers (or gradients to add to). */
-int hoisdf_linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
-                             int lddw, float* db, long M, int N, int K, void* stream);
+                      uint64_t seed, uint32_t* relu_bits, void* stream);
+/* Backward contractions.  If relu_bits (from the forward) is given, the ReLU + dropout backward
+ * is fused into the load of dy: dy_eff = dy * bit / (1 - p); NULL means dy is used as is.
+ * dx[M][K] = dy_eff[M][N] . W[N][K] */
+int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                            const float* W, int ldw, float* dx, int lddx, long M, int N, int K,
+                            void* stream);
+/* dW[N][K] = dy_eff[M][N]^T . x[M][K] ; db[N] = column sums of dy_eff (db may be NULL).
+ * Split-K over M.  With a workspace of hoisdf_linear_bwd_weight_workspace(M,N,K) floats the
+ * partial tiles are written there and summed by a second kernel: dW (dense, lddw == K) and db
+ * are fully overwritten.  Without it (workspace == NULL) the kernel accumulates with float
+ * atomics into dW / db, which the caller must have zero-filled (or hold gradients to add to). */
+long hoisdf_linear_bwd_weight_workspace(long M, int N, int K);
+int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                             const float* x, int ldx, float* dW, int lddw, float* db, long M, int N,
+                             int K, float* workspace, long workspace_floats, void* stream);
 /* dpre = dy * (y > 0) * 1/(1-p): backward of relu followed by dropout, given the
  * post-dropout output y (an element is kept-and-positive iff y > 0).  In place allowed. */
 int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,
@@ -168,7 +177,7 @@ int hoisdf_token_build_bwd(const float* dtok, const float* feat, int ldfeat, con
  * common/utils/misc.py:34-47 keeps keys < num_samp_hand).  Streaming-softmax (never
  * materialises Lq x Lk), exact fp32 on the f32 MFMA pipe; q is scaled by 1/sqrt(64).
  * o [B][Lq][ldo]; lse [B][H][Lq] log-sum-exp of the scaled scores (saved for backward).
- * Dropout on the probabilities uses index ((b*H+h)*Lq+i)*Lk+j. */
+ * Dropout on the probabilities: mask of (b,h,i,j) is a hash of (seed, (b*H+h)*Lq+i, j). */
 int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                          float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
                          float drop_p, uint64_t seed, void* stream);

@@ -14,7 +14,7 @@ HEADER = open(_lib.HEADER_PATH).read()
 def header_functions():
     body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
     fns = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(hoisdf_\w+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(hoisdf_\w+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("void", "") else len(args.split(","))
         fns[m.group(1)] = n
@@ -48,7 +48,9 @@ def test_ctypes_table_matches_header(lib):
         assert name in fns, f"{name} bound in _lib.py but not declared in hoisdf.h"
         assert len(args) == fns[name], f"{name}: {len(args)} ctypes args vs {fns[name]} in the header"
     for name in fns:
-        assert name in _lib.SIGNATURES or name in ("hoisdf_version", "hoisdf_last_error"), name
+        assert name in _lib.SIGNATURES or name in _lib._RET or name in _lib._OTHER, name
+    for name, (args, _) in _lib._OTHER.items():
+        assert len(args) == fns[name], name
 
 
 def test_version_and_error_strings(lib):
@@ -58,7 +60,7 @@ def test_version_and_error_strings(lib):
 
 def test_argument_validation_needs_no_gpu(lib):
     """bad arguments are rejected before any HIP call"""
-    rc = lib.hoisdf_linear_fwd(None, 4, None, 4, None, None, 4, 8, 4, 4, 0, 0.0, 0, None)
+    rc = lib.hoisdf_linear_fwd(None, 4, None, 4, None, None, 4, 8, 4, 4, 0, 0.0, 0, None, None)
     assert rc == -1 and b"null" in lib.hoisdf_last_error()
     with pytest.raises(_lib.HoisdfError):
         _lib.call("hoisdf_select_smallest_abs", None, None, None, 1, 1, None, None)

@@ -359,6 +359,6 @@ def test_errors_are_reported_not_swallowed():
     from hoisdf_amd import _lib
     O = ops()
     with pytest.raises(_lib.HoisdfError):
-        _lib.call("hoisdf_linear_fwd", None, 4, None, 4, None, None, 4, 8, 4, 4, 0, 0.0, 0, None)
+        _lib.call("hoisdf_linear_fwd", None, 4, None, 4, None, None, 4, 8, 4, 4, 0, 0.0, 0, None, None)
     with pytest.raises(RuntimeError):
         O.linear(torch.zeros(4, 4), torch.zeros(4, 4))               # CPU tensors: no fallback
