@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--channels-last", type=int, default=1,
+                    help="run the CNN encoder in channels_last (the pyramid is then consumed zero-copy)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 was the best of 16/32/64/256 probed on the "
@@ -114,11 +116,17 @@ def main():
     cfg.num_samp_hand, cfg.num_samp_obj = args.n_hand, args.n_obj
     torch.manual_seed(0)           # identical initial weights on every rank
     model = get_model("train", cfg=cfg).to(dev).train()
+    if args.channels_last:
+        model.backbone_net.to(memory_format=torch.channels_last)
+        model.decoder_net.to(memory_format=torch.channels_last)
     reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
     ops.manual_seed(1000 + rank)
     inputs, targets, meta = (T.to_device(x, dev) for x in T.synthetic_batch(args.batch, args.n_hand, args.n_obj,
                                                                            seed=1234 + rank))
+
+    if args.channels_last:
+        inputs["img"] = inputs["img"].contiguous(memory_format=torch.channels_last)
 
     def step():
         reducer.zero_grad()

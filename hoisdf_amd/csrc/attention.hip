@@ -25,6 +25,21 @@ constexpr int DH = 64;        // head dim
 constexpr int PITCH = 68;     // LDS row pitch in floats
 #define CROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// softmax runs in the log2 domain: scores are scaled by log2(e)/sqrt(64) and exponentiated with
+// the native v_exp_f32 (exp2); the saved LSE is log2-domain as well (internal to fwd/bwd).
+constexpr float QSCALE2 = 0.125f * 1.4426950408889634f;
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+
+// Block -> (tile, b*H+h) with every tile of one (b, head) on the same XCD (block id % 8): K/V (fwd, dQ)
+// or Q/dO (dK/dV) of that head are then fetched from HBM once into one L2 instead of into all eight
+// (PMC before: 5.5x over-fetch, 50 % L2 hit rate).
+__device__ __forceinline__ bool attn_block(int nx, int nbh, int& tile, int& bh) {
+  const int L = blockIdx.x;
+  const int slot = L >> 3;
+  bh = (slot / nx) * 8 + (L & 7);
+  tile = slot % nx;
+  return bh < nbh;
+}
 
 struct AttnArgs {
   const float* q; const float* k; const float* v;
@@ -63,8 +78,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 64 * PITCH];   // [buf][K|V][64][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, c = lane & 31;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh - b * a.H;
-  const int qrow = blockIdx.x * 128 + wave * 32 + c;
+  int qtile, bh;
+  if (!attn_block((a.Lq + 127) / 128, a.B * a.H, qtile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int qrow = qtile * 128 + wave * 32 + c;
   const float* qb = a.q + (size_t)b * a.Lq * a.ldq + head * DH;
   const float* kb = a.k + (size_t)b * a.Lk * a.ldk + head * DH;
   const float* vb = a.v + (size_t)b * a.Lk * a.ldv + head * DH;
@@ -75,8 +92,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 t = p[i];
-      qf[4 * i + 0] = t.x * 0.125f; qf[4 * i + 1] = t.y * 0.125f;
-      qf[4 * i + 2] = t.z * 0.125f; qf[4 * i + 3] = t.w * 0.125f;
+      qf[4 * i + 0] = t.x * QSCALE2; qf[4 * i + 1] = t.y * QSCALE2;
+      qf[4 * i + 2] = t.z * QSCALE2; qf[4 * i + 3] = t.w * QSCALE2;
     }
   } else {
 #pragma unroll
@@ -124,24 +141,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
     // online softmax for this lane's query column
+    if (kt == ntiles - 1) {               // only the last tile can hold keys >= kv_len
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 64 + t * 32 + CROW(r, h) >= a.kv_len) s[t][r] = -INFINITY;
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 64 + t * 32 + CROW(r, h);
-        if (key >= a.kv_len) s[t][r] = -INFINITY;
-        mt = fmaxf(mt, s[t][r]);
-      }
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[t][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m, mt);
-    const float alpha = expf(m - mn);
+    const float alpha = EXP2(m - mn);
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf(s[t][r] - mn);
+        const float p = EXP2(s[t][r] - mn);
         ps += p;
         s[t][r] = p;
       }
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                                o[t][4 * g + 3] * inv);
         *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * h) = w;
       }
-    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + logf(ltot);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);     // log2 domain
   }
 }
 
@@ -213,35 +233,44 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __re
 }
 
 // ============================================================================================
-// backward, dK / dV: block = 128 keys (4 waves x 32) of one (b, head); loops over 32-query tiles
+// backward, dK / dV: block = 128 keys (4 waves x 32) of one (b, head); loops over 32-query tiles.
+// K fragment in registers, V fragment in a per-wave LDS slab (keeps the kernel at 2 waves/SIMD
+// without spills); the next Q / dO tile is prefetched into registers during the 128 MFMAs.
 // ============================================================================================
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * PITCH + 64];   // Q tile, dO tile, lse[32], delta[32]
-  float* Qs = lds;
-  float* Ds = lds + 32 * PITCH;
-  float* Ls = lds + 2 * 32 * PITCH;
-  float* Es = Ls + 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * PITCH + 64 + 4 * 32 * PITCH];
+  float* Qs = lds;                          // [32][PITCH] query tile
+  float* Ds = lds + 32 * PITCH;             // [32][PITCH] dO tile
+  float* Ls = lds + 2 * 32 * PITCH;         // lse[32]
+  float* Es = Ls + 32;                      // delta[32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Vw = Es + 32 + wave * 32 * PITCH;  // this wave's V rows [32][PITCH]
   const int h = lane >> 5, c = lane & 31;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh - b * a.H;
-  const int key = blockIdx.x * 128 + wave * 32 + c;
+  int ktile, bh;
+  if (!attn_block((a.Lk + 127) / 128, a.B * a.H, ktile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int key = ktile * 128 + wave * 32 + c;
   const bool kvalid = key < a.kv_len;
   const float* qb = a.q + (size_t)b * a.Lq * a.ldq + head * DH;
   const float* dob = a.dout + (size_t)b * a.Lq * a.lddo + head * DH;
 
-  float kf[32], vf[32];
-  if (kvalid) {
-    const float4* pk = reinterpret_cast<const float4*>(a.k + ((size_t)b * a.Lk + key) * a.ldk + head * DH + 32 * h);
-    const float4* pv = reinterpret_cast<const float4*>(a.v + ((size_t)b * a.Lk + key) * a.ldv + head * DH + 32 * h);
+  float kf[32];
+  {
+    float4 t[8], u[8];
+    if (kvalid) {
+      const float4* pk = reinterpret_cast<const float4*>(a.k + ((size_t)b * a.Lk + key) * a.ldk + head * DH + 32 * h);
+      const float4* pv = reinterpret_cast<const float4*>(a.v + ((size_t)b * a.Lk + key) * a.ldv + head * DH + 32 * h);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = pk[i]; u[i] = pv[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = make_float4(0, 0, 0, 0); u[i] = make_float4(0, 0, 0, 0); }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float4 t = pk[i], u = pv[i];
-      kf[4 * i + 0] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-      vf[4 * i + 0] = u.x; vf[4 * i + 1] = u.y; vf[4 * i + 2] = u.z; vf[4 * i + 3] = u.w;
+      kf[4 * i + 0] = t[i].x; kf[4 * i + 1] = t[i].y; kf[4 * i + 2] = t[i].z; kf[4 * i + 3] = t[i].w;
+      *reinterpret_cast<float4*>(&Vw[c * PITCH + 32 * h + 4 * i]) = u[i];
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { kf[i] = 0.f; vf[i] = 0.f; }
   }
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -249,23 +278,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
-  const bool block_active = blockIdx.x * 128 < a.kv_len;
+  const bool block_active = ktile * 128 < a.kv_len;
   const int nq = block_active ? (a.Lq + 31) / 32 : 0;
+  float4 rq[2], rd[2];
+  float rl = INFINITY, re = 0.f;
+  if (nq > 0) {
+    tile_load<2>(rq, qb, a.ldq, 0, a.Lq, tid);
+    tile_load<2>(rd, dob, a.lddo, 0, a.Lq, tid);
+    if (tid < 32 && tid < a.Lq) { rl = a.lse_in[(size_t)bh * a.Lq + tid]; re = a.delta_in[(size_t)bh * a.Lq + tid]; }
+  }
   for (int qt = 0; qt < nq; ++qt) {
-    // stage Q and dO tiles (32 x 64 each): 2 float4 per thread per tile
-    {
-      float4 rq[2], rd[2];
-      tile_load<2>(rq, qb, a.ldq, qt * 32, a.Lq, tid);
-      tile_load<2>(rd, dob, a.lddo, qt * 32, a.Lq, tid);
-      __syncthreads();                     // previous iteration's readers are done
-      tile_store<2>(rq, Qs, tid);
-      tile_store<2>(rd, Ds, tid);
+    __syncthreads();                       // previous tile's readers are done (also orders the V slab writes)
+    tile_store<2>(rq, Qs, tid);
+    tile_store<2>(rd, Ds, tid);
+    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+    if (qt + 1 < nq) {                     // prefetch the next tile; lands during the MFMAs below
+      tile_load<2>(rq, qb, a.ldq, (qt + 1) * 32, a.Lq, tid);
+      tile_load<2>(rd, dob, a.lddo, (qt + 1) * 32, a.Lq, tid);
       if (tid < 32) {
-        const int q = qt * 32 + tid;
-        Ls[tid] = q < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q] : INFINITY;
-        Es[tid] = q < a.Lq ? a.delta_in[(size_t)bh * a.Lq + q] : 0.f;
+        const int q = (qt + 1) * 32 + tid;
+        rl = q < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q] : INFINITY;
+        re = q < a.Lq ? a.delta_in[(size_t)bh * a.Lq + q] : 0.f;
       }
-      __syncthreads();
     }
     // S = Q.K^T and dP = dO.V^T  (rows = queries, cols = this lane's key)
     f32x16 s, dp;
@@ -275,16 +310,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     for (int c4 = 0; c4 < 8; ++c4) {
       const float4 qq = *reinterpret_cast<const float4*>(&Qs[c * PITCH + 32 * h + 4 * c4]);
       const float4 dd = *reinterpret_cast<const float4*>(&Ds[c * PITCH + 32 * h + 4 * c4]);
-      s = MFMA(qq.x, kf[4 * c4 + 0], s);  dp = MFMA(dd.x, vf[4 * c4 + 0], dp);
-      s = MFMA(qq.y, kf[4 * c4 + 1], s);  dp = MFMA(dd.y, vf[4 * c4 + 1], dp);
-      s = MFMA(qq.z, kf[4 * c4 + 2], s);  dp = MFMA(dd.z, vf[4 * c4 + 2], dp);
-      s = MFMA(qq.w, kf[4 * c4 + 3], s);  dp = MFMA(dd.w, vf[4 * c4 + 3], dp);
+      const float4 vv = *reinterpret_cast<const float4*>(&Vw[c * PITCH + 32 * h + 4 * c4]);
+      s = MFMA(qq.x, kf[4 * c4 + 0], s);  dp = MFMA(dd.x, vv.x, dp);
+      s = MFMA(qq.y, kf[4 * c4 + 1], s);  dp = MFMA(dd.y, vv.y, dp);
+      s = MFMA(qq.z, kf[4 * c4 + 2], s);  dp = MFMA(dd.z, vv.z, dp);
+      s = MFMA(qq.w, kf[4 * c4 + 3], s);  dp = MFMA(dd.w, vv.w, dp);
     }
-    // P (dropped) and dS, in place: s <- Pd, dp <- dS  (keeps the kernel at 2 waves / SIMD)
+    // P (dropped) and dS, in place: s <- Pd, dp <- dS
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ql = CROW(r, h);
-      const float p = kvalid ? expf(s[r] * 0.125f - Ls[ql]) : 0.f;
+      const float p = kvalid ? EXP2(s[r] * QSCALE2 - Ls[ql]) : 0.f;
       float dscale = 1.f;
       if (a.drop_p > 0.f)
         dscale = drop_scale(drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)), (uint32_t)key,
@@ -320,16 +356,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ============================================================================================
-// backward, dQ: block = 128 queries (4 waves x 32); loops over 32-key tiles
+// backward, dQ: block = 128 queries (4 waves x 32); loops over 32-key tiles (prefetched)
 // ============================================================================================
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 32 * PITCH];   // K tile, V tile
   float* Ks = lds;
   float* Vs = lds + 32 * PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, c = lane & 31;
-  const int bh = blockIdx.y, b = bh / a.H, head = bh - b * a.H;
-  const int qrow = blockIdx.x * 128 + wave * 32 + c;
+  int qtile, bh;
+  if (!attn_block((a.Lq + 127) / 128, a.B * a.H, qtile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int qrow = qtile * 128 + wave * 32 + c;
   const bool qvalid = qrow < a.Lq;
   const float* kb = a.k + (size_t)b * a.Lk * a.ldk + head * DH;
   const float* vb = a.v + (size_t)b * a.Lk * a.ldv + head * DH;
@@ -359,15 +397,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
 
   const int nk = (a.kv_len + 31) / 32;
+  float4 rk[2], rv[2];
+  tile_load<2>(rk, kb, a.ldk, 0, a.kv_len, tid);
+  tile_load<2>(rv, vb, a.ldv, 0, a.kv_len, tid);
   for (int kt = 0; kt < nk; ++kt) {
-    {
-      float4 rk[2], rv[2];
-      tile_load<2>(rk, kb, a.ldk, kt * 32, a.kv_len, tid);
-      tile_load<2>(rv, vb, a.ldv, kt * 32, a.kv_len, tid);
-      __syncthreads();
-      tile_store<2>(rk, Ks, tid);
-      tile_store<2>(rv, Vs, tid);
-      __syncthreads();
+    __syncthreads();
+    tile_store<2>(rk, Ks, tid);
+    tile_store<2>(rv, Vs, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      tile_load<2>(rk, kb, a.ldk, (kt + 1) * 32, a.kv_len, tid);
+      tile_load<2>(rv, vb, a.ldv, (kt + 1) * 32, a.kv_len, tid);
     }
     // S^T = K.Q^T, dP^T = V.dO^T  (rows = keys, cols = this lane's query)
     f32x16 s, dp;
@@ -382,21 +422,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       s = MFMA(kk.z, qf[4 * c4 + 2], s);  dp = MFMA(vv.z, df[4 * c4 + 2], dp);
       s = MFMA(kk.w, qf[4 * c4 + 3], s);  dp = MFMA(vv.w, df[4 * c4 + 3], dp);
     }
-    f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + CROW(r, h);
-      const float p = (key < a.kv_len) ? expf(s[r] * 0.125f - lse) : 0.f;
+      const float p = (key < a.kv_len) ? EXP2(s[r] * QSCALE2 - lse) : 0.f;
       float dscale = 1.f;
       if (a.drop_p > 0.f) dscale = drop_scale(rowkey, (uint32_t)key, a.thresh, a.inv_keep);
-      ds[r] = p * (dp[r] * dscale - delta);
+      dp[r] = p * (dp[r] * dscale - delta);
     }
     // dQ^T += K^T . dS^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float* kr = &Ks[CROW(r, h) * PITCH + c];
-      dq[0] = MFMA(kr[0], ds[r], dq[0]);
-      dq[1] = MFMA(kr[32], ds[r], dq[1]);
+      dq[0] = MFMA(kr[0], dp[r], dq[0]);
+      dq[1] = MFMA(kr[32], dp[r], dq[1]);
     }
   }
   if (qvalid) {
@@ -512,7 +551,7 @@ extern "C" int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int
   if (int rc = check_attn(a, "attention_fwd")) return rc;
   HOISDF_REQUIRE(o && ldo >= H * DH && (ldo & 3) == 0 && ((uintptr_t)o & 15) == 0, HOISDF_ERR_INVALID,
                  "attention_fwd: bad output");
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(Lq, 128), B * H), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, as_stream(stream), a);
   return check_launch("attention_fwd");
 }
 
@@ -535,9 +574,9 @@ extern "C" int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, a, delta);
   if (int rc = check_launch("attention_delta")) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(Lk, 128), B * H), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
   if (int rc = check_launch("attention_bwd_dkv")) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Lq, 128), B * H), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
   return check_launch("attention_bwd_dq");
 }
 

@@ -24,17 +24,19 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- counter-based RNG for dropout ----------------------------------------------------
 // keep(row, col) is a pure function of (seed, row, col) so the backward pass regenerates the
-// mask.  The row part is hashed once per row; per element it is one multiply-xor + one 32-bit
-// finaliser and an integer compare against thresh = p * 2^32 (no float conversion).
+// mask: one 32-bit finaliser over a seeded linear combination of the two indices and an integer
+// compare against thresh = p * 2^32 (no float conversion; ~11 VALU ops per element whichever of
+// row / col varies along the registers).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
 __device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint64_t row) {
-  return mix32((uint32_t)row ^ mix32((uint32_t)(row >> 32) ^ (uint32_t)(seed >> 32)) ^ (uint32_t)seed);
+  return ((uint32_t)row * 0x9E3779B1U) ^ (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3DU) ^
+         ((uint32_t)(row >> 32) * 0x27D4EB2FU);
 }
 __device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {
-  return mix32((col * 0x9E3779B1U) ^ rowkey) >= thresh;
+  return mix32((col * 0x85EBCA77U) ^ rowkey) >= thresh;
 }
 // multiplier applied to a kept element; 0 for a dropped one.
 __device__ __forceinline__ float drop_scale(uint32_t rowkey, uint32_t col, uint32_t thresh, float inv_keep) {

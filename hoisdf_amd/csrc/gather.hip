@@ -125,7 +125,7 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 d, float w) {
 }
 
 __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, const float* __restrict__ dfeat,
-                                                         int ldf) {
+                                                         int ldf, int skip_mask) {
   const int lane = threadIdx.x & 63;
   long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long stride = (long)gridDim.x * 4;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, c
     const float4* din = reinterpret_cast<const float4*>(dfeat + (size_t)r * ldf);
     for (int u = lane; u < P.C4; u += 64) {
       const int l = level_of(P, u);
+      if ((skip_mask >> l) & 1) continue;          // coarse level: handled by the LDS-privatised kernel
       const int C = P.C[l], H = P.H[l], W = P.W[l];
       const Taps t = make_taps(g[0], g[1], W, H);
       float* base = P.grad[l] + (size_t)b * H * W * C + (size_t)(u - P.off4[l]) * 4;
@@ -145,6 +146,45 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, c
       if (t.o10 >= 0) atomic_add4(base + (size_t)t.o10 * C, d, t.w10);
       if (t.o11 >= 0) atomic_add4(base + (size_t)t.o11 * C, d, t.w11);
     }
+  }
+}
+
+// Coarse levels (<= 256 pixels): every point of a sample hits the same few pixels (128 adds per
+// address at stride 32), and those levels carry ~80 % of all channel-taps.  One workgroup owns
+// (sample, level, 64-channel chunk): it accumulates all the sample's points into an LDS image
+// with ds_add_f32 and writes the image out once - no global atomics, no hot addresses.
+struct CoarseJob { int level, chunk; };
+struct CoarseArgs { int n_jobs; CoarseJob job[96]; };
+
+__global__ __launch_bounds__(256) void gather_bwd_coarse_kernel(PyrDev P, ProjArgs a, CoarseArgs J,
+                                                                const float* __restrict__ dfeat, int ldf) {
+  extern __shared__ __attribute__((aligned(16))) float img[];       // [H*W][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const CoarseJob jb = J.job[blockIdx.x];
+  const int l = jb.level, C = P.C[l], H = P.H[l], W = P.W[l];
+  const int npix = H * W;
+  for (int i = threadIdx.x; i < npix * 64; i += 256) img[i] = 0.f;
+  __syncthreads();
+  const int ch0 = P.off4[l] * 4 + jb.chunk * 64;                    // column in dfeat rows
+  const int Pn = a.rows_per_sample;
+  for (int p = wave; p < Pn; p += 4) {
+    const long r = (long)b * Pn + p;
+    int bb;
+    float cam[3], uv[2], g[2];
+    project_row(a, r, bb, cam, uv, g);
+    const Taps t = make_taps(g[0], g[1], W, H);
+    const float d = dfeat[(size_t)r * ldf + ch0 + lane];
+    atomicAdd(&img[t.o00 * 64 + lane], d * t.w00);
+    if (t.o01 >= 0) atomicAdd(&img[t.o01 * 64 + lane], d * t.w01);
+    if (t.o10 >= 0) atomicAdd(&img[t.o10 * 64 + lane], d * t.w10);
+    if (t.o11 >= 0) atomicAdd(&img[t.o11 * 64 + lane], d * t.w11);
+  }
+  __syncthreads();
+  float* out = P.grad[l] + (size_t)b * npix * C + jb.chunk * 64;
+  for (int i = threadIdx.x; i < npix * 64; i += 256) {
+    const int px = i >> 6, c = i & 63;
+    out[(size_t)px * C + c] += img[i];
   }
 }
 
@@ -318,8 +358,29 @@ extern "C" int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const 
   if (n_rows == 0) return HOISDF_OK;
   ProjArgs a{points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale,
              (float)(img_w - 1) * 0.5f, (float)(img_h - 1) * 0.5f};
+  int skip_mask = 0;
+  if (!sample_idx && rows_per_sample > 0 && n_rows % rows_per_sample == 0) {
+    const int B = (int)(n_rows / rows_per_sample);
+    // group the coarse levels by LDS image size so one launch uses one dynamic-LDS size
+    for (int npix_cap : {64, 256}) {
+      CoarseArgs J{};
+      int max_pix = 0;
+      for (int l = 0; l < P.n_levels; ++l) {
+        const int npix = P.H[l] * P.W[l];
+        if (npix > npix_cap || (npix_cap == 256 && npix <= 64) || (P.C[l] & 63)) continue;
+        if (J.n_jobs + P.C[l] / 64 > 96) continue;
+        for (int ch = 0; ch < P.C[l] / 64; ++ch) J.job[J.n_jobs++] = CoarseJob{l, ch};
+        skip_mask |= 1 << l;
+        if (npix > max_pix) max_pix = npix;
+      }
+      if (J.n_jobs == 0) continue;
+      hipLaunchKernelGGL(gather_bwd_coarse_kernel, dim3(J.n_jobs, B), dim3(256), (size_t)max_pix * 64 * 4,
+                         as_stream(stream), P, a, J, dfeat, ldf);
+      if (int rc = check_launch("gather_bwd_coarse")) return rc;
+    }
+  }
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for_rows(n_rows)), dim3(256), 0, as_stream(stream), P, a,
-                     dfeat, ldf);
+                     dfeat, ldf, skip_mask);
   return check_launch("gather_bwd");
 }
 

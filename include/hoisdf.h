@@ -176,7 +176,8 @@ int hoisdf_token_build_bwd(const float* dtok, const float* feat, int ldfeat, con
  * [h*64, h*64+64) of each.  Only the first kv_len keys are attended (memory_mask of
  * common/utils/misc.py:34-47 keeps keys < num_samp_hand).  Streaming-softmax (never
  * materialises Lq x Lk), exact fp32 on the f32 MFMA pipe; q is scaled by 1/sqrt(64).
- * o [B][Lq][ldo]; lse [B][H][Lq] log-sum-exp of the scaled scores (saved for backward).
+ * o [B][Lq][ldo]; lse [B][H][Lq] = log2-domain log-sum-exp of the scaled scores (opaque,
+ * only to be handed back to hoisdf_attention_bwd).
  * Dropout on the probabilities: mask of (b,h,i,j) is a hash of (seed, (b*H+h)*Lq+i, j). */
 int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                          float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
