@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--channels-last", type=int, default=1,
                     help="run the CNN encoder in channels_last (the pyramid is then consumed zero-copy)")
+    ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark for the encoder convs")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 was the best of 16/32/64/256 probed on the "
@@ -98,6 +99,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -120,7 +122,7 @@ def main():
         model.backbone_net.to(memory_format=torch.channels_last)
         model.decoder_net.to(memory_format=torch.channels_last)
     reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr, fused=True)
     ops.manual_seed(1000 + rank)
     inputs, targets, meta = (T.to_device(x, dev) for x in T.synthetic_batch(args.batch, args.n_hand, args.n_obj,
                                                                            seed=1234 + rank))

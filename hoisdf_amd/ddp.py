@@ -30,9 +30,12 @@ def reducible_parameters(model: torch.nn.Module) -> List[Tuple[str, torch.nn.Par
 class GradReducer:
     """Flat gradient buckets + asynchronous all-reduce.
 
-    ``p.grad`` of every managed parameter is a view into its bucket's flat buffer, so the
-    collective runs in place on what the optimizer reads (no pack/unpack copies).  Buckets are
-    filled in reverse registration order (= roughly the order backward produces gradients)."""
+    Autograd produces each parameter's gradient normally (``p.grad`` starts as None every step, so
+    AccumulateGrad just adopts the tensor - no per-parameter add kernel).  When the last gradient
+    of a bucket has arrived (post-accumulate-grad hooks, buckets ordered like backward), the
+    bucket is packed with a multi-tensor copy (``torch._foreach_copy_``), its all-reduce is
+    launched asynchronously, and ``p.grad`` is re-pointed at views of the flat buffer, which is
+    what the optimizer then reads.  ~450 tiny kernels per step become ~2 per bucket."""
 
     def __init__(self, params: Sequence[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 64.0,
                  group: Optional[dist.ProcessGroup] = None):
@@ -40,6 +43,7 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
+        self._views: List[List[torch.Tensor]] = []
         self._pending: List[int] = []
         self._handles = []
         self._launched: List[bool] = []
@@ -58,13 +62,19 @@ class GradReducer:
         for bi, members in enumerate(groups):
             n = sum(p.numel() for p in members)
             flat = torch.zeros(n, dtype=members[0].dtype, device=members[0].device)
-            off = 0
+            views, off = [], 0
             for p in members:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                chunk = flat[off:off + p.numel()]
+                if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+                    o, i, kh, kw = p.shape           # same physical layout as the channels_last parameter
+                    views.append(chunk.view(o, kh, kw, i).permute(0, 3, 1, 2))
+                else:
+                    views.append(chunk.view_as(p))
                 off += p.numel()
                 p.register_post_accumulate_grad_hook(self._make_hook(bi))
             self.buckets.append(flat)
             self._members.append(members)
+            self._views.append(views)
             self._pending.append(len(members))
             self._launched.append(False)
 
@@ -79,20 +89,30 @@ class GradReducer:
         if self._launched[bi]:
             return
         self._launched[bi] = True
+        members, views, flat = self._members[bi], self._views[bi], self.buckets[bi]
+        if all(p.grad is not None for p in members):
+            torch._foreach_copy_(views, [p.grad for p in members])           # multi-tensor packed copy
+        else:                                   # some parameter got no gradient this step: zero + per-tensor copy
+            flat.zero_()
+            for p, v in zip(members, views):
+                if p.grad is not None:
+                    v.copy_(p.grad)
+        for p, v in zip(members, views):
+            p.grad = v
         if self.world > 1:
-            self._handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                 async_op=True))
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero_grad(self):
-        """call instead of optimizer.zero_grad(): keeps the bucket views alive"""
-        for bi, flat in enumerate(self.buckets):
-            flat.zero_()
-            self._pending[bi] = len(self._members[bi])
+        """call instead of optimizer.zero_grad()"""
+        for bi, members in enumerate(self._members):
+            for p in members:
+                p.grad = None
+            self._pending[bi] = len(members)
             self._launched[bi] = False
         self._handles = []
 
     def finish(self):
-        """after backward(): reduce buckets whose hooks did not all fire (a parameter unused this
+        """after backward(): pack + reduce buckets whose hooks did not all fire (a parameter unused this
         step keeps a zero gradient), wait, and average."""
         for bi in range(len(self.buckets)):
             self._launch(bi)

@@ -157,8 +157,9 @@ class _Linear(torch.autograd.Function):
             call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            dW = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
-            db = torch.zeros(N, device=dy.device, dtype=torch.float32) if has_b else None
+            buf = torch.zeros(N * K + (N if has_b else 0), device=dy.device, dtype=torch.float32)   # one fill
+            dW = buf[:N * K].view(N, K)
+            db = buf[N * K:] if has_b else None
             call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), p, _p(x2), x2.stride(0) if M > 1 else K, _p(dW),
                  K, _p(db), M, N, K, None, 0, _st())
         return dx, dW, db, None, None, None
@@ -475,8 +476,8 @@ class _AddLayerNorm(torch.autograd.Function):
         dy2 = dy.reshape(M, D).contiguous()
         dx = torch.empty_like(x2)
         dr = None if r2 is None else torch.empty_like(x2)
-        dg = torch.zeros(D, device=dy.device, dtype=torch.float32)
-        db = torch.zeros(D, device=dy.device, dtype=torch.float32)
+        dgb = torch.zeros(2, D, device=dy.device, dtype=torch.float32)
+        dg, db = dgb[0], dgb[1]
         call("hoisdf_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dr),
              _p(dg), _p(db), M, D, drop_p, seed, _st())
         return dx.view(shape), (None if dr is None else dr.view(shape)), dg, db, None, None, None
