@@ -12,7 +12,7 @@ import os
 from typing import Dict, List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhoisdf_hip.so")
+LIB_PATH = os.environ.get("HOISDF_LIB", os.path.join(_HERE, "libhoisdf_hip.so"))   # override: A/B experiments
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "hoisdf.h")
 MAX_LEVELS = 8
 

@@ -3,7 +3,7 @@
 //   forward      y  = x . W^T      A[m][k] k-contiguous, B[n][k] k-contiguous
 //   grad input   dx = dy . W       A[m][k] k-contiguous, B[k][n] n-contiguous
 //   grad weight  dW = dy^T . x     A[k][m] m-contiguous, B[k][n] n-contiguous   (split-K)
-// Block tile 128x128x32, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
+// Block tile 128x128x16, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
 // VGPRs).  LDS holds both operands k-major ([k][m]) so the MFMA fragment read is always one
 // conflict-free ds_read_b32 per operand per k-pair; only the global->LDS staging differs with
 // the operand's memory orientation.  Register-staged double buffering: the next tile's global
@@ -23,7 +23,13 @@ namespace hoisdf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+#ifndef HOISDF_GEMM_BK
+#define HOISDF_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = HOISDF_GEMM_BK, NT = 256;
+constexpr int NV = BK / 8;            // float4 per thread per operand tile
+constexpr int KC_LPR = BK / 4;        // lanes per row for k-contiguous staging
+constexpr int KC_RPP = NT / KC_LPR;   // rows per pass
 constexpr int LDS_KC = BM + 1;   // k-contiguous source: transposing ds_write_b32, stride = 1 mod 32
 constexpr int LDS_MC = BM + 4;   // m-contiguous source: ds_write_b128, 16-byte aligned rows
 
@@ -52,14 +58,14 @@ struct GemmArgs {
 // KC = true : element (r, k) at src[r*ld + k]   (k contiguous)
 // KC = false: element (r, k) at src[k*ld + r]   (r contiguous)
 template <bool KC>
-__device__ __forceinline__ void stage_load(float4 (&reg)[4], const float* __restrict__ src, int ld,
+__device__ __forceinline__ void stage_load(float4 (&reg)[NV], const float* __restrict__ src, int ld,
                                            int r0, int R, int k0, int kend, int vec, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV; ++i) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
-      int r = r0 + (tid >> 3) + 32 * i;
-      int k = k0 + (tid & 7) * 4;
+      int r = r0 + (tid / KC_LPR) + KC_RPP * i;
+      int k = k0 + (tid % KC_LPR) * 4;
       if (r < R) {
         const float* p = src + (size_t)r * ld + k;
         if (vec && k + 3 < kend) {
@@ -94,25 +100,29 @@ __device__ __forceinline__ void stage_load(float4 (&reg)[4], const float* __rest
 // KC (dy as [m][n], tile rows = m, k = n): word (row, k0/32), nibble at (tid&7)*4.
 // MC (dy as [k=m][i=n], tile "rows" r = n, k = m): word (m, n/32), nibble at (tid&7)*4.
 template <bool KC>
-__device__ __forceinline__ void load_bits(uint32_t (&w)[4], const uint32_t* __restrict__ bits, int ldbits, int r0,
+__device__ __forceinline__ void load_bits(uint32_t (&w)[NV], const uint32_t* __restrict__ bits, int ldbits, int r0,
                                           int R, int k0, int kend, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV; ++i) {
     uint32_t v = 0u;
+    int sh;
     if (KC) {
-      const int r = r0 + (tid >> 3) + 32 * i;
-      if (r < R && k0 < kend) v = bits[(size_t)r * ldbits + (k0 >> 5)];
+      const int r = r0 + (tid / KC_LPR) + KC_RPP * i;
+      const int k = k0 + (tid % KC_LPR) * 4;
+      sh = k & 31;
+      if (r < R && k < kend) v = bits[(size_t)r * ldbits + (k >> 5)];
     } else {
       const int k = k0 + (tid >> 5) + 8 * i;
       const int r = r0 + (tid & 31) * 4;
+      sh = r & 31;
       if (k < kend && r < R) v = bits[(size_t)k * ldbits + (r >> 5)];
     }
-    w[i] = (v >> ((tid & 7) * 4)) & 0xFu;
+    w[i] = (v >> sh) & 0xFu;
   }
 }
-__device__ __forceinline__ void apply_bits(float4 (&a)[4], const uint32_t (&w)[4], float sc) {
+__device__ __forceinline__ void apply_bits(float4 (&a)[NV], const uint32_t (&w)[NV], float sc) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV; ++i) {
     a[i].x = (w[i] & 1u) ? a[i].x * sc : 0.f;
     a[i].y = (w[i] & 2u) ? a[i].y * sc : 0.f;
     a[i].z = (w[i] & 4u) ? a[i].z * sc : 0.f;
@@ -121,12 +131,12 @@ __device__ __forceinline__ void apply_bits(float4 (&a)[4], const uint32_t (&w)[4
 }
 
 template <bool KC>
-__device__ __forceinline__ void stage_store(const float4 (&reg)[4], float* __restrict__ lds, int tid) {
+__device__ __forceinline__ void stage_store(const float4 (&reg)[NV], float* __restrict__ lds, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (KC) {
-      int r = (tid >> 3) + 32 * i;
-      int k = (tid & 7) * 4;
+      int r = (tid / KC_LPR) + KC_RPP * i;
+      int k = (tid % KC_LPR) * 4;
       lds[(k + 0) * LDS_KC + r] = reg[i].x;
       lds[(k + 1) * LDS_KC + r] = reg[i].y;
       lds[(k + 2) * LDS_KC + r] = reg[i].z;
@@ -140,12 +150,15 @@ __device__ __forceinline__ void stage_store(const float4 (&reg)[4], float* __res
 }
 
 template <bool A_KC, bool B_KC, bool MASK, bool ATOMIC>
-__global__ __launch_bounds__(NT, 3) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int SA = A_KC ? LDS_KC : LDS_MC;
   constexpr int SB = B_KC ? LDS_KC : LDS_MC;
-  // one LDS stage (33 KB) + register staging: 3 workgroups per CU (3 waves / SIMD) hide the
-  // barrier + global-load latency better than a double-buffered 66 KB stage at 2 per CU
-  // (PMC: MFMA pipe 65 % busy, 22-57 % of wave cycles parked in s_waitcnt/barrier at 2 per CU).
+  // one small LDS stage (BK = 16: 16.5 KB, 8 staging VGPRs per operand) + register staging keeps the
+  // kernel under 128 VGPRs: 4 workgroups per CU (4 waves / SIMD) hide the barrier + global-load
+  // latency.  Measured on MI355X (tools/microbench.py, 65536x512x992 fwd / masked dX / masked dW, TF/s):
+  //   BK 32 double-buffered, 2 WG/CU:  93 / 53 / 52   (PMC: MFMA pipe 65 % busy, 22-57 % of wave cycles parked)
+  //   BK 32 single stage,    3 WG/CU: 101 / 85 / 72   BK 64, 2 WG/CU: 94 / 72 / 71
+  //   BK 16 single stage,    4 WG/CU:  97 / 97 / 86   <- this build
   __shared__ __attribute__((aligned(16))) float lds[BK * SA + BK * SB];
   float* As = lds;
   float* Bs = lds + BK * SA;
@@ -184,8 +197,8 @@ __global__ __launch_bounds__(NT, 3) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[4], rb[4];
-  uint32_t rm[4];
+  float4 ra[NV], rb[NV];
+  uint32_t rm[NV];
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (nk > 0) {
     stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid);
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_f32_kernel(GemmArgs g) {
     stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid);
     if (do_colsum) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+      for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
     }
     stage_store<A_KC>(ra, As, tid);
     stage_store<B_KC>(rb, Bs, tid);
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_f32_kernel(GemmArgs g) {
       if (MASK) apply_bits(ra, rm, g.ascale);
       if (do_colsum) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+        for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
       }
       stage_store<A_KC>(ra, As, tid);
       stage_store<B_KC>(rb, Bs, tid);
