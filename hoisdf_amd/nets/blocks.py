@@ -204,10 +204,21 @@ class TransformerDecoder(nn.Module):
         return torch.stack(outs)                 # (L,B,Q,D)
 
 
+_MASK_CACHE = {}
+
+
 def _mask_to_u8(mask: Optional[torch.Tensor], nq: int, device) -> torch.Tensor:
-    if mask is None:
-        return torch.zeros(nq, nq, dtype=torch.uint8, device=device)
-    return mask.to(device=device, dtype=torch.uint8).contiguous()
+    """uint8 device copy of a (constant) boolean attention mask, uploaded once per (mask, device):
+    a per-step host->device copy of pageable memory would synchronise the host with the stream."""
+    key = (None if mask is None else mask.cpu().numpy().tobytes(), nq, str(device))
+    m = _MASK_CACHE.get(key)
+    if m is None:
+        if mask is None:
+            m = torch.zeros(nq, nq, dtype=torch.uint8, device=device)
+        else:
+            m = mask.to(dtype=torch.uint8).contiguous().to(device)
+        _MASK_CACHE[key] = m
+    return m
 
 
 def _kv_len_from_memory_mask(memory_mask: Optional[torch.Tensor], S: int) -> int:

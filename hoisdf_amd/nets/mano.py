@@ -65,13 +65,18 @@ class ManoLayer(nn.Module):
         assets = synthetic_assets() if assets is None else assets
         for k, v in assets.items():
             self.register_buffer(k, v.clone())
+        # constants live on the device with the module (no per-call host->device copies = no host syncs)
+        self.register_buffer("_eye3", torch.eye(3), persistent=False)
+        self.register_buffer("_bottom", torch.tensor([[0.0, 0, 0, 1]]), persistent=False)
+        self.register_buffer("_tip_idx", torch.tensor(_TIP_VERTS, dtype=torch.long), persistent=False)
+        self.register_buffer("_joint_idx", torch.tensor(_JOINT_ORDER, dtype=torch.long), persistent=False)
         self.center_idx = center_idx
 
     def forward(self, th_pose_coeffs: torch.Tensor, th_betas: torch.Tensor):
         B = th_pose_coeffs.shape[0]
         full = torch.cat([th_pose_coeffs[:, :3], self.th_hands_mean + th_pose_coeffs[:, 3:48]], 1)
         R = axis_angle_to_matrix(full.reshape(-1, 3)).view(B, 16, 3, 3)
-        eye = torch.eye(3, dtype=R.dtype, device=R.device)
+        eye = self._eye3
         pose_map = (R[:, 1:] - eye).reshape(B, 135)
 
         v_shaped = torch.einsum("vck,bk->bvc", self.th_shapedirs, th_betas) + self.th_v_template
@@ -79,7 +84,7 @@ class ManoLayer(nn.Module):
         v_posed = v_shaped + torch.einsum("vck,bk->bvc", self.th_posedirs, pose_map)
 
         # forward kinematics: world transform of every joint
-        bottom = torch.tensor([0.0, 0, 0, 1], dtype=R.dtype, device=R.device).expand(B, 1, 4)
+        bottom = self._bottom.expand(B, 1, 4)
         G = []
         for j, par in enumerate(_PARENTS):
             t = J[:, j] if par < 0 else J[:, j] - J[:, par]
@@ -93,7 +98,7 @@ class ManoLayer(nn.Module):
         T = torch.einsum("vj,bjrc->bvrc", self.th_weights, A)       # (B,778,3,4)
         verts = torch.matmul(T[..., :3], v_posed.unsqueeze(3)).squeeze(3) + T[..., 3]
 
-        jtr = torch.cat([G[:, :, :3, 3], verts[:, _TIP_VERTS]], 1)[:, _JOINT_ORDER]
+        jtr = torch.cat([G[:, :, :3, 3], verts.index_select(1, self._tip_idx)], 1).index_select(1, self._joint_idx)
         if self.center_idx is not None:
             c = jtr[:, self.center_idx].unsqueeze(1)
             jtr = jtr - c
