@@ -195,6 +195,21 @@ def main():
                            "avg_launch_us": round(ks[dom]["avg_us"], 2),
                            "launches_per_step": ks[dom]["launches"] / args.steps,
                            "algorithmic_gflop_per_launch": round(ks[dom]["gflop"] / ks[dom]["launches"], 3)}
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate
+        # passes; tools/pmc_attn.py / tools/pmc_gemm.py at the bench shapes; summaries in profiles/)
+        try:
+            tr = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            fam = {"hoisdf_attention_bwd": ["hoisdf::attn_delta_kernel", "hoisdf::attn_bwd_dkv_kernel",
+                                            "hoisdf::attn_bwd_dq_kernel"],
+                   "hoisdf_attention_fwd": ["hoisdf::attn_fwd_kernel"],
+                   "hoisdf_linear_fwd": ["hoisdf::gemm_f32_kernel<true, true, false, false>"],
+                   "hoisdf_linear_bwd_input": ["hoisdf::gemm_f32_kernel<true, false, true, false>"],
+                   "hoisdf_linear_bwd_weight": ["hoisdf::gemm_f32_kernel<false, false, false, true>"]}[dom]
+            res["roofline"]["traffic"] = int(sum(tr[k]["hbm_bytes_per_launch"] for k in fam))
+            res["roofline"]["traffic_note"] = ("PMC bytes of one launch at the largest shape of this family "
+                                               "(self-attention B=32,S=2048 / linear 65536x512x992)")
+        except Exception:
+            pass
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / args.steps, 3), "tflops": round(v["tflops"], 2),
                               "launches_per_step": v["launches"] / args.steps, "avg_us": round(v["avg_us"], 2)}
                           for n, v in ks.items()}
