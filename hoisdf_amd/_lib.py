@@ -64,6 +64,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_vote_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hoisdf_vote_loss_fwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long)}

@@ -27,12 +27,13 @@ class JointvoteLoss(nn.Module):
             hand_off = hand_off.permute(0, 2, 1, 3)
             hand_cls = hand_cls.permute(0, 2, 1, 3)
         L, B, P, J = hand_cls.shape
-        joints = ops.vote_aggregate(hand_off, hand_cls, hand_points)                     # HIP, K12
-        vote = hand_points[None, :, :, None, :] + hand_off.reshape(L, B, P, J, 3)
-        near = ((hand_points[:, :, None, :] - joint_gt[:, None] / 1000).norm(dim=-1) < self.hand_cls_dist).float()
-        l3d = F.smooth_l1_loss(vote * 1000, joint_gt[None, :, None].expand(L, B, P, J, 3), reduction="none")
-        l3d = (l3d * near[None, ..., None]).sum((1, 2, 3)) / near.sum()
-        lcls = F.binary_cross_entropy_with_logits(hand_cls, near[None].expand(L, B, P, J))
+        # one HIP pass: joints + the masked SmoothL1 / BCE / near-count reductions (K12); the three scalars
+        # below are means of those (L,B)-sized sums
+        joints, l3d_sum, bce_sum, near_sum = ops.vote_loss(hand_off, hand_cls, hand_points, joint_gt,
+                                                           self.hand_cls_dist)
+        # the reference sums over (b, p, j), divides by near.sum() and then averages over (l, xyz)
+        l3d = l3d_sum.sum(1) / near_sum.sum() / 3.0
+        lcls = bce_sum.sum() / float(L * B * P * J)
         lall = F.smooth_l1_loss(joints * 1000, joint_gt[None].expand(L, B, J, 3))
         return l3d.mean(), lcls, lall, joints
 

@@ -520,3 +520,40 @@ class _Vote(torch.autograd.Function):
 def vote_aggregate(off, cls, pts):
     """K12: joints[l,b,j] = sum_p softmax_p(cls)[p] (pts[p] + off[p,j])."""
     return _Vote.apply(off, cls, pts)
+
+
+class _VoteLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, off, cls, pts, gt_mm, radius):
+        off, cls, pts, gt_mm = off.contiguous(), cls.contiguous(), pts.contiguous(), gt_mm.contiguous()
+        _chk(off, cls, pts, gt_mm)
+        L, B, P, J = cls.shape
+        dev = off.device
+        joints = torch.empty(L, B, J, 3, device=dev, dtype=torch.float32)
+        stats = torch.empty(L, B, J, 2, device=dev, dtype=torch.float32)
+        l3d = torch.empty(L, B, device=dev, dtype=torch.float32)
+        bce = torch.empty(L, B, device=dev, dtype=torch.float32)
+        near = torch.empty(B, device=dev, dtype=torch.float32)
+        call("hoisdf_vote_loss_fwd", _p(off), _p(cls), _p(pts), _p(gt_mm), float(radius), _p(joints), _p(stats), _p(l3d),
+             _p(bce), _p(near), L, B, P, J, _st())
+        ctx.save_for_backward(off, cls, pts, gt_mm, joints, stats)
+        ctx.radius = float(radius)
+        ctx.mark_non_differentiable(near)
+        return joints, l3d, bce, near
+
+    @staticmethod
+    def backward(ctx, dj, dl3d, dbce, _dnear):
+        off, cls, pts, gt_mm, joints, stats = ctx.saved_tensors
+        L, B, P, J = cls.shape
+        doff = torch.empty_like(off)
+        dcls = torch.empty_like(cls)
+        c = lambda t: None if t is None else t.contiguous()
+        dj, dl3d, dbce = c(dj), c(dl3d), c(dbce)
+        call("hoisdf_vote_loss_bwd", _p(off), _p(cls), _p(pts), _p(gt_mm), ctx.radius, _p(joints), _p(stats), _p(dj),
+             _p(dl3d), _p(dbce), _p(doff), _p(dcls), L, B, P, J, _st())
+        return doff, dcls, None, None, None
+
+
+def vote_loss(off, cls, pts, gt_mm, radius: float):
+    """K12 + the JointvoteLoss reductions: -> joints (L,B,J,3), l3d_sum (L,B), bce_sum (L,B), near_sum (B)."""
+    return _VoteLoss.apply(off, cls, pts, gt_mm, radius)

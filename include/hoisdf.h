@@ -220,6 +220,21 @@ int hoisdf_vote_bwd(const float* off, const float* cls, const float* pts, const 
                     const float* stats, const float* djoints, float* doff, float* dcls, int L, int B,
                     int P, int J, void* stream);
 
+/* K12 with the three JointvoteLoss reductions fused (common/nets/loss.py:31-56): besides joints / stats
+ * (as hoisdf_vote_fwd) one pass writes, per (l, b):
+ *   l3d_sum [L][B] = sum_{p,j,d} smooth_l1(1000*(pts+off) - gt_mm) * near,   near = ||pts - gt_mm/1000|| < radius
+ *   bce_sum [L][B] = sum_{p,j} binary_cross_entropy_with_logits(cls, near);  near_sum [B] = sum_{p,j} near.
+ * The reference's scalars are loss_joint_3d = mean_l(sum_b l3d_sum / sum_b near_sum) / 3,
+ * loss_joint_cls = sum(bce_sum) / (L*B*P*J).  The backward takes d(loss)/d(l3d_sum), d/d(bce_sum) [L][B]
+ * and d/d(joints) [L][B][J][3] (any of them may be NULL = zero). */
+int hoisdf_vote_loss_fwd(const float* off, const float* cls, const float* pts, const float* joint_gt_mm,
+                         float radius, float* joints, float* stats, float* l3d_sum, float* bce_sum,
+                         float* near_sum, int L, int B, int P, int J, void* stream);
+int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, const float* joint_gt_mm,
+                         float radius, const float* joints, const float* stats, const float* djoints,
+                         const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
+                         int B, int P, int J, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -362,3 +362,25 @@ def test_errors_are_reported_not_swallowed():
         _lib.call("hoisdf_linear_fwd", None, 4, None, 4, None, None, 4, 8, 4, 4, 0, 0.0, 0, None, None)
     with pytest.raises(RuntimeError):
         O.linear(torch.zeros(4, 4), torch.zeros(4, 4))               # CPU tensors: no fallback
+
+
+def test_vote_loss_fused_matches_reference_loss():
+    """K12 + JointvoteLoss reductions (common/nets/loss.py:31-56) vs the oracle's joint_vote, fwd + bwd."""
+    O, R = ops(), oracle()
+    L, B, P, J = 3, 2, 130, 20
+    pts = rnd(B, P, 3, seed=70) * 0.05
+    gt = pts[:, :J] * 1000 + rnd(B, J, 3, seed=71) * 15            # some points fall inside the 40 mm radius
+    off = (rnd(L, B, P, J * 3, seed=72) * 0.02).requires_grad_(True)
+    cls = rnd(L, B, P, J, seed=73).requires_grad_(True)
+    # oracle wants the reference's seq-first layout
+    l1, l2, l3, joints = R.joint_vote(pts, off.permute(0, 2, 1, 3), cls.permute(0, 2, 1, 3), gt, 0.04)
+    (0.3 * l1 + 0.7 * l2 + 0.5 * l3).backward()
+    og, cg = off.detach().to(DEV).requires_grad_(True), cls.detach().to(DEV).requires_grad_(True)
+    from hoisdf_amd.nets.heads import JointvoteLoss
+    m1, m2, m3, mj = JointvoteLoss(0.04)(pts.to(DEV), og, cg, gt.to(DEV), batch_first=True)
+    (0.3 * m1 + 0.7 * m2 + 0.5 * m3).backward()
+    assert_close(mj, joints, what="joints")
+    for a, b_, n in ((m1, l1, "loss_joint_3d"), (m2, l2, "loss_joint_cls"), (m3, l3, "loss_all_joint_3d")):
+        assert abs(float(a) - float(b_)) <= 2e-5 * abs(float(b_)) + 1e-6, (n, float(a), float(b_))
+    assert_close(og.grad, off.grad, rel=1e-4, what="doff")
+    assert_close(cg.grad, cls.grad, rel=1e-4, what="dcls")
