@@ -1,0 +1,187 @@
+"""Runtime harness with the reference's driver surface:
+
+  * ``Trainer`` / ``Tester``: same roles as common/base.py:59-193 - AdamW(lr=cfg.lr) +
+    StepLR(cfg.lr_drop, cfg.lr_decay_gamma), the 1e-5 learning-rate floor (base.py:30-32), the loss
+    weighting of main/train.py:113-127;
+  * checkpoints in the reference's on-disk format: ``snapshot_{epoch}_{iter}.pth.tar`` holding
+    {"epoch", "network", "optimizer", "lr_scheduler"} with every network key prefixed ``module.``
+    (the DataParallel prefix, common/base.py:113-150), resumed from the highest (epoch, iter);
+  * released reference checkpoints load with ``strict=True`` (state-dict schema checked against the
+    reference in tests/test_checkpoint_schema.py).
+Redesigned for MI355X: one process per GPU (torchrun), gradients reduced by
+``hoisdf_amd.ddp.GradReducer`` over RCCL instead of single-process ``nn.DataParallel``.
+Datasets are licence-gated and absent offline: ``SyntheticDataset`` yields DexYCB / HO3D shaped
+samples with the schema of data/dexycb.py:627-655; a real dataset object with the same
+``__getitem__`` contract can be passed instead.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import os.path as osp
+import re
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import testing as T
+from .config import Config
+from .ddp import GradReducer, reducible_parameters
+from .model import get_model
+
+LOSS_WEIGHTS = {  # main/train.py:115-127 <- cfg attribute
+    "sdfhand_loss": "sdf_hand_weight", "sdfobj_loss": "sdf_obj_weight", "joint_heatmap": "hm_weight",
+    "obj_seg": "obj_hm_weight", "hand_seg": "obj_hm_weight", "obj_rot": "obj_rot_weight",
+    "obj_trans": "obj_trans_weight", "loss_joint_3d": "joint_weight", "loss_joint_cls": "cls_weight",
+    "loss_all_joint_3d": "joint_weight"}
+
+
+def weighted_total(model_out: Dict[str, torch.Tensor], cfg: Config):
+    """main/train.py:111-138: split on the ``_out`` suffix, mean every loss, apply cfg weights, sum."""
+    out = {k[:-4]: v for k, v in model_out.items() if "_out" in k}
+    loss = {k: v.mean() for k, v in model_out.items() if "_out" not in k}
+    for k, attr in LOSS_WEIGHTS.items():
+        if k in loss:
+            loss[k] = loss[k] * getattr(cfg, attr)
+    return sum(loss.values()), loss, out
+
+
+def adjust_learning_rate(lr_scheduler, optimizer, floor: float = 1e-5):
+    """common/base.py:30-32."""
+    if lr_scheduler.get_last_lr()[-1] < floor:
+        for g in optimizer.param_groups:
+            g["lr"] = floor
+
+
+class SyntheticDataset(torch.utils.data.Dataset):
+    def __init__(self, cfg: Config, length: int = 64, seed: int = 0):
+        self.cfg, self.length, self.seed = cfg, length, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        ins, tg, mt = T.synthetic_batch(1, self.cfg.num_samp_hand, self.cfg.num_samp_obj, seed=self.seed * 100003 + i)
+        sq = lambda d: {k: v[0] for k, v in d.items()}
+        return sq(ins), sq(tg), sq(mt)
+
+
+def snapshot_path(model_dir: str, epoch: int, itr: int) -> str:
+    return osp.join(model_dir, f"snapshot_{epoch}_{itr}.pth.tar")
+
+
+def latest_snapshot(model_dir: str) -> Optional[Tuple[str, int, int]]:
+    """highest epoch, then highest iteration (common/base.py:121-142)."""
+    best = None
+    for f in glob.glob(osp.join(model_dir, "snapshot_*.pth.tar")):
+        m = re.search(r"snapshot_(\d+)_(\d+)\.pth\.tar$", f)
+        if m:
+            key = (int(m.group(1)), int(m.group(2)))
+            if best is None or key > best[1:]:
+                best = (f, *key)
+    return best
+
+
+def to_reference_state_dict(model: torch.nn.Module) -> Dict[str, torch.Tensor]:
+    return {"module." + k: v for k, v in model.state_dict().items()}
+
+
+def load_reference_state_dict(model: torch.nn.Module, network: Dict[str, torch.Tensor], strict: bool = True):
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in network.items()}
+    return model.load_state_dict(sd, strict=strict)
+
+
+class Trainer:
+    def __init__(self, cfg: Config, device: torch.device, dataset=None, batch_size: Optional[int] = None,
+                 channels_last: bool = True):
+        self.cfg, self.device = cfg, device
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        torch.manual_seed(0)
+        self.model = get_model("train", cfg=cfg).to(device).train()
+        if channels_last:
+            self.model.backbone_net.to(memory_format=torch.channels_last)
+            self.model.decoder_net.to(memory_format=torch.channels_last)
+        self.channels_last = channels_last
+        self.reducer = GradReducer(reducible_parameters(self.model))
+        # reference: AdamW over all named parameters in one group (common/base.py:64-73)
+        self.optimizer = torch.optim.AdamW([p for p in self.model.parameters() if p.requires_grad], lr=cfg.lr,
+                                           fused=device.type == "cuda")
+        self.lr_scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=cfg.lr_drop,
+                                                            gamma=cfg.lr_decay_gamma)
+        self.start_epoch = 0
+        ds = dataset if dataset is not None else SyntheticDataset(cfg, seed=self.rank)
+        bs = batch_size or cfg.train_batch_size
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, self.world, self.rank, shuffle=True) \
+            if self.world > 1 else None
+        self.batch_generator = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=sampler is None, sampler=sampler,
+                                                           num_workers=0, drop_last=True, pin_memory=True)
+        self.itr_per_epoch = len(self.batch_generator)
+
+    def train_step(self, inputs, targets, meta, epoch: int, batch_ratio: float):
+        dev = self.device
+        inputs, targets, meta = (T.to_device(x, dev) for x in (inputs, targets, meta))
+        if self.channels_last:
+            inputs["img"] = inputs["img"].contiguous(memory_format=torch.channels_last)
+        self.reducer.zero_grad()
+        out = self.model(inputs, targets, meta, "train", epoch, batch_ratio)
+        total, loss, _ = weighted_total(out, self.cfg)
+        total.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        return total.detach(), {k: v.detach() for k, v in loss.items()}
+
+    def save_model(self, epoch: int, itr: int) -> Optional[str]:
+        if self.rank != 0:
+            return None
+        os.makedirs(self.cfg.model_dir, exist_ok=True)
+        path = snapshot_path(self.cfg.model_dir, epoch, itr)
+        torch.save({"epoch": epoch, "network": to_reference_state_dict(self.model),
+                    "optimizer": self.optimizer.state_dict(), "lr_scheduler": self.lr_scheduler.state_dict()}, path)
+        return path
+
+    def load_model(self) -> int:
+        found = latest_snapshot(self.cfg.model_dir)
+        if found is None:
+            return 0
+        ckpt = torch.load(found[0], map_location=self.device)
+        load_reference_state_dict(self.model, ckpt["network"], strict=True)
+        self.optimizer.load_state_dict(ckpt["optimizer"])
+        self.lr_scheduler.load_state_dict(ckpt["lr_scheduler"])
+        self.start_epoch = ckpt["epoch"] + 1
+        return self.start_epoch
+
+
+class Tester:
+    def __init__(self, cfg: Config, device: torch.device, ckpt_path: Optional[str] = None):
+        self.cfg, self.device = cfg, device
+        self.model = get_model("test", cfg=cfg).to(device).eval()
+        if ckpt_path:
+            ckpt = torch.load(ckpt_path, map_location=device)
+            load_reference_state_dict(self.model, ckpt["network"], strict=True)
+
+    @torch.no_grad()
+    def predict(self, inputs, targets, meta):
+        inputs, targets, meta = (T.to_device(x, self.device) for x in (inputs, targets, meta))
+        return self.model(inputs, targets, meta, "eval")
+
+
+def mpjpe(pred: torch.Tensor, gt: torch.Tensor) -> float:
+    """mean per-joint position error (common/metrics.py:213-232), inputs (N,J,3)."""
+    return float((pred - gt).norm(dim=-1).mean())
+
+
+def pa_mpjpe(pred: torch.Tensor, gt: torch.Tensor) -> float:
+    """MPJPE after a per-sample similarity (Procrustes) alignment (common/metrics.py:188-232)."""
+    errs = []
+    for p, g in zip(pred.double().cpu(), gt.double().cpu()):
+        mp, mg = p.mean(0), g.mean(0)
+        p0, g0 = p - mp, g - mg
+        U, S, Vt = torch.linalg.svd(p0.T @ g0)
+        d = torch.sign(torch.linalg.det(U @ Vt))
+        D = torch.diag(torch.tensor([1.0, 1.0, float(d)], dtype=torch.float64))
+        R = U @ D @ Vt
+        s = (S * torch.diag(D)).sum() / (p0 ** 2).sum()
+        errs.append(float(((s * p0 @ R + mg) - g).norm(dim=-1).mean()))
+    return sum(errs) / max(len(errs), 1)

@@ -276,10 +276,25 @@ def mano_golden():
     save("g9_mano", pose=pose, betas=betas, verts=v, joints=j, x6=x6, R=Rm, aa=aa, R_back=Rg)
 
 
+def schema_golden():
+    """g10: the reference Model's state-dict schema (names + shapes) for the three variants - what a released
+    snapshot_*.pth.tar holds under ckpt["network"] (minus the DataParallel "module." prefix)."""
+    import json
+    out = {}
+    for setting, rt in (("dexycb", 50), ("ho3d", 50), ("ho3d_render", 50), ("dexycb", 18)):
+        model, cfg = build_reference(setting, 600, 200, 64, resnet_type=rt)
+        out[f"{setting}_resnet{cfg.resnet_type}"] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "g10_state_dict_schema.json"), "w") as f:
+        json.dump(out, f)
+    print("  wrote g10_state_dict_schema.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "mano"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema"]
+    if "schema" in which:
+        schema_golden()
     if "mano" in which:
         mano_golden()
     if "stage" in which:
