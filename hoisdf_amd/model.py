@@ -232,14 +232,16 @@ class Model(nn.Module):
                                   self.obj_sigmoid_beta, 0)
 
         tgt_mask = None if c.use_inverse_kinematics else get_mano_tgt_mask(c)         # :564-569
+        # Only rows < nh (hand stream) / < no (object stream) of the encoder outputs are ever read (:587-593 and
+        # the memory mask), so the last layer of each stack skips the other query rows - same values, less work.
         hs, memory, hand_enc = self.hand_transformer.forward_batch_first(
-            hand_tok, self.mano_query_embed.weight, tgt_mask, nh)                      # :571-581
-        _, obj_enc = self.obj_transformer.forward_batch_first(obj_tok)                 # :582-584
+            hand_tok, self.mano_query_embed.weight, tgt_mask, nh, n_keep=nh)           # :571-581
+        _, obj_enc = self.obj_transformer.forward_batch_first(obj_tok, n_keep=no)      # :582-584
 
-        hand_off = self.linear_handvote(hand_enc[:, :, :nh])                           # :587-593 (L,B,nh,60)
-        hand_cls = self.linear_handcls(hand_enc[:, :, :nh])
-        obj_rot = self.linear_obj_rot(obj_enc[:, :, :no])                              # (L,B,no,3)
-        obj_trans = self.linear_obj_rel_trans(obj_enc[:, :, :no])
+        hand_off = self.linear_handvote(hand_enc)                                      # :587-593 (L,B,nh,60)
+        hand_cls = self.linear_handcls(hand_enc)
+        obj_rot = self.linear_obj_rot(obj_enc)                                         # (L,B,no,3)
+        obj_trans = self.linear_obj_rel_trans(obj_enc)
 
         pred_m = gt_m = None
         if c.use_inverse_kinematics:                                                   # :595-597

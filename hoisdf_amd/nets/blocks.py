@@ -120,13 +120,23 @@ class TransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.p = dropout
 
-    def forward(self, x):
+    def forward(self, x, n_query=None):
         """post-norm layer on batch-first tokens (B,S,D); pos embedding is identically zero on
-        this path (main/model.py:542-562)."""
+        this path (main/model.py:542-562).  ``n_query``: only the first n_query rows are produced
+        (all S rows still act as keys/values) - used for the last layer of a stack, whose other rows
+        nothing downstream reads (heads use rows < num_samp_*, the decoder masks keys >= num_samp_hand)."""
         p = self.p if self.training else 0.0
         a = self.self_attn
-        qkv = ops.linear(x, a.in_proj_weight, a.in_proj_bias)
-        o = ops.attention_self(qkv, a.num_heads, drop_p=p)
+        E = x.shape[-1]
+        if n_query is None or n_query >= x.shape[1]:
+            qkv = ops.linear(x, a.in_proj_weight, a.in_proj_bias)
+            o = ops.attention_self(qkv, a.num_heads, drop_p=p)
+        else:
+            xq = x[:, :n_query].contiguous()
+            q = ops.linear(xq, a.in_proj_weight[:E], a.in_proj_bias[:E])
+            kv = ops.linear(x, a.in_proj_weight[E:], a.in_proj_bias[E:])
+            o = ops.attention_cross(q, kv, a.num_heads, drop_p=p)
+            x = xq
         o = ops.linear(o, a.out_proj.weight, a.out_proj.bias)
         x = ops.add_layernorm(x, o, self.norm1.weight, self.norm1.bias, self.norm1.eps, p)
         h = ops.linear(x, self.linear1.weight, self.linear1.bias, act=True, drop_p=p)
@@ -143,13 +153,17 @@ class TransformerEncoder(nn.Module):
         self.norm = None
         self.num_layers = num_layers
 
-    def forward(self, x):
+    def forward(self, x, n_keep=None):
+        """``n_keep``: the caller only reads rows < n_keep of the outputs -> the last layer computes only
+        those rows and every returned tensor is cut to n_keep rows (results for those rows are unchanged)."""
         inter = []
         n = self.inter_norm
-        for layer in self.layers:
-            x = layer(x)
-            inter.append(ops.add_layernorm(x, None, n.weight, n.bias, n.eps))
-        return x, torch.stack(inter)            # memory (B,S,D), intermediates (L,B,S,D)
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            x = layer(x, n_keep if i == last else None)
+            y = ops.add_layernorm(x, None, n.weight, n.bias, n.eps)
+            inter.append(y if n_keep is None or y.shape[1] == n_keep else y[:, :n_keep])
+        return x, torch.stack(inter)            # memory (B,S|n_keep,D), intermediates (L,B,S|n_keep,D)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -250,8 +264,8 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward_batch_first(self, tokens, query_embed, tgt_mask, kv_len):
-        memory, inter = self.encoder(tokens)
+    def forward_batch_first(self, tokens, query_embed, tgt_mask, kv_len, n_keep=None):
+        memory, inter = self.encoder(tokens, n_keep)
         hs = self.decoder(memory, query_embed, _mask_to_u8(tgt_mask, query_embed.shape[0], tokens.device), kv_len)
         return hs, memory, inter
 
@@ -277,8 +291,8 @@ class VoteTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward_batch_first(self, tokens):
-        return self.encoder(tokens)
+    def forward_batch_first(self, tokens, n_keep=None):
+        return self.encoder(tokens, n_keep)
 
     def forward(self, src, mask, pos_embed, src_mask=None):
         assert mask is None and src_mask is None
