@@ -384,3 +384,31 @@ def test_vote_loss_fused_matches_reference_loss():
         assert abs(float(a) - float(b_)) <= 2e-5 * abs(float(b_)) + 1e-6, (n, float(a), float(b_))
     assert_close(og.grad, off.grad, rel=1e-4, what="doff")
     assert_close(cg.grad, cls.grad, rel=1e-4, what="dcls")
+
+
+def test_edge_cases_empty_and_ragged():
+    """empty batches are no-ops, ragged per-row sample indices gather from the right sample, kv_len = 1 works."""
+    O, R = ops(), oracle()
+    # empty linear
+    y = O.linear(torch.zeros(0, 16, device=DEV), torch.zeros(8, 16, device=DEV), torch.zeros(8, device=DEV))
+    assert y.shape == (0, 8)
+    # ragged gather: rows of sample 1 first, then sample 0 (what sdf_infer's compaction produces per sample)
+    B = 2
+    pyr = T.synthetic_pyramid(B, seed=9, nonneg=False)
+    levels = [v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in pyr.values()]
+    _, _, meta = T.synthetic_batch(B, 8, 8, seed=90)
+    pts = rnd(7, 3, seed=91)
+    sidx = torch.tensor([1, 1, 1, 0, 0, 1, 0], dtype=torch.int32)
+    feat, _ = O.project_gather(O.PyramidNHWC(levels), pts.to(DEV), meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV),
+                               3.1, sample_idx=sidx.to(DEV))
+    for i in range(7):
+        b = int(sidx[i])
+        _, grid = R.project_points(pts[i][None, None], meta["mano_root"][b:b + 1], meta["cam_intr"][b:b + 1], 3.1)
+        ref = R.sample_pyramid({k: v[b:b + 1] for k, v in pyr.items()}, grid, list(pyr))
+        assert_close(feat[i], ref[0, 0], what=f"ragged row {i}")
+    # a single visible key: softmax is 1 on it, output = its value row
+    E, H = 256, 4
+    q = rnd(1, 5, E, seed=92).to(DEV)
+    kv = rnd(1, 9, 2 * E, seed=93).to(DEV)
+    o = O.attention_cross(q, kv, H, kv_len=1)
+    assert_close(o, kv[:, :1, E:].expand(1, 5, E), rel=1e-6, what="kv_len=1")
