@@ -412,7 +412,7 @@ using namespace hoisdf;
 extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ldw, const float* bias,
                                  float* y, int ldy, long M, int N, int K, int act, float drop_p,
                                  uint64_t seed, uint32_t* relu_bits, void* stream) {
-  HOISDF_REQUIRE(x && W && y, HOISDF_ERR_INVALID, "linear_fwd: null pointer");
+  HOISDF_REQUIRE(M == 0 || (x && W && y), HOISDF_ERR_INVALID, "linear_fwd: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, HOISDF_ERR_INVALID,
                  "linear_fwd: bad sizes M=%ld N=%d K=%d ldx=%d ldw=%d ldy=%d", M, N, K, ldx, ldw, ldy);
   HOISDF_REQUIRE(drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "linear_fwd: drop_p=%f", drop_p);
@@ -430,7 +430,7 @@ extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ld
 extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                        const float* W, int ldw, float* dx, int lddx, long M, int N, int K,
                                        void* stream) {
-  HOISDF_REQUIRE(dy && W && dx, HOISDF_ERR_INVALID, "linear_bwd_input: null pointer");
+  HOISDF_REQUIRE(M == 0 || (dy && W && dx), HOISDF_ERR_INVALID, "linear_bwd_input: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && M < (1L << 31) &&
                      drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_input: bad sizes");
@@ -455,7 +455,7 @@ extern "C" long hoisdf_linear_bwd_weight_workspace(long M, int N, int K) {
 extern "C" int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                         const float* x, int ldx, float* dW, int lddw, float* db, long M, int N,
                                         int K, float* workspace, long workspace_floats, void* stream) {
-  HOISDF_REQUIRE(dy && x && dW, HOISDF_ERR_INVALID, "linear_bwd_weight: null pointer");
+  HOISDF_REQUIRE(dW && (M == 0 || (dy && x)), HOISDF_ERR_INVALID, "linear_bwd_weight: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K && M < (1L << 31) &&
                      drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_weight: bad sizes");
