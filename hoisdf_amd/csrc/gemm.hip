@@ -60,6 +60,22 @@ struct GemmArgs {
 template <bool KC>
 __device__ __forceinline__ void stage_load(float4 (&reg)[NV], const float* __restrict__ src, int ld,
                                            int r0, int R, int k0, int kend, int vec, int tid) {
+  // Fast path (wave-uniform test): 16-byte aligned rows and the whole k-range of the tile in bounds.
+  // k-contiguous: out-of-range rows are clamped to the last valid one (their products only reach
+  // output rows that are never stored); r-contiguous: the tile must be row-interior.
+  const bool fast = vec && (k0 + BK <= kend) && (KC ? (R > 0) : (r0 + BM <= R));
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (KC) {
+        const int r = min(r0 + (tid / KC_LPR) + KC_RPP * i, R - 1);
+        reg[i] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + k0 + (tid % KC_LPR) * 4);
+      } else {
+        reg[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + (tid >> 5) + 8 * i) * ld + r0 + (tid & 31) * 4);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -398,7 +414,11 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, int ldy, co
 static void plan_splitk(long M, int N, int K, int& splitk, int& kper) {
   int tiles = cdiv(N, BM) * cdiv(K, BN);
   int ksteps = cdiv(M, BK);
-  int want = tiles >= 1024 ? 1 : cdiv(1024, tiles);
+  // fewer, longer k-slices when the output is only a few tiles: every slice adds its whole tile with
+  // device-scope atomics, and below ~1 slice per CU-slot that traffic outweighs the occupancy
+  // (MI355X sweep, tools/microbench.py: 256x256 213 -> 162 us, 768x256 378 -> 306 us, >= 16 tiles unchanged)
+  const int target = tiles <= 4 ? 512 : (tiles <= 12 ? 768 : 1024);
+  int want = tiles >= target ? 1 : cdiv(target, tiles);
   splitk = want < 1 ? 1 : want;
   if (splitk > ksteps / 4) splitk = ksteps / 4 > 0 ? ksteps / 4 : 1;   // >= 4 k-tiles per split
   kper = cdiv(ksteps, splitk) * BK;
