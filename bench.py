@@ -188,7 +188,7 @@ def main():
                  "hoisdf_linear_bwd_input": "gemm_f32_kernel<1,0> (linear grad-input)",
                  "hoisdf_linear_bwd_weight": "gemm_f32_kernel<0,0> (linear grad-weight + fused bias grad)",
                  "hoisdf_attention_fwd": "attn_fwd_kernel",
-                 "hoisdf_attention_bwd": "attn_delta + attn_bwd_dkv + attn_bwd_dq"}[dom]
+                 "hoisdf_attention_bwd": "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)"}[dom]
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ks[dom]["tflops"], 2),
                            "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ks[dom]["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": None,
@@ -199,8 +199,7 @@ def main():
         # passes; tools/pmc_attn.py / tools/pmc_gemm.py at the bench shapes; summaries in profiles/)
         try:
             tr = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-            fam = {"hoisdf_attention_bwd": ["hoisdf::attn_delta_kernel", "hoisdf::attn_bwd_dkv_kernel",
-                                            "hoisdf::attn_bwd_dq_kernel"],
+            fam = {"hoisdf_attention_bwd": ["hoisdf::attn_delta_kernel", "hoisdf::attn_bwd_fused_kernel"],
                    "hoisdf_attention_fwd": ["hoisdf::attn_fwd_kernel"],
                    "hoisdf_linear_fwd": ["hoisdf::gemm_f32_kernel<true, true, false, false>"],
                    "hoisdf_linear_bwd_input": ["hoisdf::gemm_f32_kernel<true, false, true, false>"],

@@ -15,6 +15,7 @@
 //              instead of 5) instead of atomics on dQ: deterministic, no 2 GB/layer of atomics.
 // LDS tiles are row-major with a 68-float pitch: ds_read_b128 of 4 consecutive d for 16 keys
 // of a lane group lands on 16 distinct 4-bank slots; b32 column reads are lane-consecutive.
+#include <cstdlib>
 #include "common.h"
 
 namespace hoisdf {
@@ -356,6 +357,162 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 // ============================================================================================
+// backward, fused dK / dV / dQ (5 GEMM-equivalents instead of 7): same key-owner decomposition as the
+// dK/dV kernel; in addition every wave drops its dS block into a shared LDS tile T[32 q][128 keys] and,
+// after one more barrier, each wave contracts T with the block's K slab over all 128 keys for its own
+// 16-wide slice of d (two 16x16x4 MFMA tiles), so the 32 x 64 dQ tile of the block is complete in
+// registers and leaves with one float atomic per element (dq pre-zeroed by the host entry; measured
+// 0.1 ms per 2048-token layer).  K lives in an LDS slab (B operand of S and of dQ), V in registers.
+// LDS 69.4 KB -> 2 workgroups / CU.  The dQ summation order over key blocks is not fixed (atomics).
+// (An LDS-atomic reduction of per-wave partial dQ tiles was 2.5x slower: ds_add_f32 ~0.4 lanes/clk.)
+// ============================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TP = 132;       // pitch of the block's dS tile T[32 q][128 keys] (= 4 mod 32: 2 lanes / bank)
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 32 * PITCH + 64 + 128 * PITCH + 32 * TP];
+  float* Qs = lds;                          // [32][PITCH] query tile
+  float* Ds = lds + 32 * PITCH;             // [32][PITCH] dO tile
+  float* Ls = lds + 2 * 32 * PITCH;         // lse[32]
+  float* Es = Ls + 32;                      // delta[32]
+  float* Kall = Es + 32;                    // [128][PITCH] this block's keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Kw = Kall + wave * 32 * PITCH;     // this wave's K rows
+  float* Ts = Kall + 128 * PITCH;           // [32 q][TP] dS of the whole block
+  const int h = lane >> 5, c = lane & 31;
+  int ktile, bh;
+  if (!attn_block((a.Lk + 127) / 128, a.B * a.H, ktile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int key = ktile * 128 + wave * 32 + c;
+  const bool kvalid = key < a.kv_len;
+  const float* qb = a.q + (size_t)b * a.Lq * a.ldq + head * DH;
+  const float* dob = a.dout + (size_t)b * a.Lq * a.lddo + head * DH;
+  float* dqb = a.dq + (size_t)b * a.Lq * a.ldq + head * DH;
+
+  float vf[32];
+  {
+    float4 t[8], u[8];
+    if (kvalid) {
+      const float4* pk = reinterpret_cast<const float4*>(a.k + ((size_t)b * a.Lk + key) * a.ldk + head * DH + 32 * h);
+      const float4* pv = reinterpret_cast<const float4*>(a.v + ((size_t)b * a.Lk + key) * a.ldv + head * DH + 32 * h);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = pk[i]; u[i] = pv[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = make_float4(0, 0, 0, 0); u[i] = make_float4(0, 0, 0, 0); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      vf[4 * i + 0] = u[i].x; vf[4 * i + 1] = u[i].y; vf[4 * i + 2] = u[i].z; vf[4 * i + 3] = u[i].w;
+      *reinterpret_cast<float4*>(&Kw[c * PITCH + 32 * h + 4 * i]) = t[i];
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  const bool block_active = ktile * 128 < a.kv_len;
+  const int nq = block_active ? (a.Lq + 31) / 32 : 0;
+  float4 rq[2], rd[2];
+  float rl = INFINITY, re = 0.f;
+  if (nq > 0) {
+    tile_load<2>(rq, qb, a.ldq, 0, a.Lq, tid);
+    tile_load<2>(rd, dob, a.lddo, 0, a.Lq, tid);
+    if (tid < 32 && tid < a.Lq) { rl = a.lse_in[(size_t)bh * a.Lq + tid]; re = a.delta_in[(size_t)bh * a.Lq + tid]; }
+  }
+  for (int qt = 0; qt < nq; ++qt) {
+    __syncthreads();                       // previous tile's readers are done (also orders the K slab / R writes)
+    tile_store<2>(rq, Qs, tid);
+    tile_store<2>(rd, Ds, tid);
+    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+    // S = Q.K^T and dP = dO.V^T  (rows = queries, cols = this lane's key)
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+      const float4 qq = *reinterpret_cast<const float4*>(&Qs[c * PITCH + 32 * h + 4 * c4]);
+      const float4 dd = *reinterpret_cast<const float4*>(&Ds[c * PITCH + 32 * h + 4 * c4]);
+      const float4 kk = *reinterpret_cast<const float4*>(&Kw[c * PITCH + 32 * h + 4 * c4]);
+      s = MFMA(qq.x, kk.x, s);  dp = MFMA(dd.x, vf[4 * c4 + 0], dp);
+      s = MFMA(qq.y, kk.y, s);  dp = MFMA(dd.y, vf[4 * c4 + 1], dp);
+      s = MFMA(qq.z, kk.z, s);  dp = MFMA(dd.z, vf[4 * c4 + 2], dp);
+      s = MFMA(qq.w, kk.w, s);  dp = MFMA(dd.w, vf[4 * c4 + 3], dp);
+    }
+    // P (dropped) and dS, in place: s <- Pd, dp <- dS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = CROW(r, h);
+      const float p = kvalid ? EXP2(s[r] * QSCALE2 - Ls[ql]) : 0.f;
+      float dscale = 1.f;
+      if (a.drop_p > 0.f)
+        dscale = drop_scale(drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)), (uint32_t)key,
+                            a.thresh, a.inv_keep);
+      s[r] = p * dscale;
+      dp[r] = p * (dp[r] * dscale - Es[ql]);
+    }
+    if (qt + 1 < nq) {                     // prefetch the next tile; issued after the S/dP phase (register peak), lands during the 96 MFMAs below
+      tile_load<2>(rq, qb, a.ldq, (qt + 1) * 32, a.Lq, tid);
+      tile_load<2>(rd, dob, a.lddo, (qt + 1) * 32, a.Lq, tid);
+      if (tid < 32) {
+        const int q = (qt + 1) * 32 + tid;
+        rl = q < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q] : INFINITY;
+        re = q < a.Lq ? a.delta_in[(size_t)bh * a.Lq + q] : 0.f;
+      }
+    }
+    // dV^T += dO^T . Pd ; dK^T += Q^T . dS   (A from LDS with d along lanes, B from registers)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* dr = &Ds[CROW(r, h) * PITCH + c];
+      const float* qr = &Qs[CROW(r, h) * PITCH + c];
+      dv[0] = MFMA(dr[0], s[r], dv[0]);
+      dv[1] = MFMA(dr[32], s[r], dv[1]);
+      dk[0] = MFMA(qr[0], dp[r], dk[0]);
+      dk[1] = MFMA(qr[32], dp[r], dk[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ts[CROW(r, h) * TP + wave * 32 + c] = dp[r];     // dS[q][key] of this wave's keys
+    __syncthreads();
+    // dQ[q][d0..d0+15] = sum over the block's 128 keys of dS[q][key] K[key][d]  (16x16x4 MFMA: lane l supplies
+    // A[row l%16][k l/16] and B[k l/16][col l%16], holds C[rows 4*(l/16)..+3][col l%16])
+    {
+      const int l16 = lane & 15, kq = lane >> 4;
+      f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+      const float* tp = Ts + l16 * TP + kq;
+      const float* kp = Kall + kq * PITCH + wave * 16 + l16;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        const float bv = kp[4 * j * PITCH];
+        q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tp[4 * j], bv, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tp[16 * TP + 4 * j], bv, q1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qa = qt * 32 + 4 * kq + i, qb2 = qa + 16;
+        if (qa < a.Lq) atomicAdd(dqb + (size_t)qa * a.ldq + wave * 16 + l16, q0[i] * 0.125f);
+        if (qb2 < a.Lq) atomicAdd(dqb + (size_t)qb2 * a.ldq + wave * 16 + l16, q1[i] * 0.125f);
+      }
+    }
+  }
+  if (key < a.Lk) {
+    float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * DH;
+    float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * DH;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(pk + 32 * t + 8 * g + 4 * h) =
+            make_float4(dk[t][4 * g + 0] * 0.125f, dk[t][4 * g + 1] * 0.125f, dk[t][4 * g + 2] * 0.125f,
+                        dk[t][4 * g + 3] * 0.125f);
+        *reinterpret_cast<float4*>(pv + 32 * t + 8 * g + 4 * h) =
+            make_float4(dv[t][4 * g + 0], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
+      }
+  }
+}
+
+// ============================================================================================
 // backward, dQ: block = 128 queries (4 waves x 32); loops over 32-key tiles (prefetched)
 // ============================================================================================
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -574,6 +731,14 @@ extern "C" int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, a, delta);
   if (int rc = check_launch("attention_delta")) return rc;
+  static const int mode = [] { const char* e = getenv("HOISDF_ATTN_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
+  if (mode == 1) {
+    // fused: dq is accumulated with atomics -> zero this head block's columns first
+    const hipError_t me = hipMemset2DAsync(dq, (size_t)ldq * sizeof(float), 0, (size_t)H * DH * sizeof(float), (size_t)B * Lq, st);
+    HOISDF_REQUIRE(me == hipSuccess, HOISDF_ERR_LAUNCH, "attention_bwd: memset of dq failed: %s", hipGetErrorString(me));
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
+    return check_launch("attention_bwd_fused");
+  }
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
   if (int rc = check_launch("attention_bwd_dkv")) return rc;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
