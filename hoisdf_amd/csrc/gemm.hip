@@ -62,8 +62,8 @@ __device__ __forceinline__ void stage_load(float4 (&reg)[NV], const float* __res
                                            int r0, int R, int k0, int kend, int vec, int tid) {
   // Fast path (wave-uniform test): 16-byte aligned rows and the whole k-range of the tile in bounds.
   // k-contiguous: out-of-range rows are clamped to the last valid one (their products only reach
-  // output rows that are never stored); r-contiguous: the tile must be row-interior.
-  const bool fast = vec && (k0 + BK <= kend) && (KC ? (R > 0) : (r0 + BM <= R));
+  // output rows that are never stored); r-contiguous: whole 4-wide chunks are predicated.
+  const bool fast = vec && (k0 + BK <= kend) && (KC ? (R > 0) : ((R & 3) == 0 && R >= 4));
   if (fast) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -71,7 +71,10 @@ __device__ __forceinline__ void stage_load(float4 (&reg)[NV], const float* __res
         const int r = min(r0 + (tid / KC_LPR) + KC_RPP * i, R - 1);
         reg[i] = *reinterpret_cast<const float4*>(src + (size_t)r * ld + k0 + (tid % KC_LPR) * 4);
       } else {
-        reg[i] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + (tid >> 5) + 8 * i) * ld + r0 + (tid & 31) * 4);
+        // R is a multiple of 4, so a 4-wide chunk is entirely inside or entirely outside the tile's valid rows
+        const int r = r0 + (tid & 31) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(k0 + (tid >> 5) + 8 * i) * ld + min(r, R - 4));
+        reg[i] = r < R ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     return;
@@ -175,7 +178,12 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
   //   BK 32 double-buffered, 2 WG/CU:  93 / 53 / 52   (PMC: MFMA pipe 65 % busy, 22-57 % of wave cycles parked)
   //   BK 32 single stage,    3 WG/CU: 101 / 85 / 72   BK 64, 2 WG/CU: 94 / 72 / 71
   //   BK 16 single stage,    4 WG/CU:  97 / 97 / 86   <- this build
-  __shared__ __attribute__((aligned(16))) float lds[BK * SA + BK * SB];
+#ifndef HOISDF_GEMM_STAGES
+#define HOISDF_GEMM_STAGES 1
+#endif
+  constexpr int STAGES = HOISDF_GEMM_STAGES;
+  constexpr int STAGE_FLOATS = BK * SA + BK * SB;
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE_FLOATS];
   float* As = lds;
   float* Bs = lds + BK * SA;
 
@@ -242,8 +250,8 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
       if (MASK) load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
       stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, tid);
     }
-    const float* as = As;
-    const float* bs = Bs;
+    const float* as = As + (STAGES == 2 ? (kt & 1) * STAGE_FLOATS : 0);
+    const float* bs = Bs + (STAGES == 2 ? (kt & 1) * STAGE_FLOATS : 0);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a0 = as[(kk + khalf) * SA + arow];
@@ -255,17 +263,19 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    __syncthreads();                       // every wave is done reading this stage
+    if (STAGES == 1) __syncthreads();      // every wave is done reading this stage
     if (kt + 1 < nk) {
       if (MASK) apply_bits(ra, rm, g.ascale);
       if (do_colsum) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
       }
-      stage_store<A_KC>(ra, As, tid);
-      stage_store<B_KC>(rb, Bs, tid);
-      __syncthreads();
+      float* an = As + (STAGES == 2 ? ((kt + 1) & 1) * STAGE_FLOATS : 0);
+      float* bn = Bs + (STAGES == 2 ? ((kt + 1) & 1) * STAGE_FLOATS : 0);
+      stage_store<A_KC>(ra, an, tid);
+      stage_store<B_KC>(rb, bn, tid);
     }
+    if (STAGES == 2 || kt + 1 < nk) __syncthreads();
   }
 
   // bias gradient: this block column (tn == 0) has seen every dy element of its (m-tile, k-slice)
@@ -336,19 +346,27 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
           if (full || (row < g.M && col < g.N)) Cb[(size_t)row * g.ldc + col] = acc[i][j][r];
         }
     if (g.bits_out) {
-      // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below
+      // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below: one ballot is two
+      // mask words.  Each lane collects the two words (j = 0, 1) of "its" row of the wave's 64 x 64 sub-tile
+      // and writes them once (2 stores per lane instead of 64 two-lane stores).
+      uint32_t w0 = 0u, w1 = 0u;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
-            const bool ok = row < g.M && col < g.N;
-            const unsigned long long m = __ballot(ok && acc[i][j][r] > 0.f);
-            if ((lane & 31) == 0 && ok)
-              g.bits_out[(size_t)row * g.ldbits + (col >> 5)] = (uint32_t)(khalf ? (m >> 32) : m);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int rl = i * 32 + (r & 3) + 8 * (r >> 2);      // row (within the sub-tile) of lanes 0-31
+          const unsigned long long m0 = __ballot(acc[i][0][r] > 0.f);
+          const unsigned long long m1 = __ballot(acc[i][1][r] > 0.f);
+          if (lane == rl) { w0 = (uint32_t)m0; w1 = (uint32_t)m1; }
+          if (lane == rl + 4) { w0 = (uint32_t)(m0 >> 32); w1 = (uint32_t)(m1 >> 32); }
+        }
+      const int row = m0 + wm * 64 + lane;
+      const int wcol = (n0 + wn * 64) >> 5;
+      const int nvalid = g.N - (n0 + wn * 64);              // columns of this sub-tile inside the matrix
+      if (row < g.M) {
+        if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits + wcol] = nvalid >= 32 ? w0 : (w0 & ((1u << nvalid) - 1u));
+        if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits + wcol + 1] = nvalid >= 64 ? w1 : (w1 & ((1u << (nvalid - 32)) - 1u));
+      }
     }
   }
 }
