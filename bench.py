@@ -50,27 +50,43 @@ class KernelTimer:
         self.records = {n: [] for n in self.names}
         self._open = None
 
+    SHAPE = {"hoisdf_linear_fwd": (7, 8, 9), "hoisdf_linear_bwd_input": (8, 9, 10), "hoisdf_linear_bwd_weight": (9, 10, 11),
+             "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19)}
+
     def begin(self, name, args):
         s = torch.cuda.Event(enable_timing=True)
         s.record()
-        self._open = (s, self.FLOPS[name](args))
+        self._open = (s, self.FLOPS[name](args), tuple(int(args[i]) for i in self.SHAPE[name]))
 
     def end(self, name):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        s, fl = self._open
-        self.records[name].append((s, e, fl))
+        s, fl, shape = self._open
+        self.records[name].append((s, e, fl, shape))
 
     def summary(self):
         out = {}
         for n, recs in self.records.items():
             if not recs:
                 continue
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            fl = sum(r[2] for r in recs)
             out[n] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), gflop=fl / 1e9,
                           tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
         return out
+
+    def by_shape(self, steps):
+        """per (family, shape) time / TF table (stderr, --shape-report)"""
+        agg = {}
+        for n, recs in self.records.items():
+            for s, e, fl, shape in recs:
+                a = agg.setdefault((n, shape), [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += s.elapsed_time(e)
+                a[2] += fl
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return [f"{n:26s} {str(shape):24s} x{c / steps:5.1f}/step {ms / steps:7.3f} ms/step {fl / (ms * 1e-3) / 1e12:6.1f} TF"
+                for (n, shape), (c, ms, fl) in rows]
 
 
 def main():
@@ -84,9 +100,11 @@ def main():
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--shape-report", action="store_true", help="per-shape kernel table on stderr")
     ap.add_argument("--channels-last", type=int, default=1,
                     help="run the CNN encoder in channels_last (the pyramid is then consumed zero-copy)")
-    ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark for the encoder convs")
+    ap.add_argument("--miopen-find", type=int, default=1,
+                    help="encoder convs: MIOpen find with the shipped find-db (hoisdf_amd/miopen_db); 0 = MIOpen defaults")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="host threads for the CPU baseline (32 was the best of 16/32/64/256 probed on the "
@@ -99,7 +117,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    if args.miopen_find:
+        from hoisdf_amd import miopen_tuning
+        miopen_tuning.enable()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -183,6 +203,8 @@ def main():
     }
     if timer is not None:
         ks = timer.summary()
+        if args.shape_report:
+            print("\n".join(timer.by_shape(args.steps)), file=sys.stderr)
         dom = max(ks, key=lambda n: ks[n]["total_ms"])
         kname = {"hoisdf_linear_fwd": "gemm_f32_kernel<1,1> (linear fwd)",
                  "hoisdf_linear_bwd_input": "gemm_f32_kernel<1,0> (linear grad-input)",

@@ -101,6 +101,9 @@ class Trainer:
         torch.manual_seed(0)
         self.model = get_model("train", cfg=cfg).to(device).train()
         if channels_last:
+            if device.type == "cuda":
+                from . import miopen_tuning
+                miopen_tuning.enable()       # tuned fp32 NHWC conv solvers for the encoder (shipped find-db)
             self.model.backbone_net.to(memory_format=torch.channels_last)
             self.model.decoder_net.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
