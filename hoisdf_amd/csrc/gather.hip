@@ -133,58 +133,104 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, c
     int b;
     float cam[3], uv[2], g[2];
     project_row(a, r, b, cam, uv, g);
-    const float4* din = reinterpret_cast<const float4*>(dfeat + (size_t)r * ldf);
-    for (int u = lane; u < P.C4; u += 64) {
-      const int l = level_of(P, u);
+    // lanes sweep single channels, so one atomic instruction covers runs of consecutive floats (whole 64-byte
+    // lines per tap) instead of one float of every fourth (the L2 atomic units work per line)
+    const float* din = dfeat + (size_t)r * ldf;
+    for (int c = lane; c < P.C4 * 4; c += 64) {
+      const int l = level_of(P, c >> 2);
       if ((skip_mask >> l) & 1) continue;          // coarse level: handled by the LDS-privatised kernel
       const int C = P.C[l], H = P.H[l], W = P.W[l];
       const Taps t = make_taps(g[0], g[1], W, H);
-      float* base = P.grad[l] + (size_t)b * H * W * C + (size_t)(u - P.off4[l]) * 4;
-      const float4 d = din[u];
-      atomic_add4(base + (size_t)t.o00 * C, d, t.w00);
-      if (t.o01 >= 0) atomic_add4(base + (size_t)t.o01 * C, d, t.w01);
-      if (t.o10 >= 0) atomic_add4(base + (size_t)t.o10 * C, d, t.w10);
-      if (t.o11 >= 0) atomic_add4(base + (size_t)t.o11 * C, d, t.w11);
+      float* base = P.grad[l] + (size_t)b * H * W * C + (size_t)(c - P.off4[l] * 4);
+      const float d = din[c];
+      atomicAdd(base + (size_t)t.o00 * C, d * t.w00);
+      if (t.o01 >= 0) atomicAdd(base + (size_t)t.o01 * C, d * t.w01);
+      if (t.o10 >= 0) atomicAdd(base + (size_t)t.o10 * C, d * t.w10);
+      if (t.o11 >= 0) atomicAdd(base + (size_t)t.o11 * C, d * t.w11);
     }
   }
 }
 
 // Coarse levels (<= 256 pixels): every point of a sample hits the same few pixels (128 adds per
-// address at stride 32), and those levels carry ~80 % of all channel-taps.  One workgroup owns
-// (sample, level, 64-channel chunk): it accumulates all the sample's points into an LDS image
-// with ds_add_f32 and writes the image out once - no global atomics, no hot addresses.
+// address at stride 32), and those levels carry ~80 % of all channel-taps.  One single-wave
+// workgroup owns (sample, level, 64-channel chunk, point slice): the lanes are the 64 channels, the
+// wave walks its slice of the sample's points and accumulates into a wave-private LDS image with
+// plain read-modify-write (LDS ops of one wave execute in order, so no atomics: ds_add_f32 measured
+// ~150 cycles per wave instruction on gfx950), then adds the image to the level gradient with one
+// float atomic per element (COARSE_SLICES slices per image).
 struct CoarseJob { int level, chunk; };
 struct CoarseArgs { int n_jobs; CoarseJob job[96]; };
+constexpr int COARSE_SLICES = 4;
 
-__global__ __launch_bounds__(256) void gather_bwd_coarse_kernel(PyrDev P, ProjArgs a, CoarseArgs J,
-                                                                const float* __restrict__ dfeat, int ldf) {
-  extern __shared__ __attribute__((aligned(16))) float img[];       // [H*W][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(64) void gather_bwd_coarse_kernel(PyrDev P, ProjArgs a, CoarseArgs J,
+                                                               const float* __restrict__ dfeat, int ldf) {
+  extern __shared__ __attribute__((aligned(16))) float img[];       // [H*W][64] image, then 64 x 8 tap records
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y, slice = blockIdx.z;
   const CoarseJob jb = J.job[blockIdx.x];
   const int l = jb.level, C = P.C[l], H = P.H[l], W = P.W[l];
   const int npix = H * W;
-  for (int i = threadIdx.x; i < npix * 64; i += 256) img[i] = 0.f;
-  __syncthreads();
+  float* tapw = img + npix * 64;                                    // [64][4] weights
+  int* tapo = reinterpret_cast<int*>(tapw + 256);                   // [64][4] pixel offsets
+  for (int i = lane; i < npix * 64; i += 64) img[i] = 0.f;
   const int ch0 = P.off4[l] * 4 + jb.chunk * 64;                    // column in dfeat rows
   const int Pn = a.rows_per_sample;
-  for (int p = wave; p < Pn; p += 4) {
-    const long r = (long)b * Pn + p;
-    int bb;
-    float cam[3], uv[2], g[2];
-    project_row(a, r, bb, cam, uv, g);
-    const Taps t = make_taps(g[0], g[1], W, H);
-    const float d = dfeat[(size_t)r * ldf + ch0 + lane];
-    atomicAdd(&img[t.o00 * 64 + lane], d * t.w00);
-    if (t.o01 >= 0) atomicAdd(&img[t.o01 * 64 + lane], d * t.w01);
-    if (t.o10 >= 0) atomicAdd(&img[t.o10 * 64 + lane], d * t.w10);
-    if (t.o11 >= 0) atomicAdd(&img[t.o11 * 64 + lane], d * t.w11);
+  const int nmine = (Pn - slice + COARSE_SLICES - 1) / COARSE_SLICES;   // points p = slice + k * SLICES, k < nmine
+  const float* drow = dfeat + ((size_t)b * Pn + slice) * ldf + ch0 + lane;
+  for (int k0 = 0; k0 < nmine; k0 += 64) {
+    // projection + taps of 64 points at once (one per lane) instead of 64 redundant copies per point
+    if (k0 + lane < nmine) {
+      int bb;
+      float cam[3], uv[2], g[2];
+      project_row(a, (long)b * Pn + slice + (long)(k0 + lane) * COARSE_SLICES, bb, cam, uv, g);
+      const Taps t = make_taps(g[0], g[1], W, H);
+      // out-of-range taps alias the (always valid) nw pixel with weight 0
+      *reinterpret_cast<float4*>(&tapw[lane * 4]) =
+          make_float4(t.w00, t.o01 >= 0 ? t.w01 : 0.f, t.o10 >= 0 ? t.w10 : 0.f, t.o11 >= 0 ? t.w11 : 0.f);
+      *reinterpret_cast<int4*>(&tapo[lane * 4]) =
+          make_int4(t.o00, t.o01 >= 0 ? t.o01 : t.o00, t.o10 >= 0 ? t.o10 : t.o00, t.o11 >= 0 ? t.o11 : t.o00);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int kn = min(64, nmine - k0);
+    // this lane's channel of 16 points at a time: 16 independent global loads in flight (a one-deep
+    // prefetch exposed ~1 us of L2/HBM latency per point), next group requested before this one is used
+    float dv[16], dn[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dn[i] = i < kn ? drow[(size_t)(k0 + i) * COARSE_SLICES * ldf] : 0.f;
+    for (int j0 = 0; j0 < kn; j0 += 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dv[i] = dn[i];
+      if (j0 + 16 < kn) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          dn[i] = j0 + 16 + i < kn ? drow[(size_t)(k0 + j0 + 16 + i) * COARSE_SLICES * ldf] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = j0 + i;
+        if (j < kn) {
+          const float d = dv[i];
+          const float4 w = *reinterpret_cast<const float4*>(&tapw[j * 4]);      // broadcast reads
+          const int4 o = *reinterpret_cast<const int4*>(&tapo[j * 4]);
+          float* q00 = &img[o.x * 64 + lane];
+          float* q01 = &img[o.y * 64 + lane];
+          float* q10 = &img[o.z * 64 + lane];
+          float* q11 = &img[o.w * 64 + lane];
+          // read all four, write nw LAST: an aliased (weight-0) tap writes the old nw value back first
+          const float v00 = *q00, v01 = *q01, v10 = *q10, v11 = *q11;
+          *q11 = v11 + d * w.w;
+          *q10 = v10 + d * w.z;
+          *q01 = v01 + d * w.y;
+          *q00 = v00 + d * w.x;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();
-  float* out = P.grad[l] + (size_t)b * npix * C + jb.chunk * 64;
-  for (int i = threadIdx.x; i < npix * 64; i += 256) {
-    const int px = i >> 6, c = i & 63;
-    out[(size_t)px * C + c] += img[i];
+  float* out = P.grad[l] + (size_t)b * npix * C + jb.chunk * 64 + lane;
+  for (int px = 0; px < npix; ++px) {
+    const float v = img[px * 64 + lane];
+    if (v != 0.f) atomicAdd(out + (size_t)px * C, v);
   }
 }
 
@@ -374,8 +420,8 @@ extern "C" int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const 
         if (npix > max_pix) max_pix = npix;
       }
       if (J.n_jobs == 0) continue;
-      hipLaunchKernelGGL(gather_bwd_coarse_kernel, dim3(J.n_jobs, B), dim3(256), (size_t)max_pix * 64 * 4,
-                         as_stream(stream), P, a, J, dfeat, ldf);
+      hipLaunchKernelGGL(gather_bwd_coarse_kernel, dim3(J.n_jobs, B, COARSE_SLICES), dim3(64),
+                         (size_t)max_pix * 64 * 4 + 64 * 8 * 4, as_stream(stream), P, a, J, dfeat, ldf);
       if (int rc = check_launch("gather_bwd_coarse")) return rc;
     }
   }
