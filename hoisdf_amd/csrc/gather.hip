@@ -117,13 +117,6 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, f
   }
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, float4 d, float w) {
-  atomicAdd(p + 0, d.x * w);
-  atomicAdd(p + 1, d.y * w);
-  atomicAdd(p + 2, d.z * w);
-  atomicAdd(p + 3, d.w * w);
-}
-
 __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, const float* __restrict__ dfeat,
                                                          int ldf, int skip_mask) {
   const int lane = threadIdx.x & 63;

@@ -25,9 +25,13 @@ def enable(find_mode: str = "3") -> str | None:
     files = glob.glob(os.path.join(_DB_DIR, "*.txt"))
     if not files:
         return None
-    dst = tempfile.mkdtemp(prefix="hoisdf_miopen_db_")   # per process: ranks never share a writable db
+    # one writable copy per (user, local rank): ranks never share a db file, and a second process on the same
+    # machine reuses what the first one had to search for (shapes missing from the shipped files)
+    dst = os.path.join(tempfile.gettempdir(), f"hoisdf_miopen_db_{os.getuid()}_r{os.environ.get('LOCAL_RANK', '0')}")
+    os.makedirs(dst, exist_ok=True)
     for f in files:
-        shutil.copy(f, dst)
+        if not os.path.exists(os.path.join(dst, os.path.basename(f))):
+            shutil.copy(f, dst)
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     os.environ.setdefault("MIOPEN_FIND_MODE", find_mode)  # 3 = hybrid: db hit -> no search
     torch.backends.cudnn.benchmark = True
