@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gradient all-reduce even with one rank (single-GPU check of the N>1 path)")
     ap.add_argument("--shape-report", action="store_true", help="per-shape kernel table on stderr")
     ap.add_argument("--channels-last", type=int, default=1,
                     help="run the CNN encoder in channels_last (the pyramid is then consumed zero-copy)")
@@ -120,9 +122,11 @@ def main():
     if args.miopen_find:
         from hoisdf_amd import miopen_tuning
         miopen_tuning.enable()
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -141,7 +145,7 @@ def main():
     if args.channels_last:
         model.backbone_net.to(memory_format=torch.channels_last)
         model.decoder_net.to(memory_format=torch.channels_last)
-    reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0)
+    reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0, always_reduce=args.force_dist)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr, fused=True)
     ops.manual_seed(1000 + rank)
     inputs, targets, meta = (T.to_device(x, dev) for x in T.synthetic_batch(args.batch, args.n_hand, args.n_obj,
@@ -161,7 +165,7 @@ def main():
         return total
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +180,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     _lib.set_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -243,7 +247,7 @@ def main():
         res["cpu_baseline"] = cb
         res["speedup_vs_cpu"] = round(value / cb["value"], 1)
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

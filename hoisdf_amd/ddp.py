@@ -38,8 +38,10 @@ class GradReducer:
     what the optimizer then reads.  ~450 tiny kernels per step become ~2 per bucket."""
 
     def __init__(self, params: Sequence[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 64.0,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
         self.group = group
+        # always_reduce: issue the collective even with one rank (exercises RCCL on a single-GPU box)
+        self.always_reduce = bool(always_reduce) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets: List[torch.Tensor] = []
         self._members: List[List[torch.nn.Parameter]] = []
@@ -99,7 +101,7 @@ class GradReducer:
                     v.copy_(p.grad)
         for p, v in zip(members, views):
             p.grad = v
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero_grad(self):

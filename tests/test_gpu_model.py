@@ -193,3 +193,23 @@ def test_full_model_with_encoder_runs_and_is_finite():
     g = model.linear_sdfin.layers[0].weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
     assert model.backbone_net.resnet.conv1.weight.grad is not None
+
+
+def test_bench_distributed_path_single_rank_rccl():
+    """The N>1 code path of bench.py (RCCL init, bucketed async all-reduce from autograd hooks, barrier + MAX
+    reduction of the timing) on one GPU: world_size 1, launched through torch.distributed.run like the driver does."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--batch", "4", "--n-hand", "192", "--n-obj", "64", "--resnet", "18", "--no-cpu-baseline",
+           "--force-dist", "--miopen-find", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
