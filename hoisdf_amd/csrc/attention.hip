@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]  (one 16-lane group per (q, head))
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __restrict__ delta) {
+// zero_dq: also clears this (b, q, head) slice of dq (the fused backward accumulates dq with atomics; clearing
+// it here costs one extra 16-byte store per lane instead of a strided 2-D memset of 85 us)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __restrict__ delta, int zero_dq) {
   const long idx = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;      // (b, q, head)
   const int sub = threadIdx.x & 15;
   const long total = (long)a.B * a.Lq * a.H;
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a, float* __re
     const float4 x = *reinterpret_cast<const float4*>(a.o + ((size_t)b * a.Lq + q) * a.ldo + head * DH + sub * 4);
     const float4 y = *reinterpret_cast<const float4*>(a.dout + ((size_t)b * a.Lq + q) * a.lddo + head * DH + sub * 4);
     s = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    if (zero_dq)
+      *reinterpret_cast<float4*>(a.dq + ((size_t)b * a.Lq + q) * a.ldq + head * DH + sub * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -729,13 +733,11 @@ extern "C" int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int
                  HOISDF_ERR_INVALID, "attention_bwd: bad leading dims / alignment");
   hipStream_t st = as_stream(stream);
   const long ng = (long)B * Lq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, a, delta);
-  if (int rc = check_launch("attention_delta")) return rc;
   static const int mode = [] { const char* e = getenv("HOISDF_ATTN_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
+  // delta = rowsum(dO * O); in fused mode the same pass clears dq, which the fused kernel accumulates with atomics
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, a, delta, mode);
+  if (int rc = check_launch("attention_delta")) return rc;
   if (mode == 1) {
-    // fused: dq is accumulated with atomics -> zero this head block's columns first
-    const hipError_t me = hipMemset2DAsync(dq, (size_t)ldq * sizeof(float), 0, (size_t)H * DH * sizeof(float), (size_t)B * Lq, st);
-    HOISDF_REQUIRE(me == hipSuccess, HOISDF_ERR_LAUNCH, "attention_bwd: memset of dq failed: %s", hipGetErrorString(me));
     hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
     return check_launch("attention_bwd_fused");
   }

@@ -383,7 +383,7 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   g.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (B_KC ? (g.k_per_split % 4 == 0) : true);
   const int ntile = g.tiles_m * g.tiles_n;
   dim3 grid((unsigned)(g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile));
-  constexpr bool CAN_ATOMIC = !A_KC && !B_KC;      // only the grad-weight contraction accumulates with atomics
+  constexpr bool CAN_ATOMIC = true;   // grad-weight always; forward / grad-input when a small grid is split along k
   if (CAN_ATOMIC && g.atomic_out) {
     if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
@@ -429,6 +429,23 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, int ldy, co
   }
 }
 
+// Forward / grad-input with only a few output tiles (the 17-query decoder rows: M = 544): one workgroup per CU
+// exposes the full global-load latency on every k-step (30-124 us for 0.07-0.3 GFLOP).  Split the contraction
+// over more workgroups (>= 4 k-steps each, <= ~256 workgroups) and accumulate with atomics into a zeroed output.
+static int plan_small_splitk(int tiles, int K, int& kper) {
+  const int ksteps = cdiv(K, BK);
+  int s = 256 / (tiles > 0 ? tiles : 1);
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (tiles > 64 || s < 2) { kper = ksteps * BK; return 1; }
+  kper = cdiv(ksteps, s) * BK;
+  return cdiv(K, kper);
+}
+static int zero_rows(float* p, int ld, long rows, int cols, hipStream_t st) {
+  const hipError_t e = hipMemset2DAsync(p, (size_t)ld * sizeof(float), 0, (size_t)cols * sizeof(float), (size_t)rows, st);
+  HOISDF_REQUIRE(e == hipSuccess, HOISDF_ERR_LAUNCH, "gemm: zeroing the split-k output failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
 static void plan_splitk(long M, int N, int K, int& splitk, int& kper) {
   int tiles = cdiv(N, BM) * cdiv(K, BN);
   int ksteps = cdiv(M, BK);
@@ -462,6 +479,13 @@ extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ld
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.splitk = 1; g.k_per_split = ((K + BK - 1) / BK) * BK; g.atomic_out = 0;
   g.bits_out = relu_bits; g.ldbits = (N + 31) / 32;
+  if (act == 0 && relu_bits == nullptr) {
+    g.splitk = plan_small_splitk(cdiv(M, BM) * cdiv(N, BN), K, g.k_per_split);
+    if (g.splitk > 1) {
+      g.atomic_out = 1;
+      if (int rc = zero_rows(y, ldy, M, N, as_stream(stream))) return rc;
+    }
+  }
   return launch_gemm<true, true>(g, as_stream(stream));
 }
 
@@ -478,7 +502,10 @@ extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t
   g.A = dy; g.B = W; g.C = dx; g.bias = nullptr; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
   g.M = (int)M; g.N = K; g.K = N; g.lda = lddy; g.ldb = ldw; g.ldc = lddx;
   g.act = 0; g.drop_p = 0.f; g.inv_keep = 1.f; g.seed = 0;
-  g.splitk = 1; g.k_per_split = ((N + BK - 1) / BK) * BK; g.atomic_out = 0;
+  g.splitk = plan_small_splitk(cdiv(M, BM) * cdiv(K, BN), N, g.k_per_split);
+  g.atomic_out = g.splitk > 1;
+  if (g.atomic_out)
+    if (int rc = zero_rows(dx, lddx, M, K, as_stream(stream))) return rc;
   return launch_gemm<true, false>(g, as_stream(stream));
 }
 

@@ -40,7 +40,8 @@ def assert_close(a, b, rel=2e-5, what=""):
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,act", [(300, 223, 289, True), (1000, 512, 992, True), (17, 60, 256, False),
-                                       (4096, 768, 256, False), (129, 1, 512, False), (257, 3, 256, True)])
+                                       (4096, 768, 256, False), (129, 1, 512, False), (257, 3, 256, True),
+                                       (544, 256, 1024, False), (544, 1024, 256, True), (544, 512, 256, False)])
 def test_linear_fwd_bwd(M, N, K, act):
     O = ops()
     x = rnd(M, K, seed=1).requires_grad_(True)

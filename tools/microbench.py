@@ -25,7 +25,7 @@ def gemm():
     shapes = [(65536, 512, 992), (65536, 256, 512), (65536, 1024, 992), (65536, 512, 1024), (65536, 256, 512),
               (65536, 223, 256), (65536, 512, 289), (65536, 223, 512), (65536, 512, 512), (65536, 768, 256),
               (65536, 256, 256), (65536, 1024, 256), (65536, 256, 1024), (294912, 256, 256), (294912, 60, 256),
-              (294912, 20, 256), (49152, 3, 256), (544, 256, 256)]
+              (294912, 20, 256), (49152, 3, 256), (544, 256, 256), (544, 1024, 256), (544, 256, 1024), (544, 512, 256)]
     print(f"{'M':>7} {'N':>5} {'K':>5} | fwd TF   dX TF    dW TF")
     for M, N, K in shapes:
         x = torch.randn(M, K, device=dev)
