@@ -35,6 +35,9 @@ class Config:
     # model
     use_big_decoder = False
     use_inverse_kinematics = False
+    # not in the reference: BASELINE.json configs[4] ("fp16 MFMA attention"): f16-operand attention kernel for
+    # gradient-free forward passes (mode != "train"); off = exact f32 everywhere (the parity configuration)
+    attention_f16_eval = False
     resnet_type = 50
     mutliscale_layers = ["stride2", "stride4", "stride8", "stride16", "stride32"]
     mutliscale_dim = 32 + 64 + 128 + 256 + 512

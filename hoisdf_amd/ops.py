@@ -401,9 +401,41 @@ class _AttentionCross(torch.autograd.Function):
         return dq, dkv, None, None, None, None
 
 
+_ATTENTION_F16_EVAL = False
+
+
+def set_attention_f16_eval(on: bool) -> None:
+    """BASELINE configs[4] ("fp16 MFMA attention"): route gradient-free, dropout-free attention calls through the f16
+    MFMA kernel (f32 accumulation / softmax).  Off by default: the f32 kernel is the parity configuration."""
+    global _ATTENTION_F16_EVAL
+    _ATTENTION_F16_EVAL = bool(on)
+
+
+def _attn_fwd_f16(q, k, v, H, kv_len):
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    for t, L in ((q, Lq), (k, Lk), (v, Lk)):
+        assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
+    from ._lib import lib
+    nbytes = lib().hoisdf_attention_f16_workspace(B, H, Lk)
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_fwd_f16", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, B, H, Lq, Lk,
+         kv_len, _p(ws), nbytes, _st())
+    return o
+
+
+def _use_f16(drop_p, *tensors) -> bool:
+    return _ATTENTION_F16_EVAL and drop_p == 0.0 and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
+
 def attention_self(qkv, H: int, kv_len: Optional[int] = None, drop_p: float = 0.0):
     """K9: streaming-softmax self-attention on a packed (B,L,3E) projection; q scaled by 1/8 inside."""
     kv_len = qkv.shape[1] if kv_len is None else kv_len
+    if _use_f16(drop_p, qkv):
+        qkv = qkv.contiguous()
+        E = qkv.shape[2] // 3
+        return _attn_fwd_f16(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len)
     seed = next_seed() if drop_p > 0 else 0
     return _AttentionSelf.apply(qkv, H, kv_len, drop_p, seed)
 
@@ -412,6 +444,10 @@ def attention_cross(q, kv, H: int, kv_len: Optional[int] = None, drop_p: float =
     """K10: cross-attention of q (B,Lq,E) over a packed (B,Lk,2E) memory projection; only keys
     < kv_len are attended (memory_mask of common/utils/misc.py:34-47)."""
     kv_len = kv.shape[1] if kv_len is None else kv_len
+    if _use_f16(drop_p, q, kv):
+        q, kv = q.contiguous(), kv.contiguous()
+        E = q.shape[2]
+        return _attn_fwd_f16(q, kv[:, :, :E], kv[:, :, E:], H, kv_len)
     seed = next_seed() if drop_p > 0 else 0
     return _AttentionCross.apply(q, kv, H, kv_len, drop_p, seed)
 

@@ -188,6 +188,16 @@ int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int ldk, const
                          const float* o, int ldo, const float* dout, int lddo, const float* lse,
                          float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk,
                          int kv_len, float drop_p, uint64_t seed, void* stream);
+/* Inference-only variant with f16 MFMA operands (BASELINE.json configs[4], "fp16 MFMA attention"): Q, K, V and the
+ * probabilities are each split into f16 hi + lo parts (3 MFMA products per contraction, ~21 significant bits), both
+ * products accumulate in f32 (v_mfma_f32_32x32x16_f16), softmax state in f32.  Same layouts and kv_len semantics as
+ * hoisdf_attention_fwd; no dropout, no lse (not differentiable).  workspace: hoisdf_attention_f16_workspace(B, H, Lk)
+ * bytes of device memory (f16 hi/lo copies of K and V^T), 16-byte aligned.  Error vs float64 attention < 1e-4 of
+ * max|o| (tests); 1.8x the f32 kernel at 8192 keys.  The f32 entry point stays the parity configuration. */
+long hoisdf_attention_f16_workspace(int B, int H, int Lk);
+int hoisdf_attention_fwd_f16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                             float* o, int ldo, int B, int H, int Lq, int Lk, int kv_len, void* workspace,
+                             long workspace_bytes, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
 int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,

@@ -213,3 +213,23 @@ def test_bench_distributed_path_single_rank_rccl():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
+
+
+def test_eval_with_f16_mfma_attention_meets_the_joint_bar():
+    """BASELINE configs[4] ("fp16 MFMA attention"): with the f16-operand attention kernel switched on, the eval
+    forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m."""
+    from hoisdf_amd import ops
+    setting, nh, no, bins, b = "dexycb", 384, 128, 64, 1
+    g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
+    model, c = build(setting, nh, no, bins)
+    pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=2))
+    inputs, targets, meta = (T.to_device(x, DEV) for x in T.synthetic_batch(b, nh, no, seed=21))
+    ops.set_attention_f16_eval(True)
+    try:
+        with torch.no_grad():
+            loss, out = model.hot_path(pyr, inputs, targets, meta, "eval")
+    finally:
+        ops.set_attention_f16_eval(False)
+    for k in ("hand_joints_out", "mano_joints_out", "mano_mesh_out"):
+        err = (out[k].float().cpu() - g[k]).abs().max().item()
+        assert err <= 1e-4, f"{k}: {err:.3e}"

@@ -413,3 +413,31 @@ def test_edge_cases_empty_and_ragged():
     kv = rnd(1, 9, 2 * E, seed=93).to(DEV)
     o = O.attention_cross(q, kv, H, kv_len=1)
     assert_close(o, kv[:, :1, E:].expand(1, 5, E), rel=1e-6, what="kv_len=1")
+
+
+@pytest.mark.parametrize("B,Lq,Lk,kv", [(2, 300, 300, 300), (2, 17, 700, 530), (1, 1000, 1000, 1000)])
+def test_attention_f16_eval_kernel(B, Lq, Lk, kv):
+    """configs[4] 'fp16 MFMA attention': f16 MFMA operands split hi + lo (3 products), f32 accumulation and softmax.
+    Tolerance 1e-4 of max|o| against float64 softmax attention (the f32 kernel, 2e-5, stays the parity path)."""
+    O = ops()
+    E, H = 256, 4
+    q = rnd(B, Lq, E, seed=41)
+    k = rnd(B, Lk, E, seed=42)
+    v = rnd(B, Lk, E, seed=43)
+    qh, kh, vh = (t.double().view(t.shape[0], t.shape[1], H, 64).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) / 8.0
+    s[..., kv:] = -float("inf")
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+    O.set_attention_f16_eval(True)
+    try:
+        with torch.no_grad():
+            kvp = torch.cat([k, v], -1).to(DEV)
+            o = O.attention_cross(q.to(DEV), kvp, H, kv_len=kv)
+            if Lq == Lk:
+                o2 = O.attention_self(torch.cat([q, k, v], -1).to(DEV), H, kv_len=kv)
+                assert_close(o2, ref, rel=1e-4, what="f16 self")
+    finally:
+        O.set_attention_f16_eval(False)
+    assert_close(o, ref, rel=1e-4, what="f16 cross")
+    o32 = O.attention_cross(q.to(DEV), kvp, H, kv_len=kv)
+    assert_close(o32, ref, rel=2e-5, what="f32 path untouched")

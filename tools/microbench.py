@@ -57,6 +57,10 @@ def attn():
         d = torch.empty_like(qkv)
         t1 = timeit(lambda: ops._attn_fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, S, p, 1234), iters=5)
         t2 = timeit(lambda: ops._attn_bwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do, d[:, :, :E], d[:, :, E:2 * E], d[:, :, 2 * E:], H, S, p, 1234), iters=5)
+        if p == 0.0:
+            with torch.no_grad():
+                t3 = timeit(lambda: ops._attn_fwd_f16(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, S), iters=5)
+            print(f"attn B={B} S={S} f16-MFMA fwd (incl. K/V conversion): {fl/t3/1e12:6.1f} TF ({t3*1e3:.2f} ms)")
         print(f"attn B={B} S={S} p={p}: fwd {fl/t1/1e12:6.1f} TF ({t1*1e3:.2f} ms)  bwd {2.5*fl/t2/1e12:6.1f} TF algorithmic ({t2*1e3:.2f} ms)")
 
 

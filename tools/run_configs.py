@@ -10,8 +10,8 @@ from hoisdf_amd.model import get_model
 dev = "cuda"
 
 
-def run(name, setting, B, nh, no, steps=3):
-    c = Config(); c.resnet_type = 50; c.apply_setting(setting)
+def run(name, setting, B, nh, no, steps=3, f16=False, ref=None):
+    c = Config(); c.resnet_type = 50; c.apply_setting(setting); c.attention_f16_eval = f16
     c.num_samp_hand, c.num_samp_obj, c.bins_n = nh, no, 64
     torch.manual_seed(0)
     model = get_model("test", cfg=c).to(dev).eval()
@@ -27,9 +27,15 @@ def run(name, setting, B, nh, no, steps=3):
     ok = all(torch.isfinite(v).all() for k, v in out.items() if k.endswith("_out") and v.dtype.is_floating_point)
     print(f"{name}: B={B} N={nh}+{no} {setting}: {dt*1e3:.1f} ms/iter = {B/dt:.1f} samples/s, finite={ok}, "
           f"hand_joints {tuple(out['hand_joints_out'].shape)}, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+    if ref is not None:
+        for k in ("hand_joints_out", "mano_joints_out", "mano_mesh_out"):
+            if k in out and k in ref:
+                print(f"    max |{k} (f16 attention) - (f32)| = {float((out[k] - ref[k]).abs().max()):.3e} m")
+    return out
 
 
 if __name__ == "__main__":
     run("config4 (HO3Dv2-shape, IK variant, inference)", "ho3d_render", 16, 3072, 1024)
-    run("config5 (dense eval, per-GPU half of batch 8)", "dexycb", 4, 6144, 2048)
+    r32 = run("config5 (dense eval, per-GPU half of batch 8), f32 attention", "dexycb", 4, 6144, 2048)
+    run("config5 (dense eval, per-GPU half of batch 8), f16 MFMA attention", "dexycb", 4, 6144, 2048, f16=True, ref=r32)
     run("config1-shape on GPU", "dexycb", 1, 384, 128)
