@@ -75,6 +75,14 @@ class KernelTimer:
                           tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
         return out
 
+    def largest_launch_us(self, name):
+        """average duration of the launches of `name` with the most algorithmic FLOPs (the shape the PMC traffic was
+        collected at)"""
+        recs = self.records[name]
+        top = max(r[2] for r in recs)
+        sel = [r for r in recs if r[2] == top]
+        return 1e3 * sum(r[0].elapsed_time(r[1]) for r in sel) / len(sel)
+
     def by_shape(self, steps):
         """per (family, shape) time / TF table (stderr, --shape-report)"""
         agg = {}
@@ -231,6 +239,9 @@ def main():
                    "hoisdf_linear_bwd_input": ["hoisdf::gemm_f32_kernel<true, false, true, false>"],
                    "hoisdf_linear_bwd_weight": ["hoisdf::gemm_f32_kernel<false, false, false, true>"]}[dom]
             res["roofline"]["traffic"] = int(sum(tr[k]["hbm_bytes_per_launch"] for k in fam))
+            # north_star asks for HBM GB/s next to the MFMA fraction: PMC bytes of that launch / its measured duration
+            res["roofline"]["hbm_gbps"] = round(res["roofline"]["traffic"] / (timer.largest_launch_us(dom) * 1e-6) / 1e9, 1)
+            res["roofline"]["hbm_peak_gbps"] = 8000.0
             res["roofline"]["traffic_note"] = ("PMC bytes of one launch at the largest shape of this family "
                                                "(self-attention B=32,S=2048 / linear 65536x512x992)")
         except Exception:

@@ -71,3 +71,19 @@ def test_no_cpu_fallback():
     from hoisdf_amd import ops
     with pytest.raises(RuntimeError):
         ops.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+
+
+def test_collective_library_exports_its_header():
+    """include/hoisdf_collective.h <-> libhoisdf_rccl.so (symbol table only: loading it would pull RCCL in)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "hoisdf_amd", "libhoisdf_rccl.so")
+    if not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "hoisdf_collective.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(hoisdf_\w+)\s*\(", hdr))
+    assert {"hoisdf_allreduce", "hoisdf_coll_init", "hoisdf_coll_unique_id", "hoisdf_coll_destroy"} <= declared
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (hoisdf_\w+)", syms))
+    assert declared <= exported, declared - exported

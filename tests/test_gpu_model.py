@@ -233,3 +233,17 @@ def test_eval_with_f16_mfma_attention_meets_the_joint_bar():
     for k in ("hand_joints_out", "mano_joints_out", "mano_mesh_out"):
         err = (out[k].float().cpu() - g[k]).abs().max().item()
         assert err <= 1e-4, f"{k}: {err:.3e}"
+
+
+def test_c_host_allreduce():
+    """A plain C host (no Python, no torch) drives libhoisdf_rccl.so: RCCL communicator with one rank + all-reduce."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = "/tmp/hoisdf_test_allreduce"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", os.path.join(repo, "tests", "c", "test_allreduce.c"), "-I", os.path.join(repo, "include"),
+                    "-L", os.path.join(repo, "hoisdf_amd"), "-lhoisdf_rccl", "-Wl,-rpath," + os.path.join(repo, "hoisdf_amd"),
+                    "-o", exe], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "allreduce ok" in out.stdout, out.stdout + out.stderr
