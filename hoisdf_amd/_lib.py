@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_lattice_fill": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "hoisdf_select_smallest_abs": [_P, _P, _P, _I, _I, _P, _P],
     "hoisdf_gather_rows": [_P, _I, _P, _L, _I, _P, _I, _P],
+    "hoisdf_sdf_sample_keys": [_P, _I, _P, _P, _P, _P, _I, _I, _F, _U64, _P, _P, _P],
     "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P],

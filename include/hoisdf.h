@@ -156,6 +156,18 @@ int hoisdf_select_smallest_abs(const float* sdf_raw, const int32_t* offsets, con
 /* out[r][0:width] = src[sel[r]][0:width] */
 int hoisdf_gather_rows(const float* src, int lds, const int32_t* sel, long n_sel, int width,
                        float* out, int ldo, void* stream);
+/* ---- (f2) dataset-side SDF sample selection on the device ------------------------------------------------
+ * reference: data/dexycb.py:514-546 (np.random.choice without replacement of num_samp_hand / num_samp_obj rows of
+ * the frame's sdf_processed array, and - training - of the rows with |sdf| < points_filter_dist).
+ * rows: HBM-resident store of sdf_processed rows [.. ld >= 6 floats: x y z sdf_hand sdf_obj label].  A segment s is
+ * the row range [seg_row0[s], seg_row0[s] + seg_len[s]) of the store; seg_col[s] = 3 / 4 keeps only rows with
+ * |row[col]| < dist eligible, -1 = all rows.  Writes keys[seg_off[s] + i] = uniform [0,1) (hash of seed, s, i) for
+ * eligible rows, 1e30 otherwise, and eligible[s] = number of eligible rows.  Then
+ * hoisdf_select_smallest_abs(keys, seg_off, seg_len, n_seg, k, sel) yields k uniformly drawn rows per segment
+ * (indices into keys; the caller checks eligible[s] >= k) and hoisdf_gather_rows fetches them. */
+int hoisdf_sdf_sample_keys(const float* rows, int ld, const int64_t* seg_row0, const int32_t* seg_len,
+                           const int32_t* seg_off, const int32_t* seg_col, int n_seg, int max_len, float dist,
+                           uint64_t seed, float* keys, int32_t* eligible, void* stream);
 
 /* ---- K8: sigma gate + token assembly ----------------------------------------------------
  * reference: main/model.py:123-126 (sdf_activation), :520-562 (token concat).
