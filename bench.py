@@ -153,8 +153,11 @@ def main():
     if args.channels_last:
         model.backbone_net.to(memory_format=torch.channels_last)
         model.decoder_net.to(memory_format=torch.channels_last)
-    reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0, always_reduce=args.force_dist)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr, fused=True)
+    from hoisdf_amd.optim import FusedAdamW
+    reducer = GradReducer(reducible_parameters(model), bucket_mb=64.0, always_reduce=args.force_dist, average=False)
+    # the reference's optimizer (torch.optim.AdamW(lr=cfg.lr), common/base.py:64-73) as one HIP launch; 1/world of the
+    # gradient mean is folded into it
+    opt = FusedAdamW([p for p in model.parameters() if p.requires_grad], lr=cfg.lr, grad_scale=1.0 / world)
     ops.manual_seed(1000 + rank)
     inputs, targets, meta = (T.to_device(x, dev) for x in T.synthetic_batch(args.batch, args.n_hand, args.n_obj,
                                                                            seed=1234 + rank))

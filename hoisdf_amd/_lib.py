@@ -32,7 +32,7 @@ class Pyramid(C.Structure):
                 ("C", C.c_int * MAX_LEVELS), ("H", C.c_int * MAX_LEVELS), ("W", C.c_int * MAX_LEVELS)]
 
 
-_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+_P, _I, _L, _F, _U64, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_double
 _PYR = C.POINTER(Pyramid)
 
 # name -> argument ctypes (return type is int unless listed in _RET)
@@ -53,6 +53,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_select_smallest_abs": [_P, _P, _P, _I, _I, _P, _P],
     "hoisdf_gather_rows": [_P, _I, _P, _L, _I, _P, _I, _P],
     "hoisdf_sdf_sample_keys": [_P, _I, _P, _P, _P, _P, _I, _I, _F, _U64, _P, _P, _P],
+    "hoisdf_adamw_step": [_P, _I, _D, _D, _D, _D, _D, _L, _F, _P],
     "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P],

@@ -38,8 +38,11 @@ class GradReducer:
     what the optimizer then reads.  ~450 tiny kernels per step become ~2 per bucket."""
 
     def __init__(self, params: Sequence[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 64.0,
-                 group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
+                 group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False, average: bool = True):
         self.group = group
+        # average=False leaves the SUM over ranks in p.grad: the optimizer folds 1/world into its own pass
+        # (hoisdf_amd.optim.FusedAdamW(grad_scale=1/world)) and one 208 MB read-modify-write per step disappears
+        self.average = average
         # always_reduce: issue the collective even with one rank (exercises RCCL on a single-GPU box)
         self.always_reduce = bool(always_reduce) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -121,7 +124,7 @@ class GradReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
-        if self.world > 1:
+        if self.world > 1 and self.average:
             for flat in self.buckets:
                 flat.div_(self.world)
 

@@ -107,10 +107,15 @@ class Trainer:
             self.model.backbone_net.to(memory_format=torch.channels_last)
             self.model.decoder_net.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
-        self.reducer = GradReducer(reducible_parameters(self.model))
+        on_gpu = device.type == "cuda"
+        self.reducer = GradReducer(reducible_parameters(self.model), average=not on_gpu)
         # reference: AdamW over all named parameters in one group (common/base.py:64-73)
-        self.optimizer = torch.optim.AdamW([p for p in self.model.parameters() if p.requires_grad], lr=cfg.lr,
-                                           fused=device.type == "cuda")
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if on_gpu:
+            from .optim import FusedAdamW                       # same rule / state layout, one launch, 1/world folded in
+            self.optimizer = FusedAdamW(params, lr=cfg.lr, grad_scale=1.0 / self.world)
+        else:
+            self.optimizer = torch.optim.AdamW(params, lr=cfg.lr)
         self.lr_scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=cfg.lr_drop,
                                                             gamma=cfg.lr_decay_gamma)
         self.start_epoch = 0

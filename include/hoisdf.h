@@ -257,6 +257,23 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
                          const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
                          int B, int P, int J, void* stream);
 
+/* ---- optimizer step of the training loop ------------------------------------------------------------------
+ * reference: torch.optim.AdamW(model.parameters(), lr=cfg.lr) (common/base.py:64-73; betas (0.9, 0.999), eps 1e-8,
+ * weight_decay 1e-2 = torch defaults), stepped once per iteration (main/train.py:139).
+ * chunks: device array; chunk i updates n <= 16384 consecutive elements of one parameter in place
+ * (param, exp_avg, exp_avg_sq) from grad * grad_scale; step = 1-based count of this update (bias correction).
+ * grad_scale = 1/world_size folds the gradient averaging of the all-reduce into the same pass.  Hyper-parameters are
+ * doubles: 1 - beta2 formed from a float 0.999 is already 1.3e-5 off. */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+} hoisdf_adamw_chunk;
+int hoisdf_adamw_step(const hoisdf_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, long step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

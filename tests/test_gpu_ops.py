@@ -441,3 +441,35 @@ def test_attention_f16_eval_kernel(B, Lq, Lk, kv):
     assert_close(o, ref, rel=1e-4, what="f16 cross")
     o32 = O.attention_cross(q.to(DEV), kvp, H, kv_len=kv)
     assert_close(o32, ref, rel=2e-5, what="f32 path untouched")
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """hoisdf_adamw_step vs torch.optim.AdamW (CPU, float64 reference) over 5 steps: dense, channels_last 4-D,
+    odd sizes (unaligned tails), a parameter without gradient; grad_scale folds the 1/world averaging."""
+    from hoisdf_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1000, 333), (17,), (8, 5, 3, 3), (40000,), (3, 7)]
+    ref_p = [torch.randn(s, generator=g, dtype=torch.float64).requires_grad_(True) for s in shapes]
+    ref_unused = torch.randn(4, dtype=torch.float64).requires_grad_(True)
+    gpu_p = [r.detach().float().to(DEV).requires_grad_(True) for r in ref_p]
+    gpu_p[2] = gpu_p[2].detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gpu_unused = ref_unused.detach().float().to(DEV).requires_grad_(True)
+    ref = torch.optim.AdamW(ref_p + [ref_unused], lr=1e-2, weight_decay=0.01)
+    opt = FusedAdamW(gpu_p + [gpu_unused], lr=1e-2, weight_decay=0.01, grad_scale=0.5)
+    for it in range(5):
+        for r, q in zip(ref_p, gpu_p):
+            gr = torch.randn(r.shape, generator=g, dtype=torch.float64)
+            r.grad = gr.clone()
+            gq = (gr * 2.0).float().to(DEV)                      # grad_scale = 0.5 undoes the factor 2
+            q.grad = gq.contiguous(memory_format=torch.channels_last) if q.dim() == 4 else gq
+        ref.step()
+        opt.step()
+    for r, q in zip(ref_p, gpu_p):
+        assert_close(q, r, rel=3e-6, what=f"param {tuple(r.shape)}")
+        assert_close(opt.state[q]["exp_avg_sq"], ref.state[r]["exp_avg_sq"], rel=3e-6, what="exp_avg_sq")
+    assert torch.equal(gpu_unused.detach().cpu(), ref_unused.detach().float())      # no gradient -> untouched
+    assert float(opt.state[gpu_p[0]]["step"]) == 5.0
+    sd = opt.state_dict()                                         # torch layout: loads into a stock AdamW
+    stock = torch.optim.AdamW(gpu_p + [gpu_unused], lr=1e-2)
+    stock.load_state_dict(sd)
+    assert float(stock.state[gpu_p[0]]["step"]) == 5.0
