@@ -54,6 +54,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_gather_rows": [_P, _I, _P, _L, _I, _P, _I, _P],
     "hoisdf_sdf_sample_keys": [_P, _I, _P, _P, _P, _P, _I, _I, _F, _U64, _P, _P, _P],
     "hoisdf_adamw_step": [_P, _I, _D, _D, _D, _D, _D, _L, _F, _P],
+    "hoisdf_aux_image_losses_fwd": [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "hoisdf_aux_image_losses_bwd": [_P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P],

@@ -295,9 +295,13 @@ class Model(nn.Module):
             out["hand_seg_pred_out"] = decoder_out[:, 1]
             out["obj_seg_gt_out"] = targets["obj_seg"]
             out["obj_seg_pred_out"] = decoder_out[:, 2]
-            loss["joint_heatmap"] = (decoder_out[:, 0] - self.render_gaussian_heatmap(targets["joint_coord"])) ** 2
-            loss["obj_seg"] = F.binary_cross_entropy(decoder_out[:, 2], targets["obj_seg"], reduction="none")
-            loss["hand_seg"] = F.binary_cross_entropy(decoder_out[:, 1], targets["hand_seg"], reduction="none")
+            if decoder_out.is_cuda:          # (f4) one HIP pass: Gaussian heat-map target + MSE + the two BCE maps
+                loss["joint_heatmap"], loss["obj_seg"], loss["hand_seg"], _ = ops.aux_image_losses(
+                    decoder_out, targets["joint_coord"], targets["hand_seg"], targets["obj_seg"], c.sigma)
+            else:                            # CPU: the encoder-only plumbing path (no HIP hot path runs there anyway)
+                loss["joint_heatmap"] = (decoder_out[:, 0] - self.render_gaussian_heatmap(targets["joint_coord"])) ** 2
+                loss["obj_seg"] = F.binary_cross_entropy(decoder_out[:, 2], targets["obj_seg"], reduction="none")
+                loss["hand_seg"] = F.binary_cross_entropy(decoder_out[:, 1], targets["hand_seg"], reduction="none")
         return {**loss, **out}
 
 

@@ -593,3 +593,40 @@ class _VoteLoss(torch.autograd.Function):
 def vote_loss(off, cls, pts, gt_mm, radius: float):
     """K12 + the JointvoteLoss reductions: -> joints (L,B,J,3), l3d_sum (L,B), bce_sum (L,B), near_sum (B)."""
     return _VoteLoss.apply(off, cls, pts, gt_mm, radius)
+
+
+# ---------------------------------------------------------------------------------------------
+# (f4) auxiliary image losses of the encoder outputs
+# ---------------------------------------------------------------------------------------------
+class _AuxImageLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, joints, hand_seg, obj_seg, sigma):
+        joints, hand_seg, obj_seg = joints.contiguous().float(), hand_seg.contiguous().float(), obj_seg.contiguous().float()
+        _chk(dec, joints, hand_seg, obj_seg)
+        B, C, H, W = dec.shape
+        assert C >= 3 and hand_seg.shape == (B, H, W) and obj_seg.shape == (B, H, W) and joints.shape[0] == B
+        hm, l_hm, l_obj, l_hand = (torch.empty(B, H, W, device=dec.device, dtype=torch.float32) for _ in range(4))
+        sb, sc, sh, sw = dec.stride()
+        call("hoisdf_aux_image_losses_fwd", _p(dec), sb, sc, sh, sw, _p(joints), _p(hand_seg), _p(obj_seg), B,
+             joints.shape[1], H, W, float(sigma), _p(hm), _p(l_hm), _p(l_obj), _p(l_hand), _st())
+        ctx.save_for_backward(dec, hand_seg, obj_seg, hm)
+        ctx.mark_non_differentiable(hm)
+        return l_hm, l_obj, l_hand, hm
+
+    @staticmethod
+    def backward(ctx, g_hm, g_obj, g_hand, _g):
+        dec, hand_seg, obj_seg, hm = ctx.saved_tensors
+        B, C, H, W = dec.shape
+        ddec = torch.empty_like(dec) if C == 3 else torch.zeros_like(dec)       # preserves the (channels_last) strides
+        assert ddec.stride() == dec.stride()
+        gs = [None if g is None else g.contiguous() for g in (g_hm, g_obj, g_hand)]
+        sb, sc, sh, sw = dec.stride()
+        call("hoisdf_aux_image_losses_bwd", _p(dec), sb, sc, sh, sw, _p(hand_seg), _p(obj_seg), _p(hm), _p(gs[0]),
+             _p(gs[1]), _p(gs[2]), B, H, W, _p(ddec), _st())
+        return ddec, None, None, None, None
+
+
+def aux_image_losses(decoder_out, joint_coord, hand_seg, obj_seg, sigma: float):
+    """(f4) main/model.py:404-422 in one pass: returns (joint_heatmap, obj_seg, hand_seg) per-pixel losses (B,H,W)
+    and the rendered target heat-map; differentiable w.r.t. decoder_out (any strides)."""
+    return _AuxImageLosses.apply(decoder_out, joint_coord, hand_seg, obj_seg, sigma)

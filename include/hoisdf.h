@@ -257,6 +257,22 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
                          const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
                          int B, int P, int J, void* stream);
 
+/* ---- (f4) auxiliary image losses of the encoder outputs ---------------------------------------------------
+ * reference: main/model.py:128-143 (render_gaussian_heatmap) and :404-422 (MSELoss / BCELoss with reduction none).
+ * dec = decoder_out (B, 3, H, W) [heat-map, hand seg, object seg] with element strides (sb, sc, sh, sw) - NCHW or
+ * channels_last; joints (B, J, 2) = (x, y) in heat-map pixels; segs (B, H, W) in [0, 1].
+ * heatmap (B, H, W) = 255 * sum_j exp(-((x - jx)/sigma)^2/2 - ((y - jy)/sigma)^2/2) (kept for the backward);
+ * loss_heatmap = (dec0 - heatmap)^2, loss_*_seg = binary cross entropy with the log terms clamped at -100.
+ * bwd: ddec gets all three channels (same strides as dec); a NULL upstream gradient means zero. */
+int hoisdf_aux_image_losses_fwd(const float* dec, long sb, long sc, long sh, long sw, const float* joints,
+                                const float* hand_seg, const float* obj_seg, int B, int J, int H, int W, float sigma,
+                                float* heatmap, float* loss_heatmap, float* loss_obj_seg, float* loss_hand_seg,
+                                void* stream);
+int hoisdf_aux_image_losses_bwd(const float* dec, long sb, long sc, long sh, long sw, const float* hand_seg,
+                                const float* obj_seg, const float* heatmap, const float* g_heatmap,
+                                const float* g_obj_seg, const float* g_hand_seg, int B, int H, int W, float* ddec,
+                                void* stream);
+
 /* ---- optimizer step of the training loop ------------------------------------------------------------------
  * reference: torch.optim.AdamW(model.parameters(), lr=cfg.lr) (common/base.py:64-73; betas (0.9, 0.999), eps 1e-8,
  * weight_decay 1e-2 = torch defaults), stepped once per iteration (main/train.py:139).

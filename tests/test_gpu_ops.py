@@ -473,3 +473,39 @@ def test_fused_adamw_matches_torch_adamw():
     stock = torch.optim.AdamW(gpu_p + [gpu_unused], lr=1e-2)
     stock.load_state_dict(sd)
     assert float(stock.state[gpu_p[0]]["step"]) == 5.0
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_aux_image_losses_match_torch(channels_last):
+    """(f4) fused heat-map render + MSE + 2x BCE vs the torch formulation of main/model.py:128-143,404-422 (fwd + grad)."""
+    O = ops()
+    B, J, H, W, sigma = 3, 21, 128, 128, 1.25
+    g = torch.Generator().manual_seed(9)
+    dec = torch.rand(B, 3, H, W, generator=g) * 0.98 + 0.01
+    dec[:, 0] = dec[:, 0] * 300.0
+    dec[0, 1, 0, 0], dec[0, 2, 0, 1] = 0.0, 1.0                       # saturated probabilities: clamped logs / 1e-12 floor
+    joints = torch.rand(B, J, 2, generator=g) * 128
+    hs = (torch.rand(B, H, W, generator=g) > 0.5).float()
+    osg = (torch.rand(B, H, W, generator=g) > 0.5).float()
+    w = [torch.rand(B, H, W, generator=g) for _ in range(3)]
+    d64 = dec.double().requires_grad_(True)
+    yy, xx = torch.meshgrid(torch.arange(H).double(), torch.arange(W).double(), indexing="ij")
+    jx, jy = joints.double()[:, :, 0, None, None], joints.double()[:, :, 1, None, None]
+    hm = torch.exp(-(((xx - jx) / sigma) ** 2) / 2 - (((yy - jy) / sigma) ** 2) / 2).sum(1) * 255
+    r_hm = (d64[:, 0] - hm) ** 2
+    r_obj = F.binary_cross_entropy(d64[:, 2], osg.double(), reduction="none")
+    r_hand = F.binary_cross_entropy(d64[:, 1], hs.double(), reduction="none")
+    (r_hm * w[0].double()).sum().add((r_obj * w[1].double()).sum()).add((r_hand * w[2].double()).sum()).backward()
+    dg = dec.to(DEV)
+    if channels_last:
+        dg = dg.contiguous(memory_format=torch.channels_last)
+    dg.requires_grad_(True)
+    l_hm, l_obj, l_hand, hmg = O.aux_image_losses(dg, joints.to(DEV), hs.to(DEV), osg.to(DEV), sigma)
+    ((l_hm * w[0].to(DEV)).sum() + (l_obj * w[1].to(DEV)).sum() + (l_hand * w[2].to(DEV)).sum()).backward()
+    assert_close(hmg, hm, rel=3e-6, what="heatmap")
+    assert_close(l_hm, r_hm, rel=1e-5, what="mse")
+    assert_close(l_obj, r_obj, rel=1e-5, what="bce obj")
+    assert_close(l_hand, r_hand, rel=1e-5, what="bce hand")
+    got = dg.grad.cpu().double()
+    for ch in range(3):
+        assert_close(got[:, ch], d64.grad[:, ch], rel=1e-5, what=f"d decoder_out[{ch}]")
