@@ -247,3 +247,16 @@ def test_c_host_allreduce():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "allreduce ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_c_host_linear():
+    """A plain C program links libhoisdf_hip.so through include/hoisdf.h only (no Python, no torch types)."""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = "/tmp/hoisdf_test_linear_host"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", os.path.join(repo, "tests", "c", "test_linear_host.c"), "-I",
+                    os.path.join(repo, "include"), "-L", os.path.join(repo, "hoisdf_amd"), "-lhoisdf_hip",
+                    "-Wl,-rpath," + os.path.join(repo, "hoisdf_amd"), "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "c host ok" in out.stdout, out.stdout + out.stderr
