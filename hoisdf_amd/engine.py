@@ -170,9 +170,18 @@ class Tester:
             load_reference_state_dict(self.model, ckpt["network"], strict=True)
 
     @torch.no_grad()
-    def predict(self, inputs, targets, meta):
+    def predict(self, inputs, targets, meta, mano_layer=None):
+        """eval forward; for the IK variant (``cfg.use_inverse_kinematics``) the closed-form IK post-process of
+        main/test.py:139-160 runs on the device as well when a MANO layer is given: adds ``ik_joints_out`` /
+        ``ik_verts_out`` (root-relative metres, before the caller's mano_root shift) and ``ik_pose_out``."""
         inputs, targets, meta = (T.to_device(x, self.device) for x in (inputs, targets, meta))
-        return self.model(inputs, targets, meta, "eval")
+        out = self.model(inputs, targets, meta, "eval")
+        if self.cfg.use_inverse_kinematics and mano_layer is not None:
+            from .ik import ik_solver_mano
+            hj = torch.cat([torch.zeros_like(out["hand_joints_out"][:, :1]), out["hand_joints_out"]], 1)
+            r = ik_solver_mano(mano_layer.to(self.device), out.get("mano_shape_out"), hj)
+            out["ik_joints_out"], out["ik_verts_out"], out["ik_pose_out"] = r["joints"], r["verts"], r["pose"]
+        return out
 
 
 def mpjpe(pred: torch.Tensor, gt: torch.Tensor) -> float:
