@@ -13,7 +13,7 @@ with open(path, newline="") as f:
             g *= max(int(r[k]), 1)
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], g))
 rows.sort()
-opt = [i for i, r in enumerate(rows) if "FusedAdam" in r[2]]
+opt = [i for i, r in enumerate(rows) if "adamw_chunks_kernel" in r[2] or "FusedAdam" in r[2]]
 per = len(opt) // (warmup + steps)
 first, last = opt[per * warmup - 1] + 1, opt[-1]
 agg = defaultdict(lambda: [0, 0])

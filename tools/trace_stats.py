@@ -2,8 +2,8 @@
 """Per-kernel statistics of the TIMED steps only, from a rocprofv3 --kernel-trace CSV of `bench.py`.
 
 rocprofv3 --stats aggregates the whole process, including MIOpen's find-mode warm-up (which runs its
-naive reference convolutions a few hundred times).  The timed region is delimited with the fused AdamW
-launches: bench.py does `warmup` untimed steps, then `steps` timed ones, each ending with the same number of
+naive reference convolutions a few hundred times).  The timed region is delimited with the AdamW launches
+(hoisdf::adamw_chunks_kernel, one per step): bench.py does `warmup` untimed steps, then `steps` timed ones, each ending with the same number of
 optimizer kernels.  usage: trace_stats.py <kernel_trace.csv> <warmup> <steps> > stats.csv"""
 import csv, sys
 from collections import defaultdict
@@ -16,7 +16,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    opt = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+    opt = [i for i, r in enumerate(rows) if "adamw_chunks_kernel" in r[2] or "FusedAdam" in r[2]]
     assert opt and len(opt) % (warmup + steps) == 0, (len(opt), warmup, steps)
     per = len(opt) // (warmup + steps)
     first = opt[per * warmup - 1] + 1            # first dispatch after the last warm-up optimizer kernel
