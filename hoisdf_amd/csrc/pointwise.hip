@@ -101,38 +101,44 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
                                                            const float* __restrict__ w, float* __restrict__ dh,
                                                            int lddh, float* __restrict__ dw, float* __restrict__ db,
                                                            long n_rows, int K, float clampv) {
-  // each wave walks rows with a grid stride and keeps a private dw accumulator per lane slot
-  const int lane = threadIdx.x & 63;
+  // each wave walks rows with a grid stride (two rows in flight) and keeps a private dw accumulator per lane
+  // slot; the four waves of a block are summed in LDS so every block issues ONE atomic per column (the same 512
+  // addresses are hit by every block: per-wave atomics serialised 2048 adds per address, 238 us -> see DESIGN.md)
+  __shared__ float red[4][512 + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dwa[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};   // K <= 512: 2 float4 per lane
   float dba = 0.f;
-  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (; r < n_rows; r += (long)gridDim.x * 4) {
-    const float t = sdf_raw[r];
-    // clamp passes gradient only strictly inside (torch.clamp: grad where min <= x <= max)
-    const float gpre = (t >= -clampv && t <= clampv) ? dsdf[r] * (1.f - t * t) : 0.f;
-    const float* hr = h + (size_t)r * ldh;
-    float* dr = dh + (size_t)r * lddh;
+  const long stride = (long)gridDim.x * 4;
+  for (long r0 = (long)blockIdx.x * 4 + wave; r0 < n_rows; r0 += 2 * stride) {
+    const long r1 = r0 + stride;
+    const bool two = r1 < n_rows;
+    const float t0 = sdf_raw[r0], t1 = two ? sdf_raw[r1] : 0.f;
+    // clamp passes gradient only inside [-clamp, clamp] (torch.clamp backward)
+    const float g0 = (t0 >= -clampv && t0 <= clampv) ? dsdf[r0] * (1.f - t0 * t0) : 0.f;
+    const float g1 = (two && t1 >= -clampv && t1 <= clampv) ? dsdf[r1] * (1.f - t1 * t1) : 0.f;
+    const float* h0 = h + (size_t)r0 * ldh;
+    const float* h1 = h + (size_t)(two ? r1 : r0) * ldh;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = lane * 4 + i * 256;
       if (c < K) {
+        const float4 a0 = *reinterpret_cast<const float4*>(h0 + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(h1 + c);
         const float4 ww = *reinterpret_cast<const float4*>(w + c);
-        *reinterpret_cast<float4*>(dr + c) = make_float4(gpre * ww.x, gpre * ww.y, gpre * ww.z, gpre * ww.w);
-        const float4 a = *reinterpret_cast<const float4*>(hr + c);
-        dwa[i].x += gpre * a.x; dwa[i].y += gpre * a.y; dwa[i].z += gpre * a.z; dwa[i].w += gpre * a.w;
+        *reinterpret_cast<float4*>(dh + (size_t)r0 * lddh + c) = make_float4(g0 * ww.x, g0 * ww.y, g0 * ww.z, g0 * ww.w);
+        if (two) *reinterpret_cast<float4*>(dh + (size_t)r1 * lddh + c) = make_float4(g1 * ww.x, g1 * ww.y, g1 * ww.z, g1 * ww.w);
+        dwa[i].x += g0 * a0.x + g1 * a1.x; dwa[i].y += g0 * a0.y + g1 * a1.y;
+        dwa[i].z += g0 * a0.z + g1 * a1.z; dwa[i].w += g0 * a0.w + g1 * a1.w;
       }
     }
-    dba += gpre;
+    dba += g0 + g1;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = lane * 4 + i * 256;
-    if (c < K) {
-      atomicAdd(dw + c + 0, dwa[i].x); atomicAdd(dw + c + 1, dwa[i].y);
-      atomicAdd(dw + c + 2, dwa[i].z); atomicAdd(dw + c + 3, dwa[i].w);
-    }
-  }
-  if (lane == 0) atomicAdd(db, dba);
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&red[wave][lane * 4 + i * 256]) = dwa[i];
+  if (lane == 0) red[wave][512] = dba;
+  __syncthreads();
+  for (int c = threadIdx.x; c < K; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  if (threadIdx.x == 0) atomicAdd(db, red[0][512] + red[1][512] + red[2][512] + red[3][512]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -414,7 +420,7 @@ extern "C" int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, cons
                  HOISDF_ERR_INVALID, "sdf_head_bwd: K must be a multiple of 4 and <= 512");
   if (n_rows == 0) return HOISDF_OK;
   int blocks = row_grid(n_rows);
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dsdf, sdf_raw, h, ldh, w,
                      dh, lddh, dw, db, n_rows, K, clamp);
   return check_launch("sdf_head_bwd");
