@@ -6,17 +6,18 @@
 // Block tile 128x128x16, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
 // VGPRs).  LDS holds both operands k-major ([k][m]) so the MFMA fragment read is always one
 // conflict-free ds_read_b32 per operand per k-pair; only the global->LDS staging differs with
-// the operand's memory orientation.  Register-staged double buffering: the next tile's global
-// loads are in flight during the 64 MFMAs of the current one; one barrier per k-tile.
+// the operand's memory orientation.  Register staging: the next k-tile's global loads are in
+// flight during the 32 MFMAs of the current one, then ds_write + barrier into the single 16.5 KB LDS
+// stage; 4 workgroups per CU (<= 128 VGPRs) hide that hand-over (a second LDS stage measured +-0).
 // Block ids are remapped so that the tiles sharing an A row-panel sit on one XCD (shared L2).
 //
 // Fusions: bias + ReLU + dropout in the forward epilogue, which also emits a 1-bit/element sign map
 // (wave ballot); in both backward contractions the ReLU/dropout backward (dy * [y > 0] / (1-p)) is
 // applied from that bitmap while staging the dy operand (an L2-resident 1/32-size side input), so
 // the pre-activation gradient is never written to HBM; the bias gradient (column sums of dy) is
-// accumulated from the staged dy tiles of the grad-weight kernel.  Split-K partial tiles go to a
-// caller workspace and are summed by a second small kernel (device-scope float atomics bypass the
-// per-XCD L2 and cost ~25 % of the kernel; the atomic path remains for workspace-less calls).
+// accumulated from the staged dy tiles of the grad-weight kernel.  Split-K (grad-weight always; forward /
+// grad-input when the grid is only a few tiles) accumulates with float atomics into a zeroed output, every
+// k-slice on one XCD; a caller workspace selects partial tiles + a deterministic reduce kernel instead.
 #include "common.h"
 
 namespace hoisdf {
