@@ -260,3 +260,9 @@ def test_c_host_linear():
                     "-Wl,-rpath," + os.path.join(repo, "hoisdf_amd"), "-o", exe], check=True, capture_output=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "c host ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_graft_entry_smoke():
+    """the driver's smoke(): tiny eval forward vs the oracle + one train forward/backward"""
+    import __graft_entry__ as g
+    g.smoke()
