@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC: without this RCCL / cross-process CUDA-tensor sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (already exported on the GPU box; harmless to repeat)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))

@@ -8,6 +8,10 @@ import argparse
 import os
 import time
 
+# the host driver only supports dmabuf IPC: without this RCCL / cross-process CUDA-tensor sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (already exported on the GPU box; harmless to repeat)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 from hoisdf_amd.config import cfg
