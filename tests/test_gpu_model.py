@@ -266,3 +266,39 @@ def test_graft_entry_smoke():
     """the driver's smoke(): tiny eval forward vs the oracle + one train forward/backward"""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_trainer_checkpoint_roundtrip_with_fused_adamw(tmp_path):
+    """reference-format snapshot (module.-prefixed network, optimizer, lr_scheduler) written by one Trainer resumes in
+    another: same parameters, same AdamW moments / step, and the next step gives the same loss."""
+    from hoisdf_amd.engine import Trainer, latest_snapshot
+    c = Config()
+    c.resnet_type = 18
+    c.apply_setting("dexycb")
+    c.num_samp_hand, c.num_samp_obj = 96, 32
+    c.model_dir = str(tmp_path)
+    dev = torch.device("cuda", 0)
+    tr = Trainer(c, dev, batch_size=2)
+    it = iter(tr.batch_generator)
+    for _ in range(2):
+        tr.model._py_random = random.Random(0)
+        tr.train_step(*next(it), 0, 0.0)
+    tr.save_model(0, 1)
+    assert latest_snapshot(c.model_dir)[1:] == (0, 1)
+    tr2 = Trainer(c, dev, batch_size=2)
+    assert tr2.load_model() == 1
+    for (k, a), (_, b) in zip(tr.model.state_dict().items(), tr2.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    p1 = [p for p in tr.model.parameters() if p.requires_grad and p in tr.optimizer.state][0]
+    p2 = [p for p in tr2.model.parameters() if p.requires_grad][[id(q) for q in tr.model.parameters() if q.requires_grad].index(id(p1))]
+    assert float(tr2.optimizer.state[p2]["step"]) == 2.0
+    assert torch.equal(tr.optimizer.state[p1]["exp_avg"], tr2.optimizer.state[p2]["exp_avg"])
+    batch = next(it)
+    from hoisdf_amd import ops
+    losses = []
+    for t in (tr, tr2):
+        t.model._py_random = random.Random(1)
+        ops.manual_seed(123)
+        torch.manual_seed(5)
+        losses.append(float(t.train_step(*batch, 0, 0.0)[0]))
+    assert abs(losses[0] - losses[1]) <= 1e-4 * abs(losses[0]), losses
