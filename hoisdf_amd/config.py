@@ -38,6 +38,8 @@ class Config:
     # not in the reference: BASELINE.json configs[4] ("fp16 MFMA attention"): f16-operand attention kernel for
     # gradient-free forward passes (mode != "train"); off = exact f32 everywhere (the parity configuration)
     attention_f16_eval = False
+    # not in the reference: run the object transformer stack on a second HIP stream next to the hand stack
+    overlap_streams = True
     resnet_type = 50
     mutliscale_layers = ["stride2", "stride4", "stride8", "stride16", "stride32"]
     mutliscale_dim = 32 + 64 + 128 + 256 + 512
