@@ -52,6 +52,8 @@ class GradReducer:
         self._pending: List[int] = []
         self._handles = []
         self._launched: List[bool] = []
+        self._side_events: List[list] = []
+        self._main = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
         cur: List[torch.nn.Parameter] = []
         size = 0
@@ -82,9 +84,22 @@ class GradReducer:
             self._views.append(views)
             self._pending.append(len(members))
             self._launched.append(False)
+            self._side_events.append([])
 
     def _make_hook(self, bi: int):
-        def hook(_p):
+        def hook(p):
+            # A gradient may be produced on a side stream (the model overlaps the object stack with the hand stack on
+            # a second HIP stream; autograd replays each op's backward on its forward stream).  Buckets are packed on
+            # the stream that was current at zero_grad(); gradients that arrive on another stream leave an event for it.
+            if p.is_cuda and self._main is not None:
+                cur = torch.cuda.current_stream(p.device)
+                if cur != self._main:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    self._side_events[bi].append(ev)
+                    if p.grad is not None:
+                        p.grad.record_stream(self._main)      # freed after the pack on _main, not before
+
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -94,6 +109,16 @@ class GradReducer:
         if self._launched[bi]:
             return
         self._launched[bi] = True
+        if self._main is not None:
+            for ev in self._side_events[bi]:
+                self._main.wait_event(ev)
+            self._side_events[bi] = []
+            with torch.cuda.stream(self._main):
+                self._pack_and_reduce(bi)
+        else:
+            self._pack_and_reduce(bi)
+
+    def _pack_and_reduce(self, bi: int):
         members, views, flat = self._members[bi], self._views[bi], self.buckets[bi]
         if all(p.grad is not None for p in members):
             torch._foreach_copy_(views, [p.grad for p in members])           # multi-tensor packed copy
@@ -109,11 +134,14 @@ class GradReducer:
 
     def zero_grad(self):
         """call instead of optimizer.zero_grad()"""
+        dev = self.buckets[0].device if self.buckets else None
+        self._main = torch.cuda.current_stream(dev) if dev is not None and dev.type == "cuda" else None
         for bi, members in enumerate(self._members):
             for p in members:
                 p.grad = None
             self._pending[bi] = len(members)
             self._launched[bi] = False
+            self._side_events[bi] = []
         self._handles = []
 
     def finish(self):

@@ -47,3 +47,17 @@ for name in ("linear_sdfin.layers.0.weight", "linear_sdfin.layers.1.weight", "li
         rows = bad[:, 0].unique(); cols = bad[:, 1].unique()
         print("   rows", rows[:12].tolist(), "... cols", cols[:12].tolist(), "n_rows", rows.numel(), "n_cols", cols.numel())
         i, j = bad[0].tolist(); print("   sample", a[i, j].item(), b[i, j].item())
+
+# the bucketed reducer on top of the two-stream step must hand the optimizer the same gradients
+from hoisdf_amd.ddp import GradReducer, reducible_parameters
+red = GradReducer(reducible_parameters(model))
+def grads_reducer():
+    c.overlap_streams = True
+    red.zero_grad()
+    model._py_random = random.Random(0); ops.manual_seed(77); torch.manual_seed(3)
+    out = model(*batch, "train", 0, 0.1)
+    total = sum(v.mean() for k, v in out.items() if "_out" not in k)
+    total.backward(); red.finish(); torch.cuda.synchronize()
+    return float(total), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+for i in range(3):
+    print("single (plain autograd) vs two-stream + GradReducer:", cmp(s1, grads_reducer()))
