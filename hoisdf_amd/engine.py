@@ -94,14 +94,14 @@ def load_reference_state_dict(model: torch.nn.Module, network: Dict[str, torch.T
 
 class Trainer:
     def __init__(self, cfg: Config, device: torch.device, dataset=None, batch_size: Optional[int] = None,
-                 channels_last: bool = True):
+                 channels_last: bool = True, tune_encoder: bool = True):
         self.cfg, self.device = cfg, device
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         torch.manual_seed(0)
         self.model = get_model("train", cfg=cfg).to(device).train()
         if channels_last:
-            if device.type == "cuda":
+            if device.type == "cuda" and tune_encoder:
                 from . import miopen_tuning
                 miopen_tuning.enable()       # tuned fp32 NHWC conv solvers for the encoder (shipped find-db)
             self.model.backbone_net.to(memory_format=torch.channels_last)

@@ -13,6 +13,7 @@ Reference line numbers are cited per method.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import random
 from typing import Dict, Optional
@@ -184,37 +185,66 @@ class Model(nn.Module):
         nh, no = c.num_samp_hand, c.num_samp_obj
         B = root.shape[0]
 
-        if training or c.dataset == "dexycb":                                         # :370-402
-            sh, _, _ = self.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, hs_, "hand")
-            so, _, _ = self.sdf_forward(pyr, inputs["obj_sdf_points"], ocen, K, os_, "obj")
-            cd = c.ClampingDistance
-            loss["sdfhand_loss"], loss["sdfobj_loss"] = self.sdf_loss(
-                sh, so, targets["hand_sdf"].clamp(-cd, cd), targets["obj_sdf"].clamp(-cd, cd))
+        # Everything that starts from the OBJECT points (their SDF query, input MLP, evaluation in the hand field and,
+        # below, the object encoder stack) is independent of the hand-point work until the tokens are assembled: it is
+        # issued on a second HIP stream, so its small grids (16 384 rows) share the chip with the hand stream's kernels
+        # and kernel tails overlap.  Autograd replays every op's backward on its forward stream.
+        two = bool(getattr(c, "overlap_streams", True)) and root.is_cuda and os.environ.get("HOISDF_TWO_STREAMS", "1") != "0"
+        cur = side = None
+        if two:
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+        on_side = (lambda: torch.cuda.stream(side)) if two else contextlib.nullcontext
+        want_sdf_loss = training or c.dataset == "dexycb"                                # :370-402
 
         p = self._py_random.uniform(0, 1)                                              # :426
-        if (p < 0.4 or epoch_cnt < c.point_sampling_epoch) and training:               # :427-460
+        branch_a = (p < 0.4 or epoch_cnt < c.point_sampling_epoch) and training        # :427-460
+        if branch_a:
             d = c.random_move_dist[len([a for a in c.random_ratio if batch_ratio > a])]
             jit = self._jitter or (lambda like, dd: torch.empty_like(like).uniform_(-dd, dd))
             hand_points = inputs["hand_pre_points"] + jit(inputs["hand_pre_points"], d)
             obj_points = inputs["obj_pre_points"] + jit(inputs["obj_pre_points"], d)
-            with torch.no_grad():   # the reference tracks these two calls but only ever uses them detached
-                hand_sdf, _, hand_pe = self.sdf_forward(pyr, hand_points, root, K, hs_, "hand")
-                obj_sdf, _, obj_pe = self.sdf_forward(pyr, obj_points, ocen, K, os_, "obj")
-        else:                                                                          # :462-481
+        else:                                                                          # :462-481 (host reads: not overlapped)
             hand_points, hand_sdf, hand_pe, _ = self.sdf_infer(pyr, root, K, meta_info["bbox_hand"], hs_, nh, "hand")
             obj_points, obj_sdf, obj_pe, _ = self.sdf_infer(pyr, ocen, K, meta_info["bbox_obj"], os_, no, "obj")
-
         self.hand_sigmoid_beta.data.clamp_(min=2e-3)                                   # :124
         self.obj_sigmoid_beta.data.clamp_(min=2e-3)
-        hand_fea, hand_cam = self.get_input_transformer(pyr, hand_points, root, K, hs_)            # :486-493
-        obj_fea, obj_cam = self.get_input_transformer(pyr, obj_points, ocen, K, os_)
-        hand_rel = hand_cam - root[:, None, :]
 
-        with torch.no_grad():                                                          # :495-518 (outputs detached)
+        so = None
+        if two:
+            side.wait_stream(cur)                       # the points, the pyramid and the inputs are ready
+        with on_side():                                 # ---- object points ----
+            if want_sdf_loss:
+                so, _, _ = self.sdf_forward(pyr, inputs["obj_sdf_points"], ocen, K, os_, "obj")
+            if branch_a:
+                with torch.no_grad():   # the reference tracks these calls but only ever uses them detached
+                    obj_sdf, _, obj_pe = self.sdf_forward(pyr, obj_points, ocen, K, os_, "obj")
+            obj_fea, obj_cam = self.get_input_transformer(pyr, obj_points, ocen, K, os_)            # :486-493
+            with torch.no_grad():                                                      # :495-518 (outputs detached)
+                obj_h_pts = (obj_cam - root[:, None, :]) * hs_
+                obj_h_sdf, _, obj_h_pe = self.sdf_forward(pyr, obj_h_pts, root, K, hs_, "hand")
+        # ---- hand points (ambient stream) ----
+        if want_sdf_loss:
+            sh, _, _ = self.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, hs_, "hand")
+        if branch_a:
+            with torch.no_grad():
+                hand_sdf, _, hand_pe = self.sdf_forward(pyr, hand_points, root, K, hs_, "hand")
+        hand_fea, hand_cam = self.get_input_transformer(pyr, hand_points, root, K, hs_)
+        hand_rel = hand_cam - root[:, None, :]
+        with torch.no_grad():
             hand_o_pts = (hand_cam - ocen[:, None, :]) * os_
-            obj_h_pts = (obj_cam - root[:, None, :]) * hs_
             hand_o_sdf, _, hand_o_pe = self.sdf_forward(pyr, hand_o_pts, ocen, K, os_, "obj")
-            obj_h_sdf, _, obj_h_pe = self.sdf_forward(pyr, obj_h_pts, root, K, hs_, "hand")
+        if two:
+            cur.wait_stream(side)
+            for t in (so, obj_sdf, obj_pe, obj_fea, obj_cam, obj_h_sdf, obj_h_pe):
+                if t is not None:
+                    t.record_stream(cur)
+        if want_sdf_loss:
+            cd = c.ClampingDistance
+            loss["sdfhand_loss"], loss["sdfobj_loss"] = self.sdf_loss(
+                sh, so, targets["hand_sdf"].clamp(-cd, cd), targets["obj_sdf"].clamp(-cd, cd))
 
         # token streams (batch-first).  The appended cross-field tokens are detached (:540,:558) and use
         # the *other* centre for xyz ("# bug" lines :498,:508 replicated).
@@ -235,15 +265,8 @@ class Model(nn.Module):
         tgt_mask = None if c.use_inverse_kinematics else get_mano_tgt_mask(c)         # :564-569
         # Only rows < nh (hand stream) / < no (object stream) of the encoder outputs are ever read (:587-593 and
         # the memory mask), so the last layer of each stack skips the other query rows - same values, less work.
-        # The object encoder stack (+ its heads) is independent of the hand stack: issue it on a second HIP stream so
-        # the tail of every kernel of one stack overlaps kernels of the other (every launch here fills the chip, so the
-        # gain is the tails: 127.3 -> 126.0 ms/step).  Autograd replays each op's backward on its forward stream.
-        two = bool(getattr(c, "overlap_streams", True)) and obj_tok.is_cuda and os.environ.get("HOISDF_TWO_STREAMS", "1") != "0"
+        # The object encoder stack (+ its heads) goes to the second stream as well (127.3 -> 126.0 ms/step on its own).
         if two:
-            cur = torch.cuda.current_stream()
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream()
-            side = self._side_stream
             side.wait_stream(cur)
             obj_tok.record_stream(side)
             with torch.cuda.stream(side):

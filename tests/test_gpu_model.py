@@ -278,14 +278,14 @@ def test_trainer_checkpoint_roundtrip_with_fused_adamw(tmp_path):
     c.num_samp_hand, c.num_samp_obj = 96, 32
     c.model_dir = str(tmp_path)
     dev = torch.device("cuda", 0)
-    tr = Trainer(c, dev, batch_size=2)
+    tr = Trainer(c, dev, batch_size=2, tune_encoder=False)      # no MIOpen search for these one-off shapes
     it = iter(tr.batch_generator)
     for _ in range(2):
         tr.model._py_random = random.Random(0)
         tr.train_step(*next(it), 0, 0.0)
     tr.save_model(0, 1)
     assert latest_snapshot(c.model_dir)[1:] == (0, 1)
-    tr2 = Trainer(c, dev, batch_size=2)
+    tr2 = Trainer(c, dev, batch_size=2, tune_encoder=False)
     assert tr2.load_model() == 1
     for (k, a), (_, b) in zip(tr.model.state_dict().items(), tr2.model.state_dict().items()):
         assert torch.equal(a, b), k
