@@ -275,36 +275,49 @@ class Model(nn.Module):
                 obj_trans = self.linear_obj_rel_trans(obj_enc)
         hs, memory, hand_enc = self.hand_transformer.forward_batch_first(
             hand_tok, self.mano_query_embed.weight, tgt_mask, nh, n_keep=nh)           # :571-581
-        hand_off = self.linear_handvote(hand_enc)                                      # :587-593 (L,B,nh,60)
-        hand_cls = self.linear_handcls(hand_enc)
         if two:
-            cur.wait_stream(side)
-            obj_rot.record_stream(cur)
-            obj_trans.record_stream(cur)
+            side.wait_stream(cur)                       # hs is ready; the side stream already holds the object stack
+            hs.record_stream(side)
         else:
             _, obj_enc = self.obj_transformer.forward_batch_first(obj_tok, n_keep=no)      # :582-584
             obj_rot = self.linear_obj_rot(obj_enc)                                         # (L,B,no,3)
             obj_trans = self.linear_obj_rel_trans(obj_enc)
 
+        # ---- MANO head + its losses + the object pose losses: ~200 tiny kernels, on the second stream under the big
+        # vote-head GEMMs of the ambient stream
         pred_m = gt_m = None
-        if c.use_inverse_kinematics:                                                   # :595-597
-            mano_shape = self.linear_shape(hs[:, :, 0])
-            out["mano_shape_out"] = mano_shape[-1]
-        else:                                                                          # :599-620
-            pose6d = self.linear_pose(hs[:, :, :c.mano_shape_indx])                    # (L,B,16,6)
-            mano_shape = self.linear_shape(hs[:, :, c.mano_shape_indx])                # (L,B,10)
-            mp = targets["mano_param"] if (training or c.dataset == "dexycb") else None
-            pred_m, gt_m = self.mano_head.forward_batch_first(pose6d, mano_shape, mp)
-            out["mano_mesh_out"] = pred_m["verts3d"][-1]
-            out["mano_joints_out"] = pred_m["joints3d"][-1]
-            if c.dataset == "dexycb":
-                out["mano_joints_gt_out"] = gt_m["joints3d"]
-                out["mano_mesh_gt_out"] = gt_m["verts3d"]
+        side_made = []
+        with on_side():
+            if c.use_inverse_kinematics:                                               # :595-597
+                mano_shape = self.linear_shape(hs[:, :, 0])
+                out["mano_shape_out"] = mano_shape[-1]
+            else:                                                                      # :599-620
+                pose6d = self.linear_pose(hs[:, :, :c.mano_shape_indx])                # (L,B,16,6)
+                mano_shape = self.linear_shape(hs[:, :, c.mano_shape_indx])            # (L,B,10)
+                mp = targets["mano_param"] if (training or c.dataset == "dexycb") else None
+                pred_m, gt_m = self.mano_head.forward_batch_first(pose6d, mano_shape, mp)
+                out["mano_mesh_out"] = pred_m["verts3d"][-1]
+                out["mano_joints_out"] = pred_m["joints3d"][-1]
+                if c.dataset == "dexycb":
+                    out["mano_joints_gt_out"] = gt_m["joints3d"]
+                    out["mano_mesh_gt_out"] = gt_m["verts3d"]
+            if not training:                                                           # :622-624
+                out["obj_rot_out"] = obj_rot[-1].contiguous()
+                out["obj_trans_out"] = obj_trans[-1].contiguous()
+            if training or c.dataset == "dexycb":                                      # :640-654
+                if c.use_inverse_kinematics:
+                    loss["shape_param_loss"], loss["shape_reg_loss"] = self.mano_shape_loss(
+                        mano_shape, targets["mano_param"][:, -10:])
+                else:
+                    (loss["mano_mesh_loss"], loss["mano_joint_loss"], loss["pose_param_loss"],
+                     loss["shape_param_loss"], _, _) = self.mano_loss(pred_m, gt_m)
+            loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))    # :656-662
+            loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
+            side_made = [t for t in list(loss.values()) + list(out.values()) if torch.is_tensor(t)]
 
-        if not training:                                                               # :622-624
-            out["obj_rot_out"] = obj_rot[-1].contiguous()
-            out["obj_trans_out"] = obj_trans[-1].contiguous()
-
+        # ---- hand vote heads + vote aggregation / losses (ambient stream)
+        hand_off = self.linear_handvote(hand_enc)                                      # :587-593 (L,B,nh,60)
+        hand_cls = self.linear_handcls(hand_enc)
         if training or c.dataset == "dexycb":                                          # :626-638
             joints_gt = targets["joint_cam_no_trans"][:, 1:]
         else:
@@ -312,16 +325,10 @@ class Model(nn.Module):
         (loss["loss_joint_3d"], loss["loss_joint_cls"], loss["loss_all_joint_3d"],
          joints) = self.joints_vote_loss(hand_rel, hand_off, hand_cls, joints_gt, batch_first=True)
         out["hand_joints_out"] = joints[-1]
-
-        if training or c.dataset == "dexycb":                                          # :640-654
-            if c.use_inverse_kinematics:
-                loss["shape_param_loss"], loss["shape_reg_loss"] = self.mano_shape_loss(
-                    mano_shape, targets["mano_param"][:, -10:])
-            else:
-                (loss["mano_mesh_loss"], loss["mano_joint_loss"], loss["pose_param_loss"],
-                 loss["shape_param_loss"], _, _) = self.mano_loss(pred_m, gt_m)
-        loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))    # :656-662
-        loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
+        if two:
+            cur.wait_stream(side)
+            for t in side_made:
+                t.record_stream(cur)
         return loss, out
 
     def forward(self, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0):
