@@ -185,9 +185,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     timer = None if args.no_kernel_timing else KernelTimer()
+    for w in range(args.warmup):
+        # the event-bracketed timed steps run single-stream (see below): warm that allocation pattern up as well
+        cfg.overlap_streams = not (timer is not None and w == args.warmup - 2)
+        step()
+    cfg.overlap_streams = True
     barrier()
     # per-kernel HIP events live inside the timed region, on every `--time-every`-th step only: ~1400 event records per
     # step cost 1.7 % of the step (they serialise consecutive kernels), which `value` should not pay on every step
