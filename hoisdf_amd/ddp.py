@@ -14,7 +14,7 @@ model is 4 buckets.  Parameters that never receive a gradient on this path (``no
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist

@@ -16,7 +16,7 @@ from __future__ import annotations
 import contextlib
 import os
 import random
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn

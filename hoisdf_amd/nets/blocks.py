@@ -10,8 +10,7 @@ transformers keeps the reference's call signature and return layout.
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -11,8 +11,7 @@ defined here (standard He et al. v1.5 blocks: stride on the 3x3 conv).
 """
 from __future__ import annotations
 
-from collections import OrderedDict
-from typing import Dict, List, Tuple
+from typing import List
 
 import torch
 import torch.nn as nn

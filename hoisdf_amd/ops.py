@@ -7,11 +7,10 @@ CPU tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 
-from . import _lib
 from ._lib import Pyramid, call
 
 _SEED = [0x9E3779B97F4A7C15, 0]

@@ -3,7 +3,6 @@ inputs.  Tolerances are written next to each check (fp32 kernels: ~1e-5 relative
 tensor's scale; the f32 MFMA is an exact fmaf chain, only the summation order differs)."""
 import math
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
