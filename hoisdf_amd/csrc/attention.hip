@@ -212,6 +212,129 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ============================================================================================
+// forward, few queries (Lq <= 32: the 17 MANO queries attending 1536 hand keys, K10): the 128-query kernel would run
+// one mostly empty tile per (b, head) and walk its 24 key tiles serially (130 us, latency bound).  Here one block of
+// FEWQ_WAVES waves owns the (b, head); wave w takes the 32-key tiles w, w + FEWQ_WAVES, ... straight from global
+// memory (no LDS staging: every tile is read exactly once), keeps its own streaming-softmax state, and the waves'
+// (max, sum, O) states are merged through LDS at the end.  Same dropout hash / lse convention as attn_fwd_kernel,
+// so the fused backward applies unchanged.
+// ============================================================================================
+constexpr int FEWQ_WAVES = 8;
+__global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Os[FEWQ_WAVES][DH][33];   // O^T partials [d][q]
+  __shared__ float Ms[FEWQ_WAVES][32], Lsum[FEWQ_WAVES][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  const int bh = blockIdx.x, b = bh / a.H, head = bh - b * a.H;
+  const int qrow = c;
+  const float* kb = a.k + (size_t)b * a.Lk * a.ldk + head * DH;
+  const float* vb = a.v + (size_t)b * a.Lk * a.ldv + head * DH;
+  float qf[32];
+  if (qrow < a.Lq) {
+    const float4* p = reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + qrow) * a.ldq + head * DH + 32 * h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 t = p[i];
+      qf[4 * i + 0] = t.x * QSCALE2; qf[4 * i + 1] = t.y * QSCALE2;
+      qf[4 * i + 2] = t.z * QSCALE2; qf[4 * i + 3] = t.w * QSCALE2;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qf[i] = 0.f;
+  }
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+
+  const int ntiles = (a.kv_len + 31) / 32;
+  for (int kt = wave; kt < ntiles; kt += FEWQ_WAVES) {
+    const int key = kt * 32 + c;                       // this lane's K row (A operand of S^T = K.Q^T)
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const float4* kp = reinterpret_cast<const float4*>(kb + (size_t)(key < a.kv_len ? key : 0) * a.ldk + 32 * h);
+      float4 kk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kk[i] = kp[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s = MFMA(kk[i].x, qf[4 * i + 0], s); s = MFMA(kk[i].y, qf[4 * i + 1], s);
+        s = MFMA(kk[i].z, qf[4 * i + 2], s); s = MFMA(kk[i].w, qf[4 * i + 3], s);
+      }
+    }
+    // V rows of the 16 keys this lane's accumulator registers hold (A operand of O^T = V^T.P^T: d along lanes)
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = kt * 32 + CROW(r, h);
+      const float* vr = vb + (size_t)(kr < a.kv_len ? kr : 0) * a.ldv + c;
+      v0[r] = vr[0]; v1[r] = vr[32];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (kt * 32 + CROW(r, h) >= a.kv_len) s[r] = -INFINITY;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = EXP2(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = EXP2(s[r] - mn);
+      ps += p;
+      s[r] = p;
+    }
+    lsum = lsum * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[r] *= drop_scale(rowkey, (uint32_t)(kt * 32 + CROW(r, h)), a.thresh, a.inv_keep);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[0] = MFMA(v0[r], s[r], o[0]);
+      o[1] = MFMA(v1[r], s[r], o[1]);
+    }
+  }
+  // merge the waves: every lane holds column q = c of O^T, rows d = 32 t + CROW(r, h); m / lsum are per q (per half)
+  const float lw = lsum + __shfl_xor(lsum, 32, 64);
+  if (h == 0) { Ms[wave][c] = m; Lsum[wave][c] = lw; }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[wave][32 * t + CROW(r, h)][c] = o[t][r];
+  __syncthreads();
+  for (int e = tid; e < DH * 32; e += 64 * FEWQ_WAVES) {
+    const int d = e >> 5, q = e & 31;
+    if (q >= a.Lq) continue;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < FEWQ_WAVES; ++w) M = fmaxf(M, Ms[w][q]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < FEWQ_WAVES; ++w) {
+      const float sc = Ms[w][q] == -INFINITY ? 0.f : EXP2(Ms[w][q] - M);
+      L += Lsum[w][q] * sc;
+      acc += Os[w][d][q] * sc;
+    }
+    a.out[((size_t)b * a.Lq + q) * a.ldo + head * DH + d] = acc / L;
+    if (d == 0 && a.lse) a.lse[(size_t)bh * a.Lq + q] = M + log2f(L);
+  }
+}
+
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]  (one 16-lane group per (q, head))
 // zero_dq: also clears this (b, q, head) slice of dq (the fused backward accumulates dq with atomics; clearing
 // it here costs one extra 16-byte store per lane instead of a strided 2-D memset of 85 us)
@@ -712,6 +835,10 @@ extern "C" int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int
   if (int rc = check_attn(a, "attention_fwd")) return rc;
   HOISDF_REQUIRE(o && ldo >= H * DH && (ldo & 3) == 0 && ((uintptr_t)o & 15) == 0, HOISDF_ERR_INVALID,
                  "attention_fwd: bad output");
+  if (Lq <= 32) {
+    hipLaunchKernelGGL(attn_fwd_fewq_kernel, dim3(B * H), dim3(64 * FEWQ_WAVES), 0, as_stream(stream), a);
+    return check_launch("attention_fwd_fewq");
+  }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, as_stream(stream), a);
   return check_launch("attention_fwd");
 }

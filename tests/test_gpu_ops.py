@@ -508,3 +508,34 @@ def test_aux_image_losses_match_torch(channels_last):
     got = dg.grad.cpu().double()
     for ch in range(3):
         assert_close(got[:, ch], d64.grad[:, ch], rel=1e-5, what=f"d decoder_out[{ch}]")
+
+
+def test_attention_few_queries_kernel_incl_dropout():
+    """Lq <= 32 takes the few-query forward kernel (waves split the keys, merged through LDS): exact vs float64 without
+    dropout for several key counts (fewer tiles than waves, ragged last tile), and with dropout the fused backward
+    regenerates the same mask (linear-in-V identity)."""
+    O = ops()
+    import hoisdf_amd.ops as OO
+    E, H = 256, 4
+    for B, Lq, Lk, kv in [(2, 17, 1536, 1536), (1, 1, 40, 33), (3, 32, 700, 650), (2, 5, 96, 96)]:
+        q = rnd(B, Lq, E, seed=50)
+        kvt = rnd(B, Lk, 2 * E, seed=51)
+        ref = _ref_attention(q.double(), kvt[..., :E].double(), kvt[..., E:].double(), H, kv)
+        o = O.attention_cross(q.to(DEV), kvt.to(DEV), H, kv)
+        assert_close(o, ref, what=f"few-q {Lq}x{Lk}")
+    B, Lq, Lk, p, seed = 2, 17, 1536, 0.3, 424242
+    q = rnd(B, Lq, E, seed=52).to(DEV)
+    kvt = rnd(B, Lk, 2 * E, seed=53).to(DEV)
+    x = kvt.clone().requires_grad_(True)
+    o = OO._AttentionCross.apply(q, x, H, Lk, p, seed)
+    go = rnd(B, Lq, E, seed=54).to(DEV)
+    o.backward(go)
+    dV = torch.zeros_like(kvt)
+    dV[..., E:] = rnd(B, Lk, E, seed=55).to(DEV) * 0.5
+    o2 = OO._AttentionCross.apply(q, kvt + dV, H, Lk, p, seed)
+    lhs, rhs = ((o2 - o.detach()) * go).sum(), (x.grad * dV).sum()
+    assert abs(float(lhs - rhs)) <= 2e-4 * abs(float(rhs)) + 1e-3, (float(lhs), float(rhs))
+    ones = kvt.clone()
+    ones[..., E:] = 1.0
+    od = OO._AttentionCross.apply(q, ones, H, Lk, p, seed)
+    assert abs(float(od.mean()) - 1.0) < 0.03
