@@ -192,9 +192,9 @@ class Model(nn.Module):
         two = bool(getattr(c, "overlap_streams", True)) and root.is_cuda and os.environ.get("HOISDF_TWO_STREAMS", "1") != "0"
         cur = side = None
         if two:
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(root.device)
             if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream()
+                self._side_stream = torch.cuda.Stream(device=root.device)
             side = self._side_stream
         on_side = (lambda: torch.cuda.stream(side)) if two else contextlib.nullcontext
         want_sdf_loss = training or c.dataset == "dexycb"                                # :370-402

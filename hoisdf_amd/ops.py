@@ -36,9 +36,17 @@ def _st():
 
 
 def _chk(*ts):
+    cur = None
     for t in ts:
-        if t is not None and (not t.is_cuda or t.dtype not in (torch.float32,)):
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype not in (torch.float32,):
             raise RuntimeError("hoisdf_amd ops need float32 CUDA/HIP tensors (no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:       # the C ABI launches on the calling thread's current device and stream
+            raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: one process per "
+                               "GPU, call torch.cuda.set_device(local_rank) first")
 
 
 def _rows(x: torch.Tensor) -> torch.Tensor:
