@@ -98,7 +98,8 @@ class Trainer:
         self.cfg, self.device = cfg, device
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        torch.manual_seed(0)
+        self.base_seed = int(getattr(cfg, "seed", 0))
+        torch.manual_seed(self.base_seed)                        # identical initial weights on every rank
         self.model = get_model("train", cfg=cfg).to(device).train()
         if channels_last:
             if device.type == "cuda" and tune_encoder:
@@ -109,8 +110,10 @@ class Trainer:
         self.channels_last = channels_last
         on_gpu = device.type == "cuda"
         self.reducer = GradReducer(reducible_parameters(self.model), average=not on_gpu)
-        # reference: AdamW over all named parameters in one group (common/base.py:64-73)
-        params = [p for p in self.model.parameters() if p.requires_grad]
+        # reference: AdamW over ALL named parameters in one group, frozen BN affine included (common/base.py:64-73):
+        # the optimizer state_dict's ``params`` index list must have that length/order for snapshots to be
+        # interchangeable.  Parameters without a gradient are skipped by the update either way.
+        params = list(self.model.parameters())
         if on_gpu:
             from .optim import FusedAdamW                       # same rule / state layout, one launch, 1/world folded in
             self.optimizer = FusedAdamW(params, lr=cfg.lr, grad_scale=1.0 / self.world)
@@ -125,7 +128,21 @@ class Trainer:
             if self.world > 1 else None
         self.batch_generator = torch.utils.data.DataLoader(ds, batch_size=bs, shuffle=sampler is None, sampler=sampler,
                                                            num_workers=0, drop_last=True, pin_memory=True)
+        self.sampler = sampler
         self.itr_per_epoch = len(self.batch_generator)
+        self.begin_epoch(self.start_epoch)
+
+    def begin_epoch(self, epoch: int):
+        """Per-epoch, per-rank random streams: a new DistributedSampler shuffle every epoch, and distinct dropout masks /
+        point jitter on every rank (the weights were initialised from the shared seed above).  Also what --continue
+        resumes with, so a resumed epoch does not replay the streams of epoch 0."""
+        if self.sampler is not None:
+            self.sampler.set_epoch(epoch)
+        from . import ops
+        s = self.base_seed + 1000003 * (epoch + 1) + 7919 * self.rank
+        torch.manual_seed(s)
+        ops.manual_seed(s)
+        self.model._py_random.seed(s)                            # the branch A / B draw (main/model.py:426)
 
     def train_step(self, inputs, targets, meta, epoch: int, batch_ratio: float):
         dev = self.device

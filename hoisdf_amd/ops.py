@@ -608,6 +608,8 @@ def vote_loss(off, cls, pts, gt_mm, radius: float):
 class _AuxImageLosses(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, joints, hand_seg, obj_seg, sigma):
+        if joints.dim() != 3 or joints.shape[2] != 2:
+            raise RuntimeError(f"aux_image_losses: joint_coord must be (B, J, 2) heat-map pixels, got {tuple(joints.shape)}")
         joints, hand_seg, obj_seg = joints.contiguous().float(), hand_seg.contiguous().float(), obj_seg.contiguous().float()
         _chk(dec, joints, hand_seg, obj_seg)
         B, C, H, W = dec.shape

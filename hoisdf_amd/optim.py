@@ -28,6 +28,14 @@ class FusedAdamW(torch.optim.AdamW):
         dense = ts[0].is_contiguous() or (ts[0].dim() == 4 and ts[0].is_contiguous(memory_format=torch.channels_last))
         return same and dense
 
+    def load_state_dict(self, state_dict):
+        """torch's loader casts per-parameter state to the parameter's device; the scalar ``step`` counters stay on the
+        host so that reading them never synchronises the stream."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -46,27 +54,34 @@ class FusedAdamW(torch.optim.AdamW):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
-                         self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
-            cached = self._table.get(gi)
-            if cached is None or cached[0] != key:
-                rows = []
-                for p in ps:
-                    m, v = self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]
-                    if not self._dense_same_layout(p, p.grad, m, v):
-                        raise RuntimeError(f"FusedAdamW: parameter of shape {tuple(p.shape)} / its gradient / moments "
-                                           "must be dense float32 CUDA tensors with identical strides")
-                    n = p.numel()
-                    for o in range(0, n, CHUNK):
-                        rows.append((p.data_ptr() + 4 * o, p.grad.data_ptr() + 4 * o, m.data_ptr() + 4 * o,
-                                     v.data_ptr() + 4 * o, min(CHUNK, n - o)))
-                table = torch.tensor(rows, dtype=torch.int64).to(ps[0].device)
-                cached = (key, table)
-                self._table[gi] = cached
-            step = float(self.state[ps[0]]["step"]) + 1.0
+            # bias correction uses each parameter's OWN step count (torch.optim.AdamW semantics): parameters are grouped
+            # by step value - one launch per distinct value, i.e. one launch unless a parameter first received a
+            # gradient later than the others.  ``step`` tensors live on the host (see load_state_dict), so reading them
+            # does not synchronise with the device.
+            by_step = {}
             for p in ps:
-                self.state[p]["step"] += 1
+                by_step.setdefault(float(self.state[p]["step"]), []).append(p)
             b1, b2 = group["betas"]
-            call("hoisdf_adamw_step", ops._p(cached[1]), cached[1].shape[0], float(group["lr"]), float(b1), float(b2),
-                 float(group["eps"]), float(group["weight_decay"]), int(step), self.grad_scale, ops._st())
+            for si, (step0, sub) in enumerate(sorted(by_step.items())):
+                key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                             self.state[p]["exp_avg_sq"].data_ptr()) for p in sub)
+                cached = self._table.get((gi, si))
+                if cached is None or cached[0] != key:
+                    rows = []
+                    for p in sub:
+                        m, v = self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]
+                        if not self._dense_same_layout(p, p.grad, m, v):
+                            raise RuntimeError(f"FusedAdamW: parameter of shape {tuple(p.shape)} / its gradient / moments "
+                                               "must be dense float32 CUDA tensors with identical strides")
+                        n = p.numel()
+                        for o in range(0, n, CHUNK):
+                            rows.append((p.data_ptr() + 4 * o, p.grad.data_ptr() + 4 * o, m.data_ptr() + 4 * o,
+                                         v.data_ptr() + 4 * o, min(CHUNK, n - o)))
+                    table = torch.tensor(rows, dtype=torch.int64).to(sub[0].device)
+                    cached = (key, table)
+                    self._table[(gi, si)] = cached
+                for p in sub:
+                    self.state[p]["step"] += 1
+                call("hoisdf_adamw_step", ops._p(cached[1]), cached[1].shape[0], float(group["lr"]), float(b1), float(b2),
+                     float(group["eps"]), float(group["weight_decay"]), int(step0 + 1.0), self.grad_scale, ops._st())
         return loss

@@ -206,10 +206,14 @@ def e2e_goldens():
             save(f"g7_e2e_{setting}_n{nh + no}", **keep)
 
 
-def train_goldens():
+def train_goldens(sizes=((2, 48, 16, ""),), settings=("dexycb", "ho3d_render")):
     """g8: train-mode forward + backward with every dropout p forced to 0 (branch A)."""
-    B, nh, no = 2, 48, 16
-    for setting in ("dexycb", "ho3d_render"):
+    for (B, nh, no, suffix) in sizes:
+        _train_goldens(B, nh, no, suffix, settings)
+
+
+def _train_goldens(B, nh, no, suffix, settings):
+    for setting in settings:
         model, cfg = build_reference(setting, nh, no, 16)
         model.train()
         for m in model.modules():
@@ -246,8 +250,32 @@ def train_goldens():
             "grad.pyr.stride32": pyr["stride32"].grad[:, ::16],
             "grad.pyr.stride2_norm": pyr["stride2"].grad.double().norm().float(),
         }
-        save(f"g8_train_{setting}", total=total, **{"loss." + k: v for k, v in losses.items()},
+        save(f"g8_train_{setting}{suffix}", total=total, **{"loss." + k: v for k, v in losses.items()},
              **gn, **sel)
+
+
+def big_goldens():
+    """Fixtures at the sizes BASELINE.json's configs name: the reference itself runs these on CPU
+    in seconds to minutes.  g7 eval: configs[1] points (1536+512, dexycb, B=2), configs[3] (3072+1024, ho3d_render =
+    the IK variant, B=1), configs[4] (6144+2048, dexycb, B=1), all through sdf_infer on the 64^3 lattice;
+    g8 train fwd+bwd at 1536+512, B=2 (losses + per-parameter gradient norms + a few gradient slices)."""
+    for setting, nh, no, B in (("dexycb", 1536, 512, 2), ("ho3d_render", 3072, 1024, 1), ("dexycb", 6144, 2048, 1)):
+        model, cfg = build_reference(setting, nh, no, 64)
+        model.eval()
+        pyr = T.synthetic_pyramid(B, big=False, seed=2)
+        model.backbone_net, model.decoder_net = _Backbone(), _Decoder(pyr)
+        inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=21)
+        with torch.no_grad():
+            out = model(inputs, targets, meta, "eval")
+        keep = {k: v for k, v in out.items() if torch.is_tensor(v) and v.numel() < 200000
+                and k not in ("hand_seg_gt_out", "obj_seg_gt_out", "hand_seg_pred_out",
+                              "obj_seg_pred_out", "joint_heatmap_out", "joint_heatmap",
+                              "obj_seg", "hand_seg")}
+        for k in ("obj_rot_out", "obj_trans_out"):      # per-point rows follow the |sdf| order: keep the means only
+            if k in keep:
+                keep[k + "_mean"] = keep.pop(k).mean(1)
+        save(f"g7_e2e_{setting}_n{nh + no}", **keep)
+    train_goldens(sizes=((2, 1536, 512, "_n2048"),), settings=("dexycb",))
 
 
 def mano_golden():
@@ -292,7 +320,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema", "big"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -303,3 +331,5 @@ if __name__ == "__main__":
         e2e_goldens()
     if "train" in which:
         train_goldens()
+    if "big" in which:
+        big_goldens()

@@ -1,0 +1,224 @@
+"""-m gpu: the BACKWARD kernels at the geometry bench.py runs (BASELINE configs[1]: B = 32, 1536 + 512 points,
+S = 2048 tokens, M = 65 536 rows), where the launch geometry differs from the small parity shapes: split-K grad-weight
+with float atomics over M = 65 536, the fused attention backward summing dQ over 16 key blocks, the gather backward
+mixing wave-private LDS images and global atomics over 49 152 points.
+
+References are plain PyTorch in fp64 (on the device - the CPU would need minutes): samples and heads are independent, so
+the attention is checked on (sample, head) slices; tolerances are relative to each tensor's max and sized for fp32
+summation order only.  The last test feeds the whole training step with the REFERENCE's own N = 2048 fixture
+(g8_train_dexycb_n2048: the reference's losses and gradient norms at B = 2) tiled 16x to B = 32: every loss is a batch
+mean, so losses and parameter gradients must equal the reference's - at exactly the benchmarked launch geometry."""
+import math
+import random
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from hoisdf_amd import testing as T
+from hoisdf_amd.config import Config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, NH, NO, E, H = 32, 1536, 512, 256, 4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randn(*shape, generator=g, device=DEV) * scale
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _ref_slice(q, k, v, go, kv_len):
+    """fp64 attention forward+backward of one (sample, head): q (Lq,64), k/v (Lk,64), go (Lq,64)."""
+    q, k, v = (t.double().detach().requires_grad_(True) for t in (q, k, v))
+    s = (q / math.sqrt(q.shape[1])) @ k.T
+    if kv_len < k.shape[0]:
+        s[:, kv_len:] = float("-inf")
+    o = torch.softmax(s, -1) @ v
+    o.backward(go.double())
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+SLICES = [(0, 0), (5, 2), (31, 3)]
+
+
+def test_self_attention_backward_at_S2048_B32():
+    from hoisdf_amd import ops as O
+    S = NH + NO
+    qkv = rnd(B, S, 3 * E, seed=1).requires_grad_(True)
+    go = rnd(B, S, E, seed=2)
+    o = O.attention_self(qkv, H)
+    o.backward(go)
+    g = qkv.grad
+    for b, h in SLICES:
+        c = slice(64 * h, 64 * h + 64)
+        ro, rq, rk, rv = _ref_slice(qkv[b, :, :E][:, c], qkv[b, :, E:2 * E][:, c], qkv[b, :, 2 * E:][:, c], go[b][:, c], S)
+        assert rel_err(o[b][:, c], ro) <= 2e-5
+        assert rel_err(g[b, :, :E][:, c], rq) <= 5e-5, ("dq", b, h)
+        assert rel_err(g[b, :, E:2 * E][:, c], rk) <= 5e-5, ("dk", b, h)
+        assert rel_err(g[b, :, 2 * E:][:, c], rv) <= 5e-5, ("dv", b, h)
+
+
+@pytest.mark.parametrize("Lq,Lk,kv_len", [(1536, 2048, 2048), (512, 2048, 2048), (17, 2048, 1536)])
+def test_cross_attention_backward_at_bench_shapes(Lq, Lk, kv_len):
+    """the last encoder layers (Lq = 1536 / 512 query rows over all 2048 keys) and the decoder's 17 MANO queries over the
+    1536 visible hand keys (main/model.py:571-581 with the memory mask of common/utils/misc.py:42-47)."""
+    from hoisdf_amd import ops as O
+    q = rnd(B, Lq, E, seed=3).requires_grad_(True)
+    kv = rnd(B, Lk, 2 * E, seed=4).requires_grad_(True)
+    go = rnd(B, Lq, E, seed=5)
+    o = O.attention_cross(q, kv, H, kv_len)
+    o.backward(go)
+    for b, h in SLICES:
+        c = slice(64 * h, 64 * h + 64)
+        ro, rq, rk, rv = _ref_slice(q[b][:, c], kv[b, :, :E][:, c], kv[b, :, E:][:, c], go[b][:, c], kv_len)
+        assert rel_err(o[b][:, c], ro) <= 2e-5
+        assert rel_err(q.grad[b][:, c], rq) <= 5e-5, ("dq", b, h)
+        assert rel_err(kv.grad[b, :, :E][:, c], rk) <= 5e-5, ("dk", b, h)
+        assert rel_err(kv.grad[b, :, E:][:, c], rv) <= 5e-5, ("dv", b, h)
+    if kv_len < Lk:
+        assert float(kv.grad[:, kv_len:].abs().max()) == 0.0
+
+
+def test_attention_dropout_adjoint_identity_at_S2048():
+    """dropout ON at the bench geometry: for a fixed seed o = A(q,k) v with A = dropout(softmax); the backward must
+    regenerate the same mask, so <go, A v> == <A^T go, v> = <dv, v> (exact up to fp32 summation)."""
+    from hoisdf_amd import ops as O
+    S = NH + NO
+    qkv = rnd(B, S, 3 * E, seed=6).requires_grad_(True)
+    go = rnd(B, S, E, seed=7)
+    O.manual_seed(4242)
+    o = O.attention_self(qkv, H, drop_p=0.1)
+    o.backward(go)
+    lhs = (go.double() * o.double()).sum(dim=(1, 2))
+    rhs = (qkv.grad[:, :, 2 * E:].double() * qkv[:, :, 2 * E:].double()).sum(dim=(1, 2))
+    bound = 1e-5 * go.double().flatten(1).norm(dim=1) * o.double().flatten(1).norm(dim=1)
+    assert bool(((lhs - rhs).abs() <= bound).all()), float(((lhs - rhs).abs() / bound).max())
+    # the mask is really applied (kept fraction ~0.9 shows as a different output than p = 0)
+    o0 = O.attention_self(qkv.detach(), H)
+    assert float((o - o0).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,act,p", [(65536, 512, 992, True, 0.0), (65536, 512, 512, True, 0.2), (65536, 1024, 256, True, 0.1),
+                                         (65536, 256, 1024, False, 0.0), (49152, 60, 256, False, 0.0)])
+def test_linear_backward_at_M65536(M, N, K, act, p):
+    """grad-weight (split-K, float atomics, fused bias gradient, ReLU/dropout applied from the 1-bit map) and grad-input
+    at the row count of the step (B*S = 65 536; 49 152 = B*1536 for the vote heads) vs fp64 matmuls."""
+    from hoisdf_amd import ops as O
+    x = rnd(M, K, seed=8).requires_grad_(True)
+    W = (rnd(N, K, seed=9) / math.sqrt(K)).requires_grad_(True)
+    b = rnd(N, seed=10, scale=0.1).requires_grad_(True)
+    dy = rnd(M, N, seed=11)
+    O.manual_seed(77)
+    y = O.linear(x, W, b, act=act, drop_p=p)
+    y.backward(dy)
+    pre = x.double() @ W.double().T + b.double()
+    if act:
+        keep = (y != 0).double()                    # kept & positive (a pre-activation of exactly 0 has no gradient either way)
+        scale = 1.0 / (1.0 - p)
+        assert rel_err(y, torch.relu(pre) * keep * scale) <= 2e-5
+        if p > 0:
+            frac = float(keep.sum() / (pre > 0).double().sum())
+            assert abs(frac - (1 - p)) < 2e-3, frac
+        g = dy.double() * keep * scale
+    else:
+        assert rel_err(y, pre) <= 2e-5
+        g = dy.double()
+    assert rel_err(W.grad, g.T @ x.double()) <= 5e-5, "dW"
+    assert rel_err(b.grad, g.sum(0)) <= 5e-5, "db"
+    assert rel_err(x.grad, g @ W.double()) <= 5e-5, "dx"
+
+
+@pytest.mark.parametrize("P", [NH, NO])
+def test_gather_backward_at_B32(P):
+    """K1 backward over B*P points vs F.grid_sample's backward in fp64 (NCHW, border padding, align_corners)."""
+    from hoisdf_amd import ops as O
+    pyr = T.synthetic_pyramid(B, seed=12, nonneg=False)
+    inputs, _, meta = T.synthetic_batch(B, P, 8, seed=13)
+    pts = (inputs["hand_sdf_points"] * 1.5).to(DEV)          # a few percent project outside the image -> border clamp
+    root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
+    levels = [v.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True) for v in pyr.values()]
+    feat, cam = O.project_gather(O.PyramidNHWC(levels), pts, root, K, 3.1)
+    gy = rnd(B * P, feat.shape[1], seed=14)
+    feat.backward(gy)
+    # fp64 reference (main/model.py:153-174): cam = p / s + c; uv = K cam / z; grid = (uv - 127.5) / 127.5
+    camr = pts.double() / 3.1 + root.double()[:, None]
+    q = torch.einsum("bij,bpj->bpi", K.double(), camr)
+    grid = ((q[..., :2] / q[..., 2:]) - 127.5) / 127.5
+    off = 0
+    for lv, (name, m) in zip(levels, pyr.items()):
+        m64 = m.to(DEV).double().requires_grad_(True)
+        s = F.grid_sample(m64, grid[:, None], mode="bilinear", padding_mode="border", align_corners=True)   # (B,C,1,P)
+        c = m.shape[1]
+        f_ref = s[:, :, 0].permute(0, 2, 1).reshape(B * P, c)
+        assert rel_err(feat[:, off:off + c], f_ref) <= 2e-5, name
+        f_ref.backward(gy[:, off:off + c].double())
+        assert rel_err(lv.grad.permute(0, 3, 1, 2), m64.grad) <= 5e-5, ("dpyr", name)
+        off += c
+
+
+def test_training_step_at_B32_equals_the_reference_n2048_fixture():
+    from hoisdf_amd import ops
+    from hoisdf_amd.model import get_model
+    from hoisdf_amd.nets import mano as MANO
+    g = load_golden("g8_train_dexycb_n2048")
+    rep = B // 2
+    c = Config()
+    c.resnet_type = 18
+    c.apply_setting("dexycb")
+    c.num_samp_hand, c.num_samp_obj, c.bins_n, c.dropout = NH, NO, 16, 0.0
+    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
+    sd = model.state_dict()
+    for k in sd:
+        if not k.startswith("mano_head"):
+            sd[k] = T.det_param(k, sd[k].shape)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    for m in model.modules():
+        if hasattr(m, "p"):
+            m.p = 0.0
+        if hasattr(m, "dropout_prob"):
+            m.dropout_prob = 0.0
+    tile = lambda t: t.repeat(rep, *([1] * (t.dim() - 1)))
+    levels = [tile(v).to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+              for v in T.synthetic_pyramid(2, big=False, seed=3).values()]
+    pyr = ops.PyramidNHWC(levels)
+    inputs, targets, meta = T.synthetic_batch(2, NH, NO, seed=31)
+    torch.manual_seed(1234)                                       # the reference's CPU jitter stream: hand first, then obj
+    jit = [torch.empty_like(inputs["hand_pre_points"]).uniform_(-0.05, 0.05),
+           torch.empty_like(inputs["obj_pre_points"]).uniform_(-0.05, 0.05)]
+    model._jitter = lambda like, d: tile(jit.pop(0)).to(DEV)
+    model._py_random = random.Random(0)
+    inputs, targets, meta = ({k: tile(v).to(DEV) for k, v in d.items()} for d in (inputs, targets, meta))
+    loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
+    losses = {k: v.mean() for k, v in loss.items()}
+    for k, v in losses.items():
+        ref = float(g["loss." + k])
+        assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    total = sum(losses.values())
+    total.backward()
+    n = 0
+    for name, p in model.named_parameters():
+        key = "gradnorm." + name
+        if key in g:
+            gn = p.grad.double().norm().item()
+            assert abs(gn - float(g[key])) <= 1e-3 * float(g[key]) + 1e-6, (name, gn, float(g[key]))
+            n += 1
+    assert n > 100
+    # per-sample pyramid gradients: each of the 16 copies carries 1/16 of the B = 2 gradient
+    g32 = levels[4].grad.permute(0, 3, 1, 2)[:, ::16]
+    ref32 = g["grad.pyr.stride32"]
+    for r in (0, 7, rep - 1):
+        got = g32[2 * r:2 * r + 2].cpu() * rep
+        assert float((got - ref32).abs().max()) <= 1e-3 * float(ref32.abs().max())
+    gn2 = (levels[0].grad.double() * rep).norm().item() / math.sqrt(rep)
+    assert abs(gn2 - float(g["grad.pyr.stride2_norm"])) <= 1e-3 * float(g["grad.pyr.stride2_norm"])
+    wg = model.linear_handcls.layers[2].weight.grad.float().cpu()
+    assert float((wg - g["grad.linear_handcls.layers.2.weight"]).abs().max()) <= \
+        1e-3 * float(g["grad.linear_handcls.layers.2.weight"].abs().max())

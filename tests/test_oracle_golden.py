@@ -151,7 +151,9 @@ def test_g9_mano_and_rotations():
 
 
 E2E = [("dexycb", False, 48, 16, 16, 2), ("ho3d", True, 48, 16, 16, 2), ("ho3d_render", False, 48, 16, 16, 2),
-       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1)]
+       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1),
+       # the sizes BASELINE.json's configs[1] / configs[3] name (configs[4]'s 6144+2048 fixture is checked on the GPU only)
+       ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1)]
 
 
 @pytest.mark.parametrize("setting,big,nh,no,bins,b", E2E)
@@ -172,6 +174,10 @@ def test_g7_e2e(setting, big, nh, no, bins, b):
                                  hands_mean=layer.th_hands_mean)
     checked = 0
     for k, ref in g.items():
+        if k.endswith("_mean"):                        # big fixtures store the per-point outputs as means
+            close(out[k[:-5]].mean(1), ref, atol=2e-5)
+            checked += 1
+            continue
         if k not in out:
             raise AssertionError(f"oracle misses key {k}")
         if k in ("obj_rot_out", "obj_trans_out"):      # per-point rows follow sort order: compare means
@@ -183,11 +189,12 @@ def test_g7_e2e(setting, big, nh, no, bins, b):
     assert checked >= 6
 
 
-@pytest.mark.parametrize("setting", ["dexycb", "ho3d_render"])
-def test_g8_train_fwd_bwd(setting):
-    g = load_golden(f"g8_train_{setting}")
+@pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""),
+                                                  ("dexycb", 1536, 512, "_n2048")])
+def test_g8_train_fwd_bwd(setting, nh, no, suffix):
+    g = load_golden(f"g8_train_{setting}{suffix}")
     ik = setting == "ho3d_render"
-    nh, no, b = 48, 16, 2
+    b = 2
     Pm = T.det_params(T.hot_path_param_shapes(992, ik=ik))
     for v in Pm.values():
         v.requires_grad_(True)
@@ -216,7 +223,9 @@ def test_g8_train_fwd_bwd(setting):
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name   # unused params
     assert n > 100
-    def gclose(a, b, rel=3e-4):          # element-wise, tolerance relative to the tensor's max
+    # element-wise, tolerance relative to the tensor's max; at 2048 points each pyramid-gradient element is an fp32 sum of
+    # ~25 k terms whose order differs between the restatement's gather and ATen's (observed 3.2e-4 of the max)
+    def gclose(a, b, rel=3e-4 if nh < 1000 else 1e-3):
         close(a, b, rtol=0, atol=rel * float(b.abs().max()) + 1e-9)
 
     gclose(Pm["hand_sigmoid_beta"].grad, g["grad.hand_sigmoid_beta"])

@@ -3,7 +3,8 @@
 --point_sampling_epoch --lr_drop.  One process per GPU:
     python train.py --run_dir_name demo --gpu 0
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --run_dir_name demo --gpu 0-7
-Datasets are licence-gated: without --dataset-module the loop runs on DexYCB/HO3D-shaped synthetic samples."""
+Datasets are licence-gated and absent here: the loop runs on DexYCB/HO3D-shaped synthetic samples (a dataset object with
+the schema of data/dexycb.py:627-655 can be handed to hoisdf_amd.engine.Trainer(dataset=...) from Python)."""
 import argparse
 import os
 import time
@@ -55,6 +56,7 @@ def main():
     it_total = 0
     for epoch in range(trainer.start_epoch, cfg.end_epoch):
         adjust_learning_rate(trainer.lr_scheduler, trainer.optimizer)
+        trainer.begin_epoch(epoch)
         t0 = time.time()
         for itr, (inputs, targets, meta) in enumerate(trainer.batch_generator):
             total, loss = trainer.train_step(inputs, targets, meta, epoch, itr / max(trainer.itr_per_epoch, 1))
