@@ -52,6 +52,8 @@ class GradReducer:
         self._pending: List[int] = []
         self._handles = []
         self._launched: List[bool] = []
+        self._ready: List[bool] = []
+        self._next = 0
         self._side_events: List[list] = []
         self._main = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -66,9 +68,19 @@ class GradReducer:
             size += p.numel()
         if cur:
             groups.append(cur)
+        self._flags: List[torch.Tensor] = []          # per bucket: one "this rank produced a gradient" float per member
+        self._ones: List[List[torch.Tensor]] = []
+        self._check_unused: List[bool] = []
         for bi, members in enumerate(groups):
             n = sum(p.numel() for p in members)
-            flat = torch.zeros(n, dtype=members[0].dtype, device=members[0].device)
+            # the bucket carries one extra float per member behind the gradients: 1.0 if this rank produced a gradient
+            # for it this step.  After the SUM all-reduce a zero there means NO rank used the parameter, and its
+            # ``grad`` goes back to None (the reference's behaviour: AdamW then applies neither weight decay nor
+            # moment decay to it); the flags ride in the same collective, so the common path costs nothing extra.
+            flat = torch.zeros(n + len(members), dtype=members[0].dtype, device=members[0].device)
+            self._flags.append(flat[n:])
+            self._ones.append([torch.ones(1, dtype=flat.dtype, device=flat.device) for _ in members])
+            self._check_unused.append(False)
             views, off = [], 0
             for p in members:
                 chunk = flat[off:off + p.numel()]
@@ -84,6 +96,7 @@ class GradReducer:
             self._views.append(views)
             self._pending.append(len(members))
             self._launched.append(False)
+            self._ready.append(False)
             self._side_events.append([])
 
     def _make_hook(self, bi: int):
@@ -106,6 +119,15 @@ class GradReducer:
         return hook
 
     def _launch(self, bi: int):
+        """Collectives must be issued in the SAME order on every rank: a bucket whose last gradient arrived is only
+        marked ready, and buckets go out strictly in index order (bucket i waits for buckets < i).  A rank on which some
+        parameter got no gradient this step (its bucket is then flushed by finish()) therefore still matches the others."""
+        self._ready[bi] = True
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._launch_now(self._next)
+            self._next += 1
+
+    def _launch_now(self, bi: int):
         if self._launched[bi]:
             return
         self._launched[bi] = True
@@ -120,13 +142,17 @@ class GradReducer:
 
     def _pack_and_reduce(self, bi: int):
         members, views, flat = self._members[bi], self._views[bi], self.buckets[bi]
+        flags = self._flags[bi]
         if all(p.grad is not None for p in members):
-            torch._foreach_copy_(views, [p.grad for p in members])           # multi-tensor packed copy
+            torch._foreach_copy_(views + [flags[i:i + 1] for i in range(len(members))],
+                                 [p.grad for p in members] + self._ones[bi])       # multi-tensor packed copy (+ flags)
         else:                                   # some parameter got no gradient this step: zero + per-tensor copy
             flat.zero_()
-            for p, v in zip(members, views):
+            for i, (p, v) in enumerate(zip(members, views)):
                 if p.grad is not None:
                     v.copy_(p.grad)
+                    flags[i:i + 1].copy_(self._ones[bi][i])
+            self._check_unused[bi] = True
         for p, v in zip(members, views):
             p.grad = v
         if self.world > 1 or self.always_reduce:
@@ -141,7 +167,10 @@ class GradReducer:
                 p.grad = None
             self._pending[bi] = len(members)
             self._launched[bi] = False
+            self._ready[bi] = False
             self._side_events[bi] = []
+            self._check_unused[bi] = False
+        self._next = 0
         self._handles = []
 
     def finish(self):
@@ -153,8 +182,18 @@ class GradReducer:
             h.wait()
         self._handles = []
         if self.world > 1 and self.average:
-            for flat in self.buckets:
-                flat.div_(self.world)
+            for flat, flags in zip(self.buckets, self._flags):
+                flat[:flat.numel() - flags.numel()].div_(self.world)
+        # parameters that NO rank used this step get grad = None back.  Reading the flags synchronises the host, so it is
+        # done only for buckets that had a locally-unused member: a flag can only sum to zero if every rank, this one
+        # included, produced no gradient for that member, so every rank takes this branch together.
+        for bi, members in enumerate(self._members):
+            if not self._check_unused[bi]:
+                continue
+            fl = self._flags[bi].cpu()
+            unused = [i for i in range(len(members)) if float(fl[i]) == 0.0]
+            for i in unused:
+                members[i].grad = None
 
     def total_bytes(self) -> int:
-        return sum(b.numel() * 4 for b in self.buckets)
+        return sum((b.numel() - f.numel()) * 4 for b, f in zip(self.buckets, self._flags))
