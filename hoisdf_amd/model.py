@@ -201,6 +201,9 @@ class Model(nn.Module):
 
         p = self._py_random.uniform(0, 1)                                              # :426
         branch_a = (p < 0.4 or epoch_cnt < c.point_sampling_epoch) and training        # :427-460
+        log = getattr(self, "branch_log", None)
+        if log is not None and training:
+            log.append("A" if branch_a else "B")             # bench.py --branch-mix reports the mix it measured
         if branch_a:
             d = c.random_move_dist[len([a for a in c.random_ratio if batch_ratio > a])]
             jit = self._jitter or (lambda like, dd: torch.empty_like(like).uniform_(-dd, dd))
