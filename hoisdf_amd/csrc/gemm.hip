@@ -18,6 +18,8 @@
 // accumulated from the staged dy tiles of the grad-weight kernel.  Split-K (grad-weight always; forward /
 // grad-input when the grid is only a few tiles) accumulates with float atomics into a zeroed output, every
 // k-slice on one XCD; a caller workspace selects partial tiles + a deterministic reduce kernel instead.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -52,7 +54,8 @@ struct GemmArgs {
   int splitk, k_per_split, atomic_out, partial;
   long c_split_stride, colsum_split_stride;
   int tiles_m, tiles_n;
-  int vecA, vecB;
+  int vecA, vecB, vecC, nofast;
+  int occ;                 // workgroups per CU to run at (0 = the kernel's natural 4), see pick_occupancy
 };
 
 // Stage one 128 x 32 operand tile from global memory into registers (4 x float4 per thread).
@@ -169,6 +172,111 @@ __device__ __forceinline__ void stage_store(const float4 (&reg)[NV], float* __re
   }
 }
 
+// ---- interior-tile fast path: the tile lies fully inside both operands, every k-tile is full and all rows are 16-byte
+// aligned, so the staging is a fixed per-thread pointer that advances by one k-tile - no bounds tests, clamps or
+// fast/slow dispatch inside the main loop.  Used where it measures faster (see launch_gemm).
+template <bool KC>
+__device__ __forceinline__ const float* fast_ptr(const float* __restrict__ src, int ld, int r0, int k0, int tid) {
+  return KC ? src + (size_t)(r0 + tid / KC_LPR) * ld + k0 + (tid % KC_LPR) * 4
+            : src + (size_t)(k0 + (tid >> 5)) * ld + r0 + (tid & 31) * 4;
+}
+template <bool KC>
+__device__ __forceinline__ void fast_load(float4 (&reg)[NV], const float* __restrict__ p, int ld) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    reg[i] = *reinterpret_cast<const float4*>(p + (size_t)(KC ? KC_RPP * i : 8 * i) * ld);
+}
+template <bool KC>
+__device__ __forceinline__ void fast_bits(uint32_t (&w)[NV], const uint32_t* __restrict__ bits, int ldbits, int r0, int k0,
+                                          int tid) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (KC) {
+      const int r = r0 + (tid / KC_LPR) + KC_RPP * i, k = k0 + (tid % KC_LPR) * 4;
+      w[i] = (bits[(size_t)r * ldbits + (k >> 5)] >> (k & 31)) & 0xFu;
+    } else {
+      const int k = k0 + (tid >> 5) + 8 * i, r = r0 + (tid & 31) * 4;
+      w[i] = (bits[(size_t)k * ldbits + (r >> 5)] >> (r & 31)) & 0xFu;
+    }
+  }
+}
+
+// The k-loop of one output tile.  FAST = interior tile (see above); otherwise the guarded staging.
+template <bool A_KC, bool B_KC, bool MASK, bool FAST>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& g, float* __restrict__ As, float* __restrict__ Bs,
+                                              f32x16 (&acc)[2][2], float4& csum, const bool do_colsum, const int m0,
+                                              const int n0, const int kbeg, const int kend, const int nk, const int tid,
+                                              const int lane, const int wm, const int wn) {
+  constexpr int SA = A_KC ? LDS_KC : LDS_MC;
+  constexpr int SB = B_KC ? LDS_KC : LDS_MC;
+  float4 ra[NV], rb[NV];
+  uint32_t rm[NV];
+  const float* pa = FAST ? fast_ptr<A_KC>(g.A, g.lda, m0, kbeg, tid) : nullptr;
+  const float* pb = FAST ? fast_ptr<B_KC>(g.B, g.ldb, n0, kbeg, tid) : nullptr;
+  const size_t stepa = A_KC ? (size_t)BK : (size_t)BK * g.lda;
+  const size_t stepb = B_KC ? (size_t)BK : (size_t)BK * g.ldb;
+  if (nk > 0) {
+    if (FAST) {
+      fast_load<A_KC>(ra, pa, g.lda);
+      if (MASK) fast_bits<A_KC>(rm, g.abits, g.ldbits, m0, kbeg, tid);
+      fast_load<B_KC>(rb, pb, g.ldb);
+    } else {
+      stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid);
+      if (MASK) load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg, kend, tid);
+      stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid);
+    }
+    if (MASK) apply_bits(ra, rm, g.ascale);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+    }
+    stage_store<A_KC>(ra, As, tid);
+    stage_store<B_KC>(rb, Bs, tid);
+  }
+  __syncthreads();
+
+  const int arow = wm * 64 + (lane & 31);
+  const int brow = wn * 64 + (lane & 31);
+  const int khalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (FAST) {
+        pa += stepa;
+        pb += stepb;
+        fast_load<A_KC>(ra, pa, g.lda);
+        if (MASK) fast_bits<A_KC>(rm, g.abits, g.ldbits, m0, kbeg + (kt + 1) * BK, tid);
+        fast_load<B_KC>(rb, pb, g.ldb);
+      } else {
+        stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.vecA, tid);
+        if (MASK) load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
+        stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, tid);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a0 = As[(kk + khalf) * SA + arow];
+      float a1 = As[(kk + khalf) * SA + arow + 32];
+      float b0 = Bs[(kk + khalf) * SB + brow];
+      float b1 = Bs[(kk + khalf) * SB + brow + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();      // every wave is done reading this stage
+    if (kt + 1 < nk) {
+      if (MASK) apply_bits(ra, rm, g.ascale);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
+      }
+      stage_store<A_KC>(ra, As, tid);
+      stage_store<B_KC>(rb, Bs, tid);
+      __syncthreads();
+    }
+  }
+}
+
 template <bool A_KC, bool B_KC, bool MASK, bool ATOMIC>
 __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f32_kernel(GemmArgs g) {
   constexpr int SA = A_KC ? LDS_KC : LDS_MC;
@@ -179,12 +287,9 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
   //   BK 32 double-buffered, 2 WG/CU:  93 / 53 / 52   (PMC: MFMA pipe 65 % busy, 22-57 % of wave cycles parked)
   //   BK 32 single stage,    3 WG/CU: 101 / 85 / 72   BK 64, 2 WG/CU: 94 / 72 / 71
   //   BK 16 single stage,    4 WG/CU:  97 / 97 / 86   <- this build
-#ifndef HOISDF_GEMM_STAGES
-#define HOISDF_GEMM_STAGES 1
-#endif
-  constexpr int STAGES = HOISDF_GEMM_STAGES;
   constexpr int STAGE_FLOATS = BK * SA + BK * SB;
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE_FLOATS];
+  static_assert(STAGE_FLOATS >= 4 * 32 * 32, "the epilogue parks one 32x32 block per wave in the staging buffer");
+  __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
   float* As = lds;
   float* Bs = lds + BK * SA;
 
@@ -222,62 +327,15 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NV], rb[NV];
-  uint32_t rm[NV];
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nk > 0) {
-    stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.vecA, tid);
-    if (MASK) {
-      load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg, kend, tid);
-      apply_bits(ra, rm, g.ascale);
-    }
-    stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.vecB, tid);
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
-    }
-    stage_store<A_KC>(ra, As, tid);
-    stage_store<B_KC>(rb, Bs, tid);
-  }
-  __syncthreads();
-
-  const int arow = wm * 64 + (lane & 31);
-  const int brow = wn * 64 + (lane & 31);
   const int khalf = lane >> 5;
-
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      stage_load<A_KC>(ra, g.A, g.lda, m0, g.M, kbeg + (kt + 1) * BK, kend, g.vecA, tid);
-      if (MASK) load_bits<A_KC>(rm, g.abits, g.ldbits, m0, g.M, kbeg + (kt + 1) * BK, kend, tid);
-      stage_load<B_KC>(rb, g.B, g.ldb, n0, g.N, kbeg + (kt + 1) * BK, kend, g.vecB, tid);
-    }
-    const float* as = As + (STAGES == 2 ? (kt & 1) * STAGE_FLOATS : 0);
-    const float* bs = Bs + (STAGES == 2 ? (kt & 1) * STAGE_FLOATS : 0);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a0 = as[(kk + khalf) * SA + arow];
-      float a1 = as[(kk + khalf) * SA + arow + 32];
-      float b0 = bs[(kk + khalf) * SB + brow];
-      float b1 = bs[(kk + khalf) * SB + brow + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (STAGES == 1) __syncthreads();      // every wave is done reading this stage
-    if (kt + 1 < nk) {
-      if (MASK) apply_bits(ra, rm, g.ascale);
-      if (do_colsum) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) { csum.x += ra[i].x; csum.y += ra[i].y; csum.z += ra[i].z; csum.w += ra[i].w; }
-      }
-      float* an = As + (STAGES == 2 ? ((kt + 1) & 1) * STAGE_FLOATS : 0);
-      float* bn = Bs + (STAGES == 2 ? ((kt + 1) & 1) * STAGE_FLOATS : 0);
-      stage_store<A_KC>(ra, an, tid);
-      stage_store<B_KC>(rb, bn, tid);
-    }
-    if (STAGES == 2 || kt + 1 < nk) __syncthreads();
-  }
+  // block-uniform choice of the staging code: interior tiles (all of them for the step's aligned shapes) take the
+  // branch-free loop
+  const bool interior = !g.nofast && g.vecA && g.vecB && (m0 + BM <= g.M) && (n0 + BN <= g.N) && ((kend - kbeg) % BK == 0);
+  if (interior)
+    gemm_mainloop<A_KC, B_KC, MASK, true>(g, As, Bs, acc, csum, do_colsum, m0, n0, kbeg, kend, nk, tid, lane, wm, wn);
+  else
+    gemm_mainloop<A_KC, B_KC, MASK, false>(g, As, Bs, acc, csum, do_colsum, m0, n0, kbeg, kend, nk, tid, lane, wm, wn);
 
   // bias gradient: this block column (tn == 0) has seen every dy element of its (m-tile, k-slice)
   if (do_colsum) {
@@ -337,15 +395,37 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
           if (full || (row < g.M && col < g.N)) atomicAdd(Cb + (size_t)row * g.ldc + col, acc[i][j][r]);
         }
   } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
+    if (A_KC && full && g.vecC) {
+      // Full tile, 16-byte aligned rows: through LDS.  Each wave parks one 32x32 accumulator block at a time in its
+      // private 4 KB slice of the (now idle) staging buffer and reads it back row-wise, so one global_store_dwordx4
+      // covers 8 complete 128-byte row segments: 16 store instructions per lane instead of 64 dword stores of two
+      // row segments each (the tile's store tail is issue-bound; gemm_lab: +2.5-3 %).  All waves are past the
+      // main loop's final barrier; the slices are wave-private, so no further barrier is needed.
+      float* w = lds + wave * (32 * 32);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
-          if (full || (row < g.M && col < g.N)) Cb[(size_t)row * g.ldc + col] = acc[i][j][r];
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
+            *reinterpret_cast<float4*>(Cb + (size_t)(m0 + wm * 64 + i * 32 + rr) * g.ldc + n0 + wn * 64 + j * 32 + cc) = v;
+          }
         }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+            if (full || (row < g.M && col < g.N)) Cb[(size_t)row * g.ldc + col] = acc[i][j][r];
+          }
+    }
     if (g.bits_out) {
       // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below: one ballot is two
       // mask words.  Each lane collects the two words (j = 0, 1) of "its" row of the wave's 64 x 64 sub-tile
@@ -374,6 +454,18 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
 
 static int aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Workgroups per CU for a grid of `nwg` equal tiles on 256 CUs.  With the natural 4 per CU a grid of 1025..1536 tiles
+// runs one full round and leaves a half-empty second one; at 3 per CU the same grid is two full rounds (768 slots) and
+// 3 waves per SIMD still hide the hand-over (tools/mb_occ.py, forward: 1536 tiles +2...+9 %; 768 / 3072 / 4096 tiles
+// +-1 %; 2 per CU never wins; the split-k grad-weight grids lose at 3).  HOISDF_GEMM_OCC={2,3,4} overrides (experiments).
+static int pick_occupancy(int nwg, int splitk) {
+  if (const char* e = getenv("HOISDF_GEMM_OCC")) {
+    const int v = atoi(e);
+    if (v >= 2 && v <= 4) return v;
+  }
+  return (splitk <= 1 && nwg > 1024 && nwg <= 1536) ? 3 : 4;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs g, hipStream_t st) {
   g.tiles_m = cdiv(g.M, BM);
@@ -382,15 +474,25 @@ static int launch_gemm(GemmArgs g, hipStream_t st) {
   // (a k-chunk that crosses the end of the contraction range falls back to guarded scalars)
   g.vecA = aligned16(g.A) && (g.lda % 4 == 0) && (A_KC ? (g.k_per_split % 4 == 0) : true);
   g.vecB = aligned16(g.B) && (g.ldb % 4 == 0) && (B_KC ? (g.k_per_split % 4 == 0) : true);
+  g.vecC = aligned16(g.C) && (g.ldc % 4 == 0) && (g.c_split_stride % 4 == 0);
+  // Measured A/B (tools/mb_ab.py, MI355X): the hoisted branch-free staging loop is +-0 on the forward, -5...-9 % on
+  // grad-input and -3...-6 % on large grad-weight problems (the guarded loop's wave-uniform fast path schedules better
+  // there), but +4...+7 % on the grad-weight problems with <= 4 output tiles - so only those take it.
+  g.nofast = !(!A_KC && !B_KC && g.tiles_m * g.tiles_n <= 4);
   const int ntile = g.tiles_m * g.tiles_n;
-  dim3 grid((unsigned)(g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile));
+  const int nwg = g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile;
+  dim3 grid((unsigned)nwg);
+  // workgroups per CU: the kernel's natural residency is 4 (<= 128 VGPRs, 16.5 KB LDS); asking for extra dynamic LDS
+  // caps it at 3 or 2 when that removes a mostly-empty last round of tiles (pick_occupancy)
+  const int occ = g.occ > 0 ? g.occ : pick_occupancy(nwg, g.splitk);
+  const unsigned dyn = occ >= 4 ? 0u : (occ == 3 ? 25600u : 39936u);
   constexpr bool CAN_ATOMIC = true;   // grad-weight always; forward / grad-input when a small grid is split along k
   if (CAN_ATOMIC && g.atomic_out) {
-    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, CAN_ATOMIC>), grid, dim3(NT), 0, st, g);
+    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, CAN_ATOMIC>), grid, dim3(NT), dyn, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, CAN_ATOMIC>), grid, dim3(NT), dyn, st, g);
   } else {
-    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, false>), grid, dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, false>), grid, dim3(NT), 0, st, g);
+    if (g.abits) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, false>), grid, dim3(NT), dyn, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, false>), grid, dim3(NT), dyn, st, g);
   }
   return check_launch("gemm_f32");
 }

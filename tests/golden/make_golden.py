@@ -304,6 +304,102 @@ def mano_golden():
     save("g9_mano", pose=pose, betas=betas, verts=v, joints=j, x6=x6, R=Rm, aa=aa, R_back=Rg)
 
 
+def _stub_module(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def metrics_golden():
+    """g11: the reference's evaluation metrics (common/metrics.py:62-232, common/eval_util.py:11-103) on seeded inputs.
+    Harness stubs: ``cv2`` (metrics.py imports it at module level; only the unused per-sample ``eval_batch_obj_direct``
+    calls cv2.Rodrigues) and ``open3d`` (eval_util.py's calculate_fscore uses its nearest-neighbour distances; the
+    fixture's F-scores are therefore computed here with brute-force numpy nearest neighbours over the SAME definition,
+    eval_util.py:117-136, and labelled as such)."""
+    _stub_module("cv2")
+    _stub_module("open3d")
+    from common.metrics import eval_batched_obj_direct, eval_hand_joint, rigid_align
+    from common.eval_util import EvalUtil
+    r = np.random.default_rng(11)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    B, V = 6, 300
+    pred_j = f32(0.05 * r.standard_normal((B, 21, 3)))
+    gt_j = pred_j * 1.1 + f32(0.004 * r.standard_normal((B, 21, 3))) + 0.01
+    mje, pamje = eval_hand_joint(pred_j, gt_j)
+    aligned = np.stack([rigid_align(pred_j[i].numpy(), gt_j[i].numpy()) for i in range(B)])
+    templates = [{"verts": f32(0.05 * r.standard_normal((V, 3)))} for _ in range(4)]
+    out = {"obj_rot": f32(0.3 * r.standard_normal((B, 40, 3))), "obj_trans": f32(0.05 * r.standard_normal((B, 40, 3)))}
+    targets = {"obj_rot": f32(0.3 * r.standard_normal((B, 3))), "rel_obj_trans": f32(0.05 * r.standard_normal((B, 3)))}
+    obj_cls = torch.tensor([1, 2, 3, 4, 1, 2])
+    meta = {"cam_intr": torch.eye(3).repeat(B, 1, 1), "obj_cls": obj_cls}
+    adds, mce, oce, _, n = eval_batched_obj_direct(out, targets, meta, templates, None, None)
+    names = {0: "a", 1: "b", 2: "c", 3: "d"}
+    meta_h = {"cam_intr": meta["cam_intr"], "obj_cls": [names[int(c) - 1] for c in obj_cls]}
+    adds_h, _, _, mme_h, n_h = eval_batched_obj_direct(out, targets, meta_h, templates, None, names)
+    ev = EvalUtil(num_kp=V)
+    gt_v = f32(0.05 * r.standard_normal((B, V, 3)))
+    pr_v = gt_v + f32(0.006 * r.standard_normal((B, V, 3)))
+    for i in range(B):
+        ev.feed(gt_v[i].numpy(), np.ones(V), pr_v[i].numpy())
+    m3d, med, auc, pck, th = ev.get_measures(0.0, 0.05, 100)
+
+    def fscore_np(gt, pr, t):           # eval_util.py:117-136 with brute-force nearest neighbours
+        d = np.sqrt(((gt[:, None].astype(np.float64) - pr[None].astype(np.float64)) ** 2).sum(-1))
+        d1, d2 = d.min(1), d.min(0)
+        rec, prec = (d2 < t).mean(), (d1 < t).mean()
+        return 2 * rec * prec / (rec + prec) if rec + prec > 0 else 0.0
+
+    fs = np.array([[fscore_np(gt_v[i].numpy(), pr_v[i].numpy(), t) for t in (0.005, 0.015)] for i in range(B)])
+    save("g11_metrics", pred_j=pred_j, gt_j=gt_j, mje=np.float64(mje), pamje=np.float64(pamje), aligned=aligned,
+         templates=torch.stack([t["verts"] for t in templates]), obj_rot=out["obj_rot"], obj_trans=out["obj_trans"],
+         obj_rot_gt=targets["obj_rot"], obj_trans_gt=targets["rel_obj_trans"], obj_cls=obj_cls.numpy(),
+         adds=np.float64(adds), mce=np.float64(mce), oce=np.float64(oce), adds_ho3d=np.float64(adds_h),
+         mme_ho3d=np.float64(mme_h), gt_v=gt_v, pr_v=pr_v, mesh_mean=np.float64(m3d), mesh_median=np.float64(med),
+         mesh_auc=np.float64(auc), mesh_pck=pck, fscore_bruteforce=fs)
+
+
+def ik_golden():
+    """g12: the reference's closed-form IK post-process (common/utils/inverse_kinematics.py:15-150) run on seeded joints.
+    PARTIALLY PINNED: the reference imports ``kornia.geometry.conversions.rotation_matrix_to_axis_angle`` (kornia is not
+    installed); the harness provides that ONE function through scipy's ``Rotation.from_matrix(R).as_rotvec()`` (the same
+    SO(3) log map; kornia goes matrix -> quaternion -> axis-angle) - everything else in the fixture is the reference's own
+    code, with ``ManoLayer`` = the synthetic MANO-shaped asset (shim 4 above)."""
+    from scipy.spatial.transform import Rotation
+
+    def rotation_matrix_to_axis_angle(R):
+        # the reference converts every fit, then keeps only the proper rotations (`[batch_id]`, :66-71): reflections
+        # (scipy refuses them) get a placeholder that is never read
+        Rn = R.detach().double().numpy()
+        out = np.zeros((Rn.shape[0], 3))
+        ok = np.linalg.det(Rn) > 0
+        out[ok] = Rotation.from_matrix(Rn[ok]).as_rotvec()
+        return torch.from_numpy(out).to(R.dtype)
+
+    _stub_module("kornia")
+    _stub_module("kornia.geometry")
+    _stub_module("kornia.geometry.conversions", rotation_matrix_to_axis_angle=rotation_matrix_to_axis_angle)
+    import manopth.manopth.manolayer as ML
+    ML.ManoLayer = lambda **k: MANO.ManoLayer(MANO.synthetic_assets(0))
+    sys.modules.pop("common.utils.inverse_kinematics", None)
+    from common.utils.inverse_kinematics import ik_solver_mano
+    layer = MANO.ManoLayer(MANO.synthetic_assets(0))
+    r = np.random.default_rng(12)
+    B = 8
+    pose = torch.from_numpy((0.3 * r.standard_normal((B, 48))).astype(np.float32))
+    betas = torch.from_numpy((0.5 * r.standard_normal((B, 10))).astype(np.float32))
+    _, j = layer(pose, betas)
+    joints = j / 1000.0 + torch.from_numpy((0.004 * r.standard_normal((B, 21, 3))).astype(np.float32))   # noisy "predictions"
+    joints = joints + torch.from_numpy((0.3 * r.standard_normal((B, 1, 3))).astype(np.float32))
+    joints[-1, :, 0] *= -1                       # a mirrored hand: the palm fit is a reflection -> pose stays zero (:66-71)
+    with torch.no_grad():
+        res = ik_solver_mano(betas, joints.clone())
+        res0 = ik_solver_mano(None, joints.clone())
+    save("g12_ik", joints_in=joints, betas=betas, verts=res["verts"], joints=res["joints"], pose=res["pose"],
+         vis=res["vis"].numpy(), pose_noshape=res0["pose"], joints_noshape=res0["joints"])
+
+
 def schema_golden():
     """g10: the reference Model's state-dict schema (names + shapes) for the three variants - what a released
     snapshot_*.pth.tar holds under ckpt["network"] (minus the DataParallel "module." prefix)."""
@@ -320,7 +416,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema", "big"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema", "big", "metrics", "ik"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -333,3 +429,7 @@ if __name__ == "__main__":
         train_goldens()
     if "big" in which:
         big_goldens()
+    if "metrics" in which:
+        metrics_golden()
+    if "ik" in which:
+        ik_golden()

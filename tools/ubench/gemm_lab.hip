@@ -1,0 +1,392 @@
+// GEMM lab (round 2): candidate main loops for the f32-MFMA forward GEMM  y[M][N] = x[M][K] . W[N][K]^T,
+// as complete kernels (global -> LDS -> MFMA -> C), timed per shape against the shipped gemm_f32_kernel
+// (called through libhoisdf_hip.so).  Shapes = the transformer / MLP shapes of the training step.
+//
+//   RM layout: LDS holds both operands ROW-MAJOR [row][16 k + 4 pad]; a staged float4 (4 consecutive k of one row)
+//   goes to LDS with ONE ds_write_b128 (no transposing b32 writes) and every MFMA fragment read is ONE ds_read_b128
+//   that feeds 4 k-steps: the k index inside v_mfma_f32_32x32x2_f32 is arbitrary as long as A and B agree, so lanes
+//   0-31 take k = 8g..8g+3 and lanes 32-63 take k = 8g+4..8g+7 of each 8-k group g.  Row stride 20 floats makes the
+//   16-lane groups of ds_read_b128 hit 16 distinct 4-bank sets (conflict-free).
+//   Per k-tile and wave: 8 ds_read_b128 + 2-4 ds_write_b128 instead of 32 ds_read_b32 + 16 ds_write_b32.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gemm_lab.hip -I../../include -L../../hoisdf_amd -lhoisdf_hip \
+//        -Wl,-rpath,'$ORIGIN/../../hoisdf_amd' -o gemm_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <vector>
+#include <algorithm>
+#include "hoisdf.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int nx = 8;
+  int xcd = bid % nx, loc = bid / nx;
+  int q = nblk / nx, r = nblk % nx;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+constexpr int BK = 16, S = 20, BN = 128;
+
+// WMW = waves along M (2 -> 128-row tile, 256 threads; 4 -> 256-row tile, 512 threads); 2 waves along N.
+template <int WMW, int STAGES, int OCC>
+__global__ __launch_bounds__(WMW * 128, OCC) void gemm_rm(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                          int ldc, int tiles_m, int tiles_n) {
+  constexpr int BM = 64 * WMW, NT = 128 * WMW;
+  constexpr int NA = BM * 4 / NT;      // float4 per thread, A tile (= 2)
+  constexpr int NB = BN * 4 / NT;      // float4 per thread, B tile (2 or 1)
+  constexpr int STAGE = (BM + BN) * S;
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = K / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int srow = tid >> 2, skc = (tid & 3) * 4;
+  const float* ga = A + (size_t)(m0 + srow) * lda + skc;
+  const float* gb = B + (size_t)(n0 + srow) * ldb + skc;
+  constexpr int RPP = NT / 4;          // rows per staging pass
+  float4 ra[NA], rb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(RPP * i) * lda);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(RPP * i) * ldb);
+  float* wa = lds + srow * S + skc;
+  float* wb = lds + BM * S + srow * S + skc;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(wa + RPP * i * S) = ra[i];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(wb + RPP * i * S) = rb[i];
+  __syncthreads();
+
+  const int khalf = lane >> 5;
+  const float* fa = lds + (wm * 64 + (lane & 31)) * S + khalf * 4;
+  const float* fb = lds + BM * S + (wn * 64 + (lane & 31)) * S + khalf * 4;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(RPP * i) * lda + (kt + 1) * BK);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(RPP * i) * ldb + (kt + 1) * BK);
+    }
+    const int so = STAGES == 2 ? (kt & 1) * STAGE : 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const float4 a0 = *reinterpret_cast<const float4*>(fa + so + g * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(fa + so + 32 * S + g * 8);
+      const float4 b0 = *reinterpret_cast<const float4*>(fb + so + g * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(fb + so + 32 * S + g * 8);
+      acc[0][0] = MFMA(a0.x, b0.x, acc[0][0]); acc[0][1] = MFMA(a0.x, b1.x, acc[0][1]);
+      acc[1][0] = MFMA(a1.x, b0.x, acc[1][0]); acc[1][1] = MFMA(a1.x, b1.x, acc[1][1]);
+      acc[0][0] = MFMA(a0.y, b0.y, acc[0][0]); acc[0][1] = MFMA(a0.y, b1.y, acc[0][1]);
+      acc[1][0] = MFMA(a1.y, b0.y, acc[1][0]); acc[1][1] = MFMA(a1.y, b1.y, acc[1][1]);
+      acc[0][0] = MFMA(a0.z, b0.z, acc[0][0]); acc[0][1] = MFMA(a0.z, b1.z, acc[0][1]);
+      acc[1][0] = MFMA(a1.z, b0.z, acc[1][0]); acc[1][1] = MFMA(a1.z, b1.z, acc[1][1]);
+      acc[0][0] = MFMA(a0.w, b0.w, acc[0][0]); acc[0][1] = MFMA(a0.w, b1.w, acc[0][1]);
+      acc[1][0] = MFMA(a1.w, b0.w, acc[1][0]); acc[1][1] = MFMA(a1.w, b1.w, acc[1][1]);
+    }
+    if (STAGES == 1) __syncthreads();
+    if (kt + 1 < nk) {
+      const int sn = STAGES == 2 ? ((kt + 1) & 1) * STAGE : 0;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(wa + sn + RPP * i * S) = ra[i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(wb + sn + RPP * i * S) = rb[i];
+    }
+    if (STAGES == 2 || kt + 1 < nk) __syncthreads();
+  }
+
+  const int rbase = m0 + wm * 64 + 4 * khalf;
+  const int cbase = n0 + wn * 64 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+        C[(size_t)row * ldc + col] = acc[i][j][r];
+      }
+}
+
+
+// ---- the shipped design (k-major LDS [k][129], transposing ds_write_b32, just-in-time ds_read_b32), simplified to
+// aligned shapes, plus experiments: a first-round start stagger (co-resident workgroups stop hitting prologue / epilogue
+// in lock-step) and epilogue variants.
+constexpr int SKC = 129;
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void gemm_kc(const float* __restrict__ A, const float* __restrict__ B,
+                                                  float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc,
+                                                  int tiles_m, int tiles_n, int stagger,
+                                                  unsigned long long* __restrict__ trace) {
+  __shared__ float lds[2 * BK * SKC];
+  unsigned long long t_in = 0, t_pro = 0, t_loop = 0;
+  if (MODE == 3) t_in = wall_clock64();
+  float* As = lds;
+  float* Bs = lds + BK * SKC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  if (stagger > 0 && blockIdx.x < 1024) {
+    // slot index of this workgroup on its CU in the first round: dispatch walks XCDs, then the 32 CUs of an XCD
+    const int slot = (blockIdx.x >> 8) & 3;
+    for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int nk = K / BK;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int srow = tid >> 2, skc = (tid & 3) * 4;
+  const float* ga = A + (size_t)(m0 + srow) * lda + skc;
+  const float* gb = B + (size_t)(n0 + srow) * ldb + skc;
+  float4 ra[2], rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(64 * i) * lda);
+    rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(64 * i) * ldb);
+  }
+  auto store = [&](float* dst, const float4& v, int i) {
+    dst[(skc + 0) * SKC + srow + 64 * i] = v.x; dst[(skc + 1) * SKC + srow + 64 * i] = v.y;
+    dst[(skc + 2) * SKC + srow + 64 * i] = v.z; dst[(skc + 3) * SKC + srow + 64 * i] = v.w;
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { store(As, ra[i], i); store(Bs, rb[i], i); }
+  __syncthreads();
+  if (MODE == 3) t_pro = wall_clock64();
+  const int khalf = lane >> 5;
+  const float* fa = As + khalf * SKC + wm * 64 + (lane & 31);
+  const float* fb = Bs + khalf * SKC + wn * 64 + (lane & 31);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ra[i] = *reinterpret_cast<const float4*>(ga + (size_t)(64 * i) * lda + (kt + 1) * BK);
+        rb[i] = *reinterpret_cast<const float4*>(gb + (size_t)(64 * i) * ldb + (kt + 1) * BK);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = fa[kk * SKC], a1 = fa[kk * SKC + 32], b0 = fb[kk * SKC], b1 = fb[kk * SKC + 32];
+      acc[0][0] = MFMA(a0, b0, acc[0][0]); acc[0][1] = MFMA(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA(a1, b0, acc[1][0]); acc[1][1] = MFMA(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { store(As, ra[i], i); store(Bs, rb[i], i); }
+      __syncthreads();
+    }
+  }
+  const int rbase = m0 + wm * 64 + 4 * khalf;
+  const int cbase = n0 + wn * 64 + (lane & 31);
+  if (MODE == 3) t_loop = wall_clock64();
+  if (MODE == 4) {
+    // epilogue through LDS: each wave parks one 32x32 accumulator block at a time in its private 4.1 KB slice of the (now
+    // idle) staging buffer and reads it back as rows: one global_store_dwordx4 covers 8 full 128-byte row segments
+    // (16 store instructions per lane instead of 64 dword stores with 2 row segments each).
+    __syncthreads();
+    float* w = lds + wave * (32 * 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * khalf) * 32 + (lane & 31)] = acc[i][j][r];
+        // rows of 32 floats: lane -> (row = p * 8 + lane / 8, 4 columns at (lane % 8) * 4)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 4;
+          const float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
+          *reinterpret_cast<float4*>(C + (size_t)(m0 + wm * 64 + i * 32 + rr) * ldc + n0 + wn * 64 + j * 32 + cc) = v;
+        }
+      }
+    return;
+  }
+  if (MODE == 1) return;                       // ablation: no C stores at all (acc is dead -> compiler may drop work; see MODE 2)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+        if (MODE == 2) { if (acc[i][j][r] == 123.456f) C[(size_t)row * ldc + col] = acc[i][j][r]; }   // never true: keeps the MFMAs
+        else C[(size_t)row * ldc + col] = acc[i][j][r];
+      }
+  if (MODE == 3) {
+    __builtin_amdgcn_s_waitcnt(0);             // stores retired
+    const unsigned long long t_end = wall_clock64();
+    if (tid == 0) {
+      unsigned hwid = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned long long* p = trace + (size_t)blockIdx.x * 6;
+      p[0] = t_in; p[1] = t_pro; p[2] = t_loop; p[3] = t_end; p[4] = hwid; p[5] = xcc;
+    }
+  }
+}
+static int g_dyn_lds = 0;     // extra dynamic LDS per workgroup: caps the workgroups per CU (occupancy experiments)
+template <int MODE>
+static void launch_kc(const float* A, const float* B, float* C, int M, int N, int K, int stagger,
+                      unsigned long long* trace = nullptr) {
+  const int tm = M / 128, tn = N / 128;
+  hipLaunchKernelGGL((gemm_kc<MODE>), dim3(tm * tn), dim3(256), g_dyn_lds, 0, A, B, C, M, N, K, K, K, N, tm, tn, stagger, trace);
+}
+
+// per-workgroup phase timeline of one launch (wall_clock64 = 100 MHz): where does a tile's life go, and do the
+// co-resident workgroups move in lock-step?
+static void trace_report(const float* A, const float* B, float* C, int M, int N, int K, int stagger) {
+  const int nwg = (M / 128) * (N / 128);
+  unsigned long long* d;
+  hipMalloc(&d, (size_t)nwg * 6 * 8);
+  launch_kc<3>(A, B, C, M, N, K, stagger, d);
+  launch_kc<3>(A, B, C, M, N, K, stagger, d);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h((size_t)nwg * 6);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  hipFree(d);
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int w = 0; w < nwg; ++w) { if (h[w * 6] < t0) t0 = h[w * 6]; if (h[w * 6 + 3] > t1) t1 = h[w * 6 + 3]; }
+  double pro = 0, loop = 0, epi = 0;
+  for (int w = 0; w < nwg; ++w) { pro += h[w * 6 + 1] - h[w * 6]; loop += h[w * 6 + 2] - h[w * 6 + 1]; epi += h[w * 6 + 3] - h[w * 6 + 2]; }
+  const double tick = 0.01;   // us
+  printf("trace (%d,%d,%d) stagger %d: %d WGs, kernel span %.1f us; mean per WG: prologue %.2f us, main loop %.2f us, epilogue %.2f us\n",
+         M, N, K, stagger, nwg, (t1 - t0) * tick, pro / nwg * tick, loop / nwg * tick, epi / nwg * tick);
+  // concurrency profile: number of WGs inside their main loop per 2 us bin
+  const int nb = (int)((t1 - t0) * tick / 2) + 1;
+  std::vector<double> inloop(nb, 0.0), resident(nb, 0.0);
+  for (int w = 0; w < nwg; ++w)
+    for (int b = 0; b < nb; ++b) {
+      const double lo = t0 + b * 200.0, hi = lo + 200.0;
+      auto ov = [&](double a, double e) { double x = (e < hi ? e : hi) - (a > lo ? a : lo); return x > 0 ? x / 200.0 : 0.0; };
+      inloop[b] += ov((double)h[w * 6 + 1], (double)h[w * 6 + 2]);
+      resident[b] += ov((double)h[w * 6], (double)h[w * 6 + 3]);
+    }
+  printf("  bins of 2 us: WGs in main loop / resident:");
+  for (int b = 0; b < nb; ++b) printf(" %d/%d", (int)(inloop[b] + 0.5), (int)(resident[b] + 0.5));
+  printf("\n");
+  // distinct CUs seen and end-time spread of the last round
+  // per-CU census: HW_ID[11:8] = cu, [12] = sh, [15:13] = se; XCC_ID[3:0]
+  std::vector<int> cnt(8 * 64, 0);
+  std::vector<double> endsum(8 * 64, 0.0), loopsum(8 * 64, 0.0);
+  for (int w = 0; w < nwg; ++w) {
+    const unsigned hw = (unsigned)h[w * 6 + 4], xc = (unsigned)h[w * 6 + 5] & 7;
+    const int cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5);
+    const int id = xc * 64 + (cu & 63);
+    cnt[id]++; endsum[id] += (h[w * 6 + 3] - t0) * tick; loopsum[id] += (h[w * 6 + 2] - h[w * 6 + 1]) * tick;
+  }
+  int hist[16] = {0}, ncu = 0;
+  for (int i = 0; i < 8 * 64; ++i) if (cnt[i]) { ++ncu; hist[cnt[i] < 15 ? cnt[i] : 15]++; }
+  printf("  %d CUs seen; CUs by number of WGs executed:", ncu);
+  for (int c = 1; c < 16; ++c) if (hist[c]) printf(" %dx%d", hist[c], c);
+  printf("\n  per XCC (mean main-loop us, mean end us, max end us):");
+  for (int x = 0; x < 8; ++x) {
+    double l = 0, e = 0, mx = 0; int c = 0;
+    for (int w = 0; w < nwg; ++w) if (((unsigned)h[w * 6 + 5] & 7) == (unsigned)x) {
+      ++c; l += (h[w * 6 + 2] - h[w * 6 + 1]) * tick; const double en = (h[w * 6 + 3] - t0) * tick; e += en; if (en > mx) mx = en; }
+    if (c) printf(" [x%d] %.0f %.0f %.0f", x, l / c, e / c, mx);
+  }
+  printf("\n  xcc0 per-CU (count: mean main-loop us, mean end us):");
+  for (int i = 0; i < 64; ++i) if (cnt[i]) printf(" [%d] %d: %.0f %.0f", i, cnt[i], loopsum[i] / cnt[i], endsum[i] / cnt[i]);
+  printf("\n");
+}
+
+struct Shape { int M, N, K; };
+
+template <typename F>
+static double time_ms(F&& f, int iters) {
+  hipEvent_t s, e;
+  hipEventCreate(&s); hipEventCreate(&e);
+  for (int i = 0; i < 3; ++i) f();
+  hipEventRecord(s);
+  for (int i = 0; i < iters; ++i) f();
+  hipEventRecord(e);
+  hipEventSynchronize(e);
+  float ms;
+  hipEventElapsedTime(&ms, s, e);
+  hipEventDestroy(s); hipEventDestroy(e);
+  return ms / iters;
+}
+
+template <int WMW, int STAGES, int OCC>
+static void launch_rm(const float* A, const float* B, float* C, int M, int N, int K) {
+  constexpr int BM = 64 * WMW;
+  const int tm = M / BM, tn = N / BN;
+  hipLaunchKernelGGL((gemm_rm<WMW, STAGES, OCC>), dim3(tm * tn), dim3(WMW * 128), 0, 0, A, B, C, M, N, K, K, K, N, tm, tn);
+}
+
+static double max_abs_diff(const float* a, const float* b, size_t n) {
+  std::vector<float> ha(n), hb(n);
+  hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost);
+  hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost);
+  double m = 0;
+  for (size_t i = 0; i < n; ++i) { double d = fabs((double)ha[i] - hb[i]); if (d > m) m = d; }
+  return m;
+}
+
+int main() {
+  const Shape shapes[] = {{65536, 1024, 256}, {65536, 256, 1024}, {65536, 768, 256}, {65536, 256, 256},
+                          {65536, 512, 992}, {49152, 512, 512}, {294912, 256, 256}};
+  const size_t maxA = (size_t)294912 * 1024, maxC = (size_t)294912 * 1024;
+  float *A, *B, *C, *C2;
+  if (hipMalloc(&A, maxA * 4) || hipMalloc(&B, 1024 * 1024 * 4) || hipMalloc(&C, maxC * 4) || hipMalloc(&C2, maxC * 4)) return 1;
+  {
+    std::vector<float> h(1 << 22);
+    uint32_t s = 12345;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) / (float)(1 << 23); }
+    for (size_t o = 0; o < maxA; o += h.size()) hipMemcpy(A + o, h.data(), (o + h.size() <= maxA ? h.size() : maxA - o) * 4, hipMemcpyHostToDevice);
+    hipMemcpy(B, h.data() + 77, 1024 * 1024 * 4, hipMemcpyHostToDevice);
+  }
+  hipFuncSetAttribute((const void*)gemm_kc<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
+  // interleaved medians: every variant is timed once per round, rounds repeated, so clock / thermal drift hits all alike
+  const char* names[] = {"shipped", "kc", "kc nostore", "kc lds-epi", "kc 2WG/CU", "kc 1WG/CU"};
+  printf("%-22s", "shape (M,N,K)");
+  for (auto n : names) printf(" %11s", n);
+  printf("\n");
+  for (const Shape& s : shapes) {
+    const double fl = 2.0 * s.M * s.N * s.K;
+    const int NV = 6, R = 7;
+    std::vector<std::vector<double>> t(NV);
+    for (int r = 0; r < R; ++r) {
+      t[0].push_back(time_ms([&] { hoisdf_linear_fwd(A, s.K, B, s.K, nullptr, C, s.N, s.M, s.N, s.K, 0, 0.f, 0, nullptr, nullptr); }, 5));
+      t[1].push_back(time_ms([&] { launch_kc<0>(A, B, C2, s.M, s.N, s.K, 0); }, 5));
+      t[2].push_back(time_ms([&] { launch_kc<2>(A, B, C2, s.M, s.N, s.K, 0); }, 5));
+      t[3].push_back(time_ms([&] { launch_kc<4>(A, B, C2, s.M, s.N, s.K, 0); }, 5));
+      g_dyn_lds = 50000;
+      t[4].push_back(time_ms([&] { launch_kc<0>(A, B, C2, s.M, s.N, s.K, 0); }, 5));
+      g_dyn_lds = 120000;
+      t[5].push_back(time_ms([&] { launch_kc<0>(A, B, C2, s.M, s.N, s.K, 0); }, 5));
+      g_dyn_lds = 0;
+    }
+    launch_kc<4>(A, B, C2, s.M, s.N, s.K, 0);
+    const double err = max_abs_diff(C, C2, (size_t)4096 * s.N);
+    char nm[64];
+    snprintf(nm, sizeof nm, "(%d,%d,%d)", s.M, s.N, s.K);
+    printf("%-22s", nm);
+    for (int v = 0; v < NV; ++v) { std::sort(t[v].begin(), t[v].end()); printf(" %8.1f TF", fl / t[v][R / 2] / 1e9); }
+    printf("   lds-epi maxdiff %.1e\n", err);
+  }
+  return 0;
+}
