@@ -54,6 +54,35 @@ def adjust_learning_rate(lr_scheduler, optimizer, floor: float = 1e-5):
             g["lr"] = floor
 
 
+class SyntheticSdfDataset(torch.utils.data.Dataset):
+    """(f2) the dataset contract when the SDF rows live in HBM (``hoisdf_amd.sdf_data.SdfStore``): ``__getitem__`` yields
+    everything the reference's does EXCEPT the four point sets and the two SDF targets; in their place meta_info carries
+    ``sdf_frame`` (row of the store), ``do_flip`` and ``aug_rot`` (the 3x3 in-plane augmentation rotation) and
+    ``Trainer(sdf_store=...)`` draws the points on the device (data/dexycb.py:514-549 + :288, :593-620)."""
+
+    def __init__(self, cfg: Config, n_frames: int, length: int = 64, seed: int = 0):
+        self.cfg, self.n_frames, self.length, self.seed = cfg, n_frames, length, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        import math
+        ins, tg, mt = T.synthetic_batch(1, 1, 1, seed=self.seed * 100003 + i)
+        sq = lambda d: {k: v[0] for k, v in d.items()}
+        ins, tg, mt = sq(ins), sq(tg), sq(mt)
+        for k in ("hand_sdf_points", "obj_sdf_points", "hand_pre_points", "obj_pre_points"):
+            ins.pop(k)
+        tg.pop("hand_sdf"), tg.pop("obj_sdf")
+        g = torch.Generator().manual_seed(self.seed * 7919 + i)
+        ang = float((torch.rand(1, generator=g) - 0.5) * math.pi / 3)             # +-30 degrees, like cfg.max_rot
+        c, s_ = math.cos(ang), math.sin(ang)
+        mt["sdf_frame"] = torch.tensor(i % self.n_frames)
+        mt["do_flip"] = torch.rand(1, generator=g)[0] < 0.5
+        mt["aug_rot"] = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+        return ins, tg, mt
+
+
 class SyntheticDataset(torch.utils.data.Dataset):
     def __init__(self, cfg: Config, length: int = 64, seed: int = 0):
         self.cfg, self.length, self.seed = cfg, length, seed
@@ -94,8 +123,10 @@ def load_reference_state_dict(model: torch.nn.Module, network: Dict[str, torch.T
 
 class Trainer:
     def __init__(self, cfg: Config, device: torch.device, dataset=None, batch_size: Optional[int] = None,
-                 channels_last: bool = True, tune_encoder: bool = True):
+                 channels_last: bool = True, tune_encoder: bool = True, sdf_store=None):
         self.cfg, self.device = cfg, device
+        self.sdf_store = sdf_store          # (f2) HBM-resident sdf_processed rows: the query points are drawn on the device
+        self._sdf_draws = 0
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.base_seed = int(getattr(cfg, "seed", 0))
@@ -122,6 +153,8 @@ class Trainer:
         self.lr_scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=cfg.lr_drop,
                                                             gamma=cfg.lr_decay_gamma)
         self.start_epoch = 0
+        if dataset is None and sdf_store is not None:
+            dataset = SyntheticSdfDataset(cfg, sdf_store.n_frames, seed=self.rank)
         ds = dataset if dataset is not None else SyntheticDataset(cfg, seed=self.rank)
         bs = batch_size or cfg.train_batch_size
         sampler = torch.utils.data.distributed.DistributedSampler(ds, self.world, self.rank, shuffle=True) \
@@ -147,6 +180,17 @@ class Trainer:
     def train_step(self, inputs, targets, meta, epoch: int, batch_ratio: float):
         dev = self.device
         inputs, targets, meta = (T.to_device(x, dev) for x in (inputs, targets, meta))
+        if self.sdf_store is not None and "sdf_frame" in meta:
+            c = self.cfg
+            self._sdf_draws += 1
+            pts = self.sdf_store.make_inputs(
+                meta["sdf_frame"].cpu(), meta["mano_root"], meta["obj_center_cam"], c.num_samp_hand, c.num_samp_obj,
+                c.points_filter_dist, c.hand_sdf_scale, c.obj_sdf_scale, train=True,
+                seed=self.base_seed * 1000003 + self.rank * 7919 + self._sdf_draws,
+                do_flip=meta.get("do_flip"), rot_mat=meta.get("aug_rot"))
+            for k in ("hand_sdf_points", "obj_sdf_points", "hand_pre_points", "obj_pre_points"):
+                inputs[k] = pts[k]
+            targets["hand_sdf"], targets["obj_sdf"] = pts["hand_sdf"], pts["obj_sdf"]
         if self.channels_last:
             inputs["img"] = inputs["img"].contiguous(memory_format=torch.channels_last)
         self.reducer.zero_grad()

@@ -91,3 +91,54 @@ class SdfStore:
         rows = torch.cat(out_rows, 1)                                     # (B, n) store rows, reference order
         data = self.rows[rows.reshape(-1)].view(B, rows.shape[1], 6)
         return {"sdf_points": data[..., :5], "sdf_raw_label": data[..., 5], "rows": rows}
+
+
+    def make_inputs(self, frame_ids, hand_root: torch.Tensor, obj_center: torch.Tensor, num_hand: int, num_obj: int,
+                    dist: float, hand_scale: float, obj_scale: float, train: bool, seed: int,
+                    do_flip: Optional[torch.Tensor] = None, rot_mat: Optional[torch.Tensor] = None,
+                    validate: bool = True) -> Dict[str, torch.Tensor]:
+        """The point entries of one batch exactly as the reference's ``__getitem__`` hands them to the model
+        (data/dexycb.py:514-549 draw, :548-549 flip ``x *= -1``, data_aug :288 in-plane rotation ``p . rot_mat^T``,
+        :593-620 centre + scale), all on the device:
+          inputs : hand_sdf_points (B,N_h,3), obj_sdf_points (B,N_o,3) [, hand_pre_points, obj_pre_points]
+          targets: hand_sdf (B,N_h) = column 3 * hand_scale, obj_sdf (B,N_o) = column 4 * obj_scale
+        ``hand_root`` / ``obj_center`` (B,3) are the centres AFTER the same flip / rotation (the dataset object computes
+        them from the augmented joints / bbox); ``do_flip`` (B,) bool, ``rot_mat`` (B,3,3)."""
+        smp = self.sample(frame_ids, num_hand, num_obj, dist, train, seed, validate)
+        pts = smp["sdf_points"].clone()                                   # (B, n, 5): xyz, sdf_hand, sdf_obj
+        B = pts.shape[0]
+        if do_flip is not None:
+            sgn = torch.where(do_flip.to(self.device).bool(), -1.0, 1.0).view(B, 1)
+            pts[..., 0] = pts[..., 0] * sgn
+        if rot_mat is not None:
+            pts[..., :3] = pts[..., :3] @ rot_mat.to(self.device).transpose(1, 2)
+        hr, oc = hand_root.to(self.device)[:, None], obj_center.to(self.device)[:, None]
+        a, b = num_hand, num_hand + num_obj
+        hand, obj = pts[:, :a].clone(), pts[:, a:b].clone()
+        hand[..., :3] -= hr
+        obj[..., :3] -= oc
+        hand, obj = hand * hand_scale, obj * obj_scale
+        out = {"hand_sdf_points": hand[..., :3].contiguous(), "obj_sdf_points": obj[..., :3].contiguous(),
+               "hand_sdf": hand[..., 3].contiguous(), "obj_sdf": obj[..., 4].contiguous(), "rows": smp["rows"]}
+        if train:
+            c = b + num_hand
+            out["hand_pre_points"] = ((pts[:, b:c, :3] - hr) * hand_scale).contiguous()
+            out["obj_pre_points"] = ((pts[:, c:, :3] - oc) * obj_scale).contiguous()
+        return out
+
+
+def synthetic_store(n_frames: int, rows_hand: int = 6000, rows_obj: int = 4000, seed: int = 0, device="cuda") -> "SdfStore":
+    """A store shaped like tool/pre_process_sdf.py's output (points in a ~0.3 m box around the hand at z ~ 0.7 m,
+    |sdf| small for ~half of the rows) for smoke runs without the licence-gated datasets."""
+    r = np.random.default_rng(seed)
+    frames, index = [], []
+    for _ in range(n_frames):
+        nh, no = rows_hand + int(r.integers(0, 200)), rows_obj + int(r.integers(0, 200))
+        a = np.zeros((nh + no, 6), np.float32)
+        a[:, :3] = r.uniform(-0.1, 0.1, (nh + no, 3)) + np.array([0.0, 0.0, 0.7], np.float32)
+        a[:, 3] = r.uniform(-0.02, 0.1, nh + no)
+        a[:, 4] = r.uniform(-0.02, 0.1, nh + no)
+        a[:, 5] = r.integers(0, 6, nh + no)
+        frames.append(a)
+        index.append([nh, no])
+    return SdfStore(frames, np.asarray(index), device)

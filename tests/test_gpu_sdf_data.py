@@ -90,3 +90,61 @@ def test_too_few_eligible_rows_raises():
         st.sample([0], 8, 8, 0.05, True, seed=0)
     with pytest.raises(ValueError):
         st.sample([0], 31, 8, 0.05, False, seed=0)
+
+
+def test_make_inputs_applies_flip_rotation_centre_and_scale():
+    """(f2 hand-off) SdfStore.make_inputs vs a numpy restatement of data/dexycb.py:548-549 (flip), :288 (rotation),
+    :593-620 (centre, scale) applied to the very rows the draw selected."""
+    from hoisdf_amd.sdf_data import SdfStore
+    frames, index = make_frames(4, seed=3)
+    st = SdfStore(frames, index)
+    allrows = np.concatenate(frames)
+    B, nh, no = 4, 64, 32
+    g = torch.Generator().manual_seed(0)
+    root, oc = torch.randn(B, 3, generator=g) * 0.1, torch.randn(B, 3, generator=g) * 0.1
+    flip = torch.tensor([True, False, True, False])
+    ang = torch.tensor([0.3, -0.2, 0.0, 0.5])
+    rot = torch.zeros(B, 3, 3)
+    rot[:, 0, 0], rot[:, 0, 1], rot[:, 1, 0], rot[:, 1, 1], rot[:, 2, 2] = ang.cos(), -ang.sin(), ang.sin(), ang.cos(), 1.0
+    out = st.make_inputs([0, 1, 2, 3], root, oc, nh, no, 0.15, 3.1, 2.9, train=True, seed=5, do_flip=flip, rot_mat=rot)
+    rows = out["rows"].cpu().numpy()
+    assert rows.shape == (B, 2 * (nh + no))
+    for b in range(B):
+        d = allrows[rows[b]].copy()
+        if flip[b]:
+            d[:, 0] *= -1
+        d[:, :3] = d[:, :3].dot(rot[b].numpy().T)
+        hand, obj = d[:nh].copy(), d[nh:nh + no].copy()
+        hand[:, :3] -= root[b].numpy(); obj[:, :3] -= oc[b].numpy()
+        hand *= 3.1; obj *= 2.9
+        np.testing.assert_allclose(out["hand_sdf_points"][b].cpu().numpy(), hand[:, :3], atol=2e-6)
+        np.testing.assert_allclose(out["obj_sdf_points"][b].cpu().numpy(), obj[:, :3], atol=2e-6)
+        np.testing.assert_allclose(out["hand_sdf"][b].cpu().numpy(), hand[:, 3], atol=2e-6)
+        np.testing.assert_allclose(out["obj_sdf"][b].cpu().numpy(), obj[:, 4], atol=2e-6)
+        pre_h = (d[nh + no:2 * nh + no, :3] - root[b].numpy()) * 3.1
+        pre_o = (d[2 * nh + no:, :3] - oc[b].numpy()) * 2.9
+        np.testing.assert_allclose(out["hand_pre_points"][b].cpu().numpy(), pre_h, atol=2e-6)
+        np.testing.assert_allclose(out["obj_pre_points"][b].cpu().numpy(), pre_o, atol=2e-6)
+        assert (np.abs(allrows[rows[b, nh + no:2 * nh + no], 3]) < 0.15).all()      # the |sdf_hand| < dist pre-filter
+
+
+def test_trainer_draws_its_batches_from_the_store():
+    """Trainer(sdf_store=...): the dataset yields frame ids + augmentation, the query points come from HBM."""
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.engine import Trainer
+    from hoisdf_amd.sdf_data import synthetic_store
+    c = Config()
+    c.resnet_type = 18
+    c.apply_setting("dexycb")
+    c.num_samp_hand, c.num_samp_obj = 96, 32
+    dev = torch.device("cuda", 0)
+    store = synthetic_store(6, rows_hand=800, rows_obj=500)
+    tr = Trainer(c, dev, batch_size=2, tune_encoder=False, sdf_store=store)
+    it = iter(tr.batch_generator)
+    losses = []
+    for _ in range(2):
+        inputs, targets, meta = next(it)
+        assert "hand_sdf_points" not in inputs and "sdf_frame" in meta
+        total, loss = tr.train_step(inputs, targets, meta, 0, 0.0)
+        losses.append(float(total))
+    assert all(np.isfinite(losses)) and "sdfhand_loss" in loss and float(loss["sdfhand_loss"]) > 0
