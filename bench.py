@@ -54,6 +54,10 @@ class KernelTimer:
         "hoisdf_attention_bwd": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,B,H,Lq,Lk,kv_len,ws,nws): algorithmic QK^T + PV (the 3x split products are not counted)
         "hoisdf_attention_fwd_f16": lambda a: 4.0 * a[8] * a[9] * a[10] * a[12] * 64,
+        # the gradient-free SDF query (K1-K4 behind one C-ABI call): its six GEMMs, 2 (C*512 + 512*256) +
+        # 2 (289*512 + 512*223 + 512*512 + 512*512 + 512) FLOP per point; the gather / posenc time inside the call is
+        # charged to the GEMM family as well
+        "hoisdf_sdf_query_fwd": lambda a: a[3] * (2.0 * (a[12]._obj.C * 512 + 512 * 256) + 2.0 * (289 * 512 + 512 * 223 + 2 * 512 * 512 + 512)),
     }
 
     def __init__(self):
@@ -63,7 +67,7 @@ class KernelTimer:
 
     SHAPE = {"hoisdf_linear_fwd": (7, 8, 9), "hoisdf_linear_bwd_input": (8, 9, 10), "hoisdf_linear_bwd_weight": (9, 10, 11),
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
-             "hoisdf_attention_fwd_f16": (8, 10, 12)}
+             "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3)}
 
     def begin(self, name, args):
         s = torch.cuda.Event(enable_timing=True)
@@ -294,7 +298,7 @@ def main():
             print("\n".join(timer.by_shape(timed_steps)), file=sys.stderr)
         # kernel families = device kernels: the three linear entry points are ONE kernel template (gemm_f32_kernel)
         fams = {"gemm_f32_kernel (linear fwd + grad-input + grad-weight)":
-                    ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"],
+                    ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight", "hoisdf_sdf_query_fwd"],
                 "attn_fwd_kernel": ["hoisdf_attention_fwd"],
                 "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
                 "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"]}

@@ -32,8 +32,17 @@ class Pyramid(C.Structure):
                 ("C", C.c_int * MAX_LEVELS), ("H", C.c_int * MAX_LEVELS), ("W", C.c_int * MAX_LEVELS)]
 
 
+class SdfWeights(C.Structure):
+    """include/hoisdf.h hoisdf_sdf_weights"""
+    _fields_ = [("C", C.c_int), ("sdfin_w0", C.c_void_p), ("sdfin_b0", C.c_void_p), ("sdfin_w1", C.c_void_p),
+                ("sdfin_b1", C.c_void_p), ("dec_w0", C.c_void_p), ("dec_b0", C.c_void_p), ("dec_ld0", C.c_int),
+                ("dec_w1", C.c_void_p), ("dec_b1", C.c_void_p), ("dec_w2", C.c_void_p), ("dec_b2", C.c_void_p),
+                ("dec_w3", C.c_void_p), ("dec_b3", C.c_void_p), ("dec_w4", C.c_void_p), ("dec_b4", C.c_void_p)]
+
+
 _P, _I, _L, _F, _U64, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_double
 _PYR = C.POINTER(Pyramid)
+_SDFW = C.POINTER(SdfWeights)
 
 # name -> argument ctypes (return type is int unless listed in _RET)
 SIGNATURES: Dict[str, List] = {
@@ -44,6 +53,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
+    "hoisdf_sdf_query_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _P, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _P, _L, _P],
     "hoisdf_weightnorm_fwd": [_P, _P, _P, _I, _P, _I, _I, _P],
     "hoisdf_weightnorm_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P],
     "hoisdf_sdf_head_fwd": [_P, _I, _P, _P, _P, _P, _L, _I, _F, _P],
@@ -73,7 +83,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
-_OTHER = {"hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
+_OTHER = {"hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
+          "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long)}
 
 _lib = None

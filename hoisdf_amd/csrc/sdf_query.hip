@@ -1,0 +1,87 @@
+// hoisdf_sdf_query_fwd: the whole gradient-free SDF query (K1 gather -> K2 input MLP -> K3 posenc -> K4 decoder -> head)
+// behind ONE C-ABI call (reference main/model.py:181-244 sdf_forward and :285-354, the body of
+// sdf_infer).  What is fused is the DATAFLOW: every intermediate lives in a caller workspace laid out so that no
+// concatenation or copy kernel runs between the stages -
+//   * the gathered 992 / 3968-wide feature rows can be handed in (shared by the callers that query the same camera
+//     points: the reference gathers the same pixels three times, main/model.py:445/486/499) or out;
+//   * linear_sdfin's second layer, the positional encoding and xyz are written straight into the decoder-input row
+//     x0 = [feat256 | pe30 | xyz3 | 0 0 0], which sits at column 224 of a 516-wide row [h1 (223) | 0 | x0 (292)]; decoder
+//     layer 1 writes its 223 outputs (+ one zero column: a padded weight row) at column 0, so the skip-concatenation
+//     [h1 | x0] of common/nets/sdf_net.py:104-106 is the row itself - layer 2 contracts all 516 columns with a
+//     column-padded weight matrix (zeros under the pad columns);
+//   * the weight-norm fold of the four decoder layers is done once by the caller (cached across calls in eval mode).
+// The contractions themselves stay on gemm_f32_kernel: at ~1.7 kFLOP per byte of activations these layers are
+// MFMA-bound, and a monolithic kernel that keeps a point tile's 512-wide activations on-chip is limited to 64-row
+// tiles by the 160 KB LDS (64 x 512 x 4 B = 128 KB + weight slab), i.e. 30 FLOP per streamed weight byte and two waves
+// per SIMD - measured/estimated below the 105-120 TF the tiled GEMM reaches on these shapes.
+#include "common.h"
+
+using namespace hoisdf;
+
+namespace {
+constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, X0P = 292, CAT_LD = 516, X0_COL = 224;
+inline long align64(long v) { return (v + 63) / 64 * 64; }
+}  // namespace
+
+extern "C" long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat) {
+  if (n_rows <= 0 || C <= 0) return 0;
+  long fl = align64(n_rows * HID0) * 2 + align64(n_rows * CAT_LD);
+  if (need_feat) fl += align64(n_rows * (long)C);
+  return fl * (long)sizeof(float);
+}
+
+extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
+                                    int rows_per_sample, const float* center, const float* cam_intr, float scale,
+                                    int img_h, int img_w, const float* feat_in, float* feat_out,
+                                    const hoisdf_sdf_weights* w, float clamp, float drop_p, uint64_t seed, float* sdf,
+                                    float* sdf_raw, float* pe, float* cam_out, void* workspace, long workspace_bytes,
+                                    void* stream) {
+  HOISDF_REQUIRE(w && points && sdf && sdf_raw, HOISDF_ERR_INVALID, "sdf_query_fwd: null pointer");
+  HOISDF_REQUIRE(n_rows >= 0 && n_rows < (1L << 31), HOISDF_ERR_INVALID, "sdf_query_fwd: n_rows=%ld", n_rows);
+  HOISDF_REQUIRE(drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "sdf_query_fwd: drop_p=%f", drop_p);
+  if (n_rows == 0) return HOISDF_OK;
+  const int C = w->C;
+  HOISDF_REQUIRE(C > 0 && w->dec_ld0 >= X0, HOISDF_ERR_INVALID, "sdf_query_fwd: bad weight descriptor");
+  HOISDF_REQUIRE(feat_in != nullptr || pyr != nullptr, HOISDF_ERR_INVALID, "sdf_query_fwd: neither a pyramid nor gathered rows");
+  const int own_feat = (feat_in == nullptr && feat_out == nullptr);
+  const long need = hoisdf_sdf_query_workspace(n_rows, C, own_feat);
+  HOISDF_REQUIRE(workspace && workspace_bytes >= need, HOISDF_ERR_INVALID,
+                 "sdf_query_fwd: workspace of %ld bytes, need %ld", workspace_bytes, need);
+  float* ws = static_cast<float*>(workspace);
+  float* ha = ws;
+  float* hb = ha + align64(n_rows * HID0);
+  float* cat = hb + align64(n_rows * HID0);
+  float* feat_ws = cat + align64(n_rows * CAT_LD);
+  int rc;
+  // K1 (unless the caller shares its gathered rows)
+  const float* feat = feat_in;
+  if (!feat) {
+    float* f = feat_out ? feat_out : feat_ws;
+    rc = hoisdf_project_gather_fwd(pyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w,
+                                   f, C, cam_out, nullptr, stream);
+    if (rc) return rc;
+    feat = f;
+  } else if (cam_out) {
+    HOISDF_REQUIRE(false, HOISDF_ERR_INVALID, "sdf_query_fwd: cam_out needs the gather to run here (feat_in given)");
+  }
+  float* x0 = cat + X0_COL;
+  // K2: linear_sdfin (main/model.py:63-69): C -> 512 -> 256, ReLU after both; the second layer lands in x0[:, 0:256]
+  rc = hoisdf_linear_fwd(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, 1, 0.f, 0, nullptr, stream);
+  if (rc) return rc;
+  rc = hoisdf_linear_fwd(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, 1, 0.f, 0, nullptr, stream);
+  if (rc) return rc;
+  // K3: posenc + xyz into x0[:, 256:289], pad columns 289..291 zeroed (common/utils/sdf_utils.py:96-141)
+  rc = hoisdf_posenc_fwd(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, stream);
+  if (rc) return rc;
+  // K4: decoder (common/nets/sdf_net.py:87-122); dropout(p) after every hidden ReLU when the module is in train() mode
+  // (the reference's detached training-time queries run with it on), stream ids seed + layer
+  rc = hoisdf_linear_fwd(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, 1, drop_p, seed, nullptr, stream);
+  if (rc) return rc;
+  rc = hoisdf_linear_fwd(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, 1, drop_p, seed + 1, nullptr, stream);
+  if (rc) return rc;
+  rc = hoisdf_linear_fwd(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, 1, drop_p, seed + 2, nullptr, stream);
+  if (rc) return rc;
+  rc = hoisdf_linear_fwd(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, 1, drop_p, seed + 3, nullptr, stream);
+  if (rc) return rc;
+  return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
+}

@@ -129,6 +129,27 @@ class Model(nn.Module):
         sdf, raw = dec.forward_clamped(x0, c.ClampingDistance)
         return sdf, raw, pe, cam
 
+    def _query_weights(self, kind):
+        q = self.__dict__.get("_sdfq")
+        if q is None:
+            q = {"hand": ops.SdfQueryWeights(self.linear_sdfin, self.hand_sdf_decoder),
+                 "obj": ops.SdfQueryWeights(self.linear_sdfin, self.obj_sdf_decoder)}
+            self.__dict__["_sdfq"] = q
+        return q[kind]
+
+    @torch.no_grad()
+    def _sdf_query(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None, feat=None, want_feat=False):
+        """K1-K4 for the call sites whose results are only used detached (reference :483-484,:517-518,:540,:558) and for
+        sdf_infer: one C-ABI call (hoisdf_sdf_query_fwd), optionally on rows already gathered for the same camera points.
+        Dropout follows the decoder's train()/eval() mode like the reference's module calls do.
+        -> (sdf clamped (n,), sdf_raw (n,), pe (n,30), feat (n,C) | None)"""
+        c = self.cfg
+        dec = self.hand_sdf_decoder if kind == "hand" else self.obj_sdf_decoder
+        p = dec.dropout_prob if dec.training else 0.0
+        sdf, raw, pe, _, f = ops.sdf_query(self._query_weights(kind), pyr, points, center, cam_intr, scale,
+                                           c.ClampingDistance, c.input_img_shape, sample_idx, feat, want_feat, False, p)
+        return sdf, raw, pe, f
+
     def sdf_forward(self, feature_pyramid, sdf_points, center_joint, cam_intr, sdf_scale, type="hand"):
         """reference :181-244 -> (pred_sdf (B,P,1), None, pos_enc3d (B,P,30))."""
         B, P, _ = sdf_points.shape
@@ -156,7 +177,7 @@ class Model(nn.Module):
             raise ValueError(
                 f"sdf_infer({type}): sample {short[0]} has only {counts[short[0]]} lattice points inside its "
                 f"bbox, fewer than num_points={num_points} (the reference fails at main/model.py:348)")
-        sdf, raw, pe, _ = self._sdf_rows(pyr, pts, center_joint, cam_intr, sdf_scale, type, sample_idx=sidx)
+        sdf, raw, pe, _ = self._sdf_query(pyr, pts, center_joint, cam_intr, sdf_scale, type, sample_idx=sidx)
         sel = ops.select_smallest_abs(raw, offsets, counts_dev, num_points)
         pose_points = ops.gather_rows(pts, sel).view(B, num_points, 3)
         pose_sdf = ops.gather_rows(sdf, sel).view(B, num_points, 1)
@@ -221,24 +242,33 @@ class Model(nn.Module):
         with on_side():                                 # ---- object points ----
             if want_sdf_loss:
                 so, _, _ = self.sdf_forward(pyr, inputs["obj_sdf_points"], ocen, K, os_, "obj")
-            if branch_a:
-                with torch.no_grad():   # the reference tracks these calls but only ever uses them detached
-                    obj_sdf, _, obj_pe = self.sdf_forward(pyr, obj_points, ocen, K, os_, "obj")
-            obj_fea, obj_cam = self.get_input_transformer(pyr, obj_points, ocen, K, os_)            # :486-493
-            with torch.no_grad():                                                      # :495-518 (outputs detached)
-                obj_h_pts = (obj_cam - root[:, None, :]) * hs_
-                obj_h_sdf, _, obj_h_pe = self.sdf_forward(pyr, obj_h_pts, root, K, hs_, "hand")
+            # ONE gather of the object points' pixels feeds the token MLP (with gradient), the object field and - the
+            # camera points being the same - the evaluation of those points in the hand field (the reference gathers
+            # them three times, :445/:486/:499; its detached queries run as single hoisdf_sdf_query_fwd calls)
+            obj_feat, obj_cam = ops.project_gather(pyr, obj_points, ocen, K, os_, c.input_img_shape)
+            obj_cam = obj_cam.view(B, no, 3)
+            obj_fea = self.linear_transformerin(obj_feat).view(B, no, -1)                               # :486-493
+            fd = obj_feat.detach()
+            if branch_a:                # the reference tracks these calls but only ever uses them detached
+                obj_sdf, _, obj_pe, _ = self._sdf_query(pyr, obj_points, ocen, K, os_, "obj", feat=fd)
+                obj_sdf, obj_pe = obj_sdf.view(B, no, 1), obj_pe.view(B, no, -1)
+            obj_h_pts = (obj_cam - root[:, None, :]) * hs_                                              # :495-518
+            obj_h_sdf, _, obj_h_pe, _ = self._sdf_query(pyr, obj_h_pts, root, K, hs_, "hand", feat=fd)
+            obj_h_sdf, obj_h_pe = obj_h_sdf.view(B, no, 1), obj_h_pe.view(B, no, -1)
         # ---- hand points (ambient stream) ----
         if want_sdf_loss:
             sh, _, _ = self.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, hs_, "hand")
+        hand_feat, hand_cam = ops.project_gather(pyr, hand_points, root, K, hs_, c.input_img_shape)
+        hand_cam = hand_cam.view(B, nh, 3)
+        hand_fea = self.linear_transformerin(hand_feat).view(B, nh, -1)
+        fd = hand_feat.detach()
         if branch_a:
-            with torch.no_grad():
-                hand_sdf, _, hand_pe = self.sdf_forward(pyr, hand_points, root, K, hs_, "hand")
-        hand_fea, hand_cam = self.get_input_transformer(pyr, hand_points, root, K, hs_)
+            hand_sdf, _, hand_pe, _ = self._sdf_query(pyr, hand_points, root, K, hs_, "hand", feat=fd)
+            hand_sdf, hand_pe = hand_sdf.view(B, nh, 1), hand_pe.view(B, nh, -1)
         hand_rel = hand_cam - root[:, None, :]
-        with torch.no_grad():
-            hand_o_pts = (hand_cam - ocen[:, None, :]) * os_
-            hand_o_sdf, _, hand_o_pe = self.sdf_forward(pyr, hand_o_pts, ocen, K, os_, "obj")
+        hand_o_pts = (hand_cam - ocen[:, None, :]) * os_
+        hand_o_sdf, _, hand_o_pe, _ = self._sdf_query(pyr, hand_o_pts, ocen, K, os_, "obj", feat=fd)
+        hand_o_sdf, hand_o_pe = hand_o_sdf.view(B, nh, 1), hand_o_pe.view(B, nh, -1)
         if two:
             cur.wait_stream(side)
             for t in (so, obj_sdf, obj_pe, obj_fea, obj_cam, obj_h_sdf, obj_h_pe):

@@ -14,6 +14,12 @@ import torch
 from ._lib import Pyramid, call
 
 _SEED = [0x9E3779B97F4A7C15, 0]
+_WEIGHT_GEN = [0]      # bumped by optimizers that update parameters behind autograd's back (FusedAdamW's HIP kernel does
+                       # not touch torch's version counters): invalidates cached derived weights (SdfQueryWeights)
+
+
+def bump_weight_generation() -> None:
+    _WEIGHT_GEN[0] += 1
 
 
 def manual_seed(seed: int) -> None:
@@ -250,6 +256,91 @@ class _SdfHead(torch.autograd.Function):
 def sdf_head(h, w, b, clamp: float):
     """tail of K4: (M,512) -> clamped sdf (M,), raw tanh (M,)"""
     return _SdfHead.apply(h, w, b, clamp)
+
+
+# ---------------------------------------------------------------------------------------------
+# K1-K4 behind one call: the gradient-free SDF query
+# ---------------------------------------------------------------------------------------------
+class SdfQueryWeights:
+    """Device-side weight descriptor of ``hoisdf_sdf_query_fwd`` for one (linear_sdfin, SDFDecoder) pair: the decoder's
+    weight-norm fold and the two re-laid matrices of the in-place skip-concatenation (include/hoisdf.h).  Rebuilt only
+    when a parameter changed (torch's per-tensor version counters), i.e. once per optimizer step in training and once
+    for a whole evaluation run."""
+
+    def __init__(self, sdfin, decoder):
+        self.sdfin, self.decoder = sdfin, decoder
+        self._key = None
+        self._keep = None
+        self.struct = None
+
+    def _params(self):
+        d = self.decoder
+        ps = [l.weight for l in self.sdfin.layers] + [l.bias for l in self.sdfin.layers]
+        for i in range(4):
+            l = getattr(d, f"linh{i}")
+            ps += [l.weight_v, l.weight_g, l.bias]
+        return ps + [d.linh4.weight, d.linh4.bias]
+
+    @torch.no_grad()
+    def get(self):
+        from ._lib import SdfWeights
+        ps = self._params()
+        key = (_WEIGHT_GEN[0],) + tuple((p.data_ptr(), p._version) for p in ps)
+        if key == self._key:
+            return self.struct
+        d, dev = self.decoder, ps[0].device
+        W = [weight_norm(getattr(d, f"linh{i}").weight_v.detach(), getattr(d, f"linh{i}").weight_g.detach()) for i in range(4)]
+        w1 = torch.zeros(224, 512, device=dev)
+        w1[:223] = W[1]
+        b1 = torch.zeros(224, device=dev)
+        b1[:223] = d.linh1.bias.detach()
+        w2 = torch.zeros(512, 516, device=dev)
+        w2[:, :223] = W[2][:, :223]
+        w2[:, 224:513] = W[2][:, 223:]
+        s0, s1 = self.sdfin.layers[0], self.sdfin.layers[1]
+        keep = [s0.weight.detach().contiguous(), s0.bias.detach().contiguous(), s1.weight.detach().contiguous(),
+                s1.bias.detach().contiguous(), W[0].contiguous(), d.linh0.bias.detach().contiguous(), w1, b1, w2,
+                d.linh2.bias.detach().contiguous(), W[3].contiguous(), d.linh3.bias.detach().contiguous(),
+                d.linh4.weight.detach().reshape(-1).contiguous(), d.linh4.bias.detach().contiguous()]
+        _chk(*keep)
+        st = SdfWeights()
+        st.C = keep[0].shape[1]
+        (st.sdfin_w0, st.sdfin_b0, st.sdfin_w1, st.sdfin_b1, st.dec_w0, st.dec_b0, st.dec_w1, st.dec_b1, st.dec_w2, st.dec_b2,
+         st.dec_w3, st.dec_b3, st.dec_w4, st.dec_b4) = (t.data_ptr() for t in keep)
+        st.dec_ld0 = keep[4].stride(0)
+        assert keep[0].shape[0] == 512 and keep[2].shape == (256, 512) and keep[4].shape == (512, 289) and \
+            keep[10].shape == (512, 512), "hoisdf_sdf_query_fwd is built for the released layer sizes (512/256/223)"
+        self._key, self._keep, self.struct = key, keep, st
+        return st
+
+
+@torch.no_grad()
+def sdf_query(weights: SdfQueryWeights, pyr: "PyramidNHWC", points, center, cam_intr, scale, clamp, img_hw=(256, 256),
+              sample_idx=None, feat=None, want_feat=False, want_cam=False, drop_p: float = 0.0):
+    """hoisdf_sdf_query_fwd: -> (sdf (n,), sdf_raw (n,), pe (n,30), cam (n,3) | None, feat (n,C) | None).
+    ``feat``: rows already gathered for these camera points (shared gather); ``want_feat``: hand the gathered rows back."""
+    from ._lib import lib
+    pts = points.reshape(-1, 3).contiguous()
+    center, cam_intr = center.contiguous(), cam_intr.contiguous()
+    _chk(pts, center, cam_intr, feat)
+    n = pts.shape[0]
+    dev = pts.device
+    rps = points.shape[-2] if sample_idx is None else 1
+    w = weights.get()
+    assert w.C == pyr.C
+    if feat is not None:
+        assert feat.shape == (n, w.C) and feat.is_contiguous() and not want_cam
+    feat_out = torch.empty(n, w.C, device=dev) if (want_feat and feat is None) else None
+    nbytes = lib().hoisdf_sdf_query_workspace(n, w.C, int(feat is None and feat_out is None))
+    ws = torch.empty(max(nbytes, 4) // 4, device=dev, dtype=torch.float32)
+    sdf, raw = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    pe = torch.empty(n, 30, device=dev)
+    cam = torch.empty(n, 3, device=dev) if want_cam else None
+    s = pyr.struct()
+    call("hoisdf_sdf_query_fwd", C.byref(s), _p(pts), _p(sample_idx), n, rps, _p(center), _p(cam_intr), float(scale),
+         img_hw[0], img_hw[1], _p(feat), _p(feat_out), C.byref(w), float(clamp), float(drop_p),
+         next_seed() if drop_p > 0 else 0, _p(sdf), _p(raw), _p(pe), _p(cam), _p(ws), nbytes, _st())
+    return sdf, raw, pe, cam, (feat if feat is not None else feat_out)
 
 
 # ---------------------------------------------------------------------------------------------

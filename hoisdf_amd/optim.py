@@ -84,4 +84,5 @@ class FusedAdamW(torch.optim.AdamW):
                     self.state[p]["step"] += 1
                 call("hoisdf_adamw_step", ops._p(cached[1]), cached[1].shape[0], float(group["lr"]), float(b1), float(b2),
                      float(group["eps"]), float(group["weight_decay"]), int(step0 + 1.0), self.grad_scale, ops._st())
+        ops.bump_weight_generation()         # parameters changed without bumping torch's version counters
         return loss

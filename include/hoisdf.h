@@ -136,6 +136,39 @@ int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, const float* h,
                         const float* w, float* dh, int lddh, float* dw, float* db, long n_rows,
                         int K, float clamp, void* stream);
 
+/* ---- K1-K4 behind one call: the gradient-free SDF query ----------------------------------------------------
+ * reference: Model.sdf_forward (main/model.py:181-244) and the body of Model.sdf_infer (:285-354) - project + gather,
+ * linear_sdfin, positional encoding, SDFDecoder, tanh + clamp - for the call sites whose results are only ever used
+ * detached (:483-484,:517-518,:540,:558) and for inference.  SURVEY.md section 8(b) `hoisdf_sdf_query_fwd`.
+ * Weights: plain device pointers; the four decoder matrices are EFFECTIVE weights (weight-norm folded,
+ * hoisdf_weightnorm_fwd), two of them laid out for the in-place skip-concatenation:
+ *   dec_w1 [224][512]  rows 0..222 = layer 1, row 223 = 0 (and dec_b1[223] = 0): the extra output is the zero pad column;
+ *   dec_w2 [512][516]  columns 0..222 = W2[:, 0:223] (h1), 223 = 0, 224..512 = W2[:, 223:512] (x0), 513..515 = 0.
+ * feat_in  (optional) [n_rows][C]: rows already gathered for these camera points (skips K1; cam_out must be NULL);
+ * feat_out (optional) [n_rows][C]: receives the gathered rows for other consumers of the same points.
+ * drop_p / seed: dropout after the decoder's hidden ReLUs (the module's train() mode; 0 in eval), layer i draws
+ * stream seed + i of the counter hash.
+ * Outputs: sdf (clamped), sdf_raw (tanh, unclamped: what sdf_infer ranks on), pe [n_rows][30] (optional),
+ * cam_out [n_rows][3] (optional).  workspace: hoisdf_sdf_query_workspace(n_rows, C, need_feat) bytes, need_feat = 1
+ * when neither feat_in nor feat_out is given. */
+typedef struct hoisdf_sdf_weights {
+  int C;                                  /* pyramid channels (992 / 3968) */
+  const float *sdfin_w0, *sdfin_b0;       /* [512][C], [512] */
+  const float *sdfin_w1, *sdfin_b1;       /* [256][512], [256] */
+  const float *dec_w0, *dec_b0;           /* [512][dec_ld0 >= 289], [512] */
+  int dec_ld0;
+  const float *dec_w1, *dec_b1;           /* [224][512], [224] */
+  const float *dec_w2, *dec_b2;           /* [512][516], [512] */
+  const float *dec_w3, *dec_b3;           /* [512][512], [512] */
+  const float *dec_w4, *dec_b4;           /* [512], [1] */
+} hoisdf_sdf_weights;
+long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat);
+int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
+                         int rows_per_sample, const float* center, const float* cam_intr, float scale, int img_h,
+                         int img_w, const float* feat_in, float* feat_out, const hoisdf_sdf_weights* w, float clamp,
+                         float drop_p, uint64_t seed, float* sdf, float* sdf_raw, float* pe, float* cam_out,
+                         void* workspace, long workspace_bytes, void* stream);
+
 /* ---- K5/K6: dense-grid candidate generation + selection (sdf_infer) -------------------
  * reference: main/model.py:257-302 (sheared lattice + strict bbox filter, on CPU there) and
  * :345-352 (sort by |sdf|, keep the first num_points).

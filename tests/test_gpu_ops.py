@@ -539,3 +539,53 @@ def test_attention_few_queries_kernel_incl_dropout():
     ones[..., E:] = 1.0
     od = OO._AttentionCross.apply(q, ones, H, Lk, p, seed)
     assert abs(float(od.mean()) - 1.0) < 0.03
+
+
+def test_sdf_query_one_call_matches_the_op_chain():
+    """hoisdf_sdf_query_fwd (K1-K4 in one C-ABI call, in-place concatenations, optional shared gather) against the
+    differentiable op chain the model uses where gradients are needed, and against the oracle."""
+    from hoisdf_amd.model import get_model
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.nets import mano as MANO
+    O, R = ops(), oracle()
+    c = Config(); c.resnet_type = 18; c.apply_setting("dexycb"); c.num_samp_hand, c.num_samp_obj = 300, 100
+    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
+    sd = model.state_dict()
+    for k in sd:
+        if not k.startswith("mano_head"):
+            sd[k] = T.det_param(k, sd[k].shape)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    B, P = 2, 300
+    pyr_cpu = T.synthetic_pyramid(B, seed=4)
+    pyr = O.PyramidNHWC([v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in pyr_cpu.values()])
+    inputs, _, meta = T.synthetic_batch(B, P, 8, seed=5)
+    pts = (inputs["hand_sdf_points"] * 1.2).to(DEV)
+    root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
+    with torch.no_grad():
+        ref_sdf, ref_raw, ref_pe, ref_cam = model._sdf_rows(pyr, pts, root, K, 3.1, "hand")
+        sdf, raw, pe, feat = model._sdf_query(pyr, pts, root, K, 3.1, "hand", want_feat=True)
+        assert_close(raw, ref_raw, rel=1e-5, what="raw"); assert_close(sdf, ref_sdf, rel=1e-5, what="sdf")
+        assert_close(pe, ref_pe, rel=1e-6, what="pe")
+        # shared gather: same rows handed back in, other field
+        sdf2, raw2, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "obj", feat=feat)
+        ref2 = model._sdf_rows(pyr, pts, root, K, 3.1, "obj")
+        assert_close(raw2, ref2[1], rel=1e-5, what="raw obj via shared gather")
+        # per-row sample index form (sdf_infer)
+        sidx = torch.arange(B, device=DEV, dtype=torch.int32).repeat_interleave(P)
+        sdf3, raw3, _, _ = model._sdf_query(pyr, pts.reshape(-1, 3), root, K, 3.1, "hand", sample_idx=sidx)
+        assert torch.equal(raw3, raw)
+    P_ = T.det_params(T.hot_path_param_shapes(992))
+    o_sdf, _ = R.sdf_forward(P_, R.OracleCfg(), pyr_cpu, pts.cpu(), meta["mano_root"], meta["cam_intr"], 3.1, "hand", False)
+    assert_close(sdf, o_sdf.reshape(-1), rel=2e-5, what="sdf vs oracle")
+    # cached weights follow parameter updates (autograd-visible and FusedAdamW's raw-pointer update)
+    with torch.no_grad():
+        model.hand_sdf_decoder.linh3.bias.add_(0.05)
+        raw4 = model._sdf_query(pyr, pts, root, K, 3.1, "hand")[1]
+        assert float((raw4 - raw).abs().max()) > 1e-4
+        assert_close(raw4, model._sdf_rows(pyr, pts, root, K, 3.1, "hand")[1], rel=1e-5, what="after update")
+    # train() mode: decoder dropout is on inside the fused call as well (statistically different, finite)
+    model.train()
+    with torch.no_grad():
+        raw5 = model._sdf_query(pyr, pts, root, K, 3.1, "hand")[1]
+    assert bool(torch.isfinite(raw5).all()) and float((raw5 - raw4).abs().mean()) > 1e-3
