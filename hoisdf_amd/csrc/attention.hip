@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < 32; ++i) qf[i] = 0.f;
   }
 
-  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
   float m = -INFINITY, lsum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs
 #pragma unroll
     for (int i = 0; i < 32; ++i) qf[i] = 0.f;
   }
-  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
   float m = -INFINITY, lsum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
       const float p = kvalid ? EXP2(s[r] * QSCALE2 - Ls[ql]) : 0.f;
       float dscale = 1.f;
       if (a.drop_p > 0.f)
-        dscale = drop_scale(drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)), (uint32_t)key,
+        dscale = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)ql), (uint32_t)key,
                             a.thresh, a.inv_keep);
       s[r] = p * dscale;
       dp[r] = p * (dp[r] * dscale - Es[ql]);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(AttnArgs a) {
       const float p = kvalid ? EXP2(s[r] * QSCALE2 - Ls[ql]) : 0.f;
       float dscale = 1.f;
       if (a.drop_p > 0.f)
-        dscale = drop_scale(drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)(qt * 32 + ql)), (uint32_t)key,
+        dscale = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)ql), (uint32_t)key,
                             a.thresh, a.inv_keep);
       s[r] = p * dscale;
       dp[r] = p * (dp[r] * dscale - Es[ql]);
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) { qf[i] = 0.f; df[i] = 0.f; }
   }
-  const uint32_t rowkey = drop_rowkey(a.seed, (uint64_t)bh * a.Lq + (uint64_t)qrow);
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
   f32x16 dq[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(AttnArgs a, const u
   const float p = e / wave_sum(e);
   if (lane < a.Lk) probs[(size_t)w * a.Lk + lane] = p;
   float pd = p;
-  if (a.drop_p > 0.f && lane < a.Lk) pd *= drop_scale(drop_rowkey(a.seed, (uint64_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
+  if (a.drop_p > 0.f && lane < a.Lk) pd *= drop_scale(drop_rowkey(a.seed, (uint32_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
   // out[d = lane] = sum_j pd_j V[j][d]
   float acc = 0.f;
   for (int j = 0; j < a.Lk; ++j) {
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a, const f
   const float* dop = a.dout + ((size_t)b * a.Lq + qi) * a.lddo + head * DH;
   const float p = lane < a.Lk ? probs[(size_t)w * a.Lk + lane] : 0.f;
   float dsc = 1.f;
-  if (a.drop_p > 0.f && lane < a.Lk) dsc = drop_scale(drop_rowkey(a.seed, (uint64_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
+  if (a.drop_p > 0.f && lane < a.Lk) dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
   // dP_j = sum_d dO[d] V[j][d]  (lane = key j)
   float dpj = 0.f;
   if (lane < a.Lk) {

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-        const uint32_t rk = drop_rowkey(g.seed, (uint64_t)row);
+        const uint32_t rk = drop_rowkey(g.seed, (uint32_t)row);
         acc[i][0][r] *= drop_scale(rk, (uint32_t)cbase, g.thresh, g.inv_keep);
         acc[i][1][r] *= drop_scale(rk, (uint32_t)(cbase + 32), g.thresh, g.inv_keep);
       }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
         if (r) {
           float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
           if (drop_p > 0.f) {
-            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(u * 4);
             b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
             b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
             b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         if (r) {
           float4 b = *reinterpret_cast<const float4*>(r + (size_t)row * D + u * 4);
           if (drop_p > 0.f) {
-            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(u * 4);
             b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
             b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
             b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = o;
         if (dr) {
           if (drop_p > 0.f) {
-            const uint32_t rk = drop_rowkey(seed, (uint64_t)row), e = (uint32_t)(u * 4);
+            const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(u * 4);
             o.x *= drop_scale(rk, e + 0, thresh, inv_keep);
             o.y *= drop_scale(rk, e + 1, thresh, inv_keep);
             o.z *= drop_scale(rk, e + 2, thresh, inv_keep);

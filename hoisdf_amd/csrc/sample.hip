@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void sdf_sample_keys_kernel(const float* __res
   const int n = seg_len[s], col = seg_col[s];
   const float* base = rows + (size_t)seg_row0[s] * ld;
   float* out = keys + seg_off[s];
-  const uint32_t sk = drop_rowkey(seed, (uint64_t)s);
+  const uint32_t sk = drop_rowkey(seed, (uint32_t)s);
   int cnt = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const bool ok = col < 0 || fabsf(base[(size_t)i * ld + col]) < dist;
