@@ -162,6 +162,11 @@ class GradReducer:
         """call instead of optimizer.zero_grad()"""
         dev = self.buckets[0].device if self.buckets else None
         self._main = torch.cuda.current_stream(dev) if dev is not None and dev.type == "cuda" else None
+        if self._main is not None:
+            # every gradient this reducer handles is copied into its buckets before the optimizer reads it, so the
+            # backward's zero-initialised scratch can come from the per-step arena (one memset per step)
+            from . import ops
+            ops.zero_arena_begin_step(dev)
         for bi, members in enumerate(self._members):
             for p in members:
                 p.grad = None

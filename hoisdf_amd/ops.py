@@ -33,6 +33,56 @@ def next_seed() -> int:
     return (_SEED[0] * 6364136223846793005 + _SEED[1] * 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
 
 
+class _ZeroArena:
+    """Per-step arena of zero-initialised gradient scratch (weight / bias gradients the split-k GEMM accumulates into
+    with atomics, LayerNorm gamma/beta sums, ...): ONE memset per step instead of one fill kernel per backward op
+    (~170 launches per training step).  Off unless a trainer brackets its steps with ``zero_arena_begin_step()``: the
+    views handed out are only valid until the next ``begin_step`` - fine when the gradients are packed into the
+    reducer's buckets (hoisdf_amd.ddp.GradReducer) before the optimizer reads them, wrong for code that keeps ``p.grad``
+    across steps.  The first step measures the demand (plain ``torch.zeros``), the buffer is sized from it."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.demand = 0
+        self.active = False
+
+    def begin_step(self, device):
+        if self.active and self.buf is None and self.demand > 0:
+            self.buf = torch.empty(int(self.demand * 1.25) + 1024, device=device, dtype=torch.float32)
+        self.active = True
+        if self.buf is not None:
+            (self.buf[:self.off] if 0 < self.off < self.buf.numel() else self.buf).zero_()   # only what the last step used
+        self.off = 0
+        self.demand = 0
+
+    def zeros(self, n, device):
+        n_al = (n + 15) // 16 * 16                 # 64-byte aligned slices
+        self.demand += n_al
+        if not self.active or self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        v = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return v
+
+
+_ARENA = _ZeroArena()
+
+
+def zero_arena_begin_step(device) -> None:
+    """Call at the start of every training step (before forward) to serve the backward's zero-initialised scratch from one
+    buffer that is cleared with a single memset.  See _ZeroArena for the validity contract."""
+    _ARENA.begin_step(torch.device(device))
+
+
+def zero_arena_disable() -> None:
+    _ARENA.active = False
+
+
+def _zeros(n: int, device) -> torch.Tensor:
+    return _ARENA.zeros(int(n), torch.device(device) if not isinstance(device, torch.device) else device)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -170,7 +220,7 @@ class _Linear(torch.autograd.Function):
             call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            buf = torch.zeros(N * K + (N if has_b else 0), device=dy.device, dtype=torch.float32)   # one fill
+            buf = _zeros(N * K + (N if has_b else 0), dy.device)   # one fill (or a slice of the per-step arena)
             dW = buf[:N * K].view(N, K)
             db = buf[N * K:] if has_b else None
             call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), p, _p(x2), x2.stride(0) if M > 1 else K, _p(dW),
@@ -246,8 +296,8 @@ class _SdfHead(torch.autograd.Function):
         M, K = h2.shape
         dsdf = dsdf.reshape(-1).contiguous()
         dh = torch.empty(M, K, device=dsdf.device, dtype=torch.float32)
-        dw = torch.zeros(K, device=dsdf.device, dtype=torch.float32)
-        db = torch.zeros(1, device=dsdf.device, dtype=torch.float32)
+        dwb = _zeros(K + 1, dsdf.device)
+        dw, db = dwb[:K], dwb[K:]
         call("hoisdf_sdf_head_bwd", _p(dsdf), _p(raw), _p(h2), h2.stride(0) if M > 1 else K, _p(w), _p(dh), K,
              _p(dw), _p(db), M, K, ctx.clamp, _st())
         return dh, dw.view(1, K), db, None
@@ -412,7 +462,7 @@ class _TokenBuild(torch.autograd.Function):
         B, P, S, row0, D, fshape = ctx.meta
         dtok = dtok.contiguous()
         dfeat = torch.empty(B * P, D - 33, device=dtok.device, dtype=torch.float32)
-        dbeta = torch.zeros(1, device=dtok.device, dtype=torch.float32)
+        dbeta = _zeros(1, dtok.device)
         call("hoisdf_token_build_bwd", _p(dtok), _p(feat2), feat2.stride(0), _p(sdf), _p(beta), _p(dfeat), D - 33,
              _p(dbeta), B, P, S, row0, D, _st())
         # the rows this op wrote do not depend on the incoming buffer contents
@@ -610,7 +660,7 @@ class _AddLayerNorm(torch.autograd.Function):
         dy2 = dy.reshape(M, D).contiguous()
         dx = torch.empty_like(x2)
         dr = None if r2 is None else torch.empty_like(x2)
-        dgb = torch.zeros(2, D, device=dy.device, dtype=torch.float32)
+        dgb = _zeros(2 * D, dy.device).view(2, D)
         dg, db = dgb[0], dgb[1]
         call("hoisdf_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dr),
              _p(dg), _p(db), M, D, drop_p, seed, _st())
