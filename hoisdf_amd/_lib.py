@@ -83,7 +83,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
-_OTHER = {"hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
+_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_get_deterministic": ([], C.c_int),
+          "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long)}
 

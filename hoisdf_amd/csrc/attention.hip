@@ -807,6 +807,46 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(AttnArgs a, const f
   a.dq[((size_t)b * a.Lq + qi) * a.ldq + head * DH + lane] = dqd * 0.125f;
 }
 
+// Deterministic form of the small backward: one wave per (sample, head) walks the queries in order, so dk / dv have a
+// single writer (plain read-modify-write in query order); Lk <= 64 keys, lane = d.
+__global__ __launch_bounds__(256) void attn_small_bwd_det_kernel(AttnArgs a, const float* __restrict__ probs) {
+  const int lane = threadIdx.x & 63;
+  const long bhl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bhl >= (long)a.B * a.H) return;
+  const int bh = (int)bhl, b = bh / a.H, head = bh - b * a.H;
+  for (int qi = 0; qi < a.Lq; ++qi) {
+    const long w = (long)bh * a.Lq + qi;
+    const float* dop = a.dout + ((size_t)b * a.Lq + qi) * a.lddo + head * DH;
+    const float p = lane < a.Lk ? probs[(size_t)w * a.Lk + lane] : 0.f;
+    float dsc = 1.f;
+    if (a.drop_p > 0.f && lane < a.Lk) dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)w), (uint32_t)lane, a.thresh, a.inv_keep);
+    float dpj = 0.f;
+    if (lane < a.Lk) {
+      const float* vp = a.v + ((size_t)b * a.Lk + lane) * a.ldv + head * DH;
+#pragma unroll 8
+      for (int d = 0; d < DH; ++d) dpj += dop[d] * vp[d];
+    }
+    dpj *= dsc;
+    const float dot = wave_sum(p * dpj);
+    const float dsj = p * (dpj - dot);
+    const float pdj = p * dsc;
+    const float dod = dop[lane];
+    const float qd = a.q[((size_t)b * a.Lq + qi) * a.ldq + head * DH + lane];
+    float dqd = 0.f;
+    for (int j = 0; j < a.Lk; ++j) {
+      const float ds = __shfl(dsj, j, 64);
+      const float pj = __shfl(pdj, j, 64);
+      const size_t krow = ((size_t)b * a.Lk + j);
+      dqd += ds * a.k[krow * a.ldk + head * DH + lane];
+      float* pk = &a.dk[krow * a.ldk + head * DH + lane];
+      float* pv = &a.dv[krow * a.ldv + head * DH + lane];
+      *pk = *pk + ds * qd * 0.125f;              // same lane, same address every query: program order = query order
+      *pv = *pv + pj * dod;
+    }
+    a.dq[((size_t)b * a.Lq + qi) * a.ldq + head * DH + lane] = dqd * 0.125f;
+  }
+}
+
 static int check_attn(const AttnArgs& a, const char* who) {
   HOISDF_REQUIRE(a.q && a.k && a.v, HOISDF_ERR_INVALID, "%s: null pointer", who);
   HOISDF_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.kv_len > 0 && a.kv_len <= a.Lk, HOISDF_ERR_INVALID,
@@ -860,7 +900,8 @@ extern "C" int hoisdf_attention_bwd(const float* q, int ldq, const float* k, int
                  HOISDF_ERR_INVALID, "attention_bwd: bad leading dims / alignment");
   hipStream_t st = as_stream(stream);
   const long ng = (long)B * Lq * H;
-  static const int mode = [] { const char* e = getenv("HOISDF_ATTN_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
+  static const int env_mode = [] { const char* e = getenv("HOISDF_ATTN_BWD"); return (e && e[0] == 's') ? 0 : 1; }();
+  const int mode = deterministic_mode() ? 0 : env_mode;        // deterministic: the two-kernel form (no dQ atomics)
   // delta = rowsum(dO * O); in fused mode the same pass clears dq, which the fused kernel accumulates with atomics
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, a, delta, mode);
   if (int rc = check_launch("attention_delta")) return rc;
@@ -903,6 +944,10 @@ extern "C" int hoisdf_attention_small_bwd(const float* q, int ldq, const float* 
   HOISDF_REQUIRE(probs && dout && dq && dk && dv && Lq <= 64 && Lk <= 64, HOISDF_ERR_INVALID,
                  "attention_small_bwd: bad arguments");
   const long nw = (long)B * H * Lq;
+  if (deterministic_mode()) {
+    hipLaunchKernelGGL(attn_small_bwd_det_kernel, dim3((unsigned)((B * H + 3) / 4)), dim3(256), 0, as_stream(stream), a, probs);
+    return check_launch("attention_small_bwd_det");
+  }
   hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, as_stream(stream), a, probs);
   return check_launch("attention_small_bwd");
 }

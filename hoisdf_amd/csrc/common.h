@@ -55,6 +55,48 @@ static inline uint32_t drop_threshold(float p) {
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
 
+// ---- deterministic mode (HOISDF_DETERMINISTIC=1 / hoisdf_set_deterministic) -------------------------------
+// Every kernel that accumulates with float atomics has an order-fixed alternative, selected per launch:
+//   split-k grad-weight -> partial tiles + ordered reduce (caller workspace); small split-k forward / grad-input -> off;
+//   attention dQ -> the two-kernel form; 17-query attention dK/dV -> one wave per (sample, head) in query order;
+//   gather backward -> pixel-tile owners walking the points in order (gather.hip); per-block column sums of
+//   LayerNorm / SDF head / sigma-gate backward -> parked per block and summed in block order by the last block
+//   to arrive (block_column_sum below, library-owned scratch: deterministic mode is single-stream).
+bool deterministic_mode();
+struct DetScratch {
+  float* part;          // [gridDim.x][ncols] partials
+  unsigned* ticket;     // arrival counter, zero between launches
+  int on;
+};
+DetScratch det_scratch(size_t floats);   // on = 0 when the mode is off (or the scratch cannot be allocated)
+
+// All threads of the block call this with the block's column sums in shared memory: src[0..nA) belong to dstA,
+// src[nA..nA+nB) to dstB (pre-zeroed destinations).  Either one float atomic per column (default) or the ordered
+// last-block reduction.
+__device__ __forceinline__ void block_column_sum(float* dstA, int nA, float* dstB, int nB,
+                                                 const float* src, unsigned* s_last /* one shared word */,
+                                                 const DetScratch ds) {
+  const int n = nA + nB;
+  if (!ds.on) {
+    for (int c = threadIdx.x; c < n; c += blockDim.x) atomicAdd(c < nA ? dstA + c : dstB + (c - nA), src[c]);
+    return;
+  }
+  for (int c = threadIdx.x; c < n; c += blockDim.x) ds.part[(size_t)blockIdx.x * n + c] = src[c];
+  __threadfence();                              // agent-scope release of this block's partials
+  __syncthreads();
+  if (threadIdx.x == 0) *s_last = (atomicAdd(ds.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!*s_last) return;
+  __threadfence();                              // acquire: the other blocks' partials (other XCDs' L2 included)
+  const volatile float* part = ds.part;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    float acc = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) acc += part[(size_t)b * n + c];
+    if (c < nA) dstA[c] += acc; else dstB[c - nA] += acc;
+  }
+  if (threadIdx.x == 0) *ds.ticket = 0u;
+}
+
 // ---- wave-level reductions (64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

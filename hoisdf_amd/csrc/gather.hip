@@ -227,6 +227,83 @@ __global__ __launch_bounds__(64) void gather_bwd_coarse_kernel(PyrDev P, ProjArg
   }
 }
 
+// Deterministic backward (HOISDF_DETERMINISTIC): a single-wave workgroup OWNS a 16 x 16-pixel tile of one (sample, level,
+// 64-channel chunk) - 64 / 16 / 4 / 1 / 1 tiles for the 128^2 ... 8^2 levels - and walks ALL points of the sample in
+// order: 64 projections at a time (one per lane), a ballot keeps the points with at least one bilinear tap inside the tile,
+// and those are applied in ascending point order to a wave-private LDS image (plain in-order read-modify-write, lane =
+// channel).  The tile leaves with plain stores: no atomics anywhere, every sum has a fixed order.
+struct DetJob { short level, chunk, tx, ty; };
+struct DetArgs { int n_jobs; DetJob job[160]; };
+constexpr int DTILE = 16;
+
+__global__ __launch_bounds__(64) void gather_bwd_det_kernel(PyrDev P, ProjArgs a, DetArgs J,
+                                                            const float* __restrict__ dfeat, int ldf) {
+  __shared__ __attribute__((aligned(16))) float img[(DTILE * DTILE + 1) * 64];   // + one dummy pixel for out-of-tile taps
+  __shared__ __attribute__((aligned(16))) float tapw[64 * 4];
+  __shared__ __attribute__((aligned(16))) int tapo[64 * 4];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.y;
+  const DetJob jb = J.job[blockIdx.x];
+  const int l = jb.level, C = P.C[l], H = P.H[l], W = P.W[l];
+  const int tx = jb.tx, ty = jb.ty;
+  const int tw = min(DTILE, W - tx), th = min(DTILE, H - ty);
+  const int npix = tw * th;
+  const int cw = min(64, C - jb.chunk * 64);
+  const bool active = lane < cw;
+  for (int i = lane; i < (npix + 1) * 64; i += 64) img[i] = 0.f;
+  const int ch0 = P.off4[l] * 4 + jb.chunk * 64;
+  const int Pn = a.rows_per_sample;
+  const float* drow = dfeat + (size_t)b * Pn * ldf + ch0 + lane;
+  for (int k0 = 0; k0 < Pn; k0 += 64) {
+    bool hit = false;
+    if (k0 + lane < Pn) {
+      int bb;
+      float cam[3], uv[2], g[2];
+      project_row(a, (long)b * Pn + k0 + lane, bb, cam, uv, g);
+      const Taps t = make_taps(g[0], g[1], W, H);
+      const int o[4] = {t.o00, t.o01, t.o10, t.o11};
+      const float w[4] = {t.w00, t.w01, t.w10, t.w11};
+      int lo[4];
+      float lw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] = npix;                       // dummy pixel, weight 0
+        lw[i] = 0.f;
+        if (o[i] >= 0) {
+          const int y = o[i] / W, x = o[i] - y * W;
+          if (x >= tx && x < tx + tw && y >= ty && y < ty + th) {
+            lo[i] = (y - ty) * tw + (x - tx);
+            lw[i] = w[i];
+            hit = true;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&tapw[lane * 4]) = make_float4(lw[0], lw[1], lw[2], lw[3]);
+      *reinterpret_cast<int4*>(&tapo[lane * 4]) = make_int4(lo[0], lo[1], lo[2], lo[3]);
+    }
+    unsigned long long mask = __ballot(hit);
+    __builtin_amdgcn_wave_barrier();
+    while (mask) {                                      // ascending point order
+      const int j = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float d = active ? drow[(size_t)(k0 + j) * ldf] : 0.f;
+      const float4 w = *reinterpret_cast<const float4*>(&tapw[j * 4]);
+      const int4 o = *reinterpret_cast<const int4*>(&tapo[j * 4]);
+      // the four taps of one point are four DIFFERENT pixels (or the dummy): sequential read-modify-write is exact
+      img[o.x * 64 + lane] += d * w.x;
+      img[o.y * 64 + lane] += d * w.y;
+      img[o.z * 64 + lane] += d * w.z;
+      img[o.w * 64 + lane] += d * w.w;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (active) {
+    float* out = P.grad[l] + (size_t)b * H * W * C + jb.chunk * 64 + lane;
+    for (int py = 0; py < th; ++py)
+      for (int px = 0; px < tw; ++px) out[((size_t)(ty + py) * W + tx + px) * C] = img[(py * tw + px) * 64 + lane];
+  }
+}
+
 // ---- dense lattice (main/model.py:257-273): sheared, float32 index arithmetic --------------
 __device__ __forceinline__ void lattice_point(int idx, int n, float v32, float (&p)[3]) {
   const float fn = (float)n;
@@ -397,6 +474,27 @@ extern "C" int hoisdf_project_gather_bwd(const hoisdf_pyramid_grad* dpyr, const 
   if (n_rows == 0) return HOISDF_OK;
   ProjArgs a{points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale,
              (float)(img_w - 1) * 0.5f, (float)(img_h - 1) * 0.5f};
+  if (deterministic_mode() && !sample_idx && rows_per_sample > 0 && n_rows % rows_per_sample == 0) {
+    // tile owners, no atomics (the pyramid gradient is fully overwritten tile by tile)
+    const int B = (int)(n_rows / rows_per_sample);
+    DetArgs J{};
+    for (int l = 0; l < P.n_levels; ++l)
+      for (int ty = 0; ty < P.H[l]; ty += DTILE)
+        for (int tx = 0; tx < P.W[l]; tx += DTILE)
+          for (int ch = 0; ch < cdiv(P.C[l], 64); ++ch) {
+            if (J.n_jobs == 160) {
+              hipLaunchKernelGGL(gather_bwd_det_kernel, dim3(J.n_jobs, B), dim3(64), 0, as_stream(stream), P, a, J, dfeat, ldf);
+              if (int rc = check_launch("gather_bwd_det")) return rc;
+              J.n_jobs = 0;
+            }
+            J.job[J.n_jobs++] = DetJob{(short)l, (short)ch, (short)tx, (short)ty};
+          }
+    if (J.n_jobs) {
+      hipLaunchKernelGGL(gather_bwd_det_kernel, dim3(J.n_jobs, B), dim3(64), 0, as_stream(stream), P, a, J, dfeat, ldf);
+      if (int rc = check_launch("gather_bwd_det")) return rc;
+    }
+    return HOISDF_OK;
+  }
   int skip_mask = 0;
   if (!sample_idx && rows_per_sample > 0 && n_rows % rows_per_sample == 0) {
     const int B = (int)(n_rows / rows_per_sample);

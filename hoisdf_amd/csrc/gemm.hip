@@ -537,6 +537,7 @@ __global__ void relu_dropout_bwd_kernel(const float* __restrict__ y, int ldy, co
 // over more workgroups (>= 4 k-steps each, <= ~256 workgroups) and accumulate with atomics into a zeroed output.
 static int plan_small_splitk(int tiles, int K, int& kper) {
   const int ksteps = cdiv(K, BK);
+  if (deterministic_mode()) { kper = ksteps * BK; return 1; }      // no float atomics on the output
   int s = 256 / (tiles > 0 ? tiles : 1);
   if (s > ksteps / 4) s = ksteps / 4;
   if (tiles > 64 || s < 2) { kper = ksteps * BK; return 1; }

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
                                                            const float* __restrict__ h, int ldh,
                                                            const float* __restrict__ w, float* __restrict__ dh,
                                                            int lddh, float* __restrict__ dw, float* __restrict__ db,
-                                                           long n_rows, int K, float clampv) {
+                                                           long n_rows, int K, float clampv, DetScratch ds) {
   // each wave walks rows with a grid stride (two rows in flight) and keeps a private dw accumulator per lane
   // slot; the four waves of a block are summed in LDS so every block issues ONE atomic per column (the same 512
   // addresses are hit by every block: per-wave atomics serialised 2048 adds per address, 238 us -> see DESIGN.md)
@@ -137,8 +137,14 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
   for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&red[wave][lane * 4 + i * 256]) = dwa[i];
   if (lane == 0) red[wave][512] = dba;
   __syncthreads();
-  for (int c = threadIdx.x; c < K; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
-  if (threadIdx.x == 0) atomicAdd(db, red[0][512] + red[1][512] + red[2][512] + red[3][512]);
+  // column sums of the block: red[0][0..K) = dw, red[0][K] = db
+  for (int c = threadIdx.x; c < K; c += 256) red[0][c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+  if (threadIdx.x == 0) red[1][0] = red[0][512] + red[1][512] + red[2][512] + red[3][512];
+  __syncthreads();
+  if (threadIdx.x == 0) red[0][K] = red[1][0];
+  __syncthreads();
+  __shared__ unsigned s_last;
+  block_column_sum(dw, K, db, 1, red[0], &s_last, ds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __res
                                                               const float* __restrict__ beta_ptr,
                                                               float* __restrict__ dfeat, int lddfeat,
                                                               float* __restrict__ dbeta, int B, int P, int S,
-                                                              int row0, int D) {
+                                                              int row0, int D, DetScratch ds) {
   const int lane = threadIdx.x & 63;
   const float braw = beta_ptr[0];
   const float beta = fmaxf(braw, 2e-3f);
@@ -198,7 +204,17 @@ __global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __res
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0 && dbeta) atomicAdd(dbeta, acc);
+  if (!ds.on) {
+    if (lane == 0 && dbeta) atomicAdd(dbeta, acc);
+    return;
+  }
+  __shared__ float wsum[4];
+  if (lane == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) wsum[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  __shared__ unsigned s_last;
+  if (dbeta) block_column_sum(dbeta, 1, dbeta, 0, wsum, &s_last, ds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ dx,
                                                          float* __restrict__ dr, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, long M, int D, float drop_p,
-                                                         float inv_keep, uint64_t seed, uint32_t thresh) {
+                                                         float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds) {
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   float4 dg[4], db[4];
@@ -352,10 +368,20 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  // block column sums, contiguous: [0, D) = dgamma, [D, 2D) = dbeta  (red[0] is [4][1024] floats: D <= 1024)
+  float* flat = &red[0][0][0];
+  float g[4], bsum[4];
+  int nc = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++nc) {
+    g[nc] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    bsum[nc] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
   }
+  __syncthreads();
+  nc = 0;
+  for (int c = threadIdx.x; c < D; c += 256, ++nc) { flat[c] = g[nc]; flat[D + c] = bsum[nc]; }
+  __syncthreads();
+  __shared__ unsigned s_last;
+  block_column_sum(dgamma, D, dbeta, D, flat, &s_last, ds);
 }
 
 }  // namespace hoisdf
@@ -422,7 +448,7 @@ extern "C" int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, cons
   int blocks = row_grid(n_rows);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dsdf, sdf_raw, h, ldh, w,
-                     dh, lddh, dw, db, n_rows, K, clamp);
+                     dh, lddh, dw, db, n_rows, K, clamp, det_scratch((size_t)blocks * (K + 1)));
   return check_launch("sdf_head_bwd");
 }
 
@@ -449,7 +475,7 @@ extern "C" int hoisdf_token_build_bwd(const float* dtok, const float* feat, int 
   int blocks = row_grid((long)B * P);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(token_build_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dtok, feat, ldfeat,
-                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D);
+                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D, det_scratch((size_t)blocks));
   return check_launch("token_build_bwd");
 }
 
@@ -476,6 +502,7 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
   int blocks = row_grid(M);
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
-                     dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p));
+                     dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
+                     det_scratch((size_t)blocks * 2 * D));
   return check_launch("add_layernorm_bwd");
 }

@@ -1,6 +1,7 @@
 // Library runtime: version string and thread-local error plumbing of the C ABI.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -24,7 +25,39 @@ int check_launch(const char* what) {
   return HOISDF_OK;
 }
 
+static int g_det = -1;          // -1: not decided yet (environment), 0 / 1
+
+bool deterministic_mode() {
+  if (g_det < 0) {
+    const char* e = getenv("HOISDF_DETERMINISTIC");
+    g_det = (e && e[0] && e[0] != '0') ? 1 : 0;
+  }
+  return g_det == 1;
+}
+
+DetScratch det_scratch(size_t floats) {
+  static float* part = nullptr;
+  static unsigned* ticket = nullptr;
+  static size_t cap = 0;
+  DetScratch d{nullptr, nullptr, 0};
+  if (!deterministic_mode()) return d;
+  if (floats > cap || !ticket) {
+    // grown on demand, never freed (a few MB); deterministic mode runs on one stream, so launches never overlap
+    if (part) (void)hipFree(part);
+    cap = floats < (1u << 20) ? (1u << 20) : floats;
+    if (hipMalloc(&part, cap * sizeof(float)) != hipSuccess) { part = nullptr; cap = 0; return d; }
+    if (!ticket) {
+      if (hipMalloc(&ticket, sizeof(unsigned)) != hipSuccess) { ticket = nullptr; return d; }
+      (void)hipMemset(ticket, 0, sizeof(unsigned));
+    }
+  }
+  d.part = part; d.ticket = ticket; d.on = 1;
+  return d;
+}
+
 }  // namespace hoisdf
 
+extern "C" void hoisdf_set_deterministic(int on) { hoisdf::g_det = on ? 1 : 0; }
+extern "C" int hoisdf_get_deterministic(void) { return hoisdf::deterministic_mode() ? 1 : 0; }
 extern "C" const char* hoisdf_version(void) { return "hoisdf-hip 0.1 (gfx950)"; }
 extern "C" const char* hoisdf_last_error(void) { return hoisdf::g_err; }

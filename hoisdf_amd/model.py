@@ -210,7 +210,8 @@ class Model(nn.Module):
         # below, the object encoder stack) is independent of the hand-point work until the tokens are assembled: it is
         # issued on a second HIP stream, so its small grids (16 384 rows) share the chip with the hand stream's kernels
         # and kernel tails overlap.  Autograd replays every op's backward on its forward stream.
-        two = bool(getattr(c, "overlap_streams", True)) and root.is_cuda and os.environ.get("HOISDF_TWO_STREAMS", "1") != "0"
+        two = bool(getattr(c, "overlap_streams", True)) and root.is_cuda and os.environ.get("HOISDF_TWO_STREAMS", "1") != "0" \
+            and not ops.deterministic()
         cur = side = None
         if two:
             cur = torch.cuda.current_stream(root.device)

@@ -18,6 +18,18 @@ _WEIGHT_GEN = [0]      # bumped by optimizers that update parameters behind auto
                        # not touch torch's version counters): invalidates cached derived weights (SdfQueryWeights)
 
 
+def deterministic() -> bool:
+    """HOISDF_DETERMINISTIC=1 / ops.set_deterministic(True): order-fixed forms of every accumulating kernel (see
+    include/hoisdf.h hoisdf_set_deterministic); the model then also runs single-stream."""
+    from ._lib import lib
+    return bool(lib().hoisdf_get_deterministic())
+
+
+def set_deterministic(on: bool) -> None:
+    from ._lib import lib
+    lib().hoisdf_set_deterministic(int(bool(on)))
+
+
 def bump_weight_generation() -> None:
     _WEIGHT_GEN[0] += 1
 
@@ -223,8 +235,13 @@ class _Linear(torch.autograd.Function):
             buf = _zeros(N * K + (N if has_b else 0), dy.device)   # one fill (or a slice of the per-step arena)
             dW = buf[:N * K].view(N, K)
             db = buf[N * K:] if has_b else None
+            ws, nws = None, 0
+            if deterministic():             # partial tiles + ordered reduce instead of split-k atomics
+                from ._lib import lib
+                nws = lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
+                ws = torch.empty(max(nws, 1), device=dy.device, dtype=torch.float32) if nws > 0 else None
             call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), p, _p(x2), x2.stride(0) if M > 1 else K, _p(dW),
-                 K, _p(db), M, N, K, None, 0, _st())
+                 K, _p(db), M, N, K, _p(ws), nws, _st())
         return dx, dW, db, None, None, None
 
 

@@ -61,6 +61,12 @@ typedef struct hoisdf_pyramid_grad {
 
 const char* hoisdf_version(void);
 const char* hoisdf_last_error(void);
+/* Deterministic mode (also: environment HOISDF_DETERMINISTIC=1, read at first use).  Every entry that otherwise
+ * accumulates with float atomics switches to an order-fixed form: two identical call sequences give bit-identical
+ * results.  Contract: one stream at a time (the ordered block reductions share a library-owned scratch); grad-weight is
+ * order-fixed only when the caller passes the workspace (hoisdf_linear_bwd_weight_workspace). */
+void hoisdf_set_deterministic(int on);
+int hoisdf_get_deterministic(void);
 
 /* ---- K1: pinhole projection + 5-level bilinear gather --------------------------------
  * reference: main/model.py:148-175 (get_input_transformer), :190-214 (sdf_forward),
