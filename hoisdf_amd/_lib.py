@@ -72,6 +72,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                              _I, _F, _U64, _P],
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "hoisdf_attention_fwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _P],
+    "hoisdf_attention_bwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
+                                   _U64, _P, _L, _P],
     "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                    _U64, _P],
@@ -86,7 +89,8 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
-          "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long)}
+          "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
+          "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
 
 _lib = None
 

@@ -517,6 +517,48 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
          _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, drop_p, seed, _st())
 
 
+_ATTENTION_SPLIT = False
+
+
+def set_attention_split(on: bool) -> None:
+    """cfg.attention_split: run the TRAINING attention (forward with dropout + backward) on the 16-bit MFMA pipe with f16
+    hi + lo split operands (3 products per contraction, f32 accumulation / softmax; csrc/attention_split.hip).  Off by
+    default: the exact-f32 kernels are the parity configuration and what bench.py's headline line measures."""
+    global _ATTENTION_SPLIT
+    _ATTENTION_SPLIT = bool(on)
+
+
+def _use_split(Lq: int) -> bool:
+    return _ATTENTION_SPLIT and Lq >= 32            # the 17-query decoder attention keeps its own f32 kernels
+
+
+def _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed):
+    from ._lib import lib
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    for t, L in ((q, Lq), (k, Lk), (v, Lk)):
+        assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
+    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 0)
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_fwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H,
+         Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
+    return o, lse
+
+
+def _attn_bwd_split(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
+    from ._lib import lib
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 1)
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_bwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E,
+         _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
+
+
 class _AttentionSelf(torch.autograd.Function):
     """qkv (B,L,3E): the packed in-projection output [q | k | v]."""
 
@@ -525,19 +567,22 @@ class _AttentionSelf(torch.autograd.Function):
         qkv = qkv.contiguous()
         _chk(qkv)
         E = qkv.shape[2] // 3
-        o, lse = _attn_fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        split = _use_split(qkv.shape[1])
+        fwd = _attn_fwd_split if split else _attn_fwd
+        o, lse = fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed)
         ctx.save_for_backward(qkv, o, lse)
-        ctx.meta = (H, kv_len, float(drop_p), seed)
+        ctx.meta = (H, kv_len, float(drop_p), seed, split)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, o, lse = ctx.saved_tensors
-        H, kv_len, drop_p, seed = ctx.meta
+        H, kv_len, drop_p, seed, split = ctx.meta
         E = qkv.shape[2] // 3
         d = torch.empty_like(qkv)
-        _attn_bwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do.contiguous(), d[:, :, :E],
-                  d[:, :, E:2 * E], d[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        (_attn_bwd_split if split else _attn_bwd)(
+            qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do.contiguous(), d[:, :, :E],
+            d[:, :, E:2 * E], d[:, :, 2 * E:], H, kv_len, drop_p, seed)
         return d, None, None, None, None
 
 
@@ -549,20 +594,21 @@ class _AttentionCross(torch.autograd.Function):
         q, kv = q.contiguous(), kv.contiguous()
         _chk(q, kv)
         E = q.shape[2]
-        o, lse = _attn_fwd(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed)
+        split = _use_split(q.shape[1])
+        o, lse = (_attn_fwd_split if split else _attn_fwd)(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed)
         ctx.save_for_backward(q, kv, o, lse)
-        ctx.meta = (H, kv_len, float(drop_p), seed)
+        ctx.meta = (H, kv_len, float(drop_p), seed, split)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, kv, o, lse = ctx.saved_tensors
-        H, kv_len, drop_p, seed = ctx.meta
+        H, kv_len, drop_p, seed, split = ctx.meta
         E = q.shape[2]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        _attn_bwd(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), dq, dkv[:, :, :E], dkv[:, :, E:], H, kv_len,
-                  drop_p, seed)
+        (_attn_bwd_split if split else _attn_bwd)(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), dq,
+                                                  dkv[:, :, :E], dkv[:, :, E:], H, kv_len, drop_p, seed)
         return dq, dkv, None, None, None, None
 
 

@@ -589,3 +589,59 @@ def test_sdf_query_one_call_matches_the_op_chain():
     with torch.no_grad():
         raw5 = model._sdf_query(pyr, pts, root, K, 3.1, "hand")[1]
     assert bool(torch.isfinite(raw5).all()) and float((raw5 - raw4).abs().mean()) > 1e-3
+
+
+@pytest.mark.parametrize("B,L,kv,p", [(2, 200, None, 0.0), (3, 333, 250, 0.0), (2, 1024, None, 0.1), (1, 96, None, 0.3)])
+def test_attention_split_precision_training_kernels(B, L, kv, p):
+    """csrc/attention_split.hip (f16 hi+lo operands, 3 products, f32 accumulate): forward + backward against the fp64
+    reference (p = 0) and against the exact-f32 kernels with the SAME dropout mask (p > 0)."""
+    O = ops()
+    import hoisdf_amd.ops as OO
+    E, H = 256, 4
+    qkv = rnd(B, L, 3 * E, seed=40)
+    go = rnd(B, L, E, seed=41)
+    OO.set_attention_split(True)
+    try:
+        OO.manual_seed(99)
+        x = qkv.to(DEV).requires_grad_(True)
+        o = O.attention_self(x, H, kv, p)
+        o.backward(go.to(DEV))
+    finally:
+        OO.set_attention_split(False)
+    if p == 0.0:
+        q64 = qkv.double().requires_grad_(True)
+        ref = _ref_attention(q64[..., :E], q64[..., E:2 * E], q64[..., 2 * E:], H, kv)
+        ref.backward(go.double())
+        ro, rg = ref, q64.grad
+    else:
+        OO.manual_seed(99)                     # same seed stream -> same mask in the f32 kernels
+        y = qkv.to(DEV).requires_grad_(True)
+        ro = O.attention_self(y, H, kv, p)
+        ro.backward(go.to(DEV))
+        rg = y.grad
+    assert_close(o, ro, rel=2e-5, what="split attn out")
+    assert_close(x.grad, rg, rel=5e-5, what="split attn dqkv")
+    if kv is not None:
+        assert float(x.grad[:, kv:, E:].abs().max()) == 0.0
+
+
+def test_attention_split_cross_shapes():
+    O = ops()
+    import hoisdf_amd.ops as OO
+    B, Lq, Lk, E, H, kv = 2, 150, 700, 256, 4, 600
+    q = rnd(B, Lq, E, seed=42).double().requires_grad_(True)
+    kvt = rnd(B, Lk, 2 * E, seed=43).double().requires_grad_(True)
+    ref = _ref_attention(q, kvt[..., :E], kvt[..., E:], H, kv)
+    go = rnd(B, Lq, E, seed=44)
+    ref.backward(go.double())
+    OO.set_attention_split(True)
+    try:
+        qg = q.detach().float().to(DEV).requires_grad_(True)
+        kg = kvt.detach().float().to(DEV).requires_grad_(True)
+        o = O.attention_cross(qg, kg, H, kv)
+        o.backward(go.to(DEV))
+    finally:
+        OO.set_attention_split(False)
+    assert_close(o, ref, rel=2e-5, what="split cross out")
+    assert_close(qg.grad, q.grad, rel=5e-5, what="split cross dq")
+    assert_close(kg.grad, kvt.grad, rel=5e-5, what="split cross dkv")
