@@ -90,39 +90,58 @@ __device__ __forceinline__ f16x8 frag_trn(const _Float16* tile, int row, int jj,
 }  // namespace
 
 // ---- conversion pre-pass: f32 [B][L][ld] (head slice) -> f16 hi / lo, row-major [bh][Lp][64] and transposed
-// [bh][64][Lp]; rows >= L are zero.  One wave per (bh, 64-row block), lane = row.
+// [bh][64][Lp]; rows >= L are zero.  One block per (bh, 64-row tile): a thread owns 16 consecutive d of one row (4 threads
+// per row: 256-byte coalesced reads, 128-byte coalesced row-major writes); the transposed copies go through an LDS tile so
+// that they leave as 32-byte pieces of 128-byte d-rows as well (a lane-per-row version ran at 1.4 TB/s).
 __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, int ld, int L, int Lp, int B,
                                                             int H, float scale, _Float16* __restrict__ rh,
                                                             _Float16* __restrict__ rl, _Float16* __restrict__ th,
                                                             _Float16* __restrict__ tl) {
-  const int lane = threadIdx.x & 63;
-  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int TP = 72;                                   // halves per LDS row of the [64 d][64 rows] tile
+  __shared__ __attribute__((aligned(16))) _Float16 tile[2][64 * TP];
+  const int tid = threadIdx.x;
   const int nb = Lp / 64;
-  if (w >= (long)B * H * nb) return;
-  const int kb = (int)(w % nb), bh = (int)(w / nb), b = bh / H, head = bh - b * H;
-  const int row = kb * 64 + lane;
+  const int kb = blockIdx.x % nb, bh = blockIdx.x / nb, b = bh / H, head = bh - b * H;
+  const int r = tid >> 2, dc = (tid & 3) * 16;
+  const int row = kb * 64 + r;
   const bool valid = row < L;
-  const float* sr = src + ((size_t)b * L + (valid ? row : 0)) * ld + head * D;
+  const float* sr = src + ((size_t)b * L + (valid ? row : 0)) * ld + head * D + dc;
+  _Float16 hi[16], lo[16];
 #pragma unroll
-  for (int d4 = 0; d4 < 16; ++d4) {
-    float4 a = valid ? *reinterpret_cast<const float4*>(sr + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = valid ? *reinterpret_cast<const float4*>(sr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float e[4] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale};
-    f16x4 h4, l4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h4[i] = (_Float16)e[i];
-      l4[i] = (_Float16)(e[i] - (float)h4[i]);
+    for (int j = 0; j < 4; ++j) {
+      hi[4 * i + j] = (_Float16)e[j];
+      lo[4 * i + j] = (_Float16)(e[j] - (float)hi[4 * i + j]);
     }
-    if (rh) {
-      *reinterpret_cast<f16x4*>(rh + ((size_t)bh * Lp + row) * D + 4 * d4) = h4;
-      *reinterpret_cast<f16x4*>(rl + ((size_t)bh * Lp + row) * D + 4 * d4) = l4;
-    }
-    if (th) {
+  }
+  if (rh) {
+    _Float16* oh = rh + ((size_t)bh * Lp + row) * D + dc;
+    _Float16* ol = rl + ((size_t)bh * Lp + row) * D + dc;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                         // 64 lanes -> 64 consecutive rows of one d row: coalesced
-        th[((size_t)bh * D + 4 * d4 + i) * Lp + row] = h4[i];
-        tl[((size_t)bh * D + 4 * d4 + i) * Lp + row] = l4[i];
-      }
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f16x8*>(oh + 8 * i) = f16x8{hi[8 * i], hi[8 * i + 1], hi[8 * i + 2], hi[8 * i + 3], hi[8 * i + 4],
+                                                    hi[8 * i + 5], hi[8 * i + 6], hi[8 * i + 7]};
+      *reinterpret_cast<f16x8*>(ol + 8 * i) = f16x8{lo[8 * i], lo[8 * i + 1], lo[8 * i + 2], lo[8 * i + 3], lo[8 * i + 4],
+                                                    lo[8 * i + 5], lo[8 * i + 6], lo[8 * i + 7]};
+    }
+  }
+  if (th) {                                                // block-uniform
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      tile[0][(dc + i) * TP + r] = hi[i];
+      tile[1][(dc + i) * TP + r] = lo[i];
+    }
+    __syncthreads();
+    const int d = tid >> 2, rc = (tid & 3) * 16;           // 16 consecutive rows of d-row d
+    _Float16* oh = th + ((size_t)bh * D + d) * Lp + kb * 64 + rc;
+    _Float16* ol = tl + ((size_t)bh * D + d) * Lp + kb * 64 + rc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(oh + 8 * i) = *reinterpret_cast<const uint4*>(&tile[0][d * TP + rc + 8 * i]);
+      *reinterpret_cast<uint4*>(ol + 8 * i) = *reinterpret_cast<const uint4*>(&tile[1][d * TP + rc + 8 * i]);
     }
   }
 }
@@ -321,7 +340,6 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dq_kernel(SplitArgs a) {
   __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < ntiles) load(kt + 1);
     const _Float16* Kh = lds + cur * BUF;
     const _Float16* Kl = Kh + ROWS_T;
     const _Float16* Vh = Kh + 2 * ROWS_T;
@@ -350,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dq_kernel(SplitArgs a) {
       if (a.drop_p > 0.f) dsc = drop_scale(rowkey, (uint32_t)key, a.thresh, a.inv_keep);
       dp[r] = p * (dp[r] * dsc - delta);
     }
+    if (kt + 1 < ntiles) load(kt + 1);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       float e[8];
@@ -459,7 +478,6 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
   __syncthreads();
   for (int qt = 0; qt < nq; ++qt) {
     const int cur = qt & 1;
-    if (qt + 1 < nq) load(qt + 1);
     const _Float16* Qh = lds + cur * BUF;
     const _Float16* Ql = Qh + ROWS_T;
     const _Float16* Dh = Qh + 2 * ROWS_T;
@@ -496,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
       s[r] = p * dsc;
       dp[r] = p * (dp[r] * dsc - Es[qi]);
     }
+    if (qt + 1 < nq) load(qt + 1);          // issued after the S / dP phase (register peak), lands during the 24 MFMAs below
     // dV^T[d][key] += dO^T[d][q] . Pd[q][key];  dK^T[d][key] += Qs^T[d][q] . dS[q][key]
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -563,9 +582,9 @@ inline size_t arr_halves(int B, int H, long Lp) { return (size_t)B * H * Lp * 64
 
 int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, _Float16* rh, _Float16* rl, _Float16* th,
             _Float16* tl, hipStream_t st) {
-  const long nw = (long)B * H * (Lp / 64);
-  hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, rh,
-                     rl, th, tl);
+  const long nblk = (long)B * H * (Lp / 64);
+  hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, rh, rl, th,
+                     tl);
   return check_launch("attention_split_convert");
 }
 }  // namespace
