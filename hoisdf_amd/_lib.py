@@ -73,7 +73,7 @@ SIGNATURES: Dict[str, List] = {
                              _I, _F, _U64, _P],
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _P],
-    "hoisdf_attention_bwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
+    "hoisdf_attention_bwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
                                    _U64, _P, _L, _P],
     "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,

@@ -32,6 +32,12 @@ constexpr int ROWS_T = 32 * RP;     // halves per row-major tile
 constexpr int TRN_T = 64 * TPH;     // halves per transposed tile
 constexpr float QS2 = 0.125f * 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+// f16 keeps 11 + 11 bits in a hi + lo pair only while the lo part stays a normal number, i.e. for |x| >= 2^-3; below that
+// the pair degrades to an ABSOLUTE resolution of 2^-25.  Probabilities (~1/L) and gradients are far below 2^-3, so they are
+// moved up by exact powers of two before the split and the factor is taken out of the f32 result:
+//   P -> P * 2^12 (max 4096);  dO -> dO * sd with sd = the power of two that brings max|dO| into [2, 4) (device scalar);
+//   dS -> dS * sd * 2^5.
+constexpr float PSC = 4096.f, DSC = 32.f;
 #define CR(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -41,7 +47,7 @@ struct SplitArgs {
   const _Float16 *kh, *kl, *kth, *ktl;      // K rows, K^T
   const _Float16 *vh, *vl, *vth, *vtl;      // V rows, V^T
   const _Float16 *dh, *dl, *dth, *dtl;      // dO rows, dO^T
-  const float* lse_in; const float* delta;
+  const float* lse_in; const float* delta; const float* dscale;     // dscale: device scalar sd (nullptr = 1)
   float* out; float* lse; float* dq; float* dk; float* dv;
   int ldo, ldq, ldk, ldv;
   int B, H, Lq, Lk, Lqp, Lkp, kv_len;
@@ -94,10 +100,11 @@ __device__ __forceinline__ f16x8 frag_trn(const _Float16* tile, int row, int jj,
 // per row: 256-byte coalesced reads, 128-byte coalesced row-major writes); the transposed copies go through an LDS tile so
 // that they leave as 32-byte pieces of 128-byte d-rows as well (a lane-per-row version ran at 1.4 TB/s).
 __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, int ld, int L, int Lp, int B,
-                                                            int H, float scale, _Float16* __restrict__ rh,
-                                                            _Float16* __restrict__ rl, _Float16* __restrict__ th,
-                                                            _Float16* __restrict__ tl) {
-  constexpr int TP = 72;                                   // halves per LDS row of the [64 d][64 rows] tile
+                                                            int H, float scale, const float* __restrict__ scale_ptr,
+                                                            _Float16* __restrict__ rh, _Float16* __restrict__ rl,
+                                                            _Float16* __restrict__ th, _Float16* __restrict__ tl) {
+  constexpr int TP = 72;
+  if (scale_ptr) scale *= scale_ptr[0];                                   // halves per LDS row of the [64 d][64 rows] tile
   __shared__ __attribute__((aligned(16))) _Float16 tile[2][64 * TP];
   const int tid = threadIdx.x;
   const int nb = Lp / 64;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void split_fwd_kernel(SplitArgs a) {
     for (int jj = 0; jj < 2; ++jj) {
       float e[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) e[i] = s[8 * jj + i];
+      for (int i = 0; i < 8; ++i) e[i] = s[8 * jj + i] * PSC;
       f16x8 pf, pl;
       split8(e, pf, pl);
 #pragma unroll
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void split_fwd_kernel(SplitArgs a) {
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (qrow < a.Lq) {
-    const float inv = 1.f / ltot;
+    const float inv = 1.f / (ltot * PSC);
     float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -308,8 +315,9 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dq_kernel(SplitArgs a) {
       dlo[j] = *reinterpret_cast<const f16x8*>(a.dl + ro + 16 * j + 8 * h);
     }
   }
+  const float sd = a.dscale ? a.dscale[0] : 1.f;
   const float lse = qvalid ? a.lse_in[(size_t)bh * a.Lq + qrow] : INFINITY;
-  const float delta = qvalid ? a.delta[(size_t)bh * a.Lq + qrow] : 0.f;
+  const float delta = qvalid ? a.delta[(size_t)bh * a.Lq + qrow] * sd : 0.f;
   const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
   f32x16 dq[2];
 #pragma unroll
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dq_kernel(SplitArgs a) {
       const float p = key < a.kv_len ? __builtin_amdgcn_exp2f(s[r] - lse) : 0.f;
       float dsc = 1.f;
       if (a.drop_p > 0.f) dsc = drop_scale(rowkey, (uint32_t)key, a.thresh, a.inv_keep);
-      dp[r] = p * (dp[r] * dsc - delta);
+      dp[r] = DSC * p * (dp[r] * dsc - delta);
     }
     if (kt + 1 < ntiles) load(kt + 1);
 #pragma unroll
@@ -389,14 +397,14 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dq_kernel(SplitArgs a) {
     __syncthreads();
   }
   if (qvalid) {
+    const float us = 0.125f / (DSC * sd);
     float* op = a.dq + ((size_t)b * a.Lq + qrow) * a.ldq + head * D;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * h) =
-            make_float4(dq[t][4 * g + 0] * 0.125f, dq[t][4 * g + 1] * 0.125f, dq[t][4 * g + 2] * 0.125f,
-                        dq[t][4 * g + 3] * 0.125f);
+            make_float4(dq[t][4 * g + 0] * us, dq[t][4 * g + 1] * us, dq[t][4 * g + 2] * us, dq[t][4 * g + 3] * us);
   }
 }
 
@@ -440,6 +448,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
 
+  const float sd = a.dscale ? a.dscale[0] : 1.f;
   const bool block_active = ktile * 128 < a.kv_len;
   const int nq = block_active ? (a.Lq + 31) / 32 : 0;
   uint4 r0, r1, r2, r3, r4, r5, r6, r7;
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
     if (tid < 32) {
       const int q = qt * 32 + tid;
       rl = q < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q] : INFINITY;
-      re = q < a.Lq ? a.delta[(size_t)bh * a.Lq + q] : 0.f;
+      re = q < a.Lq ? a.delta[(size_t)bh * a.Lq + q] * sd : 0.f;
     }
   };
   auto store = [&](int bufi) {
@@ -511,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
       if (a.drop_p > 0.f)
         dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh,
                          a.inv_keep);
-      s[r] = p * dsc;
-      dp[r] = p * (dp[r] * dsc - Es[qi]);
+      s[r] = PSC * p * dsc;
+      dp[r] = DSC * p * (dp[r] * dsc - Es[qi]);
     }
     if (qt + 1 < nq) load(qt + 1);          // issued after the S / dP phase (register peak), lands during the 24 MFMAs below
     // dV^T[d][key] += dO^T[d][q] . Pd[q][key];  dK^T[d][key] += Qs^T[d][q] . dS[q][key]
@@ -539,17 +548,18 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
     __syncthreads();
   }
   if (key < a.Lk) {
+    const float uk = LN2 / (DSC * sd), uv = 1.f / (PSC * sd);
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
+        // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2; then the power-of-two factors
         *reinterpret_cast<float4*>(pk + 32 * t + 8 * g + 4 * h) =
-            make_float4(dk[t][4 * g + 0] * LN2, dk[t][4 * g + 1] * LN2, dk[t][4 * g + 2] * LN2, dk[t][4 * g + 3] * LN2);
+            make_float4(dk[t][4 * g + 0] * uk, dk[t][4 * g + 1] * uk, dk[t][4 * g + 2] * uk, dk[t][4 * g + 3] * uk);
         *reinterpret_cast<float4*>(pv + 32 * t + 8 * g + 4 * h) =
-            make_float4(dv[t][4 * g + 0], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
+            make_float4(dv[t][4 * g + 0] * uv, dv[t][4 * g + 1] * uv, dv[t][4 * g + 2] * uv, dv[t][4 * g + 3] * uv);
       }
   }
 }
@@ -580,11 +590,11 @@ namespace {
 inline long pad128(long L) { return (L + 127) / 128 * 128; }
 inline size_t arr_halves(int B, int H, long Lp) { return (size_t)B * H * Lp * 64; }
 
-int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, _Float16* rh, _Float16* rl, _Float16* th,
-            _Float16* tl, hipStream_t st) {
+int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, const float* scale_ptr, _Float16* rh,
+            _Float16* rl, _Float16* th, _Float16* tl, hipStream_t st) {
   const long nblk = (long)B * H * (Lp / 64);
-  hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, rh, rl, th,
-                     tl);
+  hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, scale_ptr, rh, rl,
+                     th, tl);
   return check_launch("attention_split_convert");
 }
 }  // namespace
@@ -625,9 +635,9 @@ extern "C" int hoisdf_attention_fwd_split(const float* q, int ldq, const float* 
   _Float16* w = reinterpret_cast<_Float16*>(workspace);
   const size_t nq = arr_halves(B, H, Lqp), nk = arr_halves(B, H, Lkp);
   _Float16 *qh = w, *ql = qh + nq, *kh = ql + nq, *kl = kh + nk, *vth = kl + nk, *vtl = vth + nk;
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, qh, ql, nullptr, nullptr, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, kh, kl, nullptr, nullptr, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, nullptr, vth, vtl, st)) return rc;
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, nullptr, nullptr, st)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, nullptr, nullptr, st)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, nullptr, nullptr, vth, vtl, st)) return rc;
   SplitArgs a{};
   a.qh = qh; a.ql = ql; a.kh = kh; a.kl = kl; a.vth = vth; a.vtl = vtl;
   a.out = o; a.lse = lse; a.ldo = ldo;
@@ -638,8 +648,9 @@ extern "C" int hoisdf_attention_fwd_split(const float* q, int ldq, const float* 
 }
 
 extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                          const float* o, int ldo, const float* dout, int lddo, const float* lse,
-                                          float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk,
+                                          const float* o, int ldo, const float* dout, int lddo,
+                                          const float* dout_scale, const float* lse, float* delta, float* dq,
+                                          float* dk, float* dv, int B, int H, int Lq, int Lk,
                                           int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
                                           void* stream) {
   if (int rc = check_split(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_bwd_split")) return rc;
@@ -658,10 +669,10 @@ extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* 
   _Float16 *qh = w, *ql = qh + nq, *qth = ql + nq, *qtl = qth + nq;
   _Float16 *kh = qtl + nq, *kl = kh + nk, *kth = kl + nk, *ktl = kth + nk, *vh = ktl + nk, *vl = vh + nk;
   _Float16 *dh = vl + nk, *dl = dh + nq, *dth = dl + nq, *dtl = dth + nq;
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, qh, ql, qth, qtl, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, kh, kl, kth, ktl, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, vh, vl, nullptr, nullptr, st)) return rc;
-  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, dh, dl, dth, dtl, st)) return rc;
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, qth, qtl, st)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, kth, ktl, st)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, vh, vl, nullptr, nullptr, st)) return rc;
+  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, dout_scale, dh, dl, dth, dtl, st)) return rc;
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(split_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, o, ldo, dout, lddo, delta,
                      B, H, Lq);
@@ -669,7 +680,7 @@ extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* 
   SplitArgs a{};
   a.qh = qh; a.ql = ql; a.qth = qth; a.qtl = qtl; a.kh = kh; a.kl = kl; a.kth = kth; a.ktl = ktl;
   a.vh = vh; a.vl = vl; a.dh = dh; a.dl = dl; a.dth = dth; a.dtl = dtl;
-  a.lse_in = lse; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+  a.lse_in = lse; a.delta = delta; a.dscale = dout_scale; a.dq = dq; a.dk = dk; a.dv = dv; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   hipLaunchKernelGGL(split_bwd_dkv_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);

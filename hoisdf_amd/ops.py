@@ -555,8 +555,11 @@ def _attn_bwd_split(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
     nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 1)
     ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    # power of two that brings max|dO| into [2, 4): computed on the device, read by the kernels through a pointer
+    mx = do.abs().max().clamp_min(1e-30)
+    sd = torch.exp2(torch.floor(torch.log2(4.0 / mx))).reshape(1).contiguous()
     call("hoisdf_attention_bwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E,
-         _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
+         _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
 
 
 class _AttentionSelf(torch.autograd.Function):

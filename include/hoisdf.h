@@ -256,14 +256,17 @@ int hoisdf_attention_fwd_f16(const float* q, int ldq, const float* k, int ldk, c
  * hi + lo operands and three products (f32 accumulation; ~21-22 significant bits instead of 24): forward S = QK^T,
  * O = PV; backward S, dP = dO V^T, dV = Pd^T dO, dK = dS^T Q, dQ = dS K as two order-fixed kernels (no atomics).
  * workspace: hoisdf_attention_split_workspace(B, H, Lq, Lk, backward) bytes, 16-byte aligned (f16 hi / lo copies of the
- * operands, row-major and transposed).  delta [B][H][Lq] is scratch of the backward. */
+ * operands, row-major and transposed).  delta [B][H][Lq] is scratch of the backward.  dout_scale (device pointer, may be
+ * NULL = 1): a power of two sd that brings max|dout| * sd into [2, 4) - f16 hi + lo pairs keep 22 bits only above 2^-3,
+ * so gradients are moved up before the split and the factor is taken out of the f32 results. */
 long hoisdf_attention_split_workspace(int B, int H, int Lq, int Lk, int backward);
 int hoisdf_attention_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
                                uint64_t seed, void* workspace, long workspace_bytes, void* stream);
 int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                               const float* o, int ldo, const float* dout, int lddo, const float* lse, float* delta,
-                               float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk, int kv_len,
+                               const float* o, int ldo, const float* dout, int lddo, const float* dout_scale,
+                               const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq,
+                               int Lk, int kv_len,
                                float drop_p, uint64_t seed, void* workspace, long workspace_bytes, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */

@@ -163,7 +163,9 @@ def test_gather_backward_at_B32(P):
         off += c
 
 
-def test_training_step_at_B32_equals_the_reference_n2048_fixture():
+@pytest.mark.parametrize("split", [False, True])
+def test_training_step_at_B32_equals_the_reference_n2048_fixture(split):
+    """split=True: the same check with cfg.attention_split (training attention in f16 hi+lo split precision)."""
     from hoisdf_amd import ops
     from hoisdf_amd.model import get_model
     from hoisdf_amd.nets import mano as MANO
@@ -196,13 +198,17 @@ def test_training_step_at_B32_equals_the_reference_n2048_fixture():
     model._jitter = lambda like, d: tile(jit.pop(0)).to(DEV)
     model._py_random = random.Random(0)
     inputs, targets, meta = ({k: tile(v).to(DEV) for k, v in d.items()} for d in (inputs, targets, meta))
-    loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
-    losses = {k: v.mean() for k, v in loss.items()}
+    ops.set_attention_split(split)
+    try:
+        loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
+        losses = {k: v.mean() for k, v in loss.items()}
+        total = sum(losses.values())
+        total.backward()
+    finally:
+        ops.set_attention_split(False)
     for k, v in losses.items():
         ref = float(g["loss." + k])
         assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
-    total = sum(losses.values())
-    total.backward()
     n = 0
     for name, p in model.named_parameters():
         key = "gradnorm." + name
