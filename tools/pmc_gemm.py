@@ -6,7 +6,7 @@ from hoisdf_amd._lib import call
 dev = "cuda"
 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-M, N, K = 65536, 512, 992
+M, N, K = 49152, 1024, 992      # the largest linear of the training step (linear_transformerin layer 0 on the hand points)
 x = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / math.sqrt(K); b = torch.randn(N, device=dev)
 dy = torch.randn(M, N, device=dev); bits = torch.zeros(M, (N + 31) // 32, dtype=torch.int32, device=dev); y = torch.relu(torch.randn(M, N, device=dev))
 out = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
