@@ -451,42 +451,54 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
   const float sd = a.dscale ? a.dscale[0] : 1.f;
   const bool block_active = ktile * 128 < a.kv_len;
   const int nq = block_active ? (a.Lq + 31) / 32 : 0;
-  uint4 r0, r1, r2, r3, r4, r5, r6, r7;
+  // The eight tile pieces of the next query tile travel through FOUR staging registers in two phases (row-major pieces
+  // during the S / dP products, transposed pieces during the dS algebra and the dV / dK products): a full eight-register
+  // prefetch pushed the kernel over 256 VGPRs (24 spilled, 50 MB of scratch writes per launch in the PMC pass).
+  uint4 r0, r1, r2, r3;
   float rl = INFINITY, re = 0.f;
-  auto load = [&](int qt) {
+  auto load_rows = [&](int qt) {
     r0 = ld_rows(qh, (size_t)qt * 32, tid);
     r1 = ld_rows(ql, (size_t)qt * 32, tid);
     r2 = ld_rows(dh, (size_t)qt * 32, tid);
     r3 = ld_rows(dl, (size_t)qt * 32, tid);
-    r4 = ld_trn(qth, a.Lqp, (size_t)qt * 32, tid);
-    r5 = ld_trn(qtl, a.Lqp, (size_t)qt * 32, tid);
-    r6 = ld_trn(dth, a.Lqp, (size_t)qt * 32, tid);
-    r7 = ld_trn(dtl, a.Lqp, (size_t)qt * 32, tid);
     if (tid < 32) {
       const int q = qt * 32 + tid;
       rl = q < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q] : INFINITY;
       re = q < a.Lq ? a.delta[(size_t)bh * a.Lq + q] * sd : 0.f;
     }
   };
-  auto store = [&](int bufi) {
+  auto store_rows = [&](int bufi) {
     _Float16* buf = lds + bufi * BUF;
     st_rows(buf, r0, tid);
     st_rows(buf + ROWS_T, r1, tid);
     st_rows(buf + 2 * ROWS_T, r2, tid);
     st_rows(buf + 3 * ROWS_T, r3, tid);
-    st_trn(buf + 4 * ROWS_T, r4, tid);
-    st_trn(buf + 4 * ROWS_T + TRN_T, r5, tid);
-    st_trn(buf + 4 * ROWS_T + 2 * TRN_T, r6, tid);
-    st_trn(buf + 4 * ROWS_T + 3 * TRN_T, r7, tid);
     if (tid < 32) { stat[bufi][0][tid] = rl; stat[bufi][1][tid] = re; }
   };
+  auto load_trn = [&](int qt) {
+    r0 = ld_trn(qth, a.Lqp, (size_t)qt * 32, tid);
+    r1 = ld_trn(qtl, a.Lqp, (size_t)qt * 32, tid);
+    r2 = ld_trn(dth, a.Lqp, (size_t)qt * 32, tid);
+    r3 = ld_trn(dtl, a.Lqp, (size_t)qt * 32, tid);
+  };
+  auto store_trn = [&](int bufi) {
+    _Float16* buf = lds + bufi * BUF + 4 * ROWS_T;
+    st_trn(buf, r0, tid);
+    st_trn(buf + TRN_T, r1, tid);
+    st_trn(buf + 2 * TRN_T, r2, tid);
+    st_trn(buf + 3 * TRN_T, r3, tid);
+  };
   if (nq > 0) {
-    load(0);
-    store(0);
+    load_rows(0);
+    store_rows(0);
+    load_trn(0);
+    store_trn(0);
   }
   __syncthreads();
   for (int qt = 0; qt < nq; ++qt) {
     const int cur = qt & 1;
+    const bool more = qt + 1 < nq;
+    if (more) load_rows(qt + 1);
     const _Float16* Qh = lds + cur * BUF;
     const _Float16* Ql = Qh + ROWS_T;
     const _Float16* Dh = Qh + 2 * ROWS_T;
@@ -511,6 +523,10 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
       s = MF(qq, klo[j], s);   dp = MF(dd, vlo[j], dp);
       s = MF(qq, kf[j], s);    dp = MF(dd, vf[j], dp);
     }
+    if (more) {
+      store_rows(cur ^ 1);
+      load_trn(qt + 1);
+    }
     // s <- Pd (dropped probabilities), dp <- dS
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -523,7 +539,6 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
       s[r] = PSC * p * dsc;
       dp[r] = DSC * p * (dp[r] * dsc - Es[qi]);
     }
-    if (qt + 1 < nq) load(qt + 1);          // issued after the S / dP phase (register peak), lands during the 24 MFMAs below
     // dV^T[d][key] += dO^T[d][q] . Pd[q][key];  dK^T[d][key] += Qs^T[d][q] . dS[q][key]
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void split_bwd_dkv_kernel(SplitArgs a) {
         dv[dt] = MF(oo, pf, dv[dt]);   dk[dt] = MF(tt, sf, dk[dt]);
       }
     }
-    if (qt + 1 < nq) store(cur ^ 1);
+    if (more) store_trn(cur ^ 1);
     __syncthreads();
   }
   if (key < a.Lk) {
