@@ -49,7 +49,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_project_gather_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P, _P, _P],
     "hoisdf_project_gather_bwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _I, _P],
     "hoisdf_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
-    "hoisdf_linear_bwd_input": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _P],
+    "hoisdf_linear_bwd_input": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
@@ -79,7 +79,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                    _U64, _P],
     "hoisdf_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _U64, _P],
-    "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
+    "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_vote_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_fwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -55,6 +55,7 @@ struct GemmArgs {
   long c_split_stride, colsum_split_stride;
   int tiles_m, tiles_n;
   int vecA, vecB, vecC, nofast;
+  int beta;                // 1: C += result (grad-input accumulating into an existing gradient), non-atomic paths
   int occ;                 // workgroups per CU to run at (0 = the kernel's natural 4), see pick_occupancy
 };
 
@@ -411,8 +412,13 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
-            *reinterpret_cast<float4*>(Cb + (size_t)(m0 + wm * 64 + i * 32 + rr) * g.ldc + n0 + wn * 64 + j * 32 + cc) = v;
+            float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
+            float4* cp = reinterpret_cast<float4*>(Cb + (size_t)(m0 + wm * 64 + i * 32 + rr) * g.ldc + n0 + wn * 64 + j * 32 + cc);
+            if (g.beta) {
+              const float4 old = *cp;
+              v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            *cp = v;
           }
         }
     } else {
@@ -423,7 +429,10 @@ __global__ __launch_bounds__(NT, BK == 16 ? 4 : (BK == 32 ? 3 : 2)) void gemm_f3
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
-            if (full || (row < g.M && col < g.N)) Cb[(size_t)row * g.ldc + col] = acc[i][j][r];
+            if (full || (row < g.M && col < g.N)) {
+              float* cp = Cb + (size_t)row * g.ldc + col;
+              *cp = g.beta ? *cp + acc[i][j][r] : acc[i][j][r];
+            }
           }
     }
     if (g.bits_out) {
@@ -595,7 +604,7 @@ extern "C" int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ld
 
 extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                        const float* W, int ldw, float* dx, int lddx, long M, int N, int K,
-                                       void* stream) {
+                                       int accumulate, void* stream) {
   HOISDF_REQUIRE(M == 0 || (dy && W && dx), HOISDF_ERR_INVALID, "linear_bwd_input: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && M < (1L << 31) &&
                      drop_p >= 0.f && drop_p < 1.f,
@@ -608,7 +617,8 @@ extern "C" int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t
   g.act = 0; g.drop_p = 0.f; g.inv_keep = 1.f; g.seed = 0;
   g.splitk = plan_small_splitk(cdiv(M, BM) * cdiv(K, BN), N, g.k_per_split);
   g.atomic_out = g.splitk > 1;
-  if (g.atomic_out)
+  g.beta = accumulate ? 1 : 0;
+  if (g.atomic_out && !accumulate)          // accumulating: the atomics simply add onto the existing gradient
     if (int rc = zero_rows(dx, lddx, M, K, as_stream(stream))) return rc;
   return launch_gemm<true, false>(g, as_stream(stream));
 }

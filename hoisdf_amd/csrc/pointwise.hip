@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ dx,
                                                          float* __restrict__ dr, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, long M, int D, float drop_p,
-                                                         float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds) {
+                                                         float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds, const float* __restrict__ dx_add) {
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   float4 dg[4], db[4];
@@ -342,7 +342,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         o.y = rs * (gd[i].y - s1 - xh[i].y * s2);
         o.z = rs * (gd[i].z - s1 - xh[i].z * s2);
         o.w = rs * (gd[i].w - s1 - xh[i].w * s2);
-        *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = o;
+        float4 ox = o;
+        if (dx_add) {                       // gradient of the same tensor arriving from another consumer: summed here
+          const float4 e = *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + u * 4);
+          ox.x += e.x; ox.y += e.y; ox.z += e.z; ox.w += e.w;
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = ox;
         if (dr) {
           if (drop_p > 0.f) {
             const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(u * 4);
@@ -492,8 +497,9 @@ extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const fl
 }
 
 extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
-                                        const float* mean, const float* rstd, float* dx, float* dr, float* dgamma,
-                                        float* dbeta, long M, int D, float drop_p, uint64_t seed, void* stream) {
+                                        const float* mean, const float* rstd, const float* dx_add, float* dx, float* dr,
+                                        float* dgamma, float* dbeta, long M, int D, float drop_p, uint64_t seed,
+                                        void* stream) {
   HOISDF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && M >= 0, HOISDF_ERR_INVALID,
                  "add_layernorm_bwd: null pointer");
   HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
@@ -503,6 +509,6 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
                      dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
-                     det_scratch((size_t)blocks * 2 * D));
+                     det_scratch((size_t)blocks * 2 * D), dx_add);
   return check_launch("add_layernorm_bwd");
 }

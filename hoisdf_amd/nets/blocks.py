@@ -15,7 +15,12 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import ops
+
+# one autograd node per encoder layer (ops.encoder_layer); HOISDF_FUSED_LAYERS=0 keeps the op-by-op graph (A/B, debugging)
+FUSED_LAYER_NODES = os.environ.get("HOISDF_FUSED_LAYERS", "1") != "0"
 
 
 class MLP(nn.Module):
@@ -158,6 +163,16 @@ class TransformerEncoder(nn.Module):
         inter = []
         n = self.inter_norm
         last = len(self.layers) - 1
+        if FUSED_LAYER_NODES and x.is_cuda:
+            # one autograd node per layer (+ its inter_norm): multi-consumer gradients are summed inside the kernels
+            for i, l in enumerate(self.layers):
+                a = l.self_attn
+                x, y = ops.encoder_layer(x, n_keep if i == last else None, l.p if l.training else 0.0, a.num_heads,
+                                         a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                                         l.norm1.weight, l.norm1.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight,
+                                         l.linear2.bias, l.norm2.weight, l.norm2.bias, n.weight, n.bias, l.norm1.eps)
+                inter.append(y if n_keep is None or y.shape[1] == n_keep else y[:, :n_keep])
+            return x, torch.stack(inter)
         for i, layer in enumerate(self.layers):
             x = layer(x, n_keep if i == last else None)
             y = ops.add_layernorm(x, None, n.weight, n.bias, n.eps)

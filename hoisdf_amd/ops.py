@@ -229,7 +229,7 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, _st())
+            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, 0, _st())
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             buf = _zeros(N * K + (N if has_b else 0), dy.device)   # one fill (or a slice of the per-step arena)
@@ -728,7 +728,7 @@ class _AddLayerNorm(torch.autograd.Function):
         dr = None if r2 is None else torch.empty_like(x2)
         dgb = _zeros(2 * D, dy.device).view(2, D)
         dg, db = dgb[0], dgb[1]
-        call("hoisdf_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dr),
+        call("hoisdf_add_layernorm_bwd", _p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), None, _p(dx), _p(dr),
              _p(dg), _p(db), M, D, drop_p, seed, _st())
         return dx.view(shape), (None if dr is None else dr.view(shape)), dg, db, None, None, None
 
@@ -737,6 +737,166 @@ def add_layernorm(x, r, gamma, beta, eps: float = 1e-5, drop_p: float = 0.0):
     """LN(x + dropout(r)); r=None -> plain LayerNorm."""
     seed = next_seed() if (drop_p > 0 and r is not None) else 0
     return _AddLayerNorm.apply(x, r, gamma, beta, eps, drop_p if r is not None else 0.0, seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# one transformer encoder layer as ONE autograd node
+# ---------------------------------------------------------------------------------------------
+def _lin_fwd(x2, W, b, act, drop_p, seed, need_bits, out=None):
+    M, K = x2.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, device=x2.device, dtype=torch.float32) if out is None else out
+    bits = torch.empty(M, (N + 31) // 32, device=x2.device, dtype=torch.int32) if (act and need_bits) else None
+    call("hoisdf_linear_fwd", _p(x2), x2.stride(0), _p(W), W.stride(0), _p(b), _p(y), y.stride(0), M, N, K, int(act),
+         float(drop_p), seed, _p(bits), _st())
+    return y, bits
+
+
+def _lin_bwd_input(dy2, bits, p, W, dx, accumulate):
+    M, N = dy2.shape
+    K = W.shape[1]
+    call("hoisdf_linear_bwd_input", _p(dy2), dy2.stride(0), _p(bits), float(p if bits is not None else 0.0), _p(W),
+         W.stride(0), _p(dx), dx.stride(0), M, N, K, int(accumulate), _st())
+
+
+def _lin_bwd_weight(dy2, bits, p, x2, dW, db):
+    M, N = dy2.shape
+    K = x2.shape[1]
+    ws, nws = None, 0
+    if deterministic():
+        from ._lib import lib
+        nws = lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
+        ws = torch.empty(max(nws, 1), device=dy2.device, dtype=torch.float32) if nws > 0 else None
+    call("hoisdf_linear_bwd_weight", _p(dy2), dy2.stride(0), _p(bits), float(p if bits is not None else 0.0), _p(x2),
+         x2.stride(0), _p(dW), dW.stride(0), _p(db), M, N, K, _p(ws), nws, _st())
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """common/nets/transformer.py:286-302 (TransformerEncoderLayer.forward_post) + the stack's ``inter_norm`` of the layer
+    output (:117-131) as ONE autograd node: the same kernels as the op-by-op path, but the gradients of tensors with several
+    consumers (x: attention projection + residual; x1: FFN + residual; x2: next layer + inter_norm) are accumulated by
+    the kernels themselves (``accumulate`` epilogue of the grad-input GEMM, ``dx_add`` of the LayerNorm backward) instead
+    of by separate autograd add kernels, and every weight-gradient buffer of the layer comes from one arena slice.
+    x (B,S,E); n_query < S: only the first n_query rows are produced (keys / values still come from all S rows)."""
+
+    @staticmethod
+    def forward(ctx, x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps):
+        x = x.contiguous()
+        _chk(x, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3)
+        B, S, E = x.shape
+        nq = S if (n_query is None or n_query >= S) else int(n_query)
+        full = nq == S
+        dev = x.device
+        x2d = x.view(B * S, E)
+        s_attn = next_seed() if p > 0 else 0
+        s_ln1 = next_seed() if p > 0 else 0
+        s_ffn = next_seed() if p > 0 else 0
+        s_ln2 = next_seed() if p > 0 else 0
+        split = _use_split(nq)
+        if full:
+            qkv, _ = _lin_fwd(x2d, w_in, b_in, False, 0.0, 0, False)
+            qkv3 = qkv.view(B, S, 3 * E)
+            q, k, v = qkv3[:, :, :E], qkv3[:, :, E:2 * E], qkv3[:, :, 2 * E:]
+            xq = x
+        else:
+            xq = x[:, :nq].contiguous()
+            qbuf, _ = _lin_fwd(xq.view(B * nq, E), w_in[:E], b_in[:E], False, 0.0, 0, False)
+            kvbuf, _ = _lin_fwd(x2d, w_in[E:], b_in[E:], False, 0.0, 0, False)
+            q = qbuf.view(B, nq, E)
+            kv3 = kvbuf.view(B, S, 2 * E)
+            k, v = kv3[:, :, :E], kv3[:, :, E:]
+        o, lse = (_attn_fwd_split if split else _attn_fwd)(q, k, v, H, S, p, s_attn)
+        M = B * nq
+        a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
+        xq2 = xq.view(M, E)
+        x1 = torch.empty(M, E, device=dev)
+        st = torch.empty(6, M, device=dev)                     # mean / rstd of the three LayerNorms
+        call("hoisdf_add_layernorm_fwd", _p(xq2), _p(a), _p(g1), _p(be1), _p(x1), _p(st[0]), _p(st[1]), M, E, float(eps),
+             float(p), s_ln1, _st())
+        h, bits = _lin_fwd(x1, w1, b1, True, p, s_ffn, True)
+        f, _ = _lin_fwd(h, w2, b2, False, 0.0, 0, False)
+        x2 = torch.empty(M, E, device=dev)
+        call("hoisdf_add_layernorm_fwd", _p(x1), _p(f), _p(g2), _p(be2), _p(x2), _p(st[2]), _p(st[3]), M, E, float(eps),
+             float(p), s_ln2, _st())
+        y = torch.empty(M, E, device=dev)
+        call("hoisdf_add_layernorm_fwd", _p(x2), None, _p(g3), _p(be3), _p(y), _p(st[4]), _p(st[5]), M, E, float(eps), 0.0,
+             0, _st())
+        ctx.save_for_backward(x, qkv if full else qbuf, qkv if full else kvbuf, o, lse, a, x1, h, bits, f, x2, st, w_in,
+                              w_out, w1, w2, g1, g2, g3)
+        ctx.meta = (B, S, E, nq, full, float(p), H, (s_attn, s_ln1, s_ffn, s_ln2), split)
+        return x2.view(B, nq, E), y.view(B, nq, E)
+
+    @staticmethod
+    def backward(ctx, g_x2, g_y):
+        (x, qs, ks, o, lse, a, x1, h, bits, f, x2, st, w_in, w_out, w1, w2, g1, g2, g3) = ctx.saved_tensors
+        B, S, E, nq, full, p, H, (s_attn, s_ln1, s_ffn, s_ln2), split = ctx.meta
+        dev = x.device
+        M, F = B * nq, w1.shape[0]
+        # one zero-initialised slice for every parameter gradient of the layer
+        sizes = [3 * E * E, 3 * E, E * E, E, E, E, F * E, F, E * F, E, E, E, E, E]
+        buf = _zeros(sum(sizes), dev)
+        parts, off = [], 0
+        for n in sizes:
+            parts.append(buf[off:off + n])
+            off += n
+        dw_in, db_in, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, dg3, dbe3 = parts
+        dw_in, dw_out, dw1, dw2 = dw_in.view(3 * E, E), dw_out.view(E, E), dw1.view(F, E), dw2.view(E, F)
+        gx2 = None if g_x2 is None else g_x2.contiguous().view(M, E)
+        dx2 = torch.empty(M, E, device=dev)
+        if g_y is not None:
+            gy = g_y.contiguous().view(M, E)
+            call("hoisdf_add_layernorm_bwd", _p(gy), _p(x2), None, _p(g3), _p(st[4]), _p(st[5]), _p(gx2), _p(dx2), None,
+                 _p(dg3), _p(dbe3), M, E, 0.0, 0, _st())
+        else:
+            dx2 = gx2
+        dx1 = torch.empty(M, E, device=dev)
+        df = torch.empty(M, E, device=dev)
+        call("hoisdf_add_layernorm_bwd", _p(dx2), _p(x1), _p(f), _p(g2), _p(st[2]), _p(st[3]), None, _p(dx1), _p(df),
+             _p(dg2), _p(dbe2), M, E, p, s_ln2, _st())
+        dh = torch.empty(M, F, device=dev)
+        _lin_bwd_input(df, None, 0.0, w2, dh, False)
+        _lin_bwd_weight(df, None, 0.0, h, dw2, db2)
+        _lin_bwd_input(dh, bits, p, w1, dx1, True)                   # dx1 += : the FFN branch joins the residual branch
+        _lin_bwd_weight(dh, bits, p, x1, dw1, db1)
+        xq2 = (x if full else x[:, :nq].contiguous()).view(M, E)
+        dxq = torch.empty(M, E, device=dev)
+        da = torch.empty(M, E, device=dev)
+        call("hoisdf_add_layernorm_bwd", _p(dx1), _p(xq2), _p(a), _p(g1), _p(st[0]), _p(st[1]), None, _p(dxq), _p(da),
+             _p(dg1), _p(dbe1), M, E, p, s_ln1, _st())
+        do = torch.empty(M, E, device=dev)
+        _lin_bwd_input(da, None, 0.0, w_out, do, False)
+        _lin_bwd_weight(da, None, 0.0, o.view(M, E), dw_out, db_out)
+        bwd = _attn_bwd_split if split else _attn_bwd
+        do3 = do.view(B, nq, E)
+        if full:
+            qkv3 = qs.view(B, S, 3 * E)
+            dqkv = torch.empty(B, S, 3 * E, device=dev)
+            bwd(qkv3[:, :, :E], qkv3[:, :, E:2 * E], qkv3[:, :, 2 * E:], o, lse, do3,
+                dqkv[:, :, :E], dqkv[:, :, E:2 * E], dqkv[:, :, 2 * E:], H, S, p, s_attn)
+            d2 = dqkv.view(B * S, 3 * E)
+            _lin_bwd_input(d2, None, 0.0, w_in, dxq, True)           # dx += : attention branch joins the residual branch
+            _lin_bwd_weight(d2, None, 0.0, x.view(B * S, E), dw_in, db_in)
+            dx = dxq.view(B, S, E)
+        else:
+            kv3 = ks.view(B, S, 2 * E)
+            dq = torch.empty(B, nq, E, device=dev)
+            dkv = torch.empty(B, S, 2 * E, device=dev)
+            bwd(qs.view(B, nq, E), kv3[:, :, :E], kv3[:, :, E:], o, lse, do3, dq, dkv[:, :, :E], dkv[:, :, E:], H, S, p,
+                s_attn)
+            _lin_bwd_input(dq.view(M, E), None, 0.0, w_in[:E], dxq, True)
+            _lin_bwd_weight(dq.view(M, E), None, 0.0, xq2, dw_in[:E], db_in[:E])
+            dxf = torch.empty(B * S, E, device=dev)
+            _lin_bwd_input(dkv.view(B * S, 2 * E), None, 0.0, w_in[E:], dxf, False)
+            _lin_bwd_weight(dkv.view(B * S, 2 * E), None, 0.0, x.view(B * S, E), dw_in[E:], db_in[E:])
+            dx = dxf.view(B, S, E)
+            dx[:, :nq] += dxq.view(B, nq, E)
+        return (dx, None, None, None, dw_in, db_in, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, dg3, dbe3, None)
+
+
+def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps=1e-5):
+    """-> (x2 (B, n_query|S, E) = the layer output, y = inter_norm(x2))"""
+    return _EncoderLayer.apply(x, n_query, float(p), int(H), w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3,
+                               be3, float(eps))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -103,6 +103,7 @@ int hoisdf_linear_fwd(const float* x, int ldx, const float* W, int ldw, const fl
  * dx[M][K] = dy_eff[M][N] . W[N][K] */
 int hoisdf_linear_bwd_input(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                             const float* W, int ldw, float* dx, int lddx, long M, int N, int K,
+                            int accumulate /* 1: dx += (the gradient another consumer of x already left there) */,
                             void* stream);
 /* dW[N][K] = dy_eff[M][N]^T . x[M][K] ; db[N] = column sums of dy_eff (db may be NULL).
  * Split-K over M.  With a workspace of hoisdf_linear_bwd_weight_workspace(M,N,K) floats the
@@ -286,9 +287,10 @@ int hoisdf_add_layernorm_fwd(const float* x, const float* r, const float* gamma,
                              float drop_p, uint64_t seed, void* stream);
 /* dx (gradient w.r.t. x), dr (w.r.t. r, may be NULL), dgamma/dbeta accumulated atomically. */
 int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
-                             const float* mean, const float* rstd, float* dx, float* dr,
-                             float* dgamma, float* dbeta, long M, int D, float drop_p, uint64_t seed,
-                             void* stream);
+                             const float* mean, const float* rstd,
+                             const float* dx_add /* optional [M][D]: added into dx (another consumer's gradient) */,
+                             float* dx, float* dr, float* dgamma, float* dbeta, long M, int D, float drop_p,
+                             uint64_t seed, void* stream);
 
 /* ---- K12: vote aggregation ----------------------------------------------------------------
  * reference: common/nets/loss.py:31-56.  off [L][B][P][J*3], cls [L][B][P][J] (batch-first

@@ -14,8 +14,8 @@ for M,N,K in [(65536,512,992),(65536,256,256)]:
     nws=_lib.lib().hoisdf_linear_bwd_weight_workspace(M,N,K); ws=torch.empty(max(nws,1),device=dev)
     fl=2.0*M*N*K
     r={}
-    r['dX nomask']=timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dx), K, M, N, K, st))
-    r['dX mask']=timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, st))
+    r['dX nomask']=timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dx), K, M, N, K, 0, st))
+    r['dX mask']=timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, 0, st))
     r['dW nomask ws']=timeit(lambda: call("hoisdf_linear_bwd_weight", p(dy), N, None, 0.0, p(x), K, p(dW), K, p(db), M, N, K, p(ws), nws, st))
     r['dW nomask ws nodb']=timeit(lambda: call("hoisdf_linear_bwd_weight", p(dy), N, None, 0.0, p(x), K, p(dW), K, None, M, N, K, p(ws), nws, st))
     r['dW mask ws']=timeit(lambda: call("hoisdf_linear_bwd_weight", p(dy), N, p(bits), 0.0, p(x), K, p(dW), K, p(db), M, N, K, p(ws), nws, st))

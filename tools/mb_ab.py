@@ -22,7 +22,7 @@ for M, N, K in SHAPES:
     y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
     fl = 2.0 * M * N * K
     fns = [lambda: call("hoisdf_linear_fwd", p(x), K, p(W), K, p(b), p(y), N, M, N, K, 1, 0.0, 0, p(bits), st),
-           lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, st),
+           lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, 0, st),
            lambda: call("hoisdf_linear_bwd_weight", p(dy), N, p(bits), 0.0, p(x), K, p(dW), K, p(db), M, N, K, None, 0, st)]
     res = {(f, v): [] for f in range(3) for v in range(len(VARS))}
     for r in range(5):

@@ -23,6 +23,6 @@ for N in (512, 1024):
         dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
         fl = 2.0 * M * N * K
         t1 = timeit(lambda: call("hoisdf_linear_fwd", p(x), ld, p(W), K, p(b), p(y), N, M, N, K, 1, 0.0, 0, None, st))
-        t2 = timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dxb), ld, M, N, K, st))
+        t2 = timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dxb), ld, M, N, K, 0, st))
         t3 = timeit(lambda: call("hoisdf_linear_bwd_weight", p(dy), N, None, 0.0, p(x), ld, p(dW), K, p(db), M, N, K, None, 0, st))
         print(f"N={N:5d} K={K:5d} ld={ld:5d} | fwd {fl/t1/1e12:6.1f} TF ({t1*1e6:6.0f} us)  dX {fl/t2/1e12:6.1f} ({t2*1e6:6.0f})  dW {fl/t3/1e12:6.1f} ({t3*1e6:6.0f})")

@@ -42,7 +42,7 @@ def gemm():
         from hoisdf_amd import _lib
         nws = _lib.lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
         ws = torch.empty(max(nws, 1), device=dev)
-        t2 = timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, st))
+        t2 = timeit(lambda: call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, 0, st))
         t3 = timeit(lambda: call("hoisdf_linear_bwd_weight", p(dy), N, p(bits), 0.0, p(x), K, p(dW), K, p(db), M, N, K, p(ws), nws, st))
         print(f"{M:7d} {N:5d} {K:5d} | {fl/t1/1e12:6.1f}  {fl/t2/1e12:6.1f}  {fl/t3/1e12:6.1f}   ({t1*1e6:7.0f} {t2*1e6:7.0f} {t3*1e6:7.0f} us)")
 

@@ -15,7 +15,7 @@ for _ in range(40):
     if which == "fwd":
         call("hoisdf_linear_fwd", p(x), K, p(W), K, p(b), p(out), N, M, N, K, 1, 0.0, 0, p(bits), st)
     elif which == "dx":
-        call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, st)
+        call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, 0, st)
     elif which == "dw":
         call("hoisdf_linear_bwd_weight", p(dy), N, None, 0.0, p(x), K, p(dW), K, p(db), M, N, K, None, 0, st)
 torch.cuda.synchronize()

@@ -12,7 +12,7 @@ dy = torch.randn(M, N, device=dev); bits = torch.zeros(M, (N + 31) // 32, dtype=
 out = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
 for _ in range(3):
     call("hoisdf_linear_fwd", p(x), K, p(W), K, p(b), p(out), N, M, N, K, 1, 0.0, 0, p(bits), st)
-    call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dx), K, M, N, K, st)
-    call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, st)
+    call("hoisdf_linear_bwd_input", p(dy), N, None, 0.0, p(W), K, p(dx), K, M, N, K, 0, st)
+    call("hoisdf_linear_bwd_input", p(dy), N, p(bits), 0.0, p(W), K, p(dx), K, M, N, K, 0, st)
     call("hoisdf_linear_bwd_weight", p(dy), N, None, 0.0, p(x), K, p(dW), K, p(db), M, N, K, None, 0, st)
 torch.cuda.synchronize()
