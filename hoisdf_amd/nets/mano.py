@@ -89,14 +89,16 @@ class ManoLayer(nn.Module):
         for j, par in enumerate(_PARENTS):
             t = J[:, j] if par < 0 else J[:, j] - J[:, par]
             local = torch.cat([torch.cat([R[:, j], t.unsqueeze(2)], 2), bottom], 1)
-            G.append(local if par < 0 else torch.matmul(G[par], local))
+            # 4x4 chain products as broadcast multiply-sums: a batched matmul over B tiny matrices goes to a rocBLAS kernel
+            # that takes ~0.8 ms per call at B = 160 (profiles/r02_bench_kernel_stats_final.csv, Cijk_* MT16x16 rows)
+            G.append(local if par < 0 else (G[par].unsqueeze(3) * local.unsqueeze(1)).sum(2))
         G = torch.stack(G, 1)                                        # (B,16,4,4)
         # skinning transforms: remove the rest-pose joint location
-        rest = torch.matmul(G[:, :, :3, :3], J.unsqueeze(3))        # (B,16,3,1)
+        rest = (G[:, :, :3, :3] * J.unsqueeze(2)).sum(3, keepdim=True)   # (B,16,3,1) = G[:3,:3] . J
         A = G[:, :, :3, :].clone()
         A[:, :, :, 3:] = A[:, :, :, 3:] - rest
         T = torch.einsum("vj,bjrc->bvrc", self.th_weights, A)       # (B,778,3,4)
-        verts = torch.matmul(T[..., :3], v_posed.unsqueeze(3)).squeeze(3) + T[..., 3]
+        verts = (T[..., :3] * v_posed.unsqueeze(2)).sum(3) + T[..., 3]   # per-vertex 3x3 . 3 (B*778 of them)
 
         jtr = torch.cat([G[:, :, :3, 3], verts.index_select(1, self._tip_idx)], 1).index_select(1, self._joint_idx)
         if self.center_idx is not None:
