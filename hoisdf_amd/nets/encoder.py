@@ -11,10 +11,61 @@ defined here (standard He et al. v1.5 blocks: stride on the 3x3 conv).
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+# (f4) training-mode BatchNorm + ReLU (+ residual add) of the CNN as one fused HIP op on channels_last activations
+# (hoisdf_amd.ops.batchnorm_relu / csrc/bnorm.hip); the convolutions stay MIOpen.  Opt-in (HOISDF_FUSED_BN=1): measured on
+# MI355X it beats MIOpen's BatchNorm + separate add/ReLU only on the two largest ResNet-50 activations and loses on the
+# small-spatial layers, a net +0 on the step, so the default is the plain torch modules.
+FUSED_BN = os.environ.get("HOISDF_FUSED_BN", "0") != "0"
+_PENDING_NBT = []          # num_batches_tracked buffers touched in this forward: bumped with ONE multi-tensor add
+
+
+def bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual=None) -> torch.Tensor:
+    """relu?(bn(x) (+ residual)): the fused HIP op when the module trains on a channels_last GPU tensor, torch otherwise"""
+    if FUSED_BN and bn.training and bn.track_running_stats and bn.momentum is not None and x.is_cuda:
+        from .. import ops
+        if ops.batchnorm_supported(x) and (residual is None or residual.is_contiguous(memory_format=torch.channels_last)):
+            _PENDING_NBT.append(bn.num_batches_tracked)
+            return ops.batchnorm_relu(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu,
+                                      residual)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def flush_bn_counters() -> None:
+    """num_batches_tracked += 1 for every BatchNorm the fused path ran since the last flush (what nn.BatchNorm2d.forward
+    does one tiny kernel at a time)"""
+    if _PENDING_NBT:
+        with torch.no_grad():
+            torch._foreach_add_(list(_PENDING_NBT), 1)
+        _PENDING_NBT.clear()
+
+
+class _FusedSeq(nn.Sequential):
+    """nn.Sequential (same child indices = same state-dict keys) whose forward runs every BatchNorm2d -> ReLU pair (or a
+    trailing BatchNorm2d) through bn_act"""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.BatchNorm2d):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = bn_act(m, x, relu)
+                i += 2 if relu else 1
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class BasicBlock(nn.Module):
@@ -31,9 +82,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + idt)
+        y = bn_act(self.bn1, self.conv1(x), True)
+        return bn_act(self.bn2, self.conv2(y), True, residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -52,10 +102,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return self.relu(y + idt)
+        y = bn_act(self.bn1, self.conv1(x), True)
+        y = bn_act(self.bn2, self.conv2(y), True)
+        return bn_act(self.bn3, self.conv3(y), True, residual=idt)
 
 
 _SPEC = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]),
@@ -82,8 +131,8 @@ class ResNetBackbone(nn.Module):
                 ds = None
                 s = stride if j == 0 else 1
                 if j == 0 and (s != 1 or inpl != planes * block.expansion):
-                    ds = nn.Sequential(nn.Conv2d(inpl, planes * block.expansion, 1, s, bias=False),
-                                       nn.BatchNorm2d(planes * block.expansion))
+                    ds = _FusedSeq(nn.Conv2d(inpl, planes * block.expansion, 1, s, bias=False),
+                                   nn.BatchNorm2d(planes * block.expansion))
                 blocks.append(block(inpl, planes, s, ds))
                 inpl = planes * block.expansion
             stages.append(nn.Sequential(*blocks))
@@ -97,7 +146,7 @@ class ResNetBackbone(nn.Module):
 
     def forward(self, x):
         skips = {}
-        x = self.relu(self.bn1(self.conv1(x)))
+        x = bn_act(self.bn1, self.conv1(x), True)
         skips["stride2"] = x
         x = self.layer1(self.maxpool(x))
         skips["stride4"] = x
@@ -107,6 +156,7 @@ class ResNetBackbone(nn.Module):
         skips["stride16"] = x
         x = self.layer4(x)
         skips["stride32"] = x
+        flush_bn_counters()
         return x, skips
 
 
@@ -126,7 +176,7 @@ def _convs(dims: List[int], kernel=3, padding=1, bnrelu_final=True) -> nn.Sequen
         mods.append(nn.Conv2d(dims[i], dims[i + 1], kernel, 1, padding))
         if i < len(dims) - 2 or bnrelu_final:
             mods += [nn.BatchNorm2d(dims[i + 1]), nn.ReLU(inplace=True)]
-    return nn.Sequential(*mods)
+    return _FusedSeq(*mods)
 
 
 def _deconvs(dims: List[int]) -> nn.Sequential:
@@ -135,7 +185,7 @@ def _deconvs(dims: List[int]) -> nn.Sequential:
     for i in range(len(dims) - 1):
         mods += [nn.ConvTranspose2d(dims[i], dims[i + 1], 4, 2, 1, 0, bias=False),
                  nn.BatchNorm2d(dims[i + 1]), nn.ReLU(inplace=True)]
-    return nn.Sequential(*mods)
+    return _FusedSeq(*mods)
 
 
 class _PyramidDecoder(nn.Module):
@@ -158,6 +208,7 @@ class _PyramidDecoder(nn.Module):
             pyramid[name] = x
         aux = torch.cat([self.convOut_hm(x), self.convOut_hand_seg(x).sigmoid(),
                          self.convOut_obj_seg(x).sigmoid()], dim=1)
+        flush_bn_counters()
         return pyramid, aux
 
 

@@ -1006,3 +1006,65 @@ def aux_image_losses(decoder_out, joint_coord, hand_seg, obj_seg, sigma: float):
     """(f4) main/model.py:404-422 in one pass: returns (joint_heatmap, obj_seg, hand_seg) per-pixel losses (B,H,W)
     and the rendered target heat-map; differentiable w.r.t. decoder_out (any strides)."""
     return _AuxImageLosses.apply(decoder_out, joint_coord, hand_seg, obj_seg, sigma)
+
+
+# ---------------------------------------------------------------------------------------------
+# (f4) encoder side: training-mode BatchNorm2d + ReLU (+ residual) on channels-last activations
+# ---------------------------------------------------------------------------------------------
+def _cl_rows(t: torch.Tensor):
+    """(N,C,H,W) channels_last tensor -> its [N*H*W][C] row view (no copy); None if the layout does not allow it"""
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        return None
+    return t.permute(0, 2, 3, 1)
+
+
+def batchnorm_supported(x: torch.Tensor) -> bool:
+    C = x.shape[1] if x.dim() == 4 else 0
+    c4 = C // 4
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and C % 4 == 0 and 0 < C <= 2048
+            and (256 % c4 == 0 if c4 <= 64 else c4 % 64 == 0)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] > 1)
+
+
+class _BatchNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        from ._lib import lib
+        N, Cn, H, W = x.shape
+        R = N * H * W
+        _chk(x, residual, gamma, beta, running_mean, running_var)
+        if residual is not None:
+            assert residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(x)                                   # keeps the channels_last strides
+        st = torch.empty(2, Cn, device=x.device, dtype=torch.float32)
+        nb = lib().hoisdf_batchnorm_workspace(R, Cn)
+        ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32)
+        call("hoisdf_batchnorm_relu_fwd", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+             float(momentum), float(eps), int(relu), _p(y), _p(st[0]), _p(st[1]), R, Cn, _p(ws), nb, _st())
+        ctx.save_for_backward(x, y if relu else None, gamma, st)
+        ctx.meta = (R, Cn, bool(relu), residual is not None)
+        ctx.mark_non_differentiable()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import lib
+        x, y, gamma, st = ctx.saved_tensors
+        R, Cn, relu, has_res = ctx.meta
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[1]) else None
+        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dgb = torch.empty(2, Cn, device=x.device, dtype=torch.float32) if need_p else None
+        nb = lib().hoisdf_batchnorm_workspace(R, Cn)
+        ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32)
+        call("hoisdf_batchnorm_relu_bwd", _p(dy), _p(x), _p(y), _p(gamma), _p(st[0]), _p(st[1]), int(relu), _p(dx), _p(dres),
+             _p(dgb[0]) if need_p else None, _p(dgb[1]) if need_p else None, R, Cn, _p(ws), nb, _st())
+        return (dx, dres, dgb[0] if ctx.needs_input_grad[2] else None, dgb[1] if ctx.needs_input_grad[3] else None,
+                None, None, None, None, None)
+
+
+def batchnorm_relu(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, residual=None):
+    """y = relu?(BN_train(x) (+ residual)) on channels_last (N,C,H,W) tensors; updates the running statistics in place."""
+    return _BatchNormReLU.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)
