@@ -57,6 +57,11 @@ class KernelTimer:
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         "hoisdf_attention_fwd_split": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_split": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
+        # split-precision linear layers: same argument positions as the f32 entries (+ workspace); algorithmic FLOPs
+        # (the 3 split products are not counted), operand conversion passes inside the timed call
+        "hoisdf_linear_fwd_split": lambda a: 2.0 * a[7] * a[8] * a[9],
+        "hoisdf_linear_bwd_input_split": lambda a: 2.0 * a[8] * a[9] * a[10],
+        "hoisdf_linear_bwd_weight_split": lambda a: 2.0 * a[9] * a[10] * a[11],
         # the gradient-free SDF query (K1-K4 behind one C-ABI call): its six GEMMs, 2 (C*512 + 512*256) +
         # 2 (289*512 + 512*223 + 512*512 + 512*512 + 512) FLOP per point; the gather / posenc time inside the call is
         # charged to the GEMM family as well
@@ -71,7 +76,9 @@ class KernelTimer:
     SHAPE = {"hoisdf_linear_fwd": (7, 8, 9), "hoisdf_linear_bwd_input": (8, 9, 10), "hoisdf_linear_bwd_weight": (9, 10, 11),
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
-             "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20)}
+             "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20),
+             "hoisdf_linear_fwd_split": (7, 8, 9), "hoisdf_linear_bwd_input_split": (8, 9, 10),
+             "hoisdf_linear_bwd_weight_split": (9, 10, 11)}
 
     def begin(self, name, args):
         s = torch.cuda.Event(enable_timing=True)
@@ -128,6 +135,9 @@ def main():
     ap.add_argument("--branch-mix", action="store_true",
                     help="configs[1] after cfg.point_sampling_epoch: per step draw p ~ U(0,1), p < 0.4 -> pre-points "
                          "(branch A), else the dense-lattice sdf_infer (branch B) - main/model.py:426-481")
+    ap.add_argument("--gemm", choices=("f32", "split"), default="f32",
+                    help="training linear layers: f32 = exact-f32 MFMA GEMM (the headline line); split = f16 hi+lo operands, "
+                         "3 products per contraction (csrc/gemm_split.hip; part of the second, separately labelled line)")
     ap.add_argument("--attention", choices=("f32", "split"), default="f32",
                     help="training attention: f32 = exact-f32 MFMA kernels (the headline line); split = f16 hi+lo operands, "
                          "3 products per contraction on the 16-bit MFMA pipe (a second, separately labelled line)")
@@ -185,6 +195,7 @@ def main():
     cfg.num_samp_hand, cfg.num_samp_obj, cfg.bins_n = args.n_hand, args.n_obj, 64
     cfg.attention_f16_eval = args.config == 4
     cfg.attention_split = train and args.attention == "split"
+    cfg.gemm_split = train and args.gemm == "split"
     torch.manual_seed(0)           # identical initial weights on every rank
     model = get_model("train" if train else "test", cfg=cfg).to(dev).train(train)
     if args.channels_last:
@@ -277,8 +288,11 @@ def main():
     value = world * args.batch * args.steps / dt
     enc = f"ResNet-{args.resnet} encoder (PyTorch/MIOpen; the reference has no HRNet)"
     if args.config == 1:
-        if args.attention == "split":
-            enc += "; SECOND LINE: training attention fwd+bwd in split precision (cfg.attention_split), not the f32 headline"
+        if args.attention == "split" or args.gemm == "split":
+            what = " and ".join(w for w, on in (("attention fwd+bwd (cfg.attention_split)", args.attention == "split"),
+                                                ("the large linear layers' three contractions (cfg.gemm_split)",
+                                                 args.gemm == "split")) if on)
+            enc += f"; SECOND LINE: training {what} in split precision, not the f32 headline"
         mix = (f"epoch >= {cfg.point_sampling_epoch} point-branch mix: {branches['A']} steps pre-points (A) / "
                f"{branches['B']} steps dense-lattice sdf_infer (B)") if args.branch_mix else "point branch A (pre-points)"
         workload = (f"BASELINE configs[1]: DexYCB-shape synthetic batch {args.batch}/GPU, {args.n_hand}+{args.n_obj} SDF "
@@ -296,8 +310,11 @@ def main():
                   f"samples/sec, inference (BASELINE configs[{args.config}])",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if (args.config != 4 and args.attention == "f32") else
-                 "f32 (attention contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax)",
+        "dtype": "f32" if (args.config != 4 and args.attention == "f32" and args.gemm == "f32") else
+                 ("f32 (attention" + (" and linear-layer" if args.gemm == "split" else "") +
+                  " contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax)"
+                  if (args.config == 4 or args.attention == "split") else
+                  "f32 (linear-layer contractions: f16 hi+lo split operands x3 products, f32 accumulate)"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config,
                    "global_batch": world * args.batch, "points": args.n_hand + args.n_obj,
@@ -313,6 +330,8 @@ def main():
                 "attn_fwd_kernel": ["hoisdf_attention_fwd"],
                 "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
                 "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"],
+                "gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)":
+                    ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"],
                 "split_fwd_kernel (+ conversion passes)": ["hoisdf_attention_fwd_split"],
                 "split_bwd_dkv + split_bwd_dq (+ conversion passes)": ["hoisdf_attention_bwd_split"]}
         agg = {}

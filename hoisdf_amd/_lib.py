@@ -51,6 +51,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
+    "hoisdf_linear_fwd_split": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _L, _P],
+    "hoisdf_linear_bwd_input_split": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P, _L, _P],
+    "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "hoisdf_batchnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _L, _I, _P, _L, _P],
@@ -91,6 +94,7 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_batchnorm_workspace": ([_L, _I], C.c_long), "hoisdf_set_deterministic": ([_I], None), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
+          "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
           "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
 

@@ -196,6 +196,68 @@ def project_gather(pyr: PyramidNHWC, points, center, cam_intr, scale, img_hw=(25
 # ---------------------------------------------------------------------------------------------
 # linear
 # ---------------------------------------------------------------------------------------------
+_GEMM_SPLIT = False
+_GEMM_SPLIT_MIN_ROWS = 2048          # below this the problem is a few tiles: latency-bound, stays on the f32 kernel
+
+
+def set_gemm_split(on: bool) -> None:
+    """cfg.gemm_split: run the large linear-layer contractions (forward, grad-input, grad-weight) on the 16-bit MFMA pipe
+    with f16 hi + lo split operands (3 products, f32 accumulation; csrc/gemm_split.hip).  Off by default: the headline
+    path is exact fp32."""
+    global _GEMM_SPLIT
+    _GEMM_SPLIT = bool(on)
+
+
+def gemm_split() -> bool:
+    return _GEMM_SPLIT
+
+
+def _split_ok(M: int, N: int, K: int) -> bool:
+    return _GEMM_SPLIT and M >= _GEMM_SPLIT_MIN_ROWS and N >= 64 and K >= 64
+
+
+def _split_ws(M, N, K, which, device):
+    from ._lib import lib
+    nbytes = lib().hoisdf_linear_split_workspace(M, N, K, which)
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
+def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
+    if _split_ok(M, N, K):
+        ws, nb = _split_ws(M, N, K, 0, y.device)
+        call("hoisdf_linear_fwd_split", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act),
+             float(drop_p), seed, _p(bits), _p(ws), nb, _st())
+    else:
+        call("hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p),
+             seed, _p(bits), _st())
+
+
+def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
+    if _split_ok(M, N, K):
+        ws, nb = _split_ws(M, N, K, 1, dx.device)
+        call("hoisdf_linear_bwd_input_split", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
+             int(accumulate), _p(ws), nb, _st())
+    else:
+        call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
+             int(accumulate), _st())
+
+
+def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K):
+    """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the split form overwrites."""
+    if _split_ok(M, N, K) and dW.stride(0) == K:
+        ws, nb = _split_ws(M, N, K, 2, dW.device)
+        call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
+             _p(ws), nb, _st())
+        return
+    ws, nws = None, 0
+    if deterministic():             # partial tiles + ordered reduce instead of split-k atomics
+        from ._lib import lib
+        nws = lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
+        ws = torch.empty(max(nws, 1), device=dW.device, dtype=torch.float32) if nws > 0 else None
+    call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), dW.stride(0), _p(db), M, N, K,
+         _p(ws), nws, _st())
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act, drop_p, seed):
@@ -210,8 +272,7 @@ class _Linear(torch.autograd.Function):
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         need_bits = bool(act) and (x.requires_grad or W.requires_grad or (b is not None and b.requires_grad))
         bits = torch.empty(M, (N + 31) // 32, device=x.device, dtype=torch.int32) if need_bits else None
-        call("hoisdf_linear_fwd", _p(x2), x2.stride(0) if M > 1 else K, _p(W), W.stride(0), _p(b), _p(y), N, M, N,
-             K, int(act), float(drop_p), seed, _p(bits), _st())
+        _gemm_fwd(x2, x2.stride(0) if M > 1 else K, W, b, y, N, M, N, K, act, drop_p, seed, bits)
         ctx.save_for_backward(x2, W, bits)
         ctx.meta = (int(act), float(drop_p), b is not None, x.shape)
         return y.view(*x.shape[:-1], N)
@@ -229,19 +290,13 @@ class _Linear(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), p, _p(W), W.stride(0), _p(dx), K, M, N, K, 0, _st())
+            _gemm_bwd_input(dy2, lddy, bits, p, W, dx, K, M, N, K, 0)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             buf = _zeros(N * K + (N if has_b else 0), dy.device)   # one fill (or a slice of the per-step arena)
             dW = buf[:N * K].view(N, K)
             db = buf[N * K:] if has_b else None
-            ws, nws = None, 0
-            if deterministic():             # partial tiles + ordered reduce instead of split-k atomics
-                from ._lib import lib
-                nws = lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
-                ws = torch.empty(max(nws, 1), device=dy.device, dtype=torch.float32) if nws > 0 else None
-            call("hoisdf_linear_bwd_weight", _p(dy2), lddy, _p(bits), p, _p(x2), x2.stride(0) if M > 1 else K, _p(dW),
-                 K, _p(db), M, N, K, _p(ws), nws, _st())
+            _gemm_bwd_weight(dy2, lddy, bits, p, x2, x2.stride(0) if M > 1 else K, dW, db, M, N, K)
         return dx, dW, db, None, None, None
 
 
@@ -747,28 +802,20 @@ def _lin_fwd(x2, W, b, act, drop_p, seed, need_bits, out=None):
     N = W.shape[0]
     y = torch.empty(M, N, device=x2.device, dtype=torch.float32) if out is None else out
     bits = torch.empty(M, (N + 31) // 32, device=x2.device, dtype=torch.int32) if (act and need_bits) else None
-    call("hoisdf_linear_fwd", _p(x2), x2.stride(0), _p(W), W.stride(0), _p(b), _p(y), y.stride(0), M, N, K, int(act),
-         float(drop_p), seed, _p(bits), _st())
+    _gemm_fwd(x2, x2.stride(0), W, b, y, y.stride(0), M, N, K, act, drop_p, seed, bits)
     return y, bits
 
 
 def _lin_bwd_input(dy2, bits, p, W, dx, accumulate):
     M, N = dy2.shape
     K = W.shape[1]
-    call("hoisdf_linear_bwd_input", _p(dy2), dy2.stride(0), _p(bits), float(p if bits is not None else 0.0), _p(W),
-         W.stride(0), _p(dx), dx.stride(0), M, N, K, int(accumulate), _st())
+    _gemm_bwd_input(dy2, dy2.stride(0), bits, p if bits is not None else 0.0, W, dx, dx.stride(0), M, N, K, accumulate)
 
 
 def _lin_bwd_weight(dy2, bits, p, x2, dW, db):
     M, N = dy2.shape
     K = x2.shape[1]
-    ws, nws = None, 0
-    if deterministic():
-        from ._lib import lib
-        nws = lib().hoisdf_linear_bwd_weight_workspace(M, N, K)
-        ws = torch.empty(max(nws, 1), device=dy2.device, dtype=torch.float32) if nws > 0 else None
-    call("hoisdf_linear_bwd_weight", _p(dy2), dy2.stride(0), _p(bits), float(p if bits is not None else 0.0), _p(x2),
-         x2.stride(0), _p(dW), dW.stride(0), _p(db), M, N, K, _p(ws), nws, _st())
+    _gemm_bwd_weight(dy2, dy2.stride(0), bits, p if bits is not None else 0.0, x2, x2.stride(0), dW, db, M, N, K)
 
 
 class _EncoderLayer(torch.autograd.Function):

@@ -114,6 +114,24 @@ long hoisdf_linear_bwd_weight_workspace(long M, int N, int K);
 int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                              const float* x, int ldx, float* dW, int lddw, float* db, long M, int N,
                              int K, float* workspace, long workspace_floats, void* stream);
+/* ---- split-precision linear layers (opt-in; cfg.gemm_split) -----------------------------------
+ * reference: the same call sites as hoisdf_linear_* (common/nets/layer.py:168-201, common/nets/transformer.py:286-302,
+ * main/model.py:181-244).  Same contracts and argument meaning as hoisdf_linear_fwd / _bwd_input / _bwd_weight, but the
+ * contraction runs on the 16-bit MFMA pipe with both operands split into f16 hi + lo parts (3 products, f32 accumulation,
+ * power-of-two operand scaling: ~21-22 significant bits per operand instead of 24) - NOT bit-compatible with the f32
+ * entries, within 1e-6 relative of them on the model's shapes.  Each call converts its operands into `workspace`
+ * (hoisdf_linear_split_workspace(M, N, K, which) BYTES; which = 0 forward, 1 grad-input, 2 grad-weight) and runs one GEMM
+ * kernel.  Grad-weight: dW (dense, lddw == K) and db are fully OVERWRITTEN, order-fixed (no atomics). */
+long hoisdf_linear_split_workspace(long M, int N, int K, int which);
+int hoisdf_linear_fwd_split(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy,
+                            long M, int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits,
+                            void* workspace, long workspace_bytes, void* stream);
+int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* W,
+                                  int ldw, float* dx, int lddx, long M, int N, int K, int accumulate, void* workspace,
+                                  long workspace_bytes, void* stream);
+int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
+                                   int ldx, float* dW, int lddw, float* db, long M, int N, int K, void* workspace,
+                                   long workspace_bytes, void* stream);
 /* dpre = dy * (y > 0) * 1/(1-p): backward of relu followed by dropout, given the
  * post-dropout output y (an element is kept-and-positive iff y > 0).  In place allowed. */
 int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,

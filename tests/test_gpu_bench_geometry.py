@@ -163,9 +163,10 @@ def test_gather_backward_at_B32(P):
         off += c
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "all"])
 def test_training_step_at_B32_equals_the_reference_n2048_fixture(split):
-    """split=True: the same check with cfg.attention_split (training attention in f16 hi+lo split precision)."""
+    """split=True: the same check with cfg.attention_split (training attention in f16 hi+lo split precision); "all": plus
+    cfg.gemm_split (the linear layers' contractions in the same split precision)."""
     from hoisdf_amd import ops
     from hoisdf_amd.model import get_model
     from hoisdf_amd.nets import mano as MANO
@@ -198,7 +199,8 @@ def test_training_step_at_B32_equals_the_reference_n2048_fixture(split):
     model._jitter = lambda like, d: tile(jit.pop(0)).to(DEV)
     model._py_random = random.Random(0)
     inputs, targets, meta = ({k: tile(v).to(DEV) for k, v in d.items()} for d in (inputs, targets, meta))
-    ops.set_attention_split(split)
+    ops.set_attention_split(bool(split))
+    ops.set_gemm_split(split == "all")
     try:
         loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
         losses = {k: v.mean() for k, v in loss.items()}
@@ -206,6 +208,7 @@ def test_training_step_at_B32_equals_the_reference_n2048_fixture(split):
         total.backward()
     finally:
         ops.set_attention_split(False)
+        ops.set_gemm_split(False)
     for k, v in losses.items():
         ref = float(g["loss." + k])
         assert abs(float(v) - ref) <= 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
@@ -222,7 +225,11 @@ def test_training_step_at_B32_equals_the_reference_n2048_fixture(split):
     ref32 = g["grad.pyr.stride32"]
     for r in (0, 7, rep - 1):
         got = g32[2 * r:2 * r + 2].cpu() * rep
-        assert float((got - ref32).abs().max()) <= 1e-3 * float(ref32.abs().max())
+        # measured: exact f32 4.0e-4, attention split 3.3e-4, attention + GEMM split 1.13e-3 of the tensor's max (the
+        # element-wise gradient is ill-conditioned - the f32 path already amplifies its 6e-8 rounding 7000x - and a hi + lo
+        # pair carries 22 bits, not 24); losses and all 260 gradient norms above hold the same 1e-4 / 1e-3 bars in all modes
+        bar = 1.5e-3 if split == "all" else 1e-3
+        assert float((got - ref32).abs().max()) <= bar * float(ref32.abs().max())
     gn2 = (levels[0].grad.double() * rep).norm().item() / math.sqrt(rep)
     assert abs(gn2 - float(g["grad.pyr.stride2_norm"])) <= 1e-3 * float(g["grad.pyr.stride2_norm"])
     wg = model.linear_handcls.layers[2].weight.grad.float().cpu()

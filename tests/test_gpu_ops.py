@@ -59,6 +59,52 @@ def test_linear_fwd_bwd(M, N, K, act):
     assert_close(bg.grad, b.grad, what="db")
 
 
+@pytest.mark.parametrize("M,N,K,act,p", [(4096, 512, 992, True, 0.0), (2500, 223, 292, True, 0.2), (2176, 128, 223, False, 0.0),
+                                         (3000, 96, 516, True, 0.0), (2048, 768, 256, False, 0.0)])
+def test_linear_split_precision_matches_fp64(M, N, K, act, p):
+    """csrc/gemm_split.hip (cfg.gemm_split: f16 hi + lo operands, 3 products, power-of-two operand scaling): forward,
+    grad-input (also accumulating), grad-weight and bias gradient against fp64 at 2e-6 of the tensor's max - the exact-f32
+    kernel's own distance on these shapes is ~1e-6.  Rows of x and dy span 8 decades (exercises the per-row / per-tensor
+    scaling), ragged M / N / K (padding, the scalar conversion path for K % 4 != 0), ReLU + dropout through the sign bitmap."""
+    O = ops()
+    O.manual_seed(77)
+    g = torch.Generator().manual_seed(M + N + K)
+    decades = lambda n: torch.pow(10.0, -8.0 * torch.rand(n, 1, generator=g))
+    x = (torch.randn(M, K, generator=g) * decades(M)).to(DEV).requires_grad_(True)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 1e-3).to(DEV).requires_grad_(True)
+    gy = (torch.randn(M, N, generator=g) * 1e-5 * decades(M)).to(DEV)
+    O.set_gemm_split(True)
+    try:
+        y = O.linear(x, W, b, act=act, drop_p=p)
+        y.backward(gy)
+        # accumulate-into form of grad-input (the fused encoder-layer node uses it)
+        dx_acc = torch.full((M, K), 0.25, device=DEV)
+        O._lin_bwd_input(gy, None, 0.0, W.detach(), dx_acc, True)
+    finally:
+        O.set_gemm_split(False)
+    pre = x.detach().double() @ W.detach().double().t() + b.detach().double()
+    if act:
+        kept = y.detach() > 0                                  # the kernel's own ReLU / dropout decisions
+        pos = pre > 0
+        flips = (kept & ~pos).sum().item()
+        assert flips <= 2, flips                               # a kept element must be positive in fp64 too (up to rounding at 0)
+        if p > 0:
+            frac = (kept & pos).sum().item() / max(pos.sum().item(), 1)
+            assert abs(frac - (1 - p)) < 0.01, frac
+        else:
+            assert (pos & ~kept).sum().item() <= 2
+        scale = kept.double() / (1 - p)
+    else:
+        scale = torch.ones_like(pre)
+    assert_close(y, pre * scale, rel=2e-6, what="y")
+    dye = gy.double() * scale
+    assert_close(x.grad, dye @ W.detach().double(), rel=2e-6, what="dx")
+    assert_close(W.grad, dye.t() @ x.detach().double(), rel=2e-6, what="dW")
+    assert_close(b.grad, dye.sum(0), rel=2e-6, what="db")
+    assert_close(dx_acc, gy.double() @ W.detach().double() + 0.25, rel=2e-6, what="dx accumulate")
+
+
 def test_linear_strided_input_and_weight_slices():
     """x rows with ld > K (the 292-wide decoder-input buffer) and W given as a row slice."""
     O = ops()
