@@ -28,29 +28,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int TM = 128, TN = 128, KS = 32;
-constexpr int RPS = 40;                 // halves per LDS row of a [128][32] slab (80 B: conflict-free ds_read_b128)
-constexpr int PLANE = 128 * RPS;        // halves per plane per stage
-constexpr int STAGE = 4 * PLANE;        // A hi, A lo, B hi, B lo: 40 KB
-constexpr unsigned LDS_BYTES = 2u * STAGE * sizeof(_Float16);
 #define MF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-struct SplitGemmArgs {
-  const _Float16 *Ah, *Al, *Bh, *Bl;    // planes [rows padded to 128][Kp]
-  const float *a_rinv, *b_rinv;         // 1 / scale per row (stride 1) or one scalar (stride 0)
-  int a_rs, b_rs;
-  float* C;
-  const float* bias;
-  uint32_t* bits_out;
-  int M, N, Kp, ldc, ldbits;      // Kp: contraction length walked (a multiple of 32, zero padded in both operands)
-  long lda, ldb;                  // plane row pitches in halves
-  int act;
-  float drop_p, inv_keep;
-  uint32_t thresh;
-  uint64_t seed;
-  int splitk, k_per_split;
-  long c_split_stride;
-  int tiles_m, tiles_n, vecC, beta;
-};
 
 // power-of-two scale that brings amax into [2^14, 2^15); inv = 1 / scale (exact)
 __device__ __forceinline__ float pow2_scale(float amax, float& inv) {
@@ -285,11 +263,94 @@ __global__ __launch_bounds__(256) void gs_reduce_partials_kernel(const float* __
   }
 }
 
+// ---- per-row scales of a k-contiguous f32 operand (the in-kernel conversion needs them before it reads a row):
+// scale[r] = the power of two that brings max |row r| (masked, times ascale) into [2^14, 2^15).  One wave per row, ONE
+// read of the operand and R floats written - the GEMM converts the f32 rows itself, no hi / lo planes go through HBM.
+__global__ __launch_bounds__(256) void gs_row_scale_kernel(const float* __restrict__ src, long ld, int R, int K,
+                                                           const uint32_t* __restrict__ bits, int ldbits, float ascale,
+                                                           int vec, float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* s = src + (size_t)row * ld;
+  const uint32_t* bw = bits ? bits + (size_t)row * ldbits : nullptr;
+  float amax = 0.f;
+  if (vec) {
+    for (int c = lane * 4; c < K; c += 256) {
+      float4 v = *reinterpret_cast<const float4*>(s + c);
+      if (bw) {
+        const uint32_t nib = bw[c >> 5] >> (c & 31);
+        v.x = (nib & 1u) ? v.x : 0.f; v.y = (nib & 2u) ? v.y : 0.f; v.z = (nib & 4u) ? v.z : 0.f; v.w = (nib & 8u) ? v.w : 0.f;
+      }
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  } else {
+    for (int c = lane; c < K; c += 64) {
+      float v = s[c];
+      if (bw && !((bw[c >> 5] >> (c & 31)) & 1u)) v = 0.f;
+      amax = fmaxf(amax, fabsf(v));
+    }
+  }
+  amax = wave_max(amax) * ascale;
+  float inv;
+  const float sc = pow2_scale(amax, inv);
+  if (lane == 0) scale[row] = sc;
+}
+// scalar form for the operands whose contraction runs over their rows: scale[0] from the tensor amax word
+__global__ void gs_scalar_scale_kernel(const uint32_t* __restrict__ amax_bits, float ascale, float* __restrict__ scale) {
+  float inv;
+  scale[0] = pow2_scale(__uint_as_float(amax_bits[0]) * ascale, inv);
+}
+
 // ============================================================================================
-// C[M][N] = epilogue( (A . B^T) / (sa[m] sb[n]) ),  A planes [Mp][Kp], B planes [Np][Kp]
+// C[M][N] = epilogue( (A . B^T) / (sa sb) ): ONE kernel, the operands converted on the way into LDS
+//   AMODE 0: A f32 [M][K] k-contiguous (x in the forward, dy in grad-input; per-row scales, optional sign bitmap)
+//   AMODE 1: A f32 [K][M] (source rows = contraction; dy in grad-weight; one scale, optional sign bitmap, column sums)
+//   BMODE 0: B = pre-converted hi / lo planes [Np][ldb] (the weights: tiny)   BMODE 1: B f32 [K][N] (x in grad-weight)
+// LDS image of a [128 rows][32 k] plane (8 KB, unpadded): row R lives in slot (R & 3) * 32 + (R >> 2), its four 16-byte
+// k-chunks at chunk ^ (R & 3).  With that permutation the MFMA fragment reads (16 consecutive rows, one chunk), the
+// k-contiguous staging writes (row = tid >> 1) and the transposing staging writes (rows 32 apart per lane group) are all
+// spread over the 64 banks.
 // ============================================================================================
-__global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+constexpr int PLANE_B = 128 * 64;                 // bytes per plane per stage
+constexpr int STAGE_B = 4 * PLANE_B;              // A hi, A lo, B hi, B lo: 32 KB
+constexpr unsigned LDS2_BYTES = 2u * STAGE_B;     // double buffered: 64 KB (2 workgroups per CU)
+
+struct FusedArgs {
+  const float* A; long lda;                 // f32 operand A
+  const float* Bf; const _Float16 *Bh, *Bl; long ldb;     // f32 operand B (BMODE 1) or planes (BMODE 0, pitch ldb halves)
+  const float* a_scale; int a_rs;           // scale of A: per row (stride 1) or scalar (stride 0)
+  const float* b_scale;                     // BMODE 1: scalar scale of B
+  const float* b_rinv; int b_rs;            // BMODE 0: 1 / scale of the planes' rows (stride 1) or scalar (stride 0)
+  const uint32_t* abits; int ldbits; float ascale;     // sign bitmap of the ORIGINAL dy [rows][ceil(cols / 32)]
+  float* colsum; long colsum_split_stride;  // AMODE 1: column sums of masked A (bias gradient), [split][M]
+  float* C; int ldc;
+  const float* bias;
+  uint32_t* bits_out; int ldbits_out;
+  int M, N, K;                              // output rows, output columns, contraction length
+  int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
+  int splitk, k_per_split; long c_split_stride;
+  int tiles_m, tiles_n, vecA, vecB, vecC, beta;
+};
+
+__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// 8 scaled values -> 16 bytes of hi, 16 bytes of lo
+__device__ __forceinline__ void split8(const float (&e)[8], uint4& hi, uint4& lo) {
+  _Float16 h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split1(e[i], h[i], l[i]);
+  hi = make_uint4(pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7]));
+  lo = make_uint4(pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7]));
+}
+__device__ __forceinline__ int lds_off(int R, int chunk) {            // byte offset inside a plane
+  return (((R & 3) * 32 + (R >> 2)) << 6) + ((chunk ^ (R & 3)) << 4);
+}
+
+template <int AMODE, int BMODE, bool MASK>
+__global__ __launch_bounds__(256, 2) void gemm_split_fused_kernel(FusedArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int c = lane & 31, h = lane >> 5;
@@ -308,9 +369,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
   const int kbeg = split * g.k_per_split;
-  const int kend = min(g.Kp, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg) / KS;
-
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg + KS - 1) / KS;
+  const bool do_colsum = AMODE == 1 && g.colsum != nullptr && tn == 0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -320,48 +381,155 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: thread -> (row tid >> 1, 16 halves at (tid & 1) * 16) of each of the four planes
-  const size_t goffA = (size_t)(m0 + (tid >> 1)) * g.lda + kbeg + (tid & 1) * 16;
-  const size_t goffB = (size_t)(n0 + (tid >> 1)) * g.ldb + kbeg + (tid & 1) * 16;
-  const _Float16 *pah = g.Ah + goffA, *pal = g.Al + goffA, *pbh = g.Bh + goffB, *pbl = g.Bl + goffB;
-  const int soff = (tid >> 1) * RPS + (tid & 1) * 16;
-  // Two register sets: the slab loaded during iteration kt is stored to LDS at the end of iteration kt + 1 and consumed in
-  // kt + 2, so a global load has two iterations (~1500 MFMA cycles per wave, two waves per SIMD) to land; with a distance
-  // of one the 768 MFMA cycles of a slab did not cover the HBM latency (measured 195 TF-equivalent).
-  uint4 p0, p1, p2, p3, p4, p5, p6, p7, q0, q1, q2, q3, q4, q5, q6, q7;      // register sets "p" and "q" (named scalars:
-                                                                             // an indexed struct went to scratch memory)
-#define GS_GLOAD(x, kt)                                                                                     \
-  do {                                                                                                      \
-    const int o_ = (kt) * KS;                                                                               \
-    x##0 = *reinterpret_cast<const uint4*>(pah + o_); x##1 = *reinterpret_cast<const uint4*>(pah + o_ + 8); \
-    x##2 = *reinterpret_cast<const uint4*>(pal + o_); x##3 = *reinterpret_cast<const uint4*>(pal + o_ + 8); \
-    x##4 = *reinterpret_cast<const uint4*>(pbh + o_); x##5 = *reinterpret_cast<const uint4*>(pbh + o_ + 8); \
-    x##6 = *reinterpret_cast<const uint4*>(pbl + o_); x##7 = *reinterpret_cast<const uint4*>(pbl + o_ + 8); \
-  } while (0)
-#define GS_SSTORE(buf, x)                                                                               \
-  do {                                                                                                  \
-    _Float16* p_ = (buf) + soff;                                                                        \
-    *reinterpret_cast<uint4*>(p_) = x##0;             *reinterpret_cast<uint4*>(p_ + 8) = x##1;             \
-    *reinterpret_cast<uint4*>(p_ + PLANE) = x##2;     *reinterpret_cast<uint4*>(p_ + PLANE + 8) = x##3;     \
-    *reinterpret_cast<uint4*>(p_ + 2 * PLANE) = x##4; *reinterpret_cast<uint4*>(p_ + 2 * PLANE + 8) = x##5; \
-    *reinterpret_cast<uint4*>(p_ + 3 * PLANE) = x##6; *reinterpret_cast<uint4*>(p_ + 3 * PLANE + 8) = x##7; \
-  } while (0)
-  const int arow = (wm * 64 + c) * RPS + 8 * h;
-  const int brow = (wn * 64 + c) * RPS + 8 * h;
-  auto compute = [&](const _Float16* Ah) {
-    const _Float16* Al = Ah + PLANE;
-    const _Float16* Bh = Ah + 2 * PLANE;
-    const _Float16* Bl = Ah + 3 * PLANE;
+  // ---------------- staging registers and the per-thread constants of each mode ----------------
+  // k-contiguous f32 (AMODE 0): thread -> (row tid >> 1, 16 k at (tid & 1) * 16): 4 float4
+  // planes (BMODE 0): thread -> (row tid >> 1, 16 halves at (tid & 1) * 16) of hi and lo: 4 uint4
+  // transposing f32 (AMODE 1 / BMODE 1): threads 0-127 stage A, 128-255 stage B: kg = (t >> 5) & 3 -> source rows
+  //   k0 + 8 kg .. + 7, lane ng = t & 31 -> tile rows ng + 32 j (j < 4): 32 scalar loads, 8 ds_write_b128
+  float fa[AMODE == 0 ? 1 : 32];            // AMODE 1: only waves 0-1 use it; BMODE 1 operand shares it (waves 2-3)
+  float4 q0, q1, q2, q3;                    // AMODE 0 (named: an array here went to scratch memory)
+  uint4 pb0, pb1, pb2, pb3;                 // BMODE 0
+  uint32_t mbits[AMODE == 0 ? 1 : 8][AMODE == 0 ? 1 : 4];
+  const int srow = tid >> 1, shalf = tid & 1;
+  const int kg = (tid >> 5) & 3, ng = tid & 31;
+  const bool stageA = AMODE == 0 || tid < 128;      // transposing modes: which operand this thread stages
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  float sA = 1.f, sB = 1.f;
+  if (AMODE == 0) sA = g.a_scale[(size_t)min(m0 + srow, g.M - 1) * g.a_rs];
+  else sA = g.a_scale[0];
+  if (BMODE == 1) sB = g.b_scale[0];
+  const float mulA = (MASK ? g.ascale : 1.f) * sA;
+
+  auto gload = [&](int kt) {
+    const int k0 = kbeg + kt * KS;
+    if (AMODE == 0) {
+      const int row = min(m0 + srow, g.M - 1);
+      const float* p = g.A + (size_t)row * g.lda + k0 + shalf * 16;
+      if (g.vecA && k0 + KS <= kend) {
+        q0 = *reinterpret_cast<const float4*>(p);
+        q1 = *reinterpret_cast<const float4*>(p + 4);
+        q2 = *reinterpret_cast<const float4*>(p + 8);
+        q3 = *reinterpret_cast<const float4*>(p + 12);
+      } else {
+        const int kk = k0 + shalf * 16;
+#define GS_LD(i) ((kk + (i) < kend) ? p[i] : 0.f)
+        q0 = make_float4(GS_LD(0), GS_LD(1), GS_LD(2), GS_LD(3));
+        q1 = make_float4(GS_LD(4), GS_LD(5), GS_LD(6), GS_LD(7));
+        q2 = make_float4(GS_LD(8), GS_LD(9), GS_LD(10), GS_LD(11));
+        q3 = make_float4(GS_LD(12), GS_LD(13), GS_LD(14), GS_LD(15));
+#undef GS_LD
+      }
+      if (MASK) mbits[0][0] = (g.abits[(size_t)row * g.ldbits + (k0 >> 5)] >> (shalf * 16)) & 0xffffu;
+    } else if (stageA) {
+      // source dy[m][n]: rows m = k0 + 8 kg + i (contraction), columns = tile rows m0 + ng + 32 j
 #pragma unroll
-    for (int ks = 0; ks < KS / 16; ++ks) {
-      const f16x8 a0 = *reinterpret_cast<const f16x8*>(Ah + arow + 16 * ks);
-      const f16x8 a1 = *reinterpret_cast<const f16x8*>(Ah + arow + 32 * RPS + 16 * ks);
-      const f16x8 a0l = *reinterpret_cast<const f16x8*>(Al + arow + 16 * ks);
-      const f16x8 a1l = *reinterpret_cast<const f16x8*>(Al + arow + 32 * RPS + 16 * ks);
-      const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bh + brow + 16 * ks);
-      const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bh + brow + 32 * RPS + 16 * ks);
-      const f16x8 b0l = *reinterpret_cast<const f16x8*>(Bl + brow + 16 * ks);
-      const f16x8 b1l = *reinterpret_cast<const f16x8*>(Bl + brow + 32 * RPS + 16 * ks);
+      for (int i = 0; i < 8; ++i) {
+        const int m = k0 + 8 * kg + i;
+        const bool mok = m < kend;
+        const float* p = g.A + (size_t)(mok ? m : kend - 1) * g.lda + m0 + ng;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[4 * i + j] = (mok && m0 + ng + 32 * j < g.M) ? p[32 * j] : 0.f;
+        if (MASK) {
+          const uint32_t* bw = g.abits + (size_t)(mok ? m : kend - 1) * g.ldbits + (m0 >> 5);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mbits[i][j] = (m0 + 32 * j < g.M) ? bw[j] : 0u;
+        }
+      }
+    }
+    if (BMODE == 0) {
+      const size_t off = (size_t)(n0 + srow) * g.ldb + k0 + shalf * 16;       // planes are padded: always in bounds
+      pb0 = *reinterpret_cast<const uint4*>(g.Bh + off); pb1 = *reinterpret_cast<const uint4*>(g.Bh + off + 8);
+      pb2 = *reinterpret_cast<const uint4*>(g.Bl + off); pb3 = *reinterpret_cast<const uint4*>(g.Bl + off + 8);
+    } else if (!stageA) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = k0 + 8 * kg + i;
+        const bool mok = m < kend;
+        const float* p = g.Bf + (size_t)(mok ? m : kend - 1) * g.ldb + n0 + ng;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[4 * i + j] = (mok && n0 + ng + 32 * j < g.N) ? p[32 * j] : 0.f;
+      }
+    }
+  };
+  auto sstore = [&](char* st) {
+    if (AMODE == 0) {
+      const uint32_t mb = MASK ? mbits[0][0] : 0xffffu;
+      auto half8 = [&](const float4& u, const float4& w, int q) {
+        float e[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (MASK) e[i] = ((mb >> (8 * q + i)) & 1u) ? e[i] : 0.f;
+          e[i] *= mulA;
+        }
+        uint4 hi, lo;
+        split8(e, hi, lo);
+        const int o = lds_off(srow, 2 * shalf + q);
+        *reinterpret_cast<uint4*>(st + o) = hi;
+        *reinterpret_cast<uint4*>(st + PLANE_B + o) = lo;
+      };
+      half8(q0, q1, 0);
+      half8(q2, q3, 1);
+    } else if (stageA) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v = fa[4 * i + j];
+          if (MASK) v = ((mbits[i][j] >> ng) & 1u) ? v : 0.f;
+          e[i] = v * mulA;
+        }
+        if (do_colsum) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) s += e[i];
+          csum[j] += s;
+        }
+        uint4 hi, lo;
+        split8(e, hi, lo);
+        const int o = lds_off(ng + 32 * j, kg);
+        *reinterpret_cast<uint4*>(st + o) = hi;
+        *reinterpret_cast<uint4*>(st + PLANE_B + o) = lo;
+      }
+    }
+    if (BMODE == 0) {
+      const int o0 = lds_off(srow, 2 * shalf), o1 = lds_off(srow, 2 * shalf + 1);
+      *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o0) = pb0;
+      *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o1) = pb1;
+      *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o0) = pb2;
+      *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o1) = pb3;
+    } else if (!stageA) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = fa[4 * i + j] * sB;
+        uint4 hi, lo;
+        split8(e, hi, lo);
+        const int o = lds_off(ng + 32 * j, kg);
+        *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o) = hi;
+        *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o) = lo;
+      }
+    }
+  };
+
+  // fragment offsets: row R = (wm|wn) * 64 + i * 32 + c -> slot (c & 3) * 32 + base / 4 + (c >> 2); chunk 2 ks + h
+  const int aoff = (((c & 3) * 32 + wm * 16 + (c >> 2)) << 6);
+  const int boff = (((c & 3) * 32 + wn * 16 + (c >> 2)) << 6);
+  const int ch0 = ((0 + h) ^ (c & 3)) << 4, ch1 = ((2 + h) ^ (c & 3)) << 4;
+  auto compute = [&](const char* st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ks == 0 ? ch0 : ch1;
+      const f16x8 a0 = *reinterpret_cast<const f16x8*>(st + aoff + ch);
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(st + aoff + 512 + ch);
+      const f16x8 a0l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + ch);
+      const f16x8 a1l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + 512 + ch);
+      const f16x8 b0 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + ch);
+      const f16x8 b1 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + 512 + ch);
+      const f16x8 b0l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + ch);
+      const f16x8 b1l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + 512 + ch);
       acc[0][0] = MF16(a0l, b0, acc[0][0]);       // small terms first
       acc[0][1] = MF16(a0l, b1, acc[0][1]);
       acc[1][0] = MF16(a1l, b0, acc[1][0]);
@@ -376,31 +544,45 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
       acc[1][1] = MF16(a1, b1, acc[1][1]);
     }
   };
+
   if (nk > 0) {
-    GS_GLOAD(p, 0);
-    GS_SSTORE(lds, p);
-    if (nk > 1) GS_GLOAD(q, 1);
+    gload(0);
+    sstore(lds);
   }
   __syncthreads();
-  // iteration kt (even): load slab kt + 2 into p, compute stage 0, park q (slab kt + 1) in stage 1; odd: mirrored
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) GS_GLOAD(p, kt + 2);
-    compute(lds);
-    if (kt + 1 < nk) GS_SSTORE(lds + STAGE, q);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(lds + cur * STAGE_B);
+    if (kt + 1 < nk) sstore(lds + (cur ^ 1) * STAGE_B);
     __syncthreads();
-    if (kt + 1 < nk) {
-      if (kt + 3 < nk) GS_GLOAD(q, kt + 3);
-      compute(lds + STAGE);
-      if (kt + 2 < nk) GS_SSTORE(lds, p);
-      __syncthreads();
+  }
+
+  // bias gradient: this block column (tn == 0) has seen every dy element of its (m-tile, k-slice)
+  if (do_colsum) {
+    float* red = reinterpret_cast<float*>(lds);            // [4 kg][128 columns]; all LDS readers are past the final barrier
+    if (tid < 128) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[kg * 128 + ng + 32 * j] = csum[j];
     }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = m0 + tid;
+      // csum carries the operand scale sA: take it out again
+      const float inv = __uint_as_float((254u << 23) - __float_as_uint(sA));
+      if (col < g.M)
+        g.colsum[(size_t)split * g.colsum_split_stride + col] = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) * inv;
+    }
+    __syncthreads();
   }
 
   // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
-  // the A-row scales of the tile go through the (now idle) staging buffer, behind the 16 KB the store path below uses: a
-  // static array would push 2 x 80 KB of dynamic LDS over the CU's 160 KB and halve the occupancy
+  // the A-row factors of the tile go through the (now idle) staging buffer, behind the 16 KB the store path below uses
   float* s_ra = reinterpret_cast<float*>(lds) + 4 * 32 * 32;
-  if (tid < TM) s_ra[tid] = g.a_rinv[(size_t)(m0 + tid) * g.a_rs];      // planes are padded: m0 + tid < Mp always
+  if (tid < TM) {
+    const float sc = AMODE == 0 ? g.a_scale[(size_t)min(m0 + tid, g.M - 1) * g.a_rs] : sA;
+    s_ra[tid] = __uint_as_float((254u << 23) - __float_as_uint(sc));        // 1 / (a power of two)
+  }
   __syncthreads();
   float* Cb = g.C + (size_t)split * g.c_split_stride;
   const int rbase = m0 + wm * 64 + 4 * h;
@@ -408,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = cbase + j * 32;
-    const float sb = g.b_rinv[(size_t)col * g.b_rs];                         // col < Np always (padded planes)
+    const float sb = BMODE == 0 ? g.b_rinv[(size_t)col * g.b_rs] : __uint_as_float((254u << 23) - __float_as_uint(sB));
     const float bv = (g.bias != nullptr && split == 0 && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -484,8 +666,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(SplitGemmArgs g) {
     const int wcol = (n0 + wn * 64) >> 5;
     const int nvalid = g.N - (n0 + wn * 64);
     if (row < g.M) {
-      if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits + wcol] = nvalid >= 32 ? w0 : (w0 & ((1u << nvalid) - 1u));
-      if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits + wcol + 1] = nvalid >= 64 ? w1 : (w1 & ((1u << (nvalid - 32)) - 1u));
+      if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol] = nvalid >= 32 ? w0 : (w0 & ((1u << nvalid) - 1u));
+      if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits_out + wcol + 1] = nvalid >= 64 ? w1 : (w1 & ((1u << (nvalid - 32)) - 1u));
     }
   }
 }
@@ -547,36 +729,62 @@ int convert_trn(const float* src, long ld, long M, int C, const uint32_t* bits, 
   return check_launch("gemm_split convert_trn");
 }
 
-int launch_split(SplitGemmArgs g, const Planes& A, const Planes& B, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_BYTES) != hipSuccess) {
-      set_error("gemm_split: cannot raise the dynamic LDS limit to %u bytes", LDS_BYTES);
+template <int AMODE, int BMODE>
+int launch_fused(FusedArgs g, hipStream_t st) {
+  static_assert(AMODE == BMODE, "supported: k-contiguous A with plane B (forward, grad-input); transposing A and B (grad-weight)");
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[0]) {
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_fused_kernel<AMODE, BMODE, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_fused_kernel<AMODE, BMODE, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES) == hipSuccess;
+    if (!ok) {
+      set_error("gemm_split: cannot raise the dynamic LDS limit to %u bytes", LDS2_BYTES);
       return HOISDF_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set[0] = true;
   }
-  g.Ah = A.hi; g.Al = A.lo; g.a_rinv = A.rinv; g.a_rs = A.rs;
-  g.Bh = B.hi; g.Bl = B.lo; g.b_rinv = B.rinv; g.b_rs = B.rs;
-  g.lda = A.kp; g.ldb = B.kp;
-  g.Kp = (int)(A.kp < B.kp ? A.kp : B.kp);        // both cover the contraction; the longer one's tail is zero padding
   g.tiles_m = cdiv(g.M, TM);
   g.tiles_n = cdiv(g.N, TN);
+  g.vecA = al16(g.A) && (g.lda % 4 == 0);
   g.vecC = al16(g.C) && (g.ldc % 4 == 0) && (g.c_split_stride % 4 == 0);
   const int ntile = g.tiles_m * g.tiles_n;
   const int nwg = g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile;
-  hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)nwg), dim3(256), LDS_BYTES, st, g);
+  if (g.abits)
+    hipLaunchKernelGGL((gemm_split_fused_kernel<AMODE, BMODE, true>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+  else
+    hipLaunchKernelGGL((gemm_split_fused_kernel<AMODE, BMODE, false>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
   return check_launch("gemm_split");
 }
 
+int row_scales(const float* src, long ld, long R, int K, const uint32_t* bits, float ascale, float* scale, hipStream_t st) {
+  const int vec = al16(src) && (ld % 4 == 0) && (K % 4 == 0);
+  hipLaunchKernelGGL(gs_row_scale_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, src, ld, (int)R, K, bits,
+                     (K + 31) / 32, ascale, vec, scale);
+  return check_launch("gemm_split row scales");
+}
+// scal[0] <- scale of the whole tensor, scal[1] = amax word (scratch)
+int tensor_scale(const float* src, long ld, long R, int C, float ascale, float* scal, hipStream_t st) {
+  uint32_t* amax = reinterpret_cast<uint32_t*>(scal + 1);
+  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), st) != hipSuccess) {
+    set_error("gemm_split: memset failed");
+    return HOISDF_ERR_LAUNCH;
+  }
+  const int vec = al16(src) && (ld % 4 == 0) && (C % 4 == 0);
+  long nb = (R + 3) / 4;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(gs_amax_kernel, dim3((unsigned)nb), dim3(256), 0, st, src, ld, R, C, vec, amax);
+  hipLaunchKernelGGL(gs_scalar_scale_kernel, dim3(1), dim3(1), 0, st, amax, ascale, scal);
+  return check_launch("gemm_split tensor scale");
+}
+
 // contraction slices for grad-weight: ~1024 workgroups, >= 8 slabs each
-void plan_split(long Kp, int tiles, int& splitk, int& kper) {
-  const int slabs = (int)(Kp / KS);
+void plan_split(long Kc, int tiles, int& splitk, int& kper) {
+  const int slabs = cdiv(Kc, KS);
   int want = tiles >= 1024 ? 1 : cdiv(1024, tiles);
   if (want > slabs / 8) want = slabs / 8 > 0 ? slabs / 8 : 1;
   kper = cdiv(slabs, want) * KS;
-  splitk = cdiv(Kp, kper);
+  splitk = cdiv(Kc, kper);
 }
 }  // namespace
 
@@ -587,19 +795,18 @@ using namespace hoisdf;
 extern "C" long hoisdf_linear_split_workspace(long M, int N, int K, int which) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   Carver c{nullptr, 0};
-  if (which == 0) {                    // forward: x rows, W rows
-    take_rows(c, M, K);
+  if (which == 0) {                    // forward: row scales of x, W planes
+    c.take<float>((size_t)M);
     take_rows(c, N, K);
-  } else if (which == 1) {             // grad-input: dy rows, W^T
-    take_rows(c, M, N);
+  } else if (which == 1) {             // grad-input: row scales of dy, W^T planes
+    c.take<float>((size_t)M);
     take_trn(c, N, K);
-  } else {                             // grad-weight: dy^T, x^T, partial tiles, bias-gradient partials
-    Planes a = take_trn(c, M, N);
-    take_trn(c, M, K);
+  } else {                             // grad-weight: two tensor scales, partial tiles, bias-gradient partials
+    c.take<float>(64);
     int splitk, kper;
-    plan_split(a.kp, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
+    plan_split(M, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
     if (splitk > 1) c.take<float>((size_t)splitk * N * K);
-    c.take<float>((size_t)(a.kp / 64) * N);
+    c.take<float>((size_t)splitk * N);
   }
   return (long)((c.off + 255) & ~(size_t)255);
 }
@@ -616,15 +823,18 @@ extern "C" int hoisdf_linear_fwd_split(const float* x, int ldx, const float* W, 
                  "linear_fwd_split: workspace too small");
   hipStream_t st = as_stream(stream);
   Carver c{static_cast<char*>(workspace), 0};
-  Planes A = take_rows(c, M, K), B = take_rows(c, N, K);
-  if (int rc = convert_rows(x, ldx, M, K, nullptr, 1.f, A, st)) return rc;
+  float* xs = c.take<float>((size_t)M);
+  Planes B = take_rows(c, N, K);
+  if (int rc = row_scales(x, ldx, M, K, nullptr, 1.f, xs, st)) return rc;
   if (int rc = convert_rows(W, ldw, N, K, nullptr, 1.f, B, st)) return rc;
-  SplitGemmArgs g{};
-  g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N;
+  FusedArgs g{};
+  g.A = x; g.lda = ldx; g.a_scale = xs; g.a_rs = 1;
+  g.Bh = B.hi; g.Bl = B.lo; g.ldb = B.kp; g.b_rinv = B.rinv; g.b_rs = 1;
+  g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
-  g.bits_out = relu_bits; g.ldbits = (N + 31) / 32;
-  g.splitk = 1; g.k_per_split = (int)A.kp;
-  return launch_split(g, A, B, st);
+  g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
+  g.splitk = 1; g.k_per_split = (int)up(K, KS);
+  return launch_fused<0, 0>(g, st);
 }
 
 extern "C" int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
@@ -639,16 +849,20 @@ extern "C" int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const ui
                  "linear_bwd_input_split: workspace too small");
   hipStream_t st = as_stream(stream);
   Carver c{static_cast<char*>(workspace), 0};
-  // dx[m][k] = sum_n dy[m][n] W[n][k]: A = dy rows (contraction n contiguous), B = W^T ([k][n])
-  Planes A = take_rows(c, M, N), B = take_trn(c, N, K);
-  if (int rc = convert_rows(dy, lddy, M, N, relu_bits, 1.f / (1.f - drop_p), A, st)) return rc;
+  // dx[m][k] = sum_n dy[m][n] W[n][k]: A = dy rows (contraction n contiguous), B = W^T planes ([k][n])
+  float* ds = c.take<float>((size_t)M);
+  Planes B = take_trn(c, N, K);
+  const float ascale = 1.f / (1.f - drop_p);
+  if (int rc = row_scales(dy, lddy, M, N, relu_bits, ascale, ds, st)) return rc;
   if (int rc = convert_trn(W, ldw, N, K, nullptr, 1.f, B, nullptr, st)) return rc;
-  SplitGemmArgs g{};
-  g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K;
+  FusedArgs g{};
+  g.A = dy; g.lda = lddy; g.a_scale = ds; g.a_rs = 1; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = ascale;
+  g.Bh = B.hi; g.Bl = B.lo; g.ldb = B.kp; g.b_rinv = B.rinv; g.b_rs = 0;
+  g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N;
   g.inv_keep = 1.f;
-  g.splitk = 1; g.k_per_split = (int)B.kp;
+  g.splitk = 1; g.k_per_split = (int)up(N, KS);
   g.beta = accumulate ? 1 : 0;
-  return launch_split(g, A, B, st);
+  return launch_fused<0, 0>(g, st);
 }
 
 extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
@@ -662,20 +876,24 @@ extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const u
                  "linear_bwd_weight_split: workspace too small");
   hipStream_t st = as_stream(stream);
   Carver c{static_cast<char*>(workspace), 0};
-  // dW[n][k] = sum_m dy[m][n] x[m][k]: A = dy^T ([n][m]), B = x^T ([k][m])
-  Planes A = take_trn(c, M, N), B = take_trn(c, M, K);
+  // dW[n][k] = sum_m dy[m][n] x[m][k]: both operands are read transposed (source rows = contraction), one scale each
+  float* scal = c.take<float>(64);               // [0] dy scale, [1] scratch, [8] x scale, [9] scratch
   int splitk, kper;
-  plan_split(A.kp, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
+  plan_split(M, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
   float* part = splitk > 1 ? c.take<float>((size_t)splitk * N * K) : nullptr;
-  float* cpart = c.take<float>((size_t)(A.kp / 64) * N);
-  if (int rc = convert_trn(dy, lddy, M, N, relu_bits, 1.f / (1.f - drop_p), A, db ? cpart : nullptr, st)) return rc;
-  if (int rc = convert_trn(x, ldx, M, K, nullptr, 1.f, B, nullptr, st)) return rc;
-  SplitGemmArgs g{};
-  g.M = N; g.N = K; g.inv_keep = 1.f;
+  float* cpart = c.take<float>((size_t)splitk * N);
+  const float ascale = 1.f / (1.f - drop_p);
+  if (int rc = tensor_scale(dy, lddy, M, N, ascale, scal, st)) return rc;
+  if (int rc = tensor_scale(x, ldx, M, K, 1.f, scal + 8, st)) return rc;
+  FusedArgs g{};
+  g.A = dy; g.lda = lddy; g.a_scale = scal; g.a_rs = 0; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = ascale;
+  g.Bf = x; g.ldb = ldx; g.b_scale = scal + 8;
+  g.colsum = db ? cpart : nullptr; g.colsum_split_stride = N;
+  g.M = N; g.N = K; g.K = (int)M; g.inv_keep = 1.f;
   g.splitk = splitk; g.k_per_split = kper;
   if (splitk > 1) { g.C = part; g.ldc = K; g.c_split_stride = (long)N * K; }
   else { g.C = dW; g.ldc = lddw; }
-  if (int rc = launch_split(g, A, B, st)) return rc;
+  if (int rc = launch_fused<1, 1>(g, st)) return rc;
   if (splitk > 1) {
     const long n = (long)N * K;
     int blocks = (int)((n / 4 + 255) / 256);
@@ -683,6 +901,6 @@ extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const u
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gs_reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, n, splitk, dW, n);
   }
-  if (db) hipLaunchKernelGGL(gs_colsum_reduce_kernel, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, cpart, (int)(A.kp / 64), N, db);
+  if (db) hipLaunchKernelGGL(gs_colsum_reduce_kernel, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, cpart, splitk, N, db);
   return check_launch("linear_bwd_weight_split reduce");
 }

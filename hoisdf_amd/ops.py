@@ -244,7 +244,10 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
 
 def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K):
     """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the split form overwrites."""
-    if _split_ok(M, N, K) and dW.stride(0) == K:
+    # the split grad-weight kernel converts both (transposed) operands once per output tile: it only beats the f32 kernel
+    # when the output is wide enough to amortise that (tools/mb_gsplit.py: 65536x512x992 599 vs 657 us, 16384x512x3968
+    # 894 vs 1095 us, but 65536x768x256 373 vs 293 us)
+    if _split_ok(M, N, K) and min(N, K) >= 512 and dW.stride(0) == K:
         ws, nb = _split_ws(M, N, K, 2, dW.device)
         call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
              _p(ws), nb, _st())
