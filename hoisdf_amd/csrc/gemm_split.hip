@@ -348,6 +348,257 @@ __device__ __forceinline__ int lds_off(int R, int chunk) {            // byte of
   return (((R & 3) * 32 + (R >> 2)) << 6) + ((chunk ^ (R & 3)) << 4);
 }
 
+// ---- epilogue shared by the split GEMM kernels (C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  PER_ROW_A: the A scale is per output row (k-contiguous A), else scalar sA;
+// PLANE_B: 1 / scale of the B rows from g.b_rinv, else the scalar sB.  All waves are past the main loop's last barrier.
+template <bool PER_ROW_A, bool PLANE_B>
+__device__ __forceinline__ void split_epilogue(const FusedArgs& g, f32x16 (&acc)[2][2], char* lds, int m0, int n0, int split,
+                                               float sA, float sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 31, h = lane >> 5;
+  // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
+  // the A-row factors of the tile go through the (now idle) staging buffer, behind the 16 KB the store path below uses
+  float* s_ra = reinterpret_cast<float*>(lds) + 4 * 32 * 32;
+  if (tid < TM) {
+    const float sc = PER_ROW_A ? g.a_scale[(size_t)min(m0 + tid, g.M - 1) * g.a_rs] : sA;
+    s_ra[tid] = __uint_as_float((254u << 23) - __float_as_uint(sc));        // 1 / (a power of two)
+  }
+  __syncthreads();
+  float* Cb = g.C + (size_t)split * g.c_split_stride;
+  const int rbase = m0 + wm * 64 + 4 * h;
+  const int cbase = n0 + wn * 64 + c;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = cbase + j * 32;
+    const float sb = PLANE_B ? g.b_rinv[(size_t)col * g.b_rs] : __uint_as_float((254u << 23) - __float_as_uint(sB));
+    const float bv = (g.bias != nullptr && split == 0 && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sa = s_ra[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        float v = acc[i][j][r] * (sa * sb) + bv;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        acc[i][j][r] = v;
+      }
+  }
+  if (g.drop_p > 0.f) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const uint32_t rk = drop_rowkey(g.seed, (uint32_t)row);
+        acc[i][0][r] *= drop_scale(rk, (uint32_t)cbase, g.thresh, g.inv_keep);
+        acc[i][1][r] *= drop_scale(rk, (uint32_t)(cbase + 32), g.thresh, g.inv_keep);
+      }
+  }
+  const bool full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
+  if (full && g.vecC) {
+    // through LDS: one 32x32 block per wave at a time in a wave-private 4 KB slice, read back row-wise so that one
+    // global_store_dwordx4 covers 8 complete 128-byte row segments (same scheme as gemm.hip)
+    float* w = reinterpret_cast<float*>(lds) + wave * (32 * 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[i][j][r];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 4;
+          float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
+          float4* cp = reinterpret_cast<float4*>(Cb + (size_t)(m0 + wm * 64 + i * 32 + rr) * g.ldc + n0 + wn * 64 + j * 32 + cc);
+          if (g.beta) {
+            const float4 old = *cp;
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+          }
+          *cp = v;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+          if (row < g.M && col < g.N) {
+            float* cp = Cb + (size_t)row * g.ldc + col;
+            *cp = g.beta ? *cp + acc[i][j][r] : acc[i][j][r];
+          }
+        }
+  }
+  if (g.bits_out) {
+    uint32_t w0 = 0u, w1 = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = i * 32 + (r & 3) + 8 * (r >> 2);
+        const unsigned long long b0 = __ballot(acc[i][0][r] > 0.f);
+        const unsigned long long b1 = __ballot(acc[i][1][r] > 0.f);
+        if (lane == rl) { w0 = (uint32_t)b0; w1 = (uint32_t)b1; }
+        if (lane == rl + 4) { w0 = (uint32_t)(b0 >> 32); w1 = (uint32_t)(b1 >> 32); }
+      }
+    const int row = m0 + wm * 64 + lane;
+    const int wcol = (n0 + wn * 64) >> 5;
+    const int nvalid = g.N - (n0 + wn * 64);
+    if (row < g.M) {
+      if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol] = nvalid >= 32 ? w0 : (w0 & ((1u << nvalid) - 1u));
+      if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits_out + wcol + 1] = nvalid >= 64 ? w1 : (w1 & ((1u << (nvalid - 32)) - 1u));
+    }
+  }
+}
+
+// ---- forward / grad-input: A f32 k-contiguous (converted here), B = weight planes.  Staging loads are raw buffer loads
+// (fixed per-thread VGPR offset + a scalar k offset: no address arithmetic in the loop, out-of-buffer reads return 0) into
+// TWO register sets, so that the slab consumed in iteration kt + 2 is requested in iteration kt: a load has two iterations
+// (~3000 cycles with two waves per SIMD) to land.  With a distance of one the 768 MFMA cycles of a slab did not cover the
+// load latency under load (measured: 4900 cycles per slab iteration).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 31, h = lane >> 5;
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int t = xcd_remap(blockIdx.x, ntile);
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kend = g.K;
+  const int nk = (kend + KS - 1) / KS;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int srow = tid >> 1, shalf = tid & 1;
+  const int arow = min(srow, g.M - 1 - m0);                   // rows past M: clamp (their products reach unstored rows only)
+  const int rows_left = g.M - m0;
+  // buffer descriptors over this tile's row panels (wave-uniform), sized so that reads past the tensor return 0
+  const long a_bytes = ((long)(min(rows_left, TM) - 1) * g.lda + g.K) * 4;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)a_bytes, 0x00020000);
+  const int b_bytes = (int)(TN * g.ldb * 2);
+  const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(g.Bh + (size_t)n0 * g.ldb), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(g.Bl + (size_t)n0 * g.ldb), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(MASK ? g.abits + (size_t)m0 * g.ldbits : nullptr), 0,
+      MASK ? (int)((long)min(rows_left, TM) * g.ldbits * 4) : 0, 0x00020000);
+  const int voA = (int)((long)arow * g.lda * 4) + shalf * 64;
+  const int voB = (int)((long)srow * g.ldb * 2) + shalf * 32;
+  const int voM = arow * g.ldbits * 4;
+  const float mulA = (MASK ? g.ascale : 1.f) * g.a_scale[(size_t)(m0 + arow) * g.a_rs];
+
+  u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+  uint32_t pm = 0xffffffffu, qm = 0xffffffffu;
+#define KC_LOAD(x, kt)                                                            \
+  do {                                                                            \
+    const int ka_ = (kt) * (KS * 4), kb_ = (kt) * (KS * 2);                       \
+    x##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA, ka_, 0);               \
+    x##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 16, ka_, 0);          \
+    x##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 32, ka_, 0);          \
+    x##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 48, ka_, 0);          \
+    x##b0 = __builtin_amdgcn_raw_buffer_load_b128(rbh, voB, kb_, 0);              \
+    x##b1 = __builtin_amdgcn_raw_buffer_load_b128(rbh, voB + 16, kb_, 0);         \
+    x##b2 = __builtin_amdgcn_raw_buffer_load_b128(rbl, voB, kb_, 0);              \
+    x##b3 = __builtin_amdgcn_raw_buffer_load_b128(rbl, voB + 16, kb_, 0);         \
+    if (MASK) x##m = __builtin_amdgcn_raw_buffer_load_b32(rm, voM, (kt) * 4, 0);  \
+  } while (0)
+  auto half8 = [&](char* st, const u32x4& u, const u32x4& w, uint32_t mb, int q, int krem) {
+    float e[8] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w),
+                  __uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (MASK) e[i] = ((mb >> (8 * q + i)) & 1u) ? e[i] : 0.f;
+      if (krem < 16) e[i] = (8 * q + i < krem) ? e[i] : 0.f;      // the k tail of the last slab (a neighbouring row's data)
+      e[i] *= mulA;
+    }
+    uint4 hi, lo;
+    split8(e, hi, lo);
+    const int o = lds_off(srow, 2 * shalf + q);
+    *reinterpret_cast<uint4*>(st + o) = hi;
+    *reinterpret_cast<uint4*>(st + PLANE_B + o) = lo;
+  };
+#define KC_STORE(st, x, kt)                                                                     \
+  do {                                                                                          \
+    const int krem_ = kend - (kt) * KS - shalf * 16;                                            \
+    const uint32_t mb_ = MASK ? (x##m >> (shalf * 16)) : 0xffffu;                               \
+    half8((st), x##a0, x##a1, mb_, 0, krem_);                                                   \
+    half8((st), x##a2, x##a3, mb_, 1, krem_);                                                   \
+    const int o0_ = lds_off(srow, 2 * shalf), o1_ = lds_off(srow, 2 * shalf + 1);              \
+    *reinterpret_cast<u32x4*>((st) + 2 * PLANE_B + o0_) = x##b0;                                \
+    *reinterpret_cast<u32x4*>((st) + 2 * PLANE_B + o1_) = x##b1;                                \
+    *reinterpret_cast<u32x4*>((st) + 3 * PLANE_B + o0_) = x##b2;                                \
+    *reinterpret_cast<u32x4*>((st) + 3 * PLANE_B + o1_) = x##b3;                                \
+  } while (0)
+
+  const int aoff = (((c & 3) * 32 + wm * 16 + (c >> 2)) << 6);
+  const int boff = (((c & 3) * 32 + wn * 16 + (c >> 2)) << 6);
+  const int ch0 = ((0 + h) ^ (c & 3)) << 4, ch1 = ((2 + h) ^ (c & 3)) << 4;
+  auto compute = [&](const char* st) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ks == 0 ? ch0 : ch1;
+      const f16x8 a0 = *reinterpret_cast<const f16x8*>(st + aoff + ch);
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(st + aoff + 512 + ch);
+      const f16x8 a0l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + ch);
+      const f16x8 a1l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + 512 + ch);
+      const f16x8 b0 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + ch);
+      const f16x8 b1 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + 512 + ch);
+      const f16x8 b0l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + ch);
+      const f16x8 b1l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + 512 + ch);
+      acc[0][0] = MF16(a0l, b0, acc[0][0]);       // small terms first
+      acc[0][1] = MF16(a0l, b1, acc[0][1]);
+      acc[1][0] = MF16(a1l, b0, acc[1][0]);
+      acc[1][1] = MF16(a1l, b1, acc[1][1]);
+      acc[0][0] = MF16(a0, b0l, acc[0][0]);
+      acc[0][1] = MF16(a0, b1l, acc[0][1]);
+      acc[1][0] = MF16(a1, b0l, acc[1][0]);
+      acc[1][1] = MF16(a1, b1l, acc[1][1]);
+      acc[0][0] = MF16(a0, b0, acc[0][0]);
+      acc[0][1] = MF16(a0, b1, acc[0][1]);
+      acc[1][0] = MF16(a1, b0, acc[1][0]);
+      acc[1][1] = MF16(a1, b1, acc[1][1]);
+    }
+  };
+
+  // The prefetch loads are UNCONDITIONAL (past the last slab they re-request it; the data is never stored): behind a
+  // branch the compiler has to assume the shorter load queue at the merge point and waits for the just-issued loads too.
+  const int last = nk - 1;
+  KC_LOAD(p, 0);
+  KC_STORE(lds, p, 0);
+  KC_LOAD(q, min(1, last));
+  __syncthreads();
+  // iteration kt (even): request slab kt + 2 into p, compute stage 0, park q (slab kt + 1) in stage 1; odd: mirrored
+  for (int kt = 0; kt < nk; kt += 2) {
+    KC_LOAD(p, min(kt + 2, last));
+    compute(lds);
+    if (kt + 1 < nk) KC_STORE(lds + STAGE_B, q, kt + 1);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      KC_LOAD(q, min(kt + 3, last));
+      compute(lds + STAGE_B);
+      if (kt + 2 < nk) KC_STORE(lds, p, kt + 2);
+      __syncthreads();
+    }
+  }
+#undef KC_LOAD
+#undef KC_STORE
+  split_epilogue<true, true>(g, acc, lds, m0, n0, 0, 1.f, 1.f);
+}
+
 template <int AMODE, int BMODE, bool MASK>
 __global__ __launch_bounds__(256, 2) void gemm_split_fused_kernel(FusedArgs g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -576,100 +827,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_fused_kernel(FusedArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) ----
-  // the A-row factors of the tile go through the (now idle) staging buffer, behind the 16 KB the store path below uses
-  float* s_ra = reinterpret_cast<float*>(lds) + 4 * 32 * 32;
-  if (tid < TM) {
-    const float sc = AMODE == 0 ? g.a_scale[(size_t)min(m0 + tid, g.M - 1) * g.a_rs] : sA;
-    s_ra[tid] = __uint_as_float((254u << 23) - __float_as_uint(sc));        // 1 / (a power of two)
-  }
-  __syncthreads();
-  float* Cb = g.C + (size_t)split * g.c_split_stride;
-  const int rbase = m0 + wm * 64 + 4 * h;
-  const int cbase = n0 + wn * 64 + c;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = cbase + j * 32;
-    const float sb = BMODE == 0 ? g.b_rinv[(size_t)col * g.b_rs] : __uint_as_float((254u << 23) - __float_as_uint(sB));
-    const float bv = (g.bias != nullptr && split == 0 && col < g.N) ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float sa = s_ra[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-        float v = acc[i][j][r] * (sa * sb) + bv;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        acc[i][j][r] = v;
-      }
-  }
-  if (g.drop_p > 0.f) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-        const uint32_t rk = drop_rowkey(g.seed, (uint32_t)row);
-        acc[i][0][r] *= drop_scale(rk, (uint32_t)cbase, g.thresh, g.inv_keep);
-        acc[i][1][r] *= drop_scale(rk, (uint32_t)(cbase + 32), g.thresh, g.inv_keep);
-      }
-  }
-  const bool full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
-  if (full && g.vecC) {
-    // through LDS: one 32x32 block per wave at a time in a wave-private 4 KB slice, read back row-wise so that one
-    // global_store_dwordx4 covers 8 complete 128-byte row segments (same scheme as gemm.hip)
-    float* w = reinterpret_cast<float*>(lds) + wave * (32 * 32);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[i][j][r];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 4;
-          float4 v = *reinterpret_cast<const float4*>(w + rr * 32 + cc);
-          float4* cp = reinterpret_cast<float4*>(Cb + (size_t)(m0 + wm * 64 + i * 32 + rr) * g.ldc + n0 + wn * 64 + j * 32 + cc);
-          if (g.beta) {
-            const float4 old = *cp;
-            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-          }
-          *cp = v;
-        }
-      }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
-          if (row < g.M && col < g.N) {
-            float* cp = Cb + (size_t)row * g.ldc + col;
-            *cp = g.beta ? *cp + acc[i][j][r] : acc[i][j][r];
-          }
-        }
-  }
-  if (g.bits_out) {
-    uint32_t w0 = 0u, w1 = 0u;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = i * 32 + (r & 3) + 8 * (r >> 2);
-        const unsigned long long b0 = __ballot(acc[i][0][r] > 0.f);
-        const unsigned long long b1 = __ballot(acc[i][1][r] > 0.f);
-        if (lane == rl) { w0 = (uint32_t)b0; w1 = (uint32_t)b1; }
-        if (lane == rl + 4) { w0 = (uint32_t)(b0 >> 32); w1 = (uint32_t)(b1 >> 32); }
-      }
-    const int row = m0 + wm * 64 + lane;
-    const int wcol = (n0 + wn * 64) >> 5;
-    const int nvalid = g.N - (n0 + wn * 64);
-    if (row < g.M) {
-      if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol] = nvalid >= 32 ? w0 : (w0 & ((1u << nvalid) - 1u));
-      if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits_out + wcol + 1] = nvalid >= 64 ? w1 : (w1 & ((1u << (nvalid - 32)) - 1u));
-    }
-  }
+  split_epilogue<AMODE == 0, BMODE == 0>(g, acc, lds, m0, n0, split, sA, sB);
 }
 
 namespace {
@@ -729,20 +887,25 @@ int convert_trn(const float* src, long ld, long M, int C, const uint32_t* bits, 
   return check_launch("gemm_split convert_trn");
 }
 
+template <typename K>
+bool raise_lds(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)LDS2_BYTES) == hipSuccess;
+}
+
 template <int AMODE, int BMODE>
 int launch_fused(FusedArgs g, hipStream_t st) {
   static_assert(AMODE == BMODE, "supported: k-contiguous A with plane B (forward, grad-input); transposing A and B (grad-weight)");
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[0]) {
-    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_fused_kernel<AMODE, BMODE, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_fused_kernel<AMODE, BMODE, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS2_BYTES) == hipSuccess;
+  static bool attr_set = false;
+  if (!attr_set) {
+    bool ok;
+    if (AMODE == 0) ok = raise_lds(gemm_split_kc_kernel<false>) && raise_lds(gemm_split_kc_kernel<true>);
+    else ok = raise_lds(gemm_split_fused_kernel<1, 1, false>) && raise_lds(gemm_split_fused_kernel<1, 1, true>);
     if (!ok) {
       set_error("gemm_split: cannot raise the dynamic LDS limit to %u bytes", LDS2_BYTES);
       return HOISDF_ERR_LAUNCH;
     }
-    attr_set[0] = true;
+    attr_set = true;
   }
   g.tiles_m = cdiv(g.M, TM);
   g.tiles_n = cdiv(g.N, TN);
@@ -750,10 +913,15 @@ int launch_fused(FusedArgs g, hipStream_t st) {
   g.vecC = al16(g.C) && (g.ldc % 4 == 0) && (g.c_split_stride % 4 == 0);
   const int ntile = g.tiles_m * g.tiles_n;
   const int nwg = g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile;
-  if (g.abits)
-    hipLaunchKernelGGL((gemm_split_fused_kernel<AMODE, BMODE, true>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
-  else
-    hipLaunchKernelGGL((gemm_split_fused_kernel<AMODE, BMODE, false>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+  if (AMODE == 0) {
+    if (g.abits) hipLaunchKernelGGL(gemm_split_kc_kernel<true>, dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+    else hipLaunchKernelGGL(gemm_split_kc_kernel<false>, dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+  } else {
+    if (g.abits)
+      hipLaunchKernelGGL((gemm_split_fused_kernel<1, 1, true>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+    else
+      hipLaunchKernelGGL((gemm_split_fused_kernel<1, 1, false>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+  }
   return check_launch("gemm_split");
 }
 
