@@ -53,7 +53,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_linear_fwd_split": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _L, _P],
     "hoisdf_linear_bwd_input_split": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P, _L, _P],
-    "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
+    "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "hoisdf_batchnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _L, _I, _P, _L, _P],

@@ -7,16 +7,21 @@
 // f16 keeps 11 + 11 bits in a hi + lo pair only while the lo part is a normal number; below that the pair degrades to an
 // absolute resolution of 2^-25.  Every operand is therefore moved up by an exact power of two before the split and the
 // factor is taken out of the f32 result in the epilogue:
-//   * an operand whose rows are k-contiguous in memory (x, W in the forward; dy in grad-input) gets one scale PER ROW
-//     (row maximum -> [2^14, 2^15)), found by the converting wave itself;
-//   * an operand that has to be transposed because the contraction runs over its rows (W in grad-input; dy and x in
-//     grad-weight) gets one scale for the whole tensor from an amax pre-pass (the scale cannot vary along the contraction).
-// A conversion pass writes the hi / lo planes k-contiguous ([rows padded to 128][k padded to 32/64], zeros in the padding),
-// applying the forward's ReLU / dropout sign bitmap to dy on the way and (grad-weight) emitting the bias gradient's
-// per-tile column sums; the GEMM itself is ONE kernel for all three contractions: 128 x 128 tile, 4 waves as 2 x 2,
-// each wave 64 x 64 = 2 x 2 MFMA tiles, 32-deep k-slabs of the four planes double-buffered in LDS (80 KB, 2 WG / CU).
-// The epilogue is the f32 kernel's (bias, ReLU, dropout, sign bitmap, accumulate-into, LDS-transposed 128-byte stores).
-// Grad-weight splits the contraction over workgroups into partial tiles + an ordered reduce (no atomics: deterministic).
+//   * forward / grad-input: the activation operand (x, dy) is read as f32 and split on its way into LDS, one scale PER ROW
+//     (row maximum -> [2^14, 2^15)) from a one-read pre-pass (gs_row_scale_kernel) - no hi / lo copy of an activation goes
+//     through HBM; the weights (tiny) are pre-converted to hi / lo planes, per row (forward) or transposed with one
+//     scale (grad-input).  The ReLU / dropout sign bitmap of the forward is applied to dy during the conversion.
+//   * grad-weight: the contraction runs over the rows of both operands, so both are written once as TRANSPOSED planes;
+//     source row m of x is multiplied by its row scale sx[m], row m of dy by p / sx[m] with p = min_m sx[m] sd[m] (the
+//     product of the two factors is constant along the contraction, every row's magnitude stays proportional to its
+//     contribution to dW).  That pass also emits the bias gradient's per-tile column sums.
+// ONE GEMM kernel (gemm_split_kc_kernel): 128 x 128 tile, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles, 32-deep
+// k-slabs of the four planes double-buffered in LDS (64 KB, 2 WG / CU), raw buffer loads two slabs ahead.  The epilogue
+// is the f32 kernel's (bias, ReLU, dropout, sign bitmap, accumulate-into, LDS-transposed 128-byte stores).  Grad-weight
+// splits the contraction over workgroups into partial tiles + an ordered reduce (no atomics: deterministic).
+// Measured (MI355X, tools/mb_gsplit.py, pre-passes included): forward / grad-input 160-215 TF-equivalent against 88-101
+// for the f32 kernel; grad-weight 110-124 against 61-103 when min(N, K) >= 512, but NO gain for the 256-wide transformer
+// shapes (the two conversion passes cost what the contraction saves), which therefore stay on the f32 kernel.
 #include "common.h"
 #include <hip/hip_fp16.h>
 
@@ -33,7 +38,10 @@ constexpr int TM = 128, TN = 128, KS = 32;
 // power-of-two scale that brings amax into [2^14, 2^15); inv = 1 / scale (exact)
 __device__ __forceinline__ float pow2_scale(float amax, float& inv) {
   const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-  if (e == 0 || e == 255) { inv = 1.f; return 1.f; }            // zero / denormal / non-finite: leave alone
+  if (e == 255) { inv = 1.f; return 1.f; }                      // non-finite: leave alone
+  // zero (or denormal) rows: a LARGE scale, so that such a row never bounds the common factor of grad-weight (a row of
+  // zeros must not cost the other rows their bits); 0 * 2^100 is still 0
+  if (e == 0) { inv = __uint_as_float((254u - 227u) << 23); return __uint_as_float(227u << 23); }
   int se = 127 + 14 - (e - 127);
   se = se < 4 ? 4 : (se > 250 ? 250 : se);
   inv = __uint_as_float((uint32_t)(254 - se) << 23);
@@ -149,23 +157,25 @@ __global__ __launch_bounds__(256) void gs_convert_rows_kernel(const float* __res
   }
 }
 
-// ---- transposing conversion: src [M][C] (C contiguous) -> planes [Cp][Mp] (M contiguous), one scale for the tensor from
-// the amax word.  One block per 64 x 64 tile through LDS (coalesced 64-byte reads, 32-byte writes).  Optionally the
+// ---- transposing conversion: src [M][C] (C contiguous) -> planes [Cp][Mp] (M contiguous); every source row m (= the
+// contraction index of the GEMM that consumes the planes) is multiplied by a power of two: one scalar for the tensor
+// (weights) or a per-row factor whose product over the two operands of the contraction is constant (grad-weight).  One block per 64 x 64 tile through LDS (coalesced 64-byte reads, 32-byte writes).  Optionally the
 // per-tile column sums of the (masked, unscaled) source: colsum_part[m-tile][C], summed in tile order afterwards.
 __global__ __launch_bounds__(256) void gs_convert_trn_kernel(const float* __restrict__ src, long ld, int M, int C, int Mp,
-                                                             const uint32_t* __restrict__ amax_bits,
+                                                             const float* __restrict__ row_scale,
+                                                             const float* __restrict__ num, int invert,
                                                              const uint32_t* __restrict__ bits, int ldbits, float ascale,
                                                              int vec, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                             float* __restrict__ sinv, float* __restrict__ colsum_part) {
+                                                             float* __restrict__ colsum_part) {
   constexpr int TP = 72;
   __shared__ __attribute__((aligned(16))) _Float16 tile[2][64 * TP];
   __shared__ float red[64][65];
   const int tid = threadIdx.x;
   const int r = tid >> 2, dc = (tid & 3) * 16;
   const int m = blockIdx.x * 64 + r, c0 = blockIdx.y * 64 + dc;
-  float inv;
-  const float sc = pow2_scale(__uint_as_float(amax_bits[0]) * ascale, inv) * ascale;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) sinv[0] = inv;
+  // multiplier of source row m (powers of two): row_scale[m], num[0] / row_scale[m] (invert) or the scalar num[0]
+  float sc = ascale;
+  if (m < M) sc *= row_scale ? (invert ? num[0] / row_scale[m] : row_scale[m]) : num[0];
   float e[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) e[i] = 0.f;
@@ -300,37 +310,53 @@ __global__ __launch_bounds__(256) void gs_row_scale_kernel(const float* __restri
 __global__ void gs_scalar_scale_kernel(const uint32_t* __restrict__ amax_bits, float ascale, float* __restrict__ scale) {
   float inv;
   scale[0] = pow2_scale(__uint_as_float(amax_bits[0]) * ascale, inv);
+  scale[2] = inv;
+}
+// grad-weight: min over m of sx[m] * sd[m] (positive powers of two: ordered as uints) into out[0] (preset to +inf bits);
+// finalize: out[1] = 1 / out[0]
+__global__ __launch_bounds__(256) void gs_min_product_kernel(const float* __restrict__ sx, const float* __restrict__ sd,
+                                                             long M, uint32_t* __restrict__ out) {
+  float m = 3.0e38f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long)gridDim.x * 256) {
+    const float p = fminf(fmaxf(sx[i] * sd[i], 1.0e-30f), 1.0e30f);
+    m = fminf(m, p);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMin(out, __float_as_uint(m));
+}
+__global__ void gs_min_product_finish_kernel(float* __restrict__ v) {
+  // round the clamped minimum down to a power of two (it is one unless a clamp hit) and publish its inverse
+  const float p = __uint_as_float(__float_as_uint(v[0]) & 0x7f800000u);
+  v[0] = p;
+  v[1] = __uint_as_float((254u << 23) - __float_as_uint(p));
 }
 
 // ============================================================================================
-// C[M][N] = epilogue( (A . B^T) / (sa sb) ): ONE kernel, the operands converted on the way into LDS
-//   AMODE 0: A f32 [M][K] k-contiguous (x in the forward, dy in grad-input; per-row scales, optional sign bitmap)
-//   AMODE 1: A f32 [K][M] (source rows = contraction; dy in grad-weight; one scale, optional sign bitmap, column sums)
-//   BMODE 0: B = pre-converted hi / lo planes [Np][ldb] (the weights: tiny)   BMODE 1: B f32 [K][N] (x in grad-weight)
+// C[M][N] = epilogue( (A . B^T) / (sa sb) )
 // LDS image of a [128 rows][32 k] plane (8 KB, unpadded): row R lives in slot (R & 3) * 32 + (R >> 2), its four 16-byte
-// k-chunks at chunk ^ (R & 3).  With that permutation the MFMA fragment reads (16 consecutive rows, one chunk), the
-// k-contiguous staging writes (row = tid >> 1) and the transposing staging writes (rows 32 apart per lane group) are all
-// spread over the 64 banks.
+// k-chunks at chunk ^ (R & 3).  With that permutation the MFMA fragment reads (16 consecutive rows, one chunk) are spread
+// over all 64 banks and the staging writes (row = tid >> 1, two chunks) are at most 2-way conflicted.
 // ============================================================================================
 constexpr int PLANE_B = 128 * 64;                 // bytes per plane per stage
 constexpr int STAGE_B = 4 * PLANE_B;              // A hi, A lo, B hi, B lo: 32 KB
 constexpr unsigned LDS2_BYTES = 2u * STAGE_B;     // double buffered: 64 KB (2 workgroups per CU)
 
 struct FusedArgs {
-  const float* A; long lda;                 // f32 operand A
-  const float* Bf; const _Float16 *Bh, *Bl; long ldb;     // f32 operand B (BMODE 1) or planes (BMODE 0, pitch ldb halves)
-  const float* a_scale; int a_rs;           // scale of A: per row (stride 1) or scalar (stride 0)
-  const float* b_scale;                     // BMODE 1: scalar scale of B
-  const float* b_rinv; int b_rs;            // BMODE 0: 1 / scale of the planes' rows (stride 1) or scalar (stride 0)
-  const uint32_t* abits; int ldbits; float ascale;     // sign bitmap of the ORIGINAL dy [rows][ceil(cols / 32)]
-  float* colsum; long colsum_split_stride;  // AMODE 1: column sums of masked A (bias gradient), [split][M]
+  const float* A;                           // f32 operand A [M][lda] (forward / grad-input), or
+  const _Float16 *Ah, *Al;                  // pre-converted planes of A [Mp][lda halves] (grad-weight)
+  long lda;
+  const _Float16 *Bh, *Bl; long ldb;        // planes of B [Np][ldb halves]
+  const float* a_scale; int a_rs;           // scale of A: per row (stride 1) or scalar (stride 0; planes: the product p)
+  const float* b_rinv; int b_rs;            // 1 / scale of B's rows (stride 1) or scalar (stride 0)
+  const uint32_t* abits; int ldbits; float ascale;     // sign bitmap of dy [rows][ceil(cols / 32)], 1 / keep
   float* C; int ldc;
   const float* bias;
   uint32_t* bits_out; int ldbits_out;
   int M, N, K;                              // output rows, output columns, contraction length
   int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
   int splitk, k_per_split; long c_split_stride;
-  int tiles_m, tiles_n, vecA, vecB, vecC, beta;
+  int tiles_m, tiles_n, vecC, beta;
 };
 
 __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
@@ -460,17 +486,27 @@ __device__ __forceinline__ void split_epilogue(const FusedArgs& g, f32x16 (&acc)
 // load latency under load (measured: 4900 cycles per slab iteration).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool MASK>
+template <bool MASK, bool APLANES>
 __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int c = lane & 31, h = lane >> 5;
   const int ntile = g.tiles_m * g.tiles_n;
-  const int t = xcd_remap(blockIdx.x, ntile);
+  const int bid = blockIdx.x;
+  int split, t;
+  if (g.splitk > 1) {
+    split = (bid & 7) + 8 * (bid / (8 * ntile));       // every tile of one k-slice on the same XCD (shared L2), as gemm.hip
+    t = (bid >> 3) % ntile;
+    if (split >= g.splitk) return;
+  } else {
+    split = 0;
+    t = xcd_remap(bid, ntile);
+  }
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int kend = g.K;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split) - kbeg;      // contraction range of this slice, relative to kbeg
   const int nk = (kend + KS - 1) / KS;
 
   f32x16 acc[2][2];
@@ -485,31 +521,42 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   const int arow = min(srow, g.M - 1 - m0);                   // rows past M: clamp (their products reach unstored rows only)
   const int rows_left = g.M - m0;
   // buffer descriptors over this tile's row panels (wave-uniform), sized so that reads past the tensor return 0
-  const long a_bytes = ((long)(min(rows_left, TM) - 1) * g.lda + g.K) * 4;
+  // (plane operands are padded to whole tiles; kbeg shifts the base so that the scalar k offsets start at 0)
+  const long a_bytes = APLANES ? (long)TM * g.lda * 2 - kbeg * 2 : ((long)(min(rows_left, TM) - 1) * g.lda + g.K) * 4;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)a_bytes, 0x00020000);
-  const int b_bytes = (int)(TN * g.ldb * 2);
+      APLANES ? (void*)const_cast<_Float16*>(g.Ah + (size_t)m0 * g.lda + kbeg) : (void*)const_cast<float*>(g.A + (size_t)m0 * g.lda),
+      0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(
+      APLANES ? (void*)const_cast<_Float16*>(g.Al + (size_t)m0 * g.lda + kbeg) : nullptr, 0, APLANES ? (int)a_bytes : 0, 0x00020000);
+  const int b_bytes = (int)((long)TN * g.ldb * 2 - kbeg * 2);
   const __amdgpu_buffer_rsrc_t rbh = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16*>(g.Bh + (size_t)n0 * g.ldb), 0, b_bytes, 0x00020000);
+      const_cast<_Float16*>(g.Bh + (size_t)n0 * g.ldb + kbeg), 0, b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rbl = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<_Float16*>(g.Bl + (size_t)n0 * g.ldb), 0, b_bytes, 0x00020000);
+      const_cast<_Float16*>(g.Bl + (size_t)n0 * g.ldb + kbeg), 0, b_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint32_t*>(MASK ? g.abits + (size_t)m0 * g.ldbits : nullptr), 0,
       MASK ? (int)((long)min(rows_left, TM) * g.ldbits * 4) : 0, 0x00020000);
-  const int voA = (int)((long)arow * g.lda * 4) + shalf * 64;
+  const int voA = APLANES ? (int)((long)srow * g.lda * 2) + shalf * 32 : (int)((long)arow * g.lda * 4) + shalf * 64;
   const int voB = (int)((long)srow * g.ldb * 2) + shalf * 32;
   const int voM = arow * g.ldbits * 4;
-  const float mulA = (MASK ? g.ascale : 1.f) * g.a_scale[(size_t)(m0 + arow) * g.a_rs];
+  const float mulA = APLANES ? 1.f : (MASK ? g.ascale : 1.f) * g.a_scale[(size_t)(m0 + arow) * g.a_rs];
 
   u32x4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
   uint32_t pm = 0xffffffffu, qm = 0xffffffffu;
 #define KC_LOAD(x, kt)                                                            \
   do {                                                                            \
-    const int ka_ = (kt) * (KS * 4), kb_ = (kt) * (KS * 2);                       \
-    x##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA, ka_, 0);               \
-    x##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 16, ka_, 0);          \
-    x##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 32, ka_, 0);          \
-    x##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 48, ka_, 0);          \
+    const int ka_ = (kt) * (KS * (APLANES ? 2 : 4)), kb_ = (kt) * (KS * 2);       \
+    if (APLANES) {                                                                \
+      x##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA, ka_, 0);             \
+      x##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 16, ka_, 0);        \
+      x##a2 = __builtin_amdgcn_raw_buffer_load_b128(ral, voA, ka_, 0);            \
+      x##a3 = __builtin_amdgcn_raw_buffer_load_b128(ral, voA + 16, ka_, 0);       \
+    } else {                                                                      \
+      x##a0 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA, ka_, 0);             \
+      x##a1 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 16, ka_, 0);        \
+      x##a2 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 32, ka_, 0);        \
+      x##a3 = __builtin_amdgcn_raw_buffer_load_b128(ra, voA + 48, ka_, 0);        \
+    }                                                                             \
     x##b0 = __builtin_amdgcn_raw_buffer_load_b128(rbh, voB, kb_, 0);              \
     x##b1 = __builtin_amdgcn_raw_buffer_load_b128(rbh, voB + 16, kb_, 0);         \
     x##b2 = __builtin_amdgcn_raw_buffer_load_b128(rbl, voB, kb_, 0);              \
@@ -535,9 +582,16 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   do {                                                                                          \
     const int krem_ = kend - (kt) * KS - shalf * 16;                                            \
     const uint32_t mb_ = MASK ? (x##m >> (shalf * 16)) : 0xffffu;                               \
-    half8((st), x##a0, x##a1, mb_, 0, krem_);                                                   \
-    half8((st), x##a2, x##a3, mb_, 1, krem_);                                                   \
     const int o0_ = lds_off(srow, 2 * shalf), o1_ = lds_off(srow, 2 * shalf + 1);              \
+    if (APLANES) {                                                                              \
+      *reinterpret_cast<u32x4*>((st) + o0_) = x##a0;                                            \
+      *reinterpret_cast<u32x4*>((st) + o1_) = x##a1;                                            \
+      *reinterpret_cast<u32x4*>((st) + PLANE_B + o0_) = x##a2;                                  \
+      *reinterpret_cast<u32x4*>((st) + PLANE_B + o1_) = x##a3;                                  \
+    } else {                                                                                    \
+      half8((st), x##a0, x##a1, mb_, 0, krem_);                                                 \
+      half8((st), x##a2, x##a3, mb_, 1, krem_);                                                 \
+    }                                                                                           \
     *reinterpret_cast<u32x4*>((st) + 2 * PLANE_B + o0_) = x##b0;                                \
     *reinterpret_cast<u32x4*>((st) + 2 * PLANE_B + o1_) = x##b1;                                \
     *reinterpret_cast<u32x4*>((st) + 3 * PLANE_B + o0_) = x##b2;                                \
@@ -596,238 +650,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   }
 #undef KC_LOAD
 #undef KC_STORE
-  split_epilogue<true, true>(g, acc, lds, m0, n0, 0, 1.f, 1.f);
-}
-
-template <int AMODE, int BMODE, bool MASK>
-__global__ __launch_bounds__(256, 2) void gemm_split_fused_kernel(FusedArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int c = lane & 31, h = lane >> 5;
-
-  const int ntile = g.tiles_m * g.tiles_n;
-  const int bid = blockIdx.x;
-  int split, t;
-  if (g.splitk > 1) {
-    split = (bid & 7) + 8 * (bid / (8 * ntile));       // every tile of one k-slice on the same XCD (shared L2), as gemm.hip
-    t = (bid >> 3) % ntile;
-    if (split >= g.splitk) return;
-  } else {
-    split = 0;
-    t = xcd_remap(bid, ntile);
-  }
-  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg + KS - 1) / KS;
-  const bool do_colsum = AMODE == 1 && g.colsum != nullptr && tn == 0;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---------------- staging registers and the per-thread constants of each mode ----------------
-  // k-contiguous f32 (AMODE 0): thread -> (row tid >> 1, 16 k at (tid & 1) * 16): 4 float4
-  // planes (BMODE 0): thread -> (row tid >> 1, 16 halves at (tid & 1) * 16) of hi and lo: 4 uint4
-  // transposing f32 (AMODE 1 / BMODE 1): threads 0-127 stage A, 128-255 stage B: kg = (t >> 5) & 3 -> source rows
-  //   k0 + 8 kg .. + 7, lane ng = t & 31 -> tile rows ng + 32 j (j < 4): 32 scalar loads, 8 ds_write_b128
-  float fa[AMODE == 0 ? 1 : 32];            // AMODE 1: only waves 0-1 use it; BMODE 1 operand shares it (waves 2-3)
-  float4 q0, q1, q2, q3;                    // AMODE 0 (named: an array here went to scratch memory)
-  uint4 pb0, pb1, pb2, pb3;                 // BMODE 0
-  uint32_t mbits[AMODE == 0 ? 1 : 8][AMODE == 0 ? 1 : 4];
-  const int srow = tid >> 1, shalf = tid & 1;
-  const int kg = (tid >> 5) & 3, ng = tid & 31;
-  const bool stageA = AMODE == 0 || tid < 128;      // transposing modes: which operand this thread stages
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
-
-  float sA = 1.f, sB = 1.f;
-  if (AMODE == 0) sA = g.a_scale[(size_t)min(m0 + srow, g.M - 1) * g.a_rs];
-  else sA = g.a_scale[0];
-  if (BMODE == 1) sB = g.b_scale[0];
-  const float mulA = (MASK ? g.ascale : 1.f) * sA;
-
-  auto gload = [&](int kt) {
-    const int k0 = kbeg + kt * KS;
-    if (AMODE == 0) {
-      const int row = min(m0 + srow, g.M - 1);
-      const float* p = g.A + (size_t)row * g.lda + k0 + shalf * 16;
-      if (g.vecA && k0 + KS <= kend) {
-        q0 = *reinterpret_cast<const float4*>(p);
-        q1 = *reinterpret_cast<const float4*>(p + 4);
-        q2 = *reinterpret_cast<const float4*>(p + 8);
-        q3 = *reinterpret_cast<const float4*>(p + 12);
-      } else {
-        const int kk = k0 + shalf * 16;
-#define GS_LD(i) ((kk + (i) < kend) ? p[i] : 0.f)
-        q0 = make_float4(GS_LD(0), GS_LD(1), GS_LD(2), GS_LD(3));
-        q1 = make_float4(GS_LD(4), GS_LD(5), GS_LD(6), GS_LD(7));
-        q2 = make_float4(GS_LD(8), GS_LD(9), GS_LD(10), GS_LD(11));
-        q3 = make_float4(GS_LD(12), GS_LD(13), GS_LD(14), GS_LD(15));
-#undef GS_LD
-      }
-      if (MASK) mbits[0][0] = (g.abits[(size_t)row * g.ldbits + (k0 >> 5)] >> (shalf * 16)) & 0xffffu;
-    } else if (stageA) {
-      // source dy[m][n]: rows m = k0 + 8 kg + i (contraction), columns = tile rows m0 + ng + 32 j
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = k0 + 8 * kg + i;
-        const bool mok = m < kend;
-        const float* p = g.A + (size_t)(mok ? m : kend - 1) * g.lda + m0 + ng;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fa[4 * i + j] = (mok && m0 + ng + 32 * j < g.M) ? p[32 * j] : 0.f;
-        if (MASK) {
-          const uint32_t* bw = g.abits + (size_t)(mok ? m : kend - 1) * g.ldbits + (m0 >> 5);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) mbits[i][j] = (m0 + 32 * j < g.M) ? bw[j] : 0u;
-        }
-      }
-    }
-    if (BMODE == 0) {
-      const size_t off = (size_t)(n0 + srow) * g.ldb + k0 + shalf * 16;       // planes are padded: always in bounds
-      pb0 = *reinterpret_cast<const uint4*>(g.Bh + off); pb1 = *reinterpret_cast<const uint4*>(g.Bh + off + 8);
-      pb2 = *reinterpret_cast<const uint4*>(g.Bl + off); pb3 = *reinterpret_cast<const uint4*>(g.Bl + off + 8);
-    } else if (!stageA) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = k0 + 8 * kg + i;
-        const bool mok = m < kend;
-        const float* p = g.Bf + (size_t)(mok ? m : kend - 1) * g.ldb + n0 + ng;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fa[4 * i + j] = (mok && n0 + ng + 32 * j < g.N) ? p[32 * j] : 0.f;
-      }
-    }
-  };
-  auto sstore = [&](char* st) {
-    if (AMODE == 0) {
-      const uint32_t mb = MASK ? mbits[0][0] : 0xffffu;
-      auto half8 = [&](const float4& u, const float4& w, int q) {
-        float e[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (MASK) e[i] = ((mb >> (8 * q + i)) & 1u) ? e[i] : 0.f;
-          e[i] *= mulA;
-        }
-        uint4 hi, lo;
-        split8(e, hi, lo);
-        const int o = lds_off(srow, 2 * shalf + q);
-        *reinterpret_cast<uint4*>(st + o) = hi;
-        *reinterpret_cast<uint4*>(st + PLANE_B + o) = lo;
-      };
-      half8(q0, q1, 0);
-      half8(q2, q3, 1);
-    } else if (stageA) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float v = fa[4 * i + j];
-          if (MASK) v = ((mbits[i][j] >> ng) & 1u) ? v : 0.f;
-          e[i] = v * mulA;
-        }
-        if (do_colsum) {
-          float s = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) s += e[i];
-          csum[j] += s;
-        }
-        uint4 hi, lo;
-        split8(e, hi, lo);
-        const int o = lds_off(ng + 32 * j, kg);
-        *reinterpret_cast<uint4*>(st + o) = hi;
-        *reinterpret_cast<uint4*>(st + PLANE_B + o) = lo;
-      }
-    }
-    if (BMODE == 0) {
-      const int o0 = lds_off(srow, 2 * shalf), o1 = lds_off(srow, 2 * shalf + 1);
-      *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o0) = pb0;
-      *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o1) = pb1;
-      *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o0) = pb2;
-      *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o1) = pb3;
-    } else if (!stageA) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = fa[4 * i + j] * sB;
-        uint4 hi, lo;
-        split8(e, hi, lo);
-        const int o = lds_off(ng + 32 * j, kg);
-        *reinterpret_cast<uint4*>(st + 2 * PLANE_B + o) = hi;
-        *reinterpret_cast<uint4*>(st + 3 * PLANE_B + o) = lo;
-      }
-    }
-  };
-
-  // fragment offsets: row R = (wm|wn) * 64 + i * 32 + c -> slot (c & 3) * 32 + base / 4 + (c >> 2); chunk 2 ks + h
-  const int aoff = (((c & 3) * 32 + wm * 16 + (c >> 2)) << 6);
-  const int boff = (((c & 3) * 32 + wn * 16 + (c >> 2)) << 6);
-  const int ch0 = ((0 + h) ^ (c & 3)) << 4, ch1 = ((2 + h) ^ (c & 3)) << 4;
-  auto compute = [&](const char* st) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ks == 0 ? ch0 : ch1;
-      const f16x8 a0 = *reinterpret_cast<const f16x8*>(st + aoff + ch);
-      const f16x8 a1 = *reinterpret_cast<const f16x8*>(st + aoff + 512 + ch);
-      const f16x8 a0l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + ch);
-      const f16x8 a1l = *reinterpret_cast<const f16x8*>(st + PLANE_B + aoff + 512 + ch);
-      const f16x8 b0 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + ch);
-      const f16x8 b1 = *reinterpret_cast<const f16x8*>(st + 2 * PLANE_B + boff + 512 + ch);
-      const f16x8 b0l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + ch);
-      const f16x8 b1l = *reinterpret_cast<const f16x8*>(st + 3 * PLANE_B + boff + 512 + ch);
-      acc[0][0] = MF16(a0l, b0, acc[0][0]);       // small terms first
-      acc[0][1] = MF16(a0l, b1, acc[0][1]);
-      acc[1][0] = MF16(a1l, b0, acc[1][0]);
-      acc[1][1] = MF16(a1l, b1, acc[1][1]);
-      acc[0][0] = MF16(a0, b0l, acc[0][0]);
-      acc[0][1] = MF16(a0, b1l, acc[0][1]);
-      acc[1][0] = MF16(a1, b0l, acc[1][0]);
-      acc[1][1] = MF16(a1, b1l, acc[1][1]);
-      acc[0][0] = MF16(a0, b0, acc[0][0]);
-      acc[0][1] = MF16(a0, b1, acc[0][1]);
-      acc[1][0] = MF16(a1, b0, acc[1][0]);
-      acc[1][1] = MF16(a1, b1, acc[1][1]);
-    }
-  };
-
-  if (nk > 0) {
-    gload(0);
-    sstore(lds);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    compute(lds + cur * STAGE_B);
-    if (kt + 1 < nk) sstore(lds + (cur ^ 1) * STAGE_B);
-    __syncthreads();
-  }
-
-  // bias gradient: this block column (tn == 0) has seen every dy element of its (m-tile, k-slice)
-  if (do_colsum) {
-    float* red = reinterpret_cast<float*>(lds);            // [4 kg][128 columns]; all LDS readers are past the final barrier
-    if (tid < 128) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) red[kg * 128 + ng + 32 * j] = csum[j];
-    }
-    __syncthreads();
-    if (tid < 128) {
-      const int col = m0 + tid;
-      // csum carries the operand scale sA: take it out again
-      const float inv = __uint_as_float((254u << 23) - __float_as_uint(sA));
-      if (col < g.M)
-        g.colsum[(size_t)split * g.colsum_split_stride + col] = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) * inv;
-    }
-    __syncthreads();
-  }
-
-  split_epilogue<AMODE == 0, BMODE == 0>(g, acc, lds, m0, n0, split, sA, sB);
+  split_epilogue<!APLANES, true>(g, acc, lds, m0, n0, split, APLANES ? g.a_scale[0] : 1.f, 1.f);
 }
 
 namespace {
@@ -870,21 +693,20 @@ int convert_rows(const float* src, long ld, long R, int K, const uint32_t* bits,
                      (int)p.rows_p, (int)p.kp, bits, (K + 31) / 32, ascale, vec, p.hi, p.lo, p.rinv);
   return check_launch("gemm_split convert_rows");
 }
-int convert_trn(const float* src, long ld, long M, int C, const uint32_t* bits, float ascale, const Planes& p,
-                float* colsum_part, hipStream_t st) {
-  uint32_t* amax = reinterpret_cast<uint32_t*>(p.rinv + 1);
-  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), st) != hipSuccess) {
-    set_error("gemm_split: memset failed");
-    return HOISDF_ERR_LAUNCH;
-  }
+int tensor_scale(const float* src, long ld, long R, int C, float ascale, float* scal, hipStream_t st);
+// planes of src^T with per-source-row multipliers (see gs_convert_trn_kernel)
+int convert_trn(const float* src, long ld, long M, int C, const float* row_scale, const float* num, int invert,
+                const uint32_t* bits, float ascale, const Planes& p, float* colsum_part, hipStream_t st) {
   const int vec = al16(src) && (ld % 4 == 0) && (C % 4 == 0);
-  long nb = (M + 3) / 4;
-  if (nb > 2048) nb = 2048;
-  if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(gs_amax_kernel, dim3((unsigned)nb), dim3(256), 0, st, src, ld, M, C, vec, amax);
   hipLaunchKernelGGL(gs_convert_trn_kernel, dim3((unsigned)(p.kp / 64), (unsigned)(p.rows_p / 64)), dim3(256), 0, st, src,
-                     ld, (int)M, C, (int)p.kp, amax, bits, (C + 31) / 32, ascale, vec, p.hi, p.lo, p.rinv, colsum_part);
+                     ld, (int)M, C, (int)p.kp, row_scale, num, invert, bits, (C + 31) / 32, ascale, vec, p.hi, p.lo,
+                     colsum_part);
   return check_launch("gemm_split convert_trn");
+}
+// weights: one scale for the tensor; p.rinv[8] = scale, p.rinv[10] = 1 / scale (what the epilogue reads)
+int convert_trn_scalar(const float* src, long ld, long M, int C, const Planes& p, hipStream_t st) {
+  if (int rc = tensor_scale(src, ld, M, C, 1.f, p.rinv + 8, st)) return rc;
+  return convert_trn(src, ld, M, C, nullptr, p.rinv + 8, 0, nullptr, 1.f, p, nullptr, st);
 }
 
 template <typename K>
@@ -893,14 +715,14 @@ bool raise_lds(K kernel) {
                              (int)LDS2_BYTES) == hipSuccess;
 }
 
-template <int AMODE, int BMODE>
+// KIND 0: A f32 k-contiguous (forward, grad-input); 1: A pre-converted planes (grad-weight)
+template <int KIND>
 int launch_fused(FusedArgs g, hipStream_t st) {
-  static_assert(AMODE == BMODE, "supported: k-contiguous A with plane B (forward, grad-input); transposing A and B (grad-weight)");
   static bool attr_set = false;
   if (!attr_set) {
     bool ok;
-    if (AMODE == 0) ok = raise_lds(gemm_split_kc_kernel<false>) && raise_lds(gemm_split_kc_kernel<true>);
-    else ok = raise_lds(gemm_split_fused_kernel<1, 1, false>) && raise_lds(gemm_split_fused_kernel<1, 1, true>);
+    if (KIND == 0) ok = raise_lds(gemm_split_kc_kernel<false, false>) && raise_lds(gemm_split_kc_kernel<true, false>);
+    else ok = raise_lds(gemm_split_kc_kernel<false, true>);
     if (!ok) {
       set_error("gemm_split: cannot raise the dynamic LDS limit to %u bytes", LDS2_BYTES);
       return HOISDF_ERR_LAUNCH;
@@ -909,18 +731,15 @@ int launch_fused(FusedArgs g, hipStream_t st) {
   }
   g.tiles_m = cdiv(g.M, TM);
   g.tiles_n = cdiv(g.N, TN);
-  g.vecA = al16(g.A) && (g.lda % 4 == 0);
   g.vecC = al16(g.C) && (g.ldc % 4 == 0) && (g.c_split_stride % 4 == 0);
   const int ntile = g.tiles_m * g.tiles_n;
   const int nwg = g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile;
-  if (AMODE == 0) {
-    if (g.abits) hipLaunchKernelGGL(gemm_split_kc_kernel<true>, dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
-    else hipLaunchKernelGGL(gemm_split_kc_kernel<false>, dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+  const dim3 grid((unsigned)nwg), block(256);
+  if (KIND == 0) {
+    if (g.abits) hipLaunchKernelGGL((gemm_split_kc_kernel<true, false>), grid, block, LDS2_BYTES, st, g);
+    else hipLaunchKernelGGL((gemm_split_kc_kernel<false, false>), grid, block, LDS2_BYTES, st, g);
   } else {
-    if (g.abits)
-      hipLaunchKernelGGL((gemm_split_fused_kernel<1, 1, true>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
-    else
-      hipLaunchKernelGGL((gemm_split_fused_kernel<1, 1, false>), dim3((unsigned)nwg), dim3(256), LDS2_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_split_kc_kernel<false, true>), grid, block, LDS2_BYTES, st, g);
   }
   return check_launch("gemm_split");
 }
@@ -969,12 +788,16 @@ extern "C" long hoisdf_linear_split_workspace(long M, int N, int K, int which) {
   } else if (which == 1) {             // grad-input: row scales of dy, W^T planes
     c.take<float>((size_t)M);
     take_trn(c, N, K);
-  } else {                             // grad-weight: two tensor scales, partial tiles, bias-gradient partials
+  } else {                             // grad-weight: row scales of x and dy, scalars, dy^T and x^T planes, partials
+    c.take<float>((size_t)M);
+    c.take<float>((size_t)M);
     c.take<float>(64);
+    Planes a = take_trn(c, M, N);
+    take_trn(c, M, K);
     int splitk, kper;
-    plan_split(M, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
+    plan_split(a.kp, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
     if (splitk > 1) c.take<float>((size_t)splitk * N * K);
-    c.take<float>((size_t)splitk * N);
+    c.take<float>((size_t)(a.kp / 64) * N);
   }
   return (long)((c.off + 255) & ~(size_t)255);
 }
@@ -1002,7 +825,7 @@ extern "C" int hoisdf_linear_fwd_split(const float* x, int ldx, const float* W, 
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
   g.splitk = 1; g.k_per_split = (int)up(K, KS);
-  return launch_fused<0, 0>(g, st);
+  return launch_fused<0>(g, st);
 }
 
 extern "C" int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
@@ -1022,20 +845,21 @@ extern "C" int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const ui
   Planes B = take_trn(c, N, K);
   const float ascale = 1.f / (1.f - drop_p);
   if (int rc = row_scales(dy, lddy, M, N, relu_bits, ascale, ds, st)) return rc;
-  if (int rc = convert_trn(W, ldw, N, K, nullptr, 1.f, B, nullptr, st)) return rc;
+  if (int rc = convert_trn_scalar(W, ldw, N, K, B, st)) return rc;
   FusedArgs g{};
   g.A = dy; g.lda = lddy; g.a_scale = ds; g.a_rs = 1; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = ascale;
-  g.Bh = B.hi; g.Bl = B.lo; g.ldb = B.kp; g.b_rinv = B.rinv; g.b_rs = 0;
+  g.Bh = B.hi; g.Bl = B.lo; g.ldb = B.kp; g.b_rinv = B.rinv + 10; g.b_rs = 0;
   g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N;
   g.inv_keep = 1.f;
   g.splitk = 1; g.k_per_split = (int)up(N, KS);
   g.beta = accumulate ? 1 : 0;
-  return launch_fused<0, 0>(g, st);
+  return launch_fused<0>(g, st);
 }
 
 extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                               const float* x, int ldx, float* dW, int lddw, float* db, long M, int N, int K,
-                                              void* workspace, long workspace_bytes, void* stream) {
+                                              const float* x_row_scale, const float* dy_row_scale, void* workspace,
+                                              long workspace_bytes, void* stream) {
   HOISDF_REQUIRE(dW && (M == 0 || (dy && x)), HOISDF_ERR_INVALID, "linear_bwd_weight_split: null pointer");
   HOISDF_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw == K && M < (1L << 31) && drop_p >= 0.f &&
                      drop_p < 1.f,
@@ -1044,24 +868,49 @@ extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const u
                  "linear_bwd_weight_split: workspace too small");
   hipStream_t st = as_stream(stream);
   Carver c{static_cast<char*>(workspace), 0};
-  // dW[n][k] = sum_m dy[m][n] x[m][k]: both operands are read transposed (source rows = contraction), one scale each
-  float* scal = c.take<float>(64);               // [0] dy scale, [1] scratch, [8] x scale, [9] scratch
+  // dW[n][k] = sum_m dy[m][n] x[m][k] = (1 / p) sum_m (dy[m][n] p / sx[m]) (x[m][k] sx[m]),  p = min_m sx[m] sd[m]:
+  // x rows are normalised by their own scale sx[m]; dy rows get p / sx[m], which keeps them below the row-normalised
+  // dy sd[m] (<= 2^15) and leaves every row with a magnitude proportional to its contribution to dW.  Both operands are
+  // written once as transposed hi / lo planes; the GEMM is the plane x plane form of the forward kernel, split along m.
+  float* sx = c.take<float>((size_t)M);
+  float* sd = c.take<float>((size_t)M);
+  float* scal = c.take<float>(64);               // [0] p, [1] 1 / p, [2] 1.0
+  Planes A = take_trn(c, M, N), B = take_trn(c, M, K);
   int splitk, kper;
-  plan_split(M, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
+  plan_split(A.kp, cdiv(N, TM) * cdiv(K, TN), splitk, kper);
   float* part = splitk > 1 ? c.take<float>((size_t)splitk * N * K) : nullptr;
-  float* cpart = c.take<float>((size_t)splitk * N);
+  float* cpart = c.take<float>((size_t)(A.kp / 64) * N);
   const float ascale = 1.f / (1.f - drop_p);
-  if (int rc = tensor_scale(dy, lddy, M, N, ascale, scal, st)) return rc;
-  if (int rc = tensor_scale(x, ldx, M, K, 1.f, scal + 8, st)) return rc;
+  if (!x_row_scale) {
+    if (int rc = row_scales(x, ldx, M, K, nullptr, 1.f, sx, st)) return rc;
+    x_row_scale = sx;
+  }
+  if (!dy_row_scale) {
+    if (int rc = row_scales(dy, lddy, M, N, relu_bits, ascale, sd, st)) return rc;
+    dy_row_scale = sd;
+  }
+  const uint32_t init[3] = {0x7f7fffffu, 0u, 0x3f800000u};
+  // (a host array copied by hipMemcpyAsync would not be stream-ordered with a pageable source: three 4-byte memsets)
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scal), init[0], 1, st) != hipSuccess ||
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scal + 2), init[2], 1, st) != hipSuccess) {
+    set_error("linear_bwd_weight_split: memset failed");
+    return HOISDF_ERR_LAUNCH;
+  }
+  long nb = (M + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(gs_min_product_kernel, dim3((unsigned)nb), dim3(256), 0, st, x_row_scale, dy_row_scale, M,
+                     reinterpret_cast<uint32_t*>(scal));
+  hipLaunchKernelGGL(gs_min_product_finish_kernel, dim3(1), dim3(1), 0, st, scal);
+  if (int rc = convert_trn(dy, lddy, M, N, x_row_scale, scal, 1, relu_bits, ascale, A, db ? cpart : nullptr, st)) return rc;
+  if (int rc = convert_trn(x, ldx, M, K, x_row_scale, nullptr, 0, nullptr, 1.f, B, nullptr, st)) return rc;
   FusedArgs g{};
-  g.A = dy; g.lda = lddy; g.a_scale = scal; g.a_rs = 0; g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = ascale;
-  g.Bf = x; g.ldb = ldx; g.b_scale = scal + 8;
-  g.colsum = db ? cpart : nullptr; g.colsum_split_stride = N;
-  g.M = N; g.N = K; g.K = (int)M; g.inv_keep = 1.f;
+  g.Ah = A.hi; g.Al = A.lo; g.lda = A.kp; g.a_scale = scal; g.a_rs = 0;
+  g.Bh = B.hi; g.Bl = B.lo; g.ldb = B.kp; g.b_rinv = scal + 2; g.b_rs = 0;
+  g.M = N; g.N = K; g.K = (int)A.kp; g.inv_keep = 1.f;
   g.splitk = splitk; g.k_per_split = kper;
   if (splitk > 1) { g.C = part; g.ldc = K; g.c_split_stride = (long)N * K; }
   else { g.C = dW; g.ldc = lddw; }
-  if (int rc = launch_fused<1, 1>(g, st)) return rc;
+  if (int rc = launch_fused<1>(g, st)) return rc;
   if (splitk > 1) {
     const long n = (long)N * K;
     int blocks = (int)((n / 4 + 255) / 256);
@@ -1069,6 +918,6 @@ extern "C" int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const u
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(gs_reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, part, n, splitk, dW, n);
   }
-  if (db) hipLaunchKernelGGL(gs_colsum_reduce_kernel, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, cpart, splitk, N, db);
+  if (db) hipLaunchKernelGGL(gs_colsum_reduce_kernel, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, st, cpart, (int)(A.kp / 64), N, db);
   return check_launch("linear_bwd_weight_split reduce");
 }

@@ -198,6 +198,7 @@ def project_gather(pyr: PyramidNHWC, points, center, cam_intr, scale, img_hw=(25
 # ---------------------------------------------------------------------------------------------
 _GEMM_SPLIT = False
 _GEMM_SPLIT_MIN_ROWS = 2048          # below this the problem is a few tiles: latency-bound, stays on the f32 kernel
+_GEMM_SPLIT_DW_MIN = 512             # grad-weight: narrower outputs stay on the f32 kernel (see _gemm_bwd_weight)
 
 
 def set_gemm_split(on: bool) -> None:
@@ -242,15 +243,18 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
              int(accumulate), _st())
 
 
-def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K):
+def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None):
     """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the split form overwrites."""
     # the split grad-weight kernel converts both (transposed) operands once per output tile: it only beats the f32 kernel
     # when the output is wide enough to amortise that (tools/mb_gsplit.py: 65536x512x992 599 vs 657 us, 16384x512x3968
     # 894 vs 1095 us, but 65536x768x256 373 vs 293 us)
-    if _split_ok(M, N, K) and min(N, K) >= 512 and dW.stride(0) == K:
+    # the split grad-weight has to write both operands as transposed planes first: it only beats the f32 kernel when the
+    # output is wide enough to amortise that (tools/mb_gsplit.py: 65536x512x992 537 vs 649 us, 16384x512x3968 608 vs 1082 us,
+    # but 65536x768x256 379 vs 285 us) - the 256-wide transformer shapes stay on the f32 kernel
+    if _split_ok(M, N, K) and min(N, K) >= _GEMM_SPLIT_DW_MIN and dW.stride(0) == K:
         ws, nb = _split_ws(M, N, K, 2, dW.device)
         call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
-             _p(ws), nb, _st())
+             _p(x_scale), _p(dy_scale), _p(ws), nb, _st())
         return
     ws, nws = None, 0
     if deterministic():             # partial tiles + ordered reduce instead of split-k atomics

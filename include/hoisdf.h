@@ -121,7 +121,11 @@ int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bit
  * power-of-two operand scaling: ~21-22 significant bits per operand instead of 24) - NOT bit-compatible with the f32
  * entries, within 1e-6 relative of them on the model's shapes.  Each call converts its operands into `workspace`
  * (hoisdf_linear_split_workspace(M, N, K, which) BYTES; which = 0 forward, 1 grad-input, 2 grad-weight) and runs one GEMM
- * kernel.  Grad-weight: dW (dense, lddw == K) and db are fully OVERWRITTEN, order-fixed (no atomics). */
+ * kernel.  Forward / grad-input read the f32 activations directly (a one-read pre-pass finds the per-row power-of-two scales,
+ * left in workspace[0..M) as floats; the rows are split into hi / lo on their way into LDS).  Grad-weight writes both
+ * operands once as transposed hi / lo planes; it needs the row scales of x and dy and recomputes them unless the caller
+ * hands over the ones the forward / grad-input calls left behind.  dW (dense, lddw == K) and db are fully OVERWRITTEN,
+ * order-fixed (no atomics). */
 long hoisdf_linear_split_workspace(long M, int N, int K, int which);
 int hoisdf_linear_fwd_split(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy,
                             long M, int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits,
@@ -130,8 +134,10 @@ int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const uint32_t* rel
                                   int ldw, float* dx, int lddx, long M, int N, int K, int accumulate, void* workspace,
                                   long workspace_bytes, void* stream);
 int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
-                                   int ldx, float* dW, int lddw, float* db, long M, int N, int K, void* workspace,
-                                   long workspace_bytes, void* stream);
+                                   int ldx, float* dW, int lddw, float* db, long M, int N, int K,
+                                   const float* x_row_scale /* optional: workspace[0..M) floats of the forward call on x */,
+                                   const float* dy_row_scale /* optional: workspace[0..M) floats of the grad-input call on dy */,
+                                   void* workspace, long workspace_bytes, void* stream);
 /* dpre = dy * (y > 0) * 1/(1-p): backward of relu followed by dropout, given the
  * post-dropout output y (an element is kept-and-positive iff y > 0).  In place allowed. */
 int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,

@@ -74,7 +74,12 @@ def test_linear_split_precision_matches_fp64(M, N, K, act, p):
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).requires_grad_(True)
     b = (torch.randn(N, generator=g) * 1e-3).to(DEV).requires_grad_(True)
     gy = (torch.randn(M, N, generator=g) * 1e-5 * decades(M)).to(DEV)
+    gy[::7] = 0.0                                              # all-zero gradient rows (masked samples) ...
+    with torch.no_grad():
+        x[5::11] = 0.0                                         # ... and all-zero activation rows must not cost the others bits
     O.set_gemm_split(True)
+    keep_min = O._GEMM_SPLIT_DW_MIN
+    O._GEMM_SPLIT_DW_MIN = 64                          # also the ragged / narrow shapes through the split grad-weight
     try:
         y = O.linear(x, W, b, act=act, drop_p=p)
         y.backward(gy)
@@ -83,6 +88,7 @@ def test_linear_split_precision_matches_fp64(M, N, K, act, p):
         O._lin_bwd_input(gy, None, 0.0, W.detach(), dx_acc, True)
     finally:
         O.set_gemm_split(False)
+        O._GEMM_SPLIT_DW_MIN = keep_min
     pre = x.detach().double() @ W.detach().double().t() + b.detach().double()
     if act:
         kept = y.detach() > 0                                  # the kernel's own ReLU / dropout decisions

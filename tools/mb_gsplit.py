@@ -74,6 +74,9 @@ if __name__ == "__main__":
     print(lib().hoisdf_version().decode())
     if "--one" in sys.argv:
         SHAPES = SHAPES[:1]
+    if "--shape" in sys.argv:
+        i = int(sys.argv[sys.argv.index("--shape") + 1])
+        SHAPES = SHAPES[i:i + 1]
     for (M, N, K) in SHAPES:
         print(f"M={M} N={N} K={K}")
         run(M, N, K, check="--no-check" not in sys.argv)
