@@ -483,7 +483,8 @@ __device__ __forceinline__ void split_epilogue(const FusedArgs& g, f32x16 (&acc)
 // (fixed per-thread VGPR offset + a scalar k offset: no address arithmetic in the loop, out-of-buffer reads return 0) into
 // TWO register sets, so that the slab consumed in iteration kt + 2 is requested in iteration kt: a load has two iterations
 // (~3000 cycles with two waves per SIMD) to land.  With a distance of one the 768 MFMA cycles of a slab did not cover the
-// load latency under load (measured: 4900 cycles per slab iteration).
+// load latency under load (measured: 4900 cycles per slab iteration).  A third set (distance 3) does not fit: 3 x 33
+// staging + 64 accumulator + 64 fragment registers spill at the 256-register budget of two waves per SIMD.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <bool MASK, bool APLANES>
@@ -632,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   // branch the compiler has to assume the shorter load queue at the merge point and waits for the just-issued loads too.
   const int last = nk - 1;
   KC_LOAD(p, 0);
+  KC_LOAD(q, min(1, last));           // both requests out before the first wait
   KC_STORE(lds, p, 0);
-  KC_LOAD(q, min(1, last));
   __syncthreads();
   // iteration kt (even): request slab kt + 2 into p, compute stage 0, park q (slab kt + 1) in stage 1; odd: mirrored
   for (int kt = 0; kt < nk; kt += 2) {
