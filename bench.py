@@ -325,13 +325,15 @@ def main():
         if args.shape_report:
             print("\n".join(timer.by_shape(timed_steps)), file=sys.stderr)
         # kernel families = device kernels: the three linear entry points are ONE kernel template (gemm_f32_kernel)
+        sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's split switch
         fams = {"gemm_f32_kernel (linear fwd + grad-input + grad-weight)":
-                    ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight", "hoisdf_sdf_query_fwd"],
+                    ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if args.gemm == "split" else sq),
                 "attn_fwd_kernel": ["hoisdf_attention_fwd"],
                 "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
                 "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"],
                 "gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)":
-                    ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"],
+                    ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] +
+                    (sq if args.gemm == "split" else []),
                 "split_fwd_kernel (+ conversion passes)": ["hoisdf_attention_fwd_split"],
                 "split_bwd_dkv + split_bwd_dq (+ conversion passes)": ["hoisdf_attention_bwd_split"]}
         agg = {}

@@ -63,6 +63,7 @@ static inline uint32_t drop_threshold(float p) {
 //   LayerNorm / SDF head / sigma-gate backward -> parked per block and summed in block order by the last block
 //   to arrive (block_column_sum below, library-owned scratch: deterministic mode is single-stream).
 bool deterministic_mode();
+bool gemm_split_mode();           // hoisdf_set_gemm_split: the contractions INSIDE composite entries (sdf_query) in split precision
 struct DetScratch {
   float* part;          // [gridDim.x][ncols] partials
   unsigned* ticket;     // arrival counter, zero between launches

@@ -26,6 +26,9 @@ int check_launch(const char* what) {
 }
 
 static int g_det = -1;          // -1: not decided yet (environment), 0 / 1
+static int g_gemm_split = 0;    // library-internal contractions (hoisdf_sdf_query_fwd) in split precision
+
+bool gemm_split_mode() { return g_gemm_split != 0; }
 
 bool deterministic_mode() {
   if (g_det < 0) {
@@ -57,6 +60,8 @@ DetScratch det_scratch(size_t floats) {
 
 }  // namespace hoisdf
 
+extern "C" void hoisdf_set_gemm_split(int on) { hoisdf::g_gemm_split = on ? 1 : 0; }
+extern "C" int hoisdf_get_gemm_split(void) { return hoisdf::g_gemm_split; }
 extern "C" void hoisdf_set_deterministic(int on) { hoisdf::g_det = on ? 1 : 0; }
 extern "C" int hoisdf_get_deterministic(void) { return hoisdf::deterministic_mode() ? 1 : 0; }
 extern "C" const char* hoisdf_version(void) { return "hoisdf-hip 0.1 (gfx950)"; }

@@ -10,7 +10,7 @@
 //     [h1 | x0] of common/nets/sdf_net.py:104-106 is the row itself - layer 2 contracts all 516 columns with a
 //     column-padded weight matrix (zeros under the pad columns);
 //   * the weight-norm fold of the four decoder layers is done once by the caller (cached across calls in eval mode).
-// The contractions themselves stay on gemm_f32_kernel: at ~1.7 kFLOP per byte of activations these layers are
+// The contractions themselves stay on gemm_f32_kernel (or, under hoisdf_set_gemm_split, the split-precision GEMM): at ~1.7 kFLOP per byte of activations these layers are
 // MFMA-bound, and a monolithic kernel that keeps a point tile's 512-wide activations on-chip is limited to 64-row
 // tiles by the 160 KB LDS (64 x 512 x 4 B = 128 KB + weight slab), i.e. 30 FLOP per streamed weight byte and two waves
 // per SIMD - measured/estimated below the 105-120 TF the tiled GEMM reaches on these shapes.
@@ -21,13 +21,28 @@ using namespace hoisdf;
 namespace {
 constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, X0P = 292, CAT_LD = 516, X0_COL = 224;
 inline long align64(long v) { return (v + 63) / 64 * 64; }
+// scratch of the split-precision form of the six layers (hoisdf_set_gemm_split): the largest of their workspaces
+inline long split_scratch_bytes(long n_rows, int C) {
+  long m = hoisdf_linear_split_workspace(n_rows, HID0, C, 0);
+  const long o = hoisdf_linear_split_workspace(n_rows, HID0, CAT_LD, 0);
+  return m > o ? m : o;
+}
+constexpr long SPLIT_MIN_ROWS = 2048;
+
+// one layer: exact-f32 MFMA GEMM, or (library switch, large point sets) the split-precision GEMM
+int layer(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, long M, int N, int K,
+          float drop_p, uint64_t seed, void* scratch, long scratch_bytes, void* stream) {
+  if (scratch && M >= SPLIT_MIN_ROWS)
+    return hoisdf_linear_fwd_split(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, scratch, scratch_bytes, stream);
+  return hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, stream);
+}
 }  // namespace
 
 extern "C" long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat) {
   if (n_rows <= 0 || C <= 0) return 0;
   long fl = align64(n_rows * HID0) * 2 + align64(n_rows * CAT_LD);
   if (need_feat) fl += align64(n_rows * (long)C);
-  return fl * (long)sizeof(float);
+  return fl * (long)sizeof(float) + split_scratch_bytes(n_rows, C);
 }
 
 extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
@@ -52,6 +67,8 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   float* hb = ha + align64(n_rows * HID0);
   float* cat = hb + align64(n_rows * HID0);
   float* feat_ws = cat + align64(n_rows * CAT_LD);
+  const long sbytes = split_scratch_bytes(n_rows, C);
+  void* scratch = gemm_split_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - sbytes)) : nullptr;
   int rc;
   // K1 (unless the caller shares its gathered rows)
   const float* feat = feat_in;
@@ -66,22 +83,22 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   }
   float* x0 = cat + X0_COL;
   // K2: linear_sdfin (main/model.py:63-69): C -> 512 -> 256, ReLU after both; the second layer lands in x0[:, 0:256]
-  rc = hoisdf_linear_fwd(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, 1, 0.f, 0, nullptr, stream);
+  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, 0.f, 0, scratch, sbytes, stream);
   if (rc) return rc;
-  rc = hoisdf_linear_fwd(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, 1, 0.f, 0, nullptr, stream);
+  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, 0.f, 0, scratch, sbytes, stream);
   if (rc) return rc;
   // K3: posenc + xyz into x0[:, 256:289], pad columns 289..291 zeroed (common/utils/sdf_utils.py:96-141)
   rc = hoisdf_posenc_fwd(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, stream);
   if (rc) return rc;
   // K4: decoder (common/nets/sdf_net.py:87-122); dropout(p) after every hidden ReLU when the module is in train() mode
   // (the reference's detached training-time queries run with it on), stream ids seed + layer
-  rc = hoisdf_linear_fwd(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, 1, drop_p, seed, nullptr, stream);
+  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, drop_p, seed, scratch, sbytes, stream);
   if (rc) return rc;
-  rc = hoisdf_linear_fwd(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, 1, drop_p, seed + 1, nullptr, stream);
+  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, drop_p, seed + 1, scratch, sbytes, stream);
   if (rc) return rc;
-  rc = hoisdf_linear_fwd(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, 1, drop_p, seed + 2, nullptr, stream);
+  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, drop_p, seed + 2, scratch, sbytes, stream);
   if (rc) return rc;
-  rc = hoisdf_linear_fwd(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, 1, drop_p, seed + 3, nullptr, stream);
+  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, drop_p, seed + 3, scratch, sbytes, stream);
   if (rc) return rc;
   return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
 }

@@ -207,6 +207,8 @@ def set_gemm_split(on: bool) -> None:
     path is exact fp32."""
     global _GEMM_SPLIT
     _GEMM_SPLIT = bool(on)
+    from ._lib import lib
+    lib().hoisdf_set_gemm_split(int(_GEMM_SPLIT))          # the layers inside hoisdf_sdf_query_fwd follow
 
 
 def gemm_split() -> bool:

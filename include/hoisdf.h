@@ -66,6 +66,11 @@ const char* hoisdf_last_error(void);
  * results.  Contract: one stream at a time (the ordered block reductions share a library-owned scratch); grad-weight is
  * order-fixed only when the caller passes the workspace (hoisdf_linear_bwd_weight_workspace). */
 void hoisdf_set_deterministic(int on);
+/* Split-precision switch for the contractions INSIDE composite entries (today: the six layers of hoisdf_sdf_query_fwd run
+ * hoisdf_linear_fwd_split instead of hoisdf_linear_fwd for >= 2048 points).  Off by default; the host mirror turns it on
+ * together with cfg.gemm_split.  The per-layer entries are chosen by the caller and are not affected. */
+void hoisdf_set_gemm_split(int on);
+int hoisdf_get_gemm_split(void);
 int hoisdf_get_deterministic(void);
 
 /* ---- K1: pinhole projection + 5-level bilinear gather --------------------------------

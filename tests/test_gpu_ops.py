@@ -593,6 +593,37 @@ def test_attention_few_queries_kernel_incl_dropout():
     assert abs(float(od.mean()) - 1.0) < 0.03
 
 
+def test_sdf_query_split_precision_layers():
+    """hoisdf_set_gemm_split: the six layers inside hoisdf_sdf_query_fwd in split precision (>= 2048 points) against the
+    exact-f32 call on the same inputs - 5e-6 of the field's range, ragged K = 289 / N = 224 / ld = 516 layers included."""
+    from hoisdf_amd.model import get_model
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.nets import mano as MANO
+    O = ops()
+    c = Config(); c.resnet_type = 18; c.apply_setting("dexycb"); c.num_samp_hand, c.num_samp_obj = 1200, 100
+    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
+    sd = model.state_dict()
+    for k in sd:
+        if not k.startswith("mano_head"):
+            sd[k] = T.det_param(k, sd[k].shape)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    B, P = 2, 1200                                               # 2400 rows: above the 2048-row threshold, not a tile multiple
+    pyr = O.PyramidNHWC([v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in T.synthetic_pyramid(B, seed=4).values()])
+    inputs, _, meta = T.synthetic_batch(B, P, 8, seed=5)
+    pts = (inputs["hand_sdf_points"] * 1.2).to(DEV)
+    root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
+    with torch.no_grad():
+        ref_sdf, ref_raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
+        O.set_gemm_split(True)
+        try:
+            sdf, raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
+        finally:
+            O.set_gemm_split(False)
+    assert not torch.equal(raw, ref_raw)                          # the split path really ran
+    assert_close(raw, ref_raw, rel=5e-6, what="raw"); assert_close(sdf, ref_sdf, rel=5e-6, what="sdf")
+
+
 def test_sdf_query_one_call_matches_the_op_chain():
     """hoisdf_sdf_query_fwd (K1-K4 in one C-ABI call, in-place concatenations, optional shared gather) against the
     differentiable op chain the model uses where gradients are needed, and against the oracle."""
