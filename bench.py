@@ -196,6 +196,7 @@ def main():
     cfg.attention_f16_eval = args.config == 4
     cfg.attention_split = train and args.attention == "split"
     cfg.gemm_split = train and args.gemm == "split"
+    cfg.gemm_split_eval = (not train) and args.gemm == "split"
     torch.manual_seed(0)           # identical initial weights on every rank
     model = get_model("train" if train else "test", cfg=cfg).to(dev).train(train)
     if args.channels_last:

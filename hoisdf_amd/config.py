@@ -38,6 +38,7 @@ class Config:
     # not in the reference: BASELINE.json configs[4] ("fp16 MFMA attention"): f16-operand attention kernel for
     # gradient-free forward passes (mode != "train"); off = exact f32 everywhere (the parity configuration)
     attention_f16_eval = False
+    gemm_split_eval = False      # the same for inference (the dense-lattice SDF query of sdf_infer is GEMM-bound); off: exact f32
     gemm_split = False           # training linear layers (fwd, grad-input, grad-weight) on the 16-bit MFMA pipe, f16 hi+lo split operands (csrc/gemm_split.hip)
     attention_split = False      # training attention on the 16-bit MFMA pipe with f16 hi+lo split operands (csrc/attention_split.hip)
     # not in the reference: run the object transformer stack on a second HIP stream next to the hand stack

@@ -373,7 +373,7 @@ class Model(nn.Module):
         pyr = self._pyramid(feature_pyramid)
         ops.set_attention_f16_eval(bool(getattr(c, "attention_f16_eval", False)) and mode != "train")
         ops.set_attention_split(bool(getattr(c, "attention_split", False)) and mode == "train")
-        ops.set_gemm_split(bool(getattr(c, "gemm_split", False)) and mode == "train")
+        ops.set_gemm_split(bool(getattr(c, "gemm_split", False)) if mode == "train" else bool(getattr(c, "gemm_split_eval", False)))
         loss, out = self.hot_path(pyr, inputs, targets, meta_info, mode, epoch_cnt, batch_ratio)
         if mode == "train" or c.dataset == "dexycb":                                   # :404-422 aux image losses
             out["joint_heatmap_out"] = decoder_out[:, 0]

@@ -861,7 +861,11 @@ class _EncoderLayer(torch.autograd.Function):
             q = qbuf.view(B, nq, E)
             kv3 = kvbuf.view(B, S, 2 * E)
             k, v = kv3[:, :, :E], kv3[:, :, E:]
-        o, lse = (_attn_fwd_split if split else _attn_fwd)(q, k, v, H, S, p, s_attn)
+        if _use_f16(p, x, w_in, w_out, w1, w2):
+            # gradient-free eval with cfg.attention_f16_eval: the f16-operand kernel (no LSE: nothing is saved for a backward)
+            o, lse = _attn_fwd_f16(q, k, v, H, S), None
+        else:
+            o, lse = (_attn_fwd_split if split else _attn_fwd)(q, k, v, H, S, p, s_attn)
         M = B * nq
         a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
         xq2 = xq.view(M, E)

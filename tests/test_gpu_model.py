@@ -224,9 +224,11 @@ def test_bench_distributed_path_single_rank_rccl():
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
 
 
-def test_eval_with_f16_mfma_attention_meets_the_joint_bar():
+@pytest.mark.parametrize("gemm", [False, True])
+def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm):
     """BASELINE configs[4] ("fp16 MFMA attention"): with the f16-operand attention kernel switched on, the eval
-    forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m."""
+    forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m.  gemm=True: the linear layers
+    (the dense-lattice SDF query included) in split precision as well (cfg.gemm_split_eval)."""
     from hoisdf_amd import ops
     setting, nh, no, bins, b = "dexycb", 384, 128, 64, 1
     g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
@@ -234,14 +236,20 @@ def test_eval_with_f16_mfma_attention_meets_the_joint_bar():
     pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=2))
     inputs, targets, meta = (T.to_device(x, DEV) for x in T.synthetic_batch(b, nh, no, seed=21))
     ops.set_attention_f16_eval(True)
+    ops.set_gemm_split(gemm)
     try:
         with torch.no_grad():
             loss, out = model.hot_path(pyr, inputs, targets, meta, "eval")
     finally:
         ops.set_attention_f16_eval(False)
+        ops.set_gemm_split(False)
     for k in ("hand_joints_out", "mano_joints_out", "mano_mesh_out"):
         err = (out[k].float().cpu() - g[k]).abs().max().item()
         assert err <= 1e-4, f"{k}: {err:.3e}"
+    # the switches really select other kernels (the fused encoder-layer node once bypassed the f16 attention silently)
+    with torch.no_grad():
+        _, out32 = model.hot_path(pyr, inputs, targets, meta, "eval")
+    assert not torch.equal(out32["hand_joints_out"], out["hand_joints_out"])
 
 
 def test_c_host_allreduce():
