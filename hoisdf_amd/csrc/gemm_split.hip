@@ -22,6 +22,8 @@
 // Measured (MI355X, tools/mb_gsplit.py, pre-passes included): forward / grad-input 160-215 TF-equivalent against 88-101
 // for the f32 kernel; grad-weight 110-124 against 61-103 when min(N, K) >= 512, but NO gain for the 256-wide transformer
 // shapes (the two conversion passes cost what the contraction saves), which therefore stay on the f32 kernel.
+#include <stdlib.h>
+
 #include "common.h"
 #include <hip/hip_fp16.h>
 
@@ -509,8 +511,11 @@ __device__ __forceinline__ void split_epilogue(const FusedArgs& g, f32x16 (&acc)
 // staging + 64 accumulator + 64 fragment registers spill at the 256-register budget of two waves per SIMD.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool MASK, bool APLANES>
-__global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
+template <bool MASK, bool APLANES, int WGS>
+__global__ __launch_bounds__(256, WGS) void gemm_split_kc_kernel(FusedArgs g) {
+  // WGS = 2: two LDS stages (64 KB), one barrier per slab.  WGS = 3: ONE stage (32 KB) and <= 168 VGPRs, a second barrier
+  // per slab, three workgroups per CU to cover the load latency of the short (K = 256) contractions.
+  constexpr int S1 = WGS == 3 ? 0 : STAGE_B;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -662,11 +667,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kc_kernel(FusedArgs g) {
   for (int kt = 0; kt < nk; kt += 2) {
     KC_LOAD(p, min(kt + 2, last));
     compute(lds);
-    if (kt + 1 < nk) KC_STORE(lds + STAGE_B, q, kt + 1);
+    if (WGS == 3) __syncthreads();
+    if (kt + 1 < nk) KC_STORE(lds + S1, q, kt + 1);
     __syncthreads();
     if (kt + 1 < nk) {
       KC_LOAD(q, min(kt + 3, last));
-      compute(lds + STAGE_B);
+      compute(lds + S1);
+      if (WGS == 3) __syncthreads();
       if (kt + 2 < nk) KC_STORE(lds, p, kt + 2);
       __syncthreads();
     }
@@ -742,10 +749,12 @@ bool raise_lds(K kernel) {
 template <int KIND>
 int launch_fused(FusedArgs g, hipStream_t st) {
   static bool attr_set = false;
+  static int wgs = 0;             // 0: rule below, 2 / 3: forced (HOISDF_GSPLIT_WG, experiments)
   if (!attr_set) {
+    if (const char* e = getenv("HOISDF_GSPLIT_WG")) wgs = atoi(e) == 3 ? 3 : (atoi(e) == 2 ? 2 : 0);
     bool ok;
-    if (KIND == 0) ok = raise_lds(gemm_split_kc_kernel<false, false>) && raise_lds(gemm_split_kc_kernel<true, false>);
-    else ok = raise_lds(gemm_split_kc_kernel<false, true>);
+    if (KIND == 0) ok = raise_lds(gemm_split_kc_kernel<false, false, 2>) && raise_lds(gemm_split_kc_kernel<true, false, 2>);
+    else ok = raise_lds(gemm_split_kc_kernel<false, true, 2>);
     if (!ok) {
       set_error("gemm_split: cannot raise the dynamic LDS limit to %u bytes", LDS2_BYTES);
       return HOISDF_ERR_LAUNCH;
@@ -758,11 +767,21 @@ int launch_fused(FusedArgs g, hipStream_t st) {
   const int ntile = g.tiles_m * g.tiles_n;
   const int nwg = g.splitk > 1 ? ntile * 8 * cdiv(g.splitk, 8) : ntile;
   const dim3 grid((unsigned)nwg), block(256);
+  // three workgroups per CU (single LDS stage, 168 VGPRs): measured +5...+9 % on the unmasked K = 256 forwards
+  // (65536x768x256 151 -> 138 us, x1024x256 190 -> 181 us), -1...-20 % with the sign bitmap or K >= 512 (spills, two
+  // barriers per slab) - tools/mb_gsplit.py with HOISDF_GSPLIT_WG=3
+  const bool three = wgs == 3 ? g.K <= 512 : (wgs == 0 && KIND == 0 && !g.abits && g.K <= 256);
+  const unsigned lb = three ? (unsigned)STAGE_B : LDS2_BYTES;
   if (KIND == 0) {
-    if (g.abits) hipLaunchKernelGGL((gemm_split_kc_kernel<true, false>), grid, block, LDS2_BYTES, st, g);
-    else hipLaunchKernelGGL((gemm_split_kc_kernel<false, false>), grid, block, LDS2_BYTES, st, g);
+    if (three) {
+      if (g.abits) hipLaunchKernelGGL((gemm_split_kc_kernel<true, false, 3>), grid, block, lb, st, g);
+      else hipLaunchKernelGGL((gemm_split_kc_kernel<false, false, 3>), grid, block, lb, st, g);
+    } else {
+      if (g.abits) hipLaunchKernelGGL((gemm_split_kc_kernel<true, false, 2>), grid, block, lb, st, g);
+      else hipLaunchKernelGGL((gemm_split_kc_kernel<false, false, 2>), grid, block, lb, st, g);
+    }
   } else {
-    hipLaunchKernelGGL((gemm_split_kc_kernel<false, true>), grid, block, LDS2_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_split_kc_kernel<false, true, 2>), grid, block, LDS2_BYTES, st, g);
   }
   return check_launch("gemm_split");
 }
