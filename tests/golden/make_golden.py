@@ -212,7 +212,13 @@ def train_goldens(sizes=((2, 48, 16, ""),), settings=("dexycb", "ho3d_render")):
         _train_goldens(B, nh, no, suffix, settings)
 
 
-def _train_goldens(B, nh, no, suffix, settings):
+def train_branch_b_golden():
+    """g8 ..._branchB: the training step after cfg.point_sampling_epoch when the draw p >= 0.4 (random.seed(0): 0.844):
+    query points come from the dense-lattice sdf_infer under no_grad (main/model.py:470-481), everything after it trains."""
+    _train_goldens(2, 48, 16, "_branchB", ("dexycb",), epoch_cnt=10 ** 8)
+
+
+def _train_goldens(B, nh, no, suffix, settings, epoch_cnt=0):
     for setting in settings:
         model, cfg = build_reference(setting, nh, no, 16)
         model.train()
@@ -230,7 +236,7 @@ def _train_goldens(B, nh, no, suffix, settings):
         targets["joint_coord"] = targets["joint_coord"]
         random.seed(0)
         torch.manual_seed(1234)
-        out = model(inputs, targets, meta, "train", 0, 0.5)
+        out = model(inputs, targets, meta, "train", epoch_cnt, 0.5)
         skip = ("joint_heatmap", "obj_seg", "hand_seg")
         losses = {k: v.mean() for k, v in out.items() if "_out" not in k and k not in skip}
         total = sum(losses.values())
@@ -416,7 +422,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "mano", "schema", "big", "metrics", "ik"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -427,6 +433,8 @@ if __name__ == "__main__":
         e2e_goldens()
     if "train" in which:
         train_goldens()
+    if "trainB" in which:
+        train_branch_b_golden()
     if "big" in which:
         big_goldens()
     if "metrics" in which:

@@ -114,11 +114,13 @@ def test_sdf_infer_selects_the_oracle_set():
 
 
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""),
-                                                  ("dexycb", 1536, 512, "_n2048")])
+                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
 def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suffix):
     """branch A (pre-points + jitter), every dropout p = 0: losses and gradients vs g8 goldens (the _n2048 fixture is the
-    reference's own fwd+bwd at BASELINE configs[1]'s 1536+512 points)."""
+    reference's own fwd+bwd at BASELINE configs[1]'s 1536+512 points).  _branchB: the training step after
+    cfg.point_sampling_epoch with the draw p >= 0.4 - query points from the dense-lattice sdf_infer (main/model.py:470-481)."""
     g = load_golden(f"g8_train_{setting}{suffix}")
+    epoch_cnt = 10 ** 8 if suffix == "_branchB" else 0
     b = 2
     model, c = build(setting, nh, no, 16, train=True)
     c.dropout = 0.0
@@ -136,7 +138,7 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
     model._jitter = lambda like, d: jit.pop(0).to(DEV)
     model._py_random = random.Random(0)
     inputs, targets, meta = (T.to_device(x, DEV) for x in (inputs, targets, meta))
-    loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
+    loss, out = model.hot_path(pyr, inputs, targets, meta, "train", epoch_cnt, 0.5)
     losses = {k: v.mean() for k, v in loss.items()}
     for k, v in losses.items():
         ref = g["loss." + k]
@@ -150,7 +152,10 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
         if key in g:
             assert p.grad is not None, name
             gn = p.grad.double().norm().item()
-            assert abs(gn - float(g[key])) <= 1e-3 * float(g[key]) + 1e-6, (name, gn, float(g[key]))
+            # branch B: the scalar beta gradients are heavily cancelling sums over near-surface points (two fp32 summation
+            # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py)
+            rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
+            assert abs(gn - float(g[key])) <= rt * float(g[key]) + 1e-6, (name, gn, float(g[key]))
             n += 1
         elif not name.startswith(("backbone", "decoder_net")):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
@@ -160,8 +165,9 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
         err = (a.float().cpu() - ref).abs().max().item()
         assert err <= rel * float(ref.abs().max()) + 1e-9, err
 
-    gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"])
-    gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"])
+    brel = 3e-3 if suffix == "_branchB" else 1e-3
+    gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"], brel)
+    gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
     gclose(model.linear_handcls.layers[2].weight.grad, g["grad.linear_handcls.layers.2.weight"])
     gclose(model.hand_sdf_decoder.linh0.weight_g.grad, g["grad.hand_sdf_decoder.linh0.weight_g"])
     gclose(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"])

@@ -190,9 +190,12 @@ def test_g7_e2e(setting, big, nh, no, bins, b):
 
 
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""),
-                                                  ("dexycb", 1536, 512, "_n2048")])
+                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
 def test_g8_train_fwd_bwd(setting, nh, no, suffix):
+    """_branchB: epoch >= cfg.point_sampling_epoch and the draw p = 0.844 >= 0.4 -> the query points come from the
+    dense-lattice sdf_infer (main/model.py:470-481), the rest of the step trains on them."""
     g = load_golden(f"g8_train_{setting}{suffix}")
+    epoch_cnt = 10 ** 8 if suffix == "_branchB" else 0
     ik = setting == "ho3d_render"
     b = 2
     Pm = T.det_params(T.hot_path_param_shapes(992, ik=ik))
@@ -205,7 +208,7 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     layer = MANO.ManoLayer(MANO.synthetic_assets(0))
     random.seed(0)
     torch.manual_seed(1234)
-    out = O.hot_path_forward(Pm, cfg, pyr, inputs, targets, meta, "train", 0, 0.5, mano_layer=layer,
+    out = O.hot_path_forward(Pm, cfg, pyr, inputs, targets, meta, "train", epoch_cnt, 0.5, mano_layer=layer,
                              hands_mean=layer.th_hands_mean)
     losses = {k: v.mean() for k, v in out.items() if "_out" not in k}
     for k, v in losses.items():
@@ -218,7 +221,10 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
         key = "gradnorm." + name
         if key in g:
             assert p.grad is not None, name
-            close(p.grad.double().norm().float(), g[key], rtol=2e-4, atol=1e-6)
+            # branch B samples the points closest to the surface: d sigma / d beta is large there and the scalar beta
+            # gradient is a heavily cancelling sum (observed 1.3e-3 between two fp32 summation orders)
+            rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 2e-4
+            close(p.grad.double().norm().float(), g[key], rtol=rt, atol=1e-6)
             n += 1
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name   # unused params
@@ -228,7 +234,7 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     def gclose(a, b, rel=3e-4 if nh < 1000 else 1e-3):
         close(a, b, rtol=0, atol=rel * float(b.abs().max()) + 1e-9)
 
-    gclose(Pm["hand_sigmoid_beta"].grad, g["grad.hand_sigmoid_beta"])
+    gclose(Pm["hand_sigmoid_beta"].grad, g["grad.hand_sigmoid_beta"], **({"rel": 3e-3} if suffix == "_branchB" else {}))
     gclose(Pm["linear_handcls.layers.2.weight"].grad, g["grad.linear_handcls.layers.2.weight"])
     gclose(pyr["stride32"].grad[:, ::16], g["grad.pyr.stride32"])
     close(pyr["stride2"].grad.double().norm().float(), g["grad.pyr.stride2_norm"], rtol=1e-4)
