@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--branch-mix", action="store_true",
                     help="configs[1] after cfg.point_sampling_epoch: per step draw p ~ U(0,1), p < 0.4 -> pre-points "
                          "(branch A), else the dense-lattice sdf_infer (branch B) - main/model.py:426-481")
+    ap.add_argument("--aten-report", action="store_true",
+                    help="after the warm-up, run one extra step under torch.profiler and print the ATen ops by name and input "
+                         "shape (stderr): where the glue launches come from")
     ap.add_argument("--gemm", choices=("f32", "split"), default="f32",
                     help="training linear layers: f32 = exact-f32 MFMA GEMM (the headline line); split = f16 hi+lo operands, "
                          "3 products per contraction (csrc/gemm_split.hip; part of the second, separately labelled line)")
@@ -258,6 +261,26 @@ def main():
         step()
     cfg.overlap_streams = True
     barrier()
+    if args.aten_report and rank == 0:
+        from torch.profiler import profile, ProfilerActivity
+        # (record_shapes cannot marshal the 64-bit dropout seeds of the custom autograd functions: group by source line)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        from collections import Counter
+        cnt, dev_us = Counter(), Counter()
+        watch = ("aten::add_", "aten::add", "aten::mul", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::sum",
+                 "aten::sub", "aten::div", "aten::clamp_min", "aten::index", "aten::select_backward", "aten::slice_backward")
+        for e in prof.events():
+            if e.name in watch:
+                frames = [f for f in (e.stack or []) if "hoisdf_amd" in f or "bench.py" in f or "torch/nn/modules" in f
+                          or "autograd" in f]
+                where = frames[0].strip()[-80:] if frames else "(no python frame: autograd engine)"
+                cnt[(e.name, where)] += 1
+                dev_us[(e.name, where)] += e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
+        for (name, where), n in cnt.most_common(70):
+            print(f"{n:5d}x {dev_us[(name, where)] / 1e3:7.3f} ms  {name:22s} {where}", file=sys.stderr)
+        barrier()
     # per-kernel HIP events live inside the timed region, on every `--time-every`-th step only: ~1400 event records per
     # step cost 1.7 % of the step (they serialise consecutive kernels), which `value` should not pay on every step
     timed_steps = 0
