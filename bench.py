@@ -397,7 +397,7 @@ def main():
                 res["roofline"]["hbm_gbps"] = round(res["roofline"]["traffic"] / (timer.largest_launch_us(m0) * 1e-6) / 1e9, 1)
                 res["roofline"]["hbm_peak_gbps"] = 8000.0
                 res["roofline"]["traffic_note"] = (f"PMC bytes (profiles/{TRAFFIC_FILE}) of one launch at the largest shape of "
-                                                   "this family (self-attention B=32,S=2048 / linear fwd 65536x512x992)")
+                                                   "this family (self-attention B=32,S=2048 / linear fwd 49152x1024x992)")
         except Exception:
             pass
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),
