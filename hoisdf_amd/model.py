@@ -199,6 +199,8 @@ class Model(nn.Module):
         """reference :370-402 and :424-662: everything after decoder_net except the aux image losses."""
         c = self.cfg
         training = mode == "train"
+        if training:
+            pyr = pyr.shared_grad()          # the step's four gather backwards scatter into ONE set of level gradients
         loss: Dict[str, torch.Tensor] = {}
         out: Dict[str, torch.Tensor] = {}
         root, ocen, K = meta_info["mano_root"], meta_info["obj_center_cam"], meta_info["cam_intr"]

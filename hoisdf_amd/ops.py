@@ -7,6 +7,7 @@ CPU tensor or a missing library raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional, Sequence
 
 import torch
@@ -128,6 +129,9 @@ def _rows(x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # pyramid handling
 # ---------------------------------------------------------------------------------------------
+_SHARED_PYR_GRAD = __import__("os").environ.get("HOISDF_SHARED_PYR_GRAD", "1") != "0"      # A/B switch
+
+
 class PyramidNHWC:
     """The feature pyramid in the layout the kernels want: per level a contiguous
     [B][H][W][C] float32 tensor (a zero-copy view when the encoder ran channels_last)."""
@@ -142,6 +146,21 @@ class PyramidNHWC:
     def from_nchw(maps: Sequence[torch.Tensor]) -> "PyramidNHWC":
         return PyramidNHWC([m.permute(0, 2, 3, 1) for m in maps])
 
+    acc = None       # set by shared_grad(): the accumulator every project_gather backward of this pyramid scatters into
+
+    def shared_grad(self) -> "PyramidNHWC":
+        """Training: the pyramid is gathered from several times per step (hand points, object points, the two SDF-loss
+        point sets) and every gather's backward used to fill its own five zeroed level gradients, which autograd then
+        summed (3 x 312 MB of adds + 4 x 312 MB of fills at B = 32).  The returned pyramid routes all of them into ONE set
+        of zeroed buffers (float atomics already accumulate) that a sink node hands to the encoder once, after the last
+        gather backward.  No-op without gradients and in deterministic mode (the order-fixed gather owns its output)."""
+        if not (torch.is_grad_enabled() and any(l.requires_grad for l in self.levels)) or deterministic() or not _SHARED_PYR_GRAD:
+            return self
+        acc = _PyrAcc([tuple(l.shape) for l in self.levels], self.levels[0].device)
+        out = PyramidNHWC(list(_PyrSink.apply(acc, *self.levels)))
+        out.acc = acc
+        return out
+
     def struct(self, tensors: Optional[Sequence[torch.Tensor]] = None) -> Pyramid:
         ts = self.levels if tensors is None else tensors
         s = Pyramid()
@@ -152,9 +171,53 @@ class PyramidNHWC:
         return s
 
 
+class _PyrAcc:
+    """shared level-gradient buffers of one step (PyramidNHWC.shared_grad): zeroed at creation (a slice of the per-step
+    arena when it is active), written by every gather backward on whatever stream that node runs on"""
+
+    def __init__(self, shapes, device):
+        self.shapes = shapes
+        sizes = [math.prod(sh) for sh in shapes]
+        flat = _zeros(sum(sizes), device)
+        self.bufs, off = [], 0
+        for sh, n in zip(shapes, sizes):
+            self.bufs.append(flat[off:off + n].view(sh))
+            off += n
+        self.flat = flat
+        self.events = []          # one per gather backward: the sink waits for them (other streams included)
+        self.touched = False
+
+
+class _PyrSink(torch.autograd.Function):
+    """identity on the pyramid levels; its backward runs after every consumer's and returns the accumulated gradients"""
+
+    @staticmethod
+    def forward(ctx, acc, *levels):
+        ctx.acc = acc
+        ctx.set_materialize_grads(False)
+        return tuple(l.view_as(l) for l in levels)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        acc = ctx.acc
+        cur = torch.cuda.current_stream(acc.flat.device)
+        for ev in acc.events:
+            cur.wait_event(ev)
+        acc.flat.record_stream(cur)
+        out = []
+        for g, b in zip(gs, acc.bufs):
+            if g is not None:                 # a consumer other than project_gather returned a real gradient
+                b = b + g if acc.touched else g
+            elif not acc.touched:
+                b = None
+            out.append(b)
+        return (None, *out)
+
+
 class _ProjectGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points, sample_idx, center, cam_intr, scale, img_hw, *levels):
+    def forward(ctx, points, sample_idx, center, cam_intr, scale, img_hw, acc, *levels):
+        ctx.acc = acc
         pyr = PyramidNHWC(levels)
         pts = points.reshape(-1, 3).contiguous()
         _chk(pts, center, cam_intr)
@@ -175,7 +238,12 @@ class _ProjectGather(torch.autograd.Function):
         pts, sample_idx, center, cam_intr = ctx.saved_tensors
         scale, img_hw, rps, shapes, B = ctx.meta
         dfeat = dfeat.contiguous()
-        grads = [torch.zeros(sh, device=dfeat.device, dtype=torch.float32) for sh in shapes]
+        acc = ctx.acc
+        if acc is not None:
+            grads = acc.bufs
+            acc.flat.record_stream(torch.cuda.current_stream(dfeat.device))
+        else:
+            grads = [torch.zeros(sh, device=dfeat.device, dtype=torch.float32) for sh in shapes]
         g = Pyramid()
         g.n_levels, g.B = len(grads), B
         for i, t in enumerate(grads):
@@ -183,14 +251,20 @@ class _ProjectGather(torch.autograd.Function):
             g.C[i], g.H[i], g.W[i] = t.shape[3], t.shape[1], t.shape[2]
         call("hoisdf_project_gather_bwd", C.byref(g), _p(pts), _p(sample_idx), pts.shape[0], rps, _p(center),
              _p(cam_intr), scale, img_hw[0], img_hw[1], _p(dfeat), dfeat.shape[1], _st())
-        return (None, None, None, None, None, None, *grads)
+        if acc is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dfeat.device))
+            acc.events.append(ev)
+            acc.touched = True
+            return (None,) * (7 + len(shapes))
+        return (None, None, None, None, None, None, None, *grads)
 
 
 def project_gather(pyr: PyramidNHWC, points, center, cam_intr, scale, img_hw=(256, 256), sample_idx=None):
     """K1. points (B,P,3) [or (n,3) with sample_idx] -> feat (n, C), cam (n, 3).
     Differentiable w.r.t. the pyramid levels only (the grid is detached in the reference)."""
     return _ProjectGather.apply(points, sample_idx, center.contiguous(), cam_intr.contiguous(), scale,
-                                tuple(img_hw), *pyr.levels)
+                                tuple(img_hw), pyr.acc, *pyr.levels)
 
 
 # ---------------------------------------------------------------------------------------------
