@@ -34,7 +34,13 @@ def bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual=None) -> to
             _PENDING_NBT.append(bn.num_batches_tracked)
             return ops.batchnorm_relu(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu,
                                       residual)
-    y = bn(x)
+    if bn.training and bn.track_running_stats and bn.momentum is not None and x.is_cuda:
+        # what nn.BatchNorm2d.forward does, minus its per-module `num_batches_tracked += 1` kernel (69 tiny launches per
+        # step for ResNet-50 + decoder): the counters are bumped together by flush_bn_counters()
+        _PENDING_NBT.append(bn.num_batches_tracked)
+        y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    else:
+        y = bn(x)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
