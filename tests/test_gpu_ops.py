@@ -111,6 +111,41 @@ def test_linear_split_precision_matches_fp64(M, N, K, act, p):
     assert_close(dx_acc, gy.double() @ W.detach().double() + 0.25, rel=2e-6, what="dx accumulate")
 
 
+def test_linear_split_grad_weight_accepts_the_row_scales_of_the_other_calls():
+    """hoisdf_linear_bwd_weight_split's optional hints: the per-row scales the forward call left in its workspace (x) and the
+    grad-input call in its own (dy) replace the two pre-passes; the result stays within 2e-6 of fp64 and of the hint-free call."""
+    O = ops()
+    from hoisdf_amd._lib import lib
+    M, N, K = 4096, 512, 640
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * torch.pow(10.0, -4.0 * torch.rand(M, 1, generator=g))).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    dy = (torch.randn(M, N, generator=g) * 1e-4 * torch.pow(10.0, -4.0 * torch.rand(M, 1, generator=g))).to(DEV)
+    st = O._st()
+    ws = [torch.empty(lib().hoisdf_linear_split_workspace(M, N, K, w), device=DEV, dtype=torch.uint8) for w in (0, 1, 2)]
+    y = torch.empty(M, N, device=DEV)
+    dx = torch.empty(M, K, device=DEV)
+    O.call("hoisdf_linear_fwd_split", O._p(x), K, O._p(W), K, None, O._p(y), N, M, N, K, 0, 0.0, 0, None, O._p(ws[0]),
+           ws[0].numel(), st)
+    O.call("hoisdf_linear_bwd_input_split", O._p(dy), N, None, 0.0, O._p(W), K, O._p(dx), K, M, N, K, 0, O._p(ws[1]),
+           ws[1].numel(), st)
+    xs, ds = ws[0][:4 * M].view(torch.float32), ws[1][:4 * M].view(torch.float32)
+    assert float(xs.min()) > 0 and float(ds.min()) > 0                      # powers of two left by the two calls
+    assert torch.equal(torch.exp2(torch.log2(xs).round()), xs)
+    outs = []
+    for hints in (False, True):
+        dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        O.call("hoisdf_linear_bwd_weight_split", O._p(dy), N, None, 0.0, O._p(x), K, O._p(dW), K, O._p(db), M, N, K,
+               O._p(xs) if hints else None, O._p(ds) if hints else None, O._p(ws[2]), ws[2].numel(), st)
+        outs.append((dW, db))
+    ref = dy.double().t() @ x.double()
+    for dW, db in outs:
+        assert_close(dW, ref, rel=2e-6, what="dW")
+        assert_close(db, dy.double().sum(0), rel=2e-6, what="db")
+    assert_close(y, x.double() @ W.double().t(), rel=2e-6, what="y")
+    assert_close(dx, dy.double() @ W.double(), rel=2e-6, what="dx")
+
+
 def test_linear_strided_input_and_weight_slices():
     """x rows with ld > K (the 292-wide decoder-input buffer) and W given as a row slice."""
     O = ops()
