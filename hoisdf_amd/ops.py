@@ -300,23 +300,27 @@ def _split_ws(M, N, K, which, device):
 
 
 def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
+    """-> the per-row scales of x the split call left in its workspace (a hint for the split grad-weight), or None"""
     if _split_ok(M, N, K):
         ws, nb = _split_ws(M, N, K, 0, y.device)
         call("hoisdf_linear_fwd_split", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _p(ws), nb, _st())
-    else:
-        call("hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p),
-             seed, _p(bits), _st())
+        return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
+    call("hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p),
+         seed, _p(bits), _st())
+    return None
 
 
 def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
+    """-> the per-row scales of dy the split call left in its workspace (hint for the split grad-weight), or None"""
     if _split_ok(M, N, K):
         ws, nb = _split_ws(M, N, K, 1, dx.device)
         call("hoisdf_linear_bwd_input_split", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
              int(accumulate), _p(ws), nb, _st())
-    else:
-        call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
-             int(accumulate), _st())
+        return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
+    call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
+         int(accumulate), _st())
+    return None
 
 
 def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None):
@@ -355,7 +359,7 @@ class _Linear(torch.autograd.Function):
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         need_bits = bool(act) and (x.requires_grad or W.requires_grad or (b is not None and b.requires_grad))
         bits = torch.empty(M, (N + 31) // 32, device=x.device, dtype=torch.int32) if need_bits else None
-        _gemm_fwd(x2, x2.stride(0) if M > 1 else K, W, b, y, N, M, N, K, act, drop_p, seed, bits)
+        ctx.x_scale = _gemm_fwd(x2, x2.stride(0) if M > 1 else K, W, b, y, N, M, N, K, act, drop_p, seed, bits)
         ctx.save_for_backward(x2, W, bits)
         ctx.meta = (int(act), float(drop_p), b is not None, x.shape)
         return y.view(*x.shape[:-1], N)
@@ -370,16 +374,16 @@ class _Linear(torch.autograd.Function):
         lddy = dy2.stride(0) if M > 1 else N
         # relu/dropout backward is fused into the staging of dy inside both contractions (1-bit sign map)
         p = drop_p if bits is not None else 0.0
-        dx = dW = db = None
+        dx = dW = db = dy_scale = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
-            _gemm_bwd_input(dy2, lddy, bits, p, W, dx, K, M, N, K, 0)
+            dy_scale = _gemm_bwd_input(dy2, lddy, bits, p, W, dx, K, M, N, K, 0)
             dx = dx.view(xshape)
         if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
             buf = _zeros(N * K + (N if has_b else 0), dy.device)   # one fill (or a slice of the per-step arena)
             dW = buf[:N * K].view(N, K)
             db = buf[N * K:] if has_b else None
-            _gemm_bwd_weight(dy2, lddy, bits, p, x2, x2.stride(0) if M > 1 else K, dW, db, M, N, K)
+            _gemm_bwd_weight(dy2, lddy, bits, p, x2, x2.stride(0) if M > 1 else K, dW, db, M, N, K, ctx.x_scale, dy_scale)
         return dx, dW, db, None, None, None
 
 
