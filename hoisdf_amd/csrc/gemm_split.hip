@@ -19,8 +19,8 @@
 // k-slabs of the four planes double-buffered in LDS (64 KB, 2 WG / CU), raw buffer loads two slabs ahead.  The epilogue
 // is the f32 kernel's (bias, ReLU, dropout, sign bitmap, accumulate-into, LDS-transposed 128-byte stores).  Grad-weight
 // splits the contraction over workgroups into partial tiles + an ordered reduce (no atomics: deterministic).
-// Measured (MI355X, tools/mb_gsplit.py, pre-passes included): forward / grad-input 160-215 TF-equivalent against 88-101
-// for the f32 kernel; grad-weight 110-124 against 61-103 when min(N, K) >= 512, but NO gain for the 256-wide transformer
+// Measured (MI355X, tools/mb_gsplit.py, pre-passes included): forward / grad-input 155-215 TF-equivalent against 88-108
+// for the f32 kernel; grad-weight 110-127 against 61-103 when min(N, K) >= 512, but NO gain for the 256-wide transformer
 // shapes (the two conversion passes cost what the contraction saves), which therefore stay on the f32 kernel.
 #include <stdlib.h>
 
@@ -697,11 +697,11 @@ struct Carver {
     return p;
   }
 };
-struct Planes { _Float16 *hi, *lo; float* rinv; long rows_p, kp; int rs; };
+struct Planes { _Float16 *hi, *lo; float* rinv; long rows_p, kp; };
 
 Planes take_rows(Carver& c, long R, long K) {
   Planes p;
-  p.rows_p = up(R, 128); p.kp = up(K, KS); p.rs = 1;
+  p.rows_p = up(R, 128); p.kp = up(K, KS);
   p.hi = c.take<_Float16>((size_t)p.rows_p * p.kp);
   p.lo = c.take<_Float16>((size_t)p.rows_p * p.kp);
   p.rinv = c.take<float>((size_t)p.rows_p);
@@ -710,10 +710,10 @@ Planes take_rows(Carver& c, long R, long K) {
 // transposed operand: rows = the source's columns (padded to 128), contraction = the source's rows (padded to 64)
 Planes take_trn(Carver& c, long Msrc, long Csrc) {
   Planes p;
-  p.rows_p = up(Csrc, 128); p.kp = up(Msrc, 64); p.rs = 0;
+  p.rows_p = up(Csrc, 128); p.kp = up(Msrc, 64);
   p.hi = c.take<_Float16>((size_t)p.rows_p * p.kp);
   p.lo = c.take<_Float16>((size_t)p.rows_p * p.kp);
-  p.rinv = c.take<float>(64);           // [0] = 1 / scale, [1] = amax bits
+  p.rinv = c.take<float>(64);           // scalar slots: [8] scale, [9] amax word, [10] 1 / scale (convert_trn_scalar)
   return p;
 }
 
