@@ -19,7 +19,7 @@
 using namespace hoisdf;
 
 namespace {
-constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, X0P = 292, CAT_LD = 516, X0_COL = 224;
+constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, CAT_LD = 516, X0_COL = 224;
 inline long align64(long v) { return (v + 63) / 64 * 64; }
 // scratch of the split-precision form of the six layers (hoisdf_set_gemm_split): the largest of their workspaces
 inline long split_scratch_bytes(long n_rows, int C) {
