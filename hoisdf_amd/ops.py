@@ -151,7 +151,7 @@ class PyramidNHWC:
     def shared_grad(self) -> "PyramidNHWC":
         """Training: the pyramid is gathered from several times per step (hand points, object points, the two SDF-loss
         point sets) and every gather's backward used to fill its own five zeroed level gradients, which autograd then
-        summed (3 x 312 MB of adds + 4 x 312 MB of fills at B = 32).  The returned pyramid routes all of them into ONE set
+        summed (15 adds over 3 x 130 MB + 4 x 130 MB of fills at B = 32).  The returned pyramid routes all of them into ONE set
         of zeroed buffers (float atomics already accumulate) that a sink node hands to the encoder once, after the last
         gather backward.  No-op without gradients and in deterministic mode (the order-fixed gather owns its output)."""
         if not (torch.is_grad_enabled() and any(l.requires_grad for l in self.levels)) or deterministic() or not _SHARED_PYR_GRAD:
