@@ -57,6 +57,8 @@ class KernelTimer:
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         "hoisdf_attention_fwd_split": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_split": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
+        "hoisdf_attention_fwd_split_keep": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
+        "hoisdf_attention_bwd_split_kept": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
         # split-precision linear layers: same argument positions as the f32 entries (+ workspace); algorithmic FLOPs
         # (the 3 split products are not counted), operand conversion passes inside the timed call
         "hoisdf_linear_fwd_split": lambda a: 2.0 * a[7] * a[8] * a[9],
@@ -77,6 +79,7 @@ class KernelTimer:
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20),
+             "hoisdf_attention_fwd_split_keep": (9, 11, 13), "hoisdf_attention_bwd_split_kept": (16, 18, 20),
              "hoisdf_linear_fwd_split": (7, 8, 9), "hoisdf_linear_bwd_input_split": (8, 9, 10),
              "hoisdf_linear_bwd_weight_split": (9, 10, 11)}
 
@@ -358,8 +361,9 @@ def main():
                 "gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)":
                     ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] +
                     (sq if args.gemm == "split" else []),
-                "split_fwd_kernel (+ conversion passes)": ["hoisdf_attention_fwd_split"],
-                "split_bwd_dkv + split_bwd_dq (+ conversion passes)": ["hoisdf_attention_bwd_split"]}
+                "split_fwd_kernel (+ conversion passes)": ["hoisdf_attention_fwd_split", "hoisdf_attention_fwd_split_keep"],
+                "split_bwd_dkv + split_bwd_dq (+ conversion passes)": ["hoisdf_attention_bwd_split",
+                                                                       "hoisdf_attention_bwd_split_kept"]}
         agg = {}
         for fam, members in fams.items():
             ms = sum(ks[m]["total_ms"] for m in members if m in ks)

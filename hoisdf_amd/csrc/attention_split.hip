@@ -617,9 +617,11 @@ int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, 
 extern "C" long hoisdf_attention_split_workspace(int B, int H, int Lq, int Lk, int backward) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
   const long Lqp = pad128(Lq), Lkp = pad128(Lk);
-  // forward: Q rows (2), K rows (2), V^T (2).  backward: Q rows + Q^T (4), K rows + K^T (4), V rows (2), dO rows + dO^T (4)
-  const size_t halves = backward ? 4 * arr_halves(B, H, Lqp) + 6 * arr_halves(B, H, Lkp) + 4 * arr_halves(B, H, Lqp)
-                                 : 2 * arr_halves(B, H, Lqp) + 4 * arr_halves(B, H, Lkp);
+  // 0 forward: Q rows (2), K rows (2), V^T (2).  1 backward: Q rows + Q^T (4), K rows + K^T (4), V rows (2), dO rows + dO^T (4)
+  // 2 forward that keeps every plane the backward needs: Q, K, V rows + transposed (12).  3 backward on top of a mode-2
+  //   forward workspace: dO rows + dO^T (4)
+  const size_t q = arr_halves(B, H, Lqp), k = arr_halves(B, H, Lkp);
+  const size_t halves = backward == 0 ? 2 * q + 4 * k : backward == 1 ? 8 * q + 6 * k : backward == 2 ? 4 * q + 8 * k : 4 * q;
   return (long)(halves * sizeof(_Float16));
 }
 
@@ -635,24 +637,45 @@ static int check_split(const void* q, const void* k, const void* v, int ldq, int
   return HOISDF_OK;
 }
 
-extern "C" int hoisdf_attention_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                          float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
-                                          float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
-                                          void* stream) {
+// the planes of Q, K, V in the layout of a "kept" forward workspace (mode 2): [qh ql qth qtl | kh kl kth ktl | vh vl vth vtl]
+struct KeptPlanes { _Float16 *qh, *ql, *qth, *qtl, *kh, *kl, *kth, *ktl, *vh, *vl, *vth, *vtl; };
+static KeptPlanes kept_planes(void* workspace, int B, int H, int Lqp, int Lkp) {
+  _Float16* w = reinterpret_cast<_Float16*>(workspace);
+  const size_t nq = arr_halves(B, H, Lqp), nk = arr_halves(B, H, Lkp);
+  KeptPlanes p;
+  p.qh = w; p.ql = p.qh + nq; p.qth = p.ql + nq; p.qtl = p.qth + nq;
+  p.kh = p.qtl + nq; p.kl = p.kh + nk; p.kth = p.kl + nk; p.ktl = p.kth + nk;
+  p.vh = p.ktl + nk; p.vl = p.vh + nk; p.vth = p.vl + nk; p.vtl = p.vth + nk;
+  return p;
+}
+
+static int attention_fwd_split_impl(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
+                                    float drop_p, uint64_t seed, void* workspace, long workspace_bytes, int keep,
+                                    void* stream) {
   if (int rc = check_split(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_split")) return rc;
   HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
                  HOISDF_ERR_INVALID, "attention_fwd_split: bad output / workspace");
-  HOISDF_REQUIRE(workspace_bytes >= hoisdf_attention_split_workspace(B, H, Lq, Lk, 0), HOISDF_ERR_WORKSPACE,
+  HOISDF_REQUIRE(workspace_bytes >= hoisdf_attention_split_workspace(B, H, Lq, Lk, keep ? 2 : 0), HOISDF_ERR_WORKSPACE,
                  "attention_fwd_split: workspace %ld < %ld bytes", workspace_bytes,
-                 hoisdf_attention_split_workspace(B, H, Lq, Lk, 0));
+                 hoisdf_attention_split_workspace(B, H, Lq, Lk, keep ? 2 : 0));
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
   hipStream_t st = as_stream(stream);
   _Float16* w = reinterpret_cast<_Float16*>(workspace);
   const size_t nq = arr_halves(B, H, Lqp), nk = arr_halves(B, H, Lkp);
   _Float16 *qh = w, *ql = qh + nq, *kh = ql + nq, *kl = kh + nk, *vth = kl + nk, *vtl = vth + nk;
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, nullptr, nullptr, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, nullptr, nullptr, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, nullptr, nullptr, vth, vtl, st)) return rc;
+  if (keep) {
+    // one pass per tensor writes the rows AND the transposed planes: the backward will not convert Q, K, V again
+    const KeptPlanes p = kept_planes(workspace, B, H, Lqp, Lkp);
+    qh = p.qh; ql = p.ql; kh = p.kh; kl = p.kl; vth = p.vth; vtl = p.vtl;
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, p.qh, p.ql, p.qth, p.qtl, st)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, p.kh, p.kl, p.kth, p.ktl, st)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, p.vh, p.vl, p.vth, p.vtl, st)) return rc;
+  } else {
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, nullptr, nullptr, st)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, nullptr, nullptr, st)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, nullptr, nullptr, vth, vtl, st)) return rc;
+  }
   SplitArgs a{};
   a.qh = qh; a.ql = ql; a.kh = kh; a.kl = kl; a.vth = vth; a.vtl = vtl;
   a.out = o; a.lse = lse; a.ldo = ldo;
@@ -662,31 +685,55 @@ extern "C" int hoisdf_attention_fwd_split(const float* q, int ldq, const float* 
   return check_launch("attention_fwd_split");
 }
 
-extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                          const float* o, int ldo, const float* dout, int lddo,
-                                          const float* dout_scale, const float* lse, float* delta, float* dq,
-                                          float* dk, float* dv, int B, int H, int Lq, int Lk,
-                                          int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
+extern "C" int hoisdf_attention_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                          float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
+                                          float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
                                           void* stream) {
+  return attention_fwd_split_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace,
+                                  workspace_bytes, 0, stream);
+}
+extern "C" int hoisdf_attention_fwd_split_keep(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                               float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len,
+                                               float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
+                                               void* stream) {
+  return attention_fwd_split_impl(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace,
+                                  workspace_bytes, 1, stream);
+}
+
+static int attention_bwd_split_impl(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const float* o, int ldo, const float* dout, int lddo,
+                                    const float* dout_scale, const float* lse, float* delta, float* dq,
+                                    float* dk, float* dv, int B, int H, int Lq, int Lk,
+                                    int kv_len, float drop_p, uint64_t seed, const void* kept, void* workspace,
+                                    long workspace_bytes, void* stream) {
   if (int rc = check_split(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_bwd_split")) return rc;
   HOISDF_REQUIRE(o && dout && lse && delta && dq && dk && dv && workspace, HOISDF_ERR_INVALID,
                  "attention_bwd_split: null pointer");
   HOISDF_REQUIRE(ldo >= H * 64 && lddo >= H * 64 && ((ldo | lddo) & 3) == 0 &&
                      (((uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)workspace) & 15) == 0,
                  HOISDF_ERR_INVALID, "attention_bwd_split: bad leading dims / alignment");
-  HOISDF_REQUIRE(workspace_bytes >= hoisdf_attention_split_workspace(B, H, Lq, Lk, 1), HOISDF_ERR_WORKSPACE,
+  HOISDF_REQUIRE(workspace_bytes >= hoisdf_attention_split_workspace(B, H, Lq, Lk, kept ? 3 : 1), HOISDF_ERR_WORKSPACE,
                  "attention_bwd_split: workspace %ld < %ld bytes", workspace_bytes,
-                 hoisdf_attention_split_workspace(B, H, Lq, Lk, 1));
+                 hoisdf_attention_split_workspace(B, H, Lq, Lk, kept ? 3 : 1));
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
   hipStream_t st = as_stream(stream);
   _Float16* w = reinterpret_cast<_Float16*>(workspace);
   const size_t nq = arr_halves(B, H, Lqp), nk = arr_halves(B, H, Lkp);
-  _Float16 *qh = w, *ql = qh + nq, *qth = ql + nq, *qtl = qth + nq;
-  _Float16 *kh = qtl + nq, *kl = kh + nk, *kth = kl + nk, *ktl = kth + nk, *vh = ktl + nk, *vl = vh + nk;
-  _Float16 *dh = vl + nk, *dl = dh + nq, *dth = dl + nq, *dtl = dth + nq;
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, qth, qtl, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, kth, ktl, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, vh, vl, nullptr, nullptr, st)) return rc;
+  _Float16 *qh, *ql, *qth, *qtl, *kh, *kl, *kth, *ktl, *vh, *vl, *dh;
+  if (kept) {
+    // Q, K, V planes left by hoisdf_attention_fwd_split_keep on the same q, k, v: only dO is converted here
+    const KeptPlanes p = kept_planes(const_cast<void*>(kept), B, H, Lqp, Lkp);
+    qh = p.qh; ql = p.ql; qth = p.qth; qtl = p.qtl; kh = p.kh; kl = p.kl; kth = p.kth; ktl = p.ktl; vh = p.vh; vl = p.vl;
+    dh = w;
+  } else {
+    qh = w; ql = qh + nq; qth = ql + nq; qtl = qth + nq;
+    kh = qtl + nq; kl = kh + nk; kth = kl + nk; ktl = kth + nk; vh = ktl + nk; vl = vh + nk;
+    dh = vl + nk;
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, nullptr, qh, ql, qth, qtl, st)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, nullptr, kh, kl, kth, ktl, st)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, nullptr, vh, vl, nullptr, nullptr, st)) return rc;
+  }
+  _Float16 *dl = dh + nq, *dth = dl + nq, *dtl = dth + nq;
   if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, dout_scale, dh, dl, dth, dtl, st)) return rc;
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(split_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, o, ldo, dout, lddo, delta,
@@ -702,4 +749,25 @@ extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* 
   if (int rc = check_launch("attention_bwd_split_dkv")) return rc;
   hipLaunchKernelGGL(split_bwd_dq_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
   return check_launch("attention_bwd_split_dq");
+}
+
+extern "C" int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                          const float* o, int ldo, const float* dout, int lddo,
+                                          const float* dout_scale, const float* lse, float* delta, float* dq,
+                                          float* dk, float* dv, int B, int H, int Lq, int Lk,
+                                          int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes,
+                                          void* stream) {
+  return attention_bwd_split_impl(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dout_scale, lse, delta, dq, dk, dv, B, H, Lq,
+                                  Lk, kv_len, drop_p, seed, nullptr, workspace, workspace_bytes, stream);
+}
+extern "C" int hoisdf_attention_bwd_split_kept(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                               const float* o, int ldo, const float* dout, int lddo,
+                                               const float* dout_scale, const float* lse, float* delta, float* dq,
+                                               float* dk, float* dv, int B, int H, int Lq, int Lk,
+                                               int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
+                                               void* workspace, long workspace_bytes, void* stream) {
+  HOISDF_REQUIRE(fwd_workspace && (((uintptr_t)fwd_workspace) & 15) == 0, HOISDF_ERR_INVALID,
+                 "attention_bwd_split_kept: the forward's kept workspace is required");
+  return attention_bwd_split_impl(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dout_scale, lse, delta, dq, dk, dv, B, H, Lq,
+                                  Lk, kv_len, drop_p, seed, fwd_workspace, workspace, workspace_bytes, stream);
 }

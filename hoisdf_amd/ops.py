@@ -86,6 +86,7 @@ def zero_arena_begin_step(device) -> None:
     """Call at the start of every training step (before forward) to serve the backward's zero-initialised scratch from one
     buffer that is cleared with a single memset.  See _ZeroArena for the validity contract."""
     _ARENA.begin_step(torch.device(device))
+    _SPLIT_PLANES.clear()          # kept attention planes of graphs that never ran their backward
 
 
 def zero_arena_disable() -> None:
@@ -674,18 +675,35 @@ def _use_split(Lq: int) -> bool:
     return _ATTENTION_SPLIT and Lq >= 32            # the 17-query decoder attention keeps its own f32 kernels
 
 
-def _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed):
+# forward workspaces whose Q / K / V planes the matching backward reuses (hoisdf_attention_fwd_split_keep /
+# _bwd_split_kept): keyed by the operands' addresses - the autograd node keeps q, k, v alive until its backward, so a key
+# cannot be taken over by another live call; leftovers of graphs that never ran backward go at the next step / at 64 entries
+_SPLIT_PLANES = {}
+_SPLIT_KEEP = __import__("os").environ.get("HOISDF_SPLIT_KEEP", "1") != "0"
+
+
+def _planes_key(q, k, v, H, kv_len):
+    return (q.data_ptr(), k.data_ptr(), v.data_ptr(), tuple(q.shape), k.shape[1], H, kv_len)
+
+
+def _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed, keep=False):
+    """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it"""
     from ._lib import lib
     B, Lq, E = q.shape
     Lk = k.shape[1]
     for t, L in ((q, Lq), (k, Lk), (v, Lk)):
         assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
-    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 0)
+    keep = keep and _SPLIT_KEEP
+    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 2 if keep else 0)
     ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    call("hoisdf_attention_fwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H,
-         Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
+    call("hoisdf_attention_fwd_split_keep" if keep else "hoisdf_attention_fwd_split", _p(q), q.stride(1), _p(k), k.stride(1),
+         _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
+    if keep:
+        if len(_SPLIT_PLANES) >= 64:
+            _SPLIT_PLANES.clear()
+        _SPLIT_PLANES[_planes_key(q, k, v, H, kv_len)] = ws
     return o, lse
 
 
@@ -694,12 +712,19 @@ def _attn_bwd_split(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
     B, Lq, E = q.shape
     Lk = k.shape[1]
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
-    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 1)
+    kept = _SPLIT_PLANES.pop(_planes_key(q, k, v, H, kv_len), None)
+    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 3 if kept is not None else 1)
     ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
     # power of two that brings max|dO| into [2, 4): computed on the device, read by the kernels through a pointer
     mx = do.abs().max().clamp_min(1e-30)
     sd = torch.exp2(torch.floor(torch.log2(4.0 / mx))).reshape(1).contiguous()
+    if kept is not None:
+        kept.record_stream(torch.cuda.current_stream(q.device))
+        call("hoisdf_attention_bwd_split_kept", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do),
+             E, _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept),
+             _p(ws), nbytes, _st())
+        return
     call("hoisdf_attention_bwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E,
          _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
 
@@ -713,7 +738,7 @@ class _AttentionSelf(torch.autograd.Function):
         _chk(qkv)
         E = qkv.shape[2] // 3
         split = _use_split(qkv.shape[1])
-        fwd = _attn_fwd_split if split else _attn_fwd
+        fwd = (lambda *a: _attn_fwd_split(*a, keep=any(ctx.needs_input_grad))) if split else _attn_fwd
         o, lse = fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed)
         ctx.save_for_backward(qkv, o, lse)
         ctx.meta = (H, kv_len, float(drop_p), seed, split)
@@ -740,7 +765,8 @@ class _AttentionCross(torch.autograd.Function):
         _chk(q, kv)
         E = q.shape[2]
         split = _use_split(q.shape[1])
-        o, lse = (_attn_fwd_split if split else _attn_fwd)(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed)
+        o, lse = (_attn_fwd_split(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed, keep=any(ctx.needs_input_grad)) if split else
+                  _attn_fwd(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed))
         ctx.save_for_backward(q, kv, o, lse)
         ctx.meta = (H, kv_len, float(drop_p), seed, split)
         return o
@@ -943,7 +969,8 @@ class _EncoderLayer(torch.autograd.Function):
             # gradient-free eval with cfg.attention_f16_eval: the f16-operand kernel (no LSE: nothing is saved for a backward)
             o, lse = _attn_fwd_f16(q, k, v, H, S), None
         else:
-            o, lse = (_attn_fwd_split if split else _attn_fwd)(q, k, v, H, S, p, s_attn)
+            o, lse = (_attn_fwd_split(q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad)) if split else
+                      _attn_fwd(q, k, v, H, S, p, s_attn))
         M = B * nq
         a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
         xq2 = xq.view(M, E)

@@ -285,11 +285,11 @@ int hoisdf_attention_fwd_f16(const float* q, int ldq, const float* k, int ldk, c
  * function of (seed, query, key), LSE in the log2 domain), but every contraction runs on the 16-bit MFMA pipe with f16
  * hi + lo operands and three products (f32 accumulation; ~21-22 significant bits instead of 24): forward S = QK^T,
  * O = PV; backward S, dP = dO V^T, dV = Pd^T dO, dK = dS^T Q, dQ = dS K as two order-fixed kernels (no atomics).
- * workspace: hoisdf_attention_split_workspace(B, H, Lq, Lk, backward) bytes, 16-byte aligned (f16 hi / lo copies of the
- * operands, row-major and transposed).  delta [B][H][Lq] is scratch of the backward.  dout_scale (device pointer, may be
+ * workspace: hoisdf_attention_split_workspace(B, H, Lq, Lk, mode) bytes, 16-byte aligned (f16 hi / lo copies of the
+ * operands, row-major and transposed; mode 0 forward, 1 backward, 2 / 3 the plane-sharing pair below).  delta [B][H][Lq] is scratch of the backward.  dout_scale (device pointer, may be
  * NULL = 1): a power of two sd that brings max|dout| * sd into [2, 4) - f16 hi + lo pairs keep 22 bits only above 2^-3,
  * so gradients are moved up before the split and the factor is taken out of the f32 results. */
-long hoisdf_attention_split_workspace(int B, int H, int Lq, int Lk, int backward);
+long hoisdf_attention_split_workspace(int B, int H, int Lq, int Lk, int mode);
 int hoisdf_attention_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
                                uint64_t seed, void* workspace, long workspace_bytes, void* stream);
@@ -298,6 +298,18 @@ int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk,
                                const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq,
                                int Lk, int kv_len,
                                float drop_p, uint64_t seed, void* workspace, long workspace_bytes, void* stream);
+/* The same pair with the operand planes shared: the forward converts Q, K, V once into ALL the planes the backward needs
+ * (workspace mode 2: rows + transposed of the three operands) and the backward, given that workspace, converts only dO
+ * (its own workspace: mode 3).  Saves three conversion passes per attention call of a training step; the caller keeps the
+ * forward workspace alive and untouched until the backward of the same q, k, v. */
+int hoisdf_attention_fwd_split_keep(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                    int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
+                                    uint64_t seed, void* workspace, long workspace_bytes, void* stream);
+int hoisdf_attention_bwd_split_kept(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                                    const float* o, int ldo, const float* dout, int lddo, const float* dout_scale,
+                                    const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq,
+                                    int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
+                                    void* workspace, long workspace_bytes, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
 int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,

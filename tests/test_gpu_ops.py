@@ -741,6 +741,21 @@ def test_attention_split_precision_training_kernels(B, L, kv, p):
     assert_close(x.grad, rg, rel=5e-5, what="split attn dqkv")
     if kv is not None:
         assert float(x.grad[:, kv:, E:].abs().max()) == 0.0
+    # the plane-sharing pair (forward keeps the Q / K / V planes for the backward: hoisdf_attention_fwd_split_keep /
+    # _bwd_split_kept, the default above) against the self-contained pair: same planes, bit-identical results
+    keep = OO._SPLIT_KEEP
+    OO._SPLIT_KEEP = False
+    OO.set_attention_split(True)
+    try:
+        OO.manual_seed(99)
+        z = qkv.to(DEV).requires_grad_(True)
+        oz = O.attention_self(z, H, kv, p)
+        oz.backward(go.to(DEV))
+    finally:
+        OO.set_attention_split(False)
+        OO._SPLIT_KEEP = keep
+    assert keep and not OO._SPLIT_PLANES                                  # every kept workspace was consumed by its backward
+    assert torch.equal(oz, o) and torch.equal(z.grad, x.grad)
 
 
 def test_attention_split_cross_shapes():
