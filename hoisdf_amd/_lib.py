@@ -88,6 +88,8 @@ SIGNATURES: Dict[str, List] = {
                                    _U64, _P],
     "hoisdf_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _U64, _P],
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
+    "hoisdf_layernorm_rows_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
+    "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "hoisdf_vote_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_fwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

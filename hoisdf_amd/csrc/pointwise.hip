@@ -224,11 +224,14 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, long M,
                                                          int D, float eps, float drop_p, float inv_keep,
-                                                         uint64_t seed, uint32_t thresh) {
+                                                         uint64_t seed, uint32_t thresh, int rpg, int take) {
+  // rpg > 0 (hoisdf_layernorm_rows_fwd): only the first `take` rows of every group of `rpg` input rows are normalised;
+  // y / mean / rstd are compact ([groups * take]), M counts the compact rows
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
-  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (; row < M; row += (long)gridDim.x * 4) {
+  long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (; orow < M; orow += (long)gridDim.x * 4) {
+    const long row = rpg > 0 ? (orow / take) * rpg + orow % take : orow;       // input row
     float4 v[4];
     float s = 0.f;
 #pragma unroll
@@ -274,12 +277,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
         o.y = (v[i].y - mu) * rs * g.y + bb.y;
         o.z = (v[i].z - mu) * rs * g.z + bb.z;
         o.w = (v[i].w - mu) * rs * g.w + bb.w;
-        *reinterpret_cast<float4*>(y + (size_t)row * D + u * 4) = o;
+        *reinterpret_cast<float4*>(y + (size_t)orow * D + u * 4) = o;
       }
     }
     if (lane == 0) {
-      if (mean) mean[row] = mu;
-      if (rstd) rstd[row] = rs;
+      if (mean) mean[orow] = mu;
+      if (rstd) rstd[orow] = rs;
     }
   }
 }
@@ -293,7 +296,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ dx,
                                                          float* __restrict__ dr, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, long M, int D, float drop_p,
-                                                         float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds, const float* __restrict__ dx_add) {
+                                                         float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds, const float* __restrict__ dx_add,
+                                                         int rpg, int take) {
+  // rpg > 0 (hoisdf_layernorm_rows_bwd): M counts ALL input rows; dy / mean / rstd are compact - only rows t < take of a
+  // group carry a gradient, the others just pass dx_add through (or get 0)
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   float4 dg[4], db[4];
@@ -301,7 +307,23 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
   for (int i = 0; i < 4; ++i) { dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); }
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   for (; row < M; row += (long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+    long crow = row;                        // row of dy / mean / rstd
+    if (rpg > 0) {
+      const long grp = row / rpg;
+      const int t = (int)(row - grp * rpg);
+      if (t >= take) {                      // wave-uniform: no gradient through this row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int u = lane + 64 * i;
+          if (u < nu)
+            *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) =
+                dx_add ? *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + u * 4) : make_float4(0, 0, 0, 0);
+        }
+        continue;
+      }
+      crow = grp * take + t;
+    }
+    const float mu = mean[crow], rs = rstd[crow];
     float4 xh[4], gd[4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
           }
           a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)row * D + u * 4);
+        const float4 d = *reinterpret_cast<const float4*>(dy + (size_t)crow * D + u * 4);
         const float4 g = *reinterpret_cast<const float4*>(gamma + u * 4);
         xh[i] = make_float4((a.x - mu) * rs, (a.y - mu) * rs, (a.z - mu) * rs, (a.w - mu) * rs);
         gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
@@ -492,8 +514,21 @@ extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const fl
                  "add_layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
   if (M == 0) return HOISDF_OK;
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
-                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p));
+                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0);
   return check_launch("add_layernorm_fwd");
+}
+
+extern "C" int hoisdf_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                         float* rstd, long groups, int rows_per_group, int take, int D, float eps,
+                                         void* stream) {
+  HOISDF_REQUIRE(x && gamma && beta && y && groups >= 0, HOISDF_ERR_INVALID, "layernorm_rows_fwd: null pointer");
+  HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && rows_per_group > 0 && take > 0 && take <= rows_per_group,
+                 HOISDF_ERR_INVALID, "layernorm_rows_fwd: D=%d rows_per_group=%d take=%d", D, rows_per_group, take);
+  const long M = groups * take;
+  if (M == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, (const float*)nullptr, gamma,
+                     beta, y, mean, rstd, M, D, eps, 0.f, 1.f, (uint64_t)0, 0u, rows_per_group, take);
+  return check_launch("layernorm_rows_fwd");
 }
 
 extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
@@ -509,6 +544,23 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
                      dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
-                     det_scratch((size_t)blocks * 2 * D), dx_add);
+                     det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0);
   return check_launch("add_layernorm_bwd");
+}
+
+extern "C" int hoisdf_layernorm_rows_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                         const float* rstd, const float* dx_add, float* dx, float* dgamma, float* dbeta,
+                                         long groups, int rows_per_group, int take, int D, void* stream) {
+  HOISDF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && groups >= 0, HOISDF_ERR_INVALID,
+                 "layernorm_rows_bwd: null pointer");
+  HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && rows_per_group > 0 && take > 0 && take <= rows_per_group,
+                 HOISDF_ERR_INVALID, "layernorm_rows_bwd: D=%d rows_per_group=%d take=%d", D, rows_per_group, take);
+  const long M = groups * rows_per_group;
+  if (M == 0) return HOISDF_OK;
+  int blocks = row_grid(M);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, (const float*)nullptr, gamma,
+                     mean, rstd, dx, (float*)nullptr, dgamma, dbeta, M, D, 0.f, 1.f, (uint64_t)0, 0u,
+                     det_scratch((size_t)blocks * 2 * D), dx_add, rows_per_group, take);
+  return check_launch("layernorm_rows_bwd");
 }

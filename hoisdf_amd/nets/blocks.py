@@ -21,6 +21,7 @@ from .. import ops
 
 # one autograd node per encoder layer (ops.encoder_layer); HOISDF_FUSED_LAYERS=0 keeps the op-by-op graph (A/B, debugging)
 FUSED_LAYER_NODES = os.environ.get("HOISDF_FUSED_LAYERS", "1") != "0"
+INTER_ROWS = os.environ.get("HOISDF_INTER_ROWS", "1") != "0"        # A/B switch: inter_norm on the kept rows only
 
 
 class MLP(nn.Module):
@@ -170,7 +171,8 @@ class TransformerEncoder(nn.Module):
                 x, y = ops.encoder_layer(x, n_keep if i == last else None, l.p if l.training else 0.0, a.num_heads,
                                          a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                                          l.norm1.weight, l.norm1.bias, l.linear1.weight, l.linear1.bias, l.linear2.weight,
-                                         l.linear2.bias, l.norm2.weight, l.norm2.bias, n.weight, n.bias, l.norm1.eps)
+                                         l.linear2.bias, l.norm2.weight, l.norm2.bias, n.weight, n.bias, l.norm1.eps,
+                                         n_inter=n_keep if INTER_ROWS else None)   # inter_norm only on the rows the caller reads
                 inter.append(y if n_keep is None or y.shape[1] == n_keep else y[:, :n_keep])
             return x, torch.stack(inter)
         for i, layer in enumerate(self.layers):

@@ -940,7 +940,7 @@ class _EncoderLayer(torch.autograd.Function):
     x (B,S,E); n_query < S: only the first n_query rows are produced (keys / values still come from all S rows)."""
 
     @staticmethod
-    def forward(ctx, x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps):
+    def forward(ctx, x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps, n_inter=None):
         x = x.contiguous()
         _chk(x, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3)
         B, S, E = x.shape
@@ -983,18 +983,24 @@ class _EncoderLayer(torch.autograd.Function):
         x2 = torch.empty(M, E, device=dev)
         call("hoisdf_add_layernorm_fwd", _p(x1), _p(f), _p(g2), _p(be2), _p(x2), _p(st[2]), _p(st[3]), M, E, float(eps),
              float(p), s_ln2, _st())
-        y = torch.empty(M, E, device=dev)
-        call("hoisdf_add_layernorm_fwd", _p(x2), None, _p(g3), _p(be3), _p(y), _p(st[4]), _p(st[5]), M, E, float(eps), 0.0,
-             0, _st())
+        # inter_norm of the layer output: only rows < n_inter of every sample are ever read by the caller
+        ni = nq if (n_inter is None or n_inter >= nq) else int(n_inter)
+        y = torch.empty(B * ni, E, device=dev)
+        if ni == nq:
+            call("hoisdf_add_layernorm_fwd", _p(x2), None, _p(g3), _p(be3), _p(y), _p(st[4]), _p(st[5]), M, E, float(eps),
+                 0.0, 0, _st())
+        else:
+            call("hoisdf_layernorm_rows_fwd", _p(x2), _p(g3), _p(be3), _p(y), _p(st[4]), _p(st[5]), B, nq, ni, E, float(eps),
+                 _st())
         ctx.save_for_backward(x, qkv if full else qbuf, qkv if full else kvbuf, o, lse, a, x1, h, bits, f, x2, st, w_in,
                               w_out, w1, w2, g1, g2, g3)
-        ctx.meta = (B, S, E, nq, full, float(p), H, (s_attn, s_ln1, s_ffn, s_ln2), split)
-        return x2.view(B, nq, E), y.view(B, nq, E)
+        ctx.meta = (B, S, E, nq, full, float(p), H, (s_attn, s_ln1, s_ffn, s_ln2), split, ni)
+        return x2.view(B, nq, E), y.view(B, ni, E)
 
     @staticmethod
     def backward(ctx, g_x2, g_y):
         (x, qs, ks, o, lse, a, x1, h, bits, f, x2, st, w_in, w_out, w1, w2, g1, g2, g3) = ctx.saved_tensors
-        B, S, E, nq, full, p, H, (s_attn, s_ln1, s_ffn, s_ln2), split = ctx.meta
+        B, S, E, nq, full, p, H, (s_attn, s_ln1, s_ffn, s_ln2), split, ni = ctx.meta
         dev = x.device
         M, F = B * nq, w1.shape[0]
         # one zero-initialised slice for every parameter gradient of the layer
@@ -1009,9 +1015,13 @@ class _EncoderLayer(torch.autograd.Function):
         gx2 = None if g_x2 is None else g_x2.contiguous().view(M, E)
         dx2 = torch.empty(M, E, device=dev)
         if g_y is not None:
-            gy = g_y.contiguous().view(M, E)
-            call("hoisdf_add_layernorm_bwd", _p(gy), _p(x2), None, _p(g3), _p(st[4]), _p(st[5]), _p(gx2), _p(dx2), None,
-                 _p(dg3), _p(dbe3), M, E, 0.0, 0, _st())
+            gy = g_y.contiguous().view(B * ni, E)
+            if ni == nq:
+                call("hoisdf_add_layernorm_bwd", _p(gy), _p(x2), None, _p(g3), _p(st[4]), _p(st[5]), _p(gx2), _p(dx2), None,
+                     _p(dg3), _p(dbe3), M, E, 0.0, 0, _st())
+            else:
+                call("hoisdf_layernorm_rows_bwd", _p(gy), _p(x2), _p(g3), _p(st[4]), _p(st[5]), _p(gx2), _p(dx2), _p(dg3),
+                     _p(dbe3), B, nq, ni, E, _st())
         else:
             dx2 = gx2
         dx1 = torch.empty(M, E, device=dev)
@@ -1055,13 +1065,14 @@ class _EncoderLayer(torch.autograd.Function):
             _lin_bwd_weight(dkv.view(B * S, 2 * E), None, 0.0, x.view(B * S, E), dw_in[E:], db_in[E:])
             dx = dxf.view(B, S, E)
             dx[:, :nq] += dxq.view(B, nq, E)
-        return (dx, None, None, None, dw_in, db_in, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, dg3, dbe3, None)
+        return (dx, None, None, None, dw_in, db_in, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, dg3, dbe3, None, None)
 
 
-def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps=1e-5):
-    """-> (x2 (B, n_query|S, E) = the layer output, y = inter_norm(x2))"""
+def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps=1e-5,
+                  n_inter=None):
+    """-> (x2 (B, n_query|S, E) = the layer output, y = inter_norm(x2) (B, n_inter|n_query|S, E): rows < n_inter only)"""
     return _EncoderLayer.apply(x, n_query, float(p), int(H), w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3,
-                               be3, float(eps))
+                               be3, float(eps), n_inter)
 
 
 # ---------------------------------------------------------------------------------------------

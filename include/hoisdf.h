@@ -333,6 +333,16 @@ int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, co
                              float* dx, float* dr, float* dgamma, float* dbeta, long M, int D, float drop_p,
                              uint64_t seed, void* stream);
 
+/* Plain LayerNorm of the FIRST `take` rows of every group of `rows_per_group` input rows (the encoder stack's inter_norm:
+ * main/model.py:587-593 only ever reads the hand / object rows of each layer's normalised output).  x [groups *
+ * rows_per_group][D]; y, mean, rstd compact [groups * take].  Backward: dy compact; dx covers ALL input rows - rows that
+ * were normalised get their LayerNorm gradient (+ dx_add), the others dx_add (or 0 when dx_add is NULL). */
+int hoisdf_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                              long groups, int rows_per_group, int take, int D, float eps, void* stream);
+int hoisdf_layernorm_rows_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* dx_add, float* dx, float* dgamma, float* dbeta, long groups, int rows_per_group,
+                              int take, int D, void* stream);
+
 /* ---- K12: vote aggregation ----------------------------------------------------------------
  * reference: common/nets/loss.py:31-56.  off [L][B][P][J*3], cls [L][B][P][J] (batch-first
  * rows), pts [B][P][3].  joints[l][b][j] = sum_p softmax_p(cls)[p] * (pts[p] + off[p][j]).

@@ -146,6 +146,32 @@ def test_linear_split_grad_weight_accepts_the_row_scales_of_the_other_calls():
     assert_close(dx, dy.double() @ W.double(), rel=2e-6, what="dx")
 
 
+def test_layernorm_on_the_first_rows_of_every_group():
+    """hoisdf_layernorm_rows_fwd / _bwd (the encoder stack's inter_norm on the rows the caller reads): compact output and
+    statistics, full-size dx with the untouched rows passing dx_add through, vs torch in fp64."""
+    O = ops()
+    G, R, Tk, D = 5, 37, 11, 256
+    x = rnd(G * R, D, seed=71).to(DEV)
+    gam, bet = (rnd(D, seed=72) * 0.3 + 1.0).to(DEV), rnd(D, seed=73).to(DEV)
+    gy = rnd(G * Tk, D, seed=74).to(DEV)
+    add = rnd(G * R, D, seed=75).to(DEV)
+    y, mean, rstd = torch.empty(G * Tk, D, device=DEV), torch.empty(G * Tk, device=DEV), torch.empty(G * Tk, device=DEV)
+    O.call("hoisdf_layernorm_rows_fwd", O._p(x), O._p(gam), O._p(bet), O._p(y), O._p(mean), O._p(rstd), G, R, Tk, D, 1e-5, O._st())
+    x64 = x.double().view(G, R, D).requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = F.layer_norm(x64[:, :Tk], (D,), g64, b64, 1e-5)
+    assert_close(y, ref.reshape(-1, D), what="y")
+    ref.backward(gy.double().view(G, Tk, D))
+    for use_add in (True, False):
+        dx = torch.full((G * R, D), float("nan"), device=DEV)
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        O.call("hoisdf_layernorm_rows_bwd", O._p(gy), O._p(x), O._p(gam), O._p(mean), O._p(rstd), O._p(add) if use_add else None,
+               O._p(dx), O._p(dg), O._p(db), G, R, Tk, D, O._st())
+        want = x64.grad.reshape(-1, D) + (add.double() if use_add else 0.0)
+        assert_close(dx, want, what="dx")
+        assert_close(dg, g64.grad, what="dgamma"); assert_close(db, b64.grad, what="dbeta")
+
+
 def test_linear_strided_input_and_weight_slices():
     """x rows with ld > K (the 292-wide decoder-input buffer) and W given as a row slice."""
     O = ops()
