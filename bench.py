@@ -266,23 +266,23 @@ def main():
     barrier()
     if args.aten_report and rank == 0:
         from torch.profiler import profile, ProfilerActivity
-        # (record_shapes cannot marshal the 64-bit dropout seeds of the custom autograd functions: group by source line)
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        from collections import Counter
+        # record_shapes cannot marshal 64-bit unsigned seeds of the custom autograd functions: 63-bit ones for this step
+        _ns = ops.next_seed
+        ops.next_seed = lambda: _ns() & 0x7FFFFFFFFFFFFFFF
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
             step()
             torch.cuda.synchronize()
-        from collections import Counter
+        ops.next_seed = _ns
         cnt, dev_us = Counter(), Counter()
-        watch = ("aten::add_", "aten::add", "aten::mul", "aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::sum",
-                 "aten::sub", "aten::div", "aten::clamp_min", "aten::index", "aten::select_backward", "aten::slice_backward")
         for e in prof.events():
-            if e.name in watch:
-                frames = [f for f in (e.stack or []) if "hoisdf_amd" in f or "bench.py" in f or "torch/nn/modules" in f
-                          or "autograd" in f]
-                where = frames[0].strip()[-80:] if frames else "(no python frame: autograd engine)"
-                cnt[(e.name, where)] += 1
-                dev_us[(e.name, where)] += e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
-        for (name, where), n in cnt.most_common(70):
-            print(f"{n:5d}x {dev_us[(name, where)] / 1e3:7.3f} ms  {name:22s} {where}", file=sys.stderr)
+            if e.name.startswith("aten::") and e.device_time_total > 0 and e.cpu_parent is not None and \
+                    not e.cpu_parent.name.startswith("aten::"):
+                key = (e.name, e.cpu_parent.name[:40], str(e.input_shapes)[:90])
+                cnt[key] += 1
+                dev_us[key] += e.device_time_total
+        for key, us in dev_us.most_common(60):
+            print(f"{us / 1e3:7.3f} ms {cnt[key]:4d}x  {key[0]:24s} <- {key[1]:40s} {key[2]}", file=sys.stderr)
         barrier()
     # per-kernel HIP events live inside the timed region, on every `--time-every`-th step only: ~1400 event records per
     # step cost 1.7 % of the step (they serialise consecutive kernels), which `value` should not pay on every step
