@@ -175,6 +175,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP hot path has no CPU fallback)"
+    # functional test hook (tests/test_gpu_model.py): on a one-GPU box every rank runs on cuda:0 and the collectives go over
+    # gloo (RCCL refuses two ranks on one device) - exercises the N > 1 control flow of this file, says nothing about speed
+    one_gpu = os.environ.get("HOISDF_BENCH_ONE_GPU_GLOO", "") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.miopen_find:
@@ -185,7 +190,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from hoisdf_amd import _lib, ops, testing as T

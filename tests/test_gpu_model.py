@@ -230,6 +230,31 @@ def test_bench_distributed_path_single_rank_rccl():
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "dp1"
 
 
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py launched exactly like the driver launches it for N = 2 (torch.distributed.run, --gpus 2): rendezvous,
+    identical-weights / distinct-seeds asserts, per-rank synthetic shards, bucketed all-reduce from the hooks, barrier +
+    MAX-over-ranks timing, one JSON line from rank 0 with the whole-job rate.  One GPU here, so both ranks sit on cuda:0
+    with gloo as the transport (HOISDF_BENCH_ONE_GPU_GLOO=1): a functional check of the control flow, not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HOISDF_BENCH_ONE_GPU_GLOO="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29643", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "4", "--n-hand", "192", "--n-obj", "64", "--resnet", "18", "--no-cpu-baseline",
+           "--miopen-find", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 8
+    assert res["scaling"] == "weak" and res["value"] > 0
+    assert abs(res["value"] - 8 / (res["ms_per_step"] * 1e-3)) <= 1e-2 * res["value"]     # whole-job samples / max-rank time
+
+
 @pytest.mark.parametrize("gemm", [False, True])
 def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm):
     """BASELINE configs[4] ("fp16 MFMA attention"): with the f16-operand attention kernel switched on, the eval
