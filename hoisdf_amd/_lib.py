@@ -56,8 +56,6 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
-    "hoisdf_batchnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _L, _I, _P, _L, _P],
-    "hoisdf_batchnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "hoisdf_sdf_query_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _P, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _P, _L, _P],
     "hoisdf_weightnorm_fwd": [_P, _P, _P, _I, _P, _I, _I, _P],
     "hoisdf_weightnorm_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _P],
@@ -96,7 +94,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
-_OTHER = {"hoisdf_batchnorm_workspace": ([_L, _I], C.c_long), "hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
+_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),

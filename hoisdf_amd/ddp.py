@@ -186,6 +186,9 @@ class GradReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self._main is not None:
+            from . import ops
+            ops.zero_arena_end_step()        # every arena-backed gradient now lives in a bucket
         if self.world > 1 and self.average:
             for flat, flags in zip(self.buckets, self._flags):
                 flat[:flat.numel() - flags.numel()].div_(self.world)

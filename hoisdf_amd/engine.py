@@ -37,6 +37,18 @@ LOSS_WEIGHTS = {  # main/train.py:115-127 <- cfg attribute
     "loss_all_joint_3d": "joint_weight"}
 
 
+def _mix_seed(epoch_seed: int, draw: int) -> int:
+    """splitmix64 of (per-epoch per-rank seed, draw index within the epoch): streams of different ranks / epochs / resumed
+    runs are unrelated instead of shifted copies of each other"""
+    x = (epoch_seed * 0x9E3779B97F4A7C15 + draw * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return x >> 3            # 61 bits: SdfStore.sample derives 4 sub-streams as seed * 4 + i in 64 bits
+
+
 def weighted_total(model_out: Dict[str, torch.Tensor], cfg: Config):
     """main/train.py:111-138: split on the ``_out`` suffix, mean every loss, apply cfg weights, sum."""
     out = {k[:-4]: v for k, v in model_out.items() if "_out" in k}
@@ -176,6 +188,7 @@ class Trainer:
         torch.manual_seed(s)
         ops.manual_seed(s)
         self.model._py_random.seed(s)                            # the branch A / B draw (main/model.py:426)
+        self._epoch_seed, self._sdf_draws = s, 0                 # the device-side SDF point draw restarts per epoch too
 
     def train_step(self, inputs, targets, meta, epoch: int, batch_ratio: float):
         dev = self.device
@@ -186,7 +199,7 @@ class Trainer:
             pts = self.sdf_store.make_inputs(
                 meta["sdf_frame"].cpu(), meta["mano_root"], meta["obj_center_cam"], c.num_samp_hand, c.num_samp_obj,
                 c.points_filter_dist, c.hand_sdf_scale, c.obj_sdf_scale, train=True,
-                seed=self.base_seed * 1000003 + self.rank * 7919 + self._sdf_draws,
+                seed=_mix_seed(self._epoch_seed, self._sdf_draws),
                 do_flip=meta.get("do_flip"), rot_mat=meta.get("aug_rot"))
             for k in ("hand_sdf_points", "obj_sdf_points", "hand_pre_points", "obj_pre_points"):
                 inputs[k] = pts[k]

@@ -16,6 +16,7 @@ from __future__ import annotations
 import contextlib
 import os
 import random
+import weakref
 from typing import Dict
 
 import torch
@@ -53,6 +54,11 @@ def get_manoshape_memory_mask(cfg=_global_cfg):
     m = torch.zeros(1, cfg.num_samp_hand + cfg.num_samp_obj, dtype=torch.bool)
     m[:, cfg.num_samp_hand:] = True
     return m
+
+
+# per-model cache of the hoisdf_sdf_query_fwd weight descriptors (ctypes structs of raw device pointers): kept OUT of the
+# module's __dict__ so that copy.deepcopy(model) / torch.save(model) never see them
+_SDFQ_CACHE = weakref.WeakKeyDictionary()
 
 
 class Model(nn.Module):
@@ -130,12 +136,22 @@ class Model(nn.Module):
         return sdf, raw, pe, cam
 
     def _query_weights(self, kind):
-        q = self.__dict__.get("_sdfq")
+        q = _SDFQ_CACHE.get(self)
         if q is None:
             q = {"hand": ops.SdfQueryWeights(self.linear_sdfin, self.hand_sdf_decoder),
                  "obj": ops.SdfQueryWeights(self.linear_sdfin, self.obj_sdf_decoder)}
-            self.__dict__["_sdfq"] = q
+            _SDFQ_CACHE[self] = q
         return q[kind]
+
+    def invalidate_sdf_query_weights(self):
+        """drop the cached weight-norm folds (call after changing SDF-MLP weights in a way torch's version counters and
+        FusedAdamW cannot see, e.g. a foreign kernel writing the parameters in place)"""
+        _SDFQ_CACHE.pop(self, None)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_sdf_query_weights()
+        return r
 
     @torch.no_grad()
     def _sdf_query(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None, feat=None, want_feat=False):
@@ -240,8 +256,13 @@ class Model(nn.Module):
         self.obj_sigmoid_beta.data.clamp_(min=2e-3)
 
         so = None
+        if root.is_cuda:
+            # both streams read the cached SDF-query weight descriptors: (re)build them HERE, on the ambient stream and
+            # ahead of side.wait_stream, so neither stream can launch a query before the folded weights are written
+            self._query_weights("hand").get()
+            self._query_weights("obj").get()
         if two:
-            side.wait_stream(cur)                       # the points, the pyramid and the inputs are ready
+            side.wait_stream(cur)                       # the points, the pyramid, the inputs and the query weights are ready
         with on_side():                                 # ---- object points ----
             if want_sdf_loss:
                 so, _, _ = self.sdf_forward(pyr, inputs["obj_sdf_points"], ocen, K, os_, "obj")

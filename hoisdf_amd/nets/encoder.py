@@ -18,22 +18,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-# (f4) training-mode BatchNorm + ReLU (+ residual add) of the CNN as one fused HIP op on channels_last activations
-# (hoisdf_amd.ops.batchnorm_relu / csrc/bnorm.hip); the convolutions stay MIOpen.  Opt-in (HOISDF_FUSED_BN=1): measured on
-# MI355X it beats MIOpen's BatchNorm + separate add/ReLU only on the two largest ResNet-50 activations and loses on the
-# small-spatial layers, a net +0 on the step, so the default is the plain torch modules.
-FUSED_BN = os.environ.get("HOISDF_FUSED_BN", "0") != "0"
 _PENDING_NBT = []          # num_batches_tracked buffers touched in this forward: bumped with ONE multi-tensor add
 
 
 def bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual=None) -> torch.Tensor:
-    """relu?(bn(x) (+ residual)): the fused HIP op when the module trains on a channels_last GPU tensor, torch otherwise"""
-    if FUSED_BN and bn.training and bn.track_running_stats and bn.momentum is not None and x.is_cuda:
-        from .. import ops
-        if ops.batchnorm_supported(x) and (residual is None or residual.is_contiguous(memory_format=torch.channels_last)):
-            _PENDING_NBT.append(bn.num_batches_tracked)
-            return ops.batchnorm_relu(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu,
-                                      residual)
+    """relu?(bn(x) (+ residual)) with the plain torch (MIOpen) BatchNorm"""
     if bn.training and bn.track_running_stats and bn.momentum is not None and x.is_cuda:
         # what nn.BatchNorm2d.forward does, minus its per-module `num_batches_tracked += 1` kernel (69 tiny launches per
         # step for ResNet-50 + decoder): the counters are bumped together by flush_bn_counters()

@@ -49,21 +49,24 @@ def next_seed() -> int:
 class _ZeroArena:
     """Per-step arena of zero-initialised gradient scratch (weight / bias gradients the split-k GEMM accumulates into
     with atomics, LayerNorm gamma/beta sums, ...): ONE memset per step instead of one fill kernel per backward op
-    (~170 launches per training step).  Off unless a trainer brackets its steps with ``zero_arena_begin_step()``: the
-    views handed out are only valid until the next ``begin_step`` - fine when the gradients are packed into the
-    reducer's buckets (hoisdf_amd.ddp.GradReducer) before the optimizer reads them, wrong for code that keeps ``p.grad``
-    across steps.  The first step measures the demand (plain ``torch.zeros``), the buffer is sized from it."""
+    (~170 launches per training step).  Only active between ``zero_arena_begin_step()`` and ``zero_arena_end_step()``
+    (GradReducer.zero_grad() ... GradReducer.finish()): the views handed out are only valid until the next ``begin_step`` -
+    fine for gradients that are packed into the reducer's buckets before the optimizer reads them; any backward that runs
+    outside that window (another model, a test, a gradient kept across steps) gets plain ``torch.zeros``.  The first step
+    measures the demand, the buffer is sized from it."""
 
     def __init__(self):
         self.buf = None
         self.off = 0
         self.demand = 0
         self.active = False
+        self.measured = False
 
     def begin_step(self, device):
-        if self.active and self.buf is None and self.demand > 0:
+        if self.measured and self.buf is None and self.demand > 0:
             self.buf = torch.empty(int(self.demand * 1.25) + 1024, device=device, dtype=torch.float32)
         self.active = True
+        self.measured = True
         if self.buf is not None:
             (self.buf[:self.off] if 0 < self.off < self.buf.numel() else self.buf).zero_()   # only what the last step used
         self.off = 0
@@ -71,8 +74,11 @@ class _ZeroArena:
 
     def zeros(self, n, device):
         n_al = (n + 15) // 16 * 16                 # 64-byte aligned slices
-        self.demand += n_al
-        if not self.active or self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+        if self.active:
+            self.demand += n_al
+        if not self.active:
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             return torch.zeros(n, device=device, dtype=torch.float32)
         v = self.buf[self.off:self.off + n]
         self.off += n_al
@@ -89,8 +95,12 @@ def zero_arena_begin_step(device) -> None:
     _SPLIT_PLANES.clear()          # kept attention planes of graphs that never ran their backward
 
 
-def zero_arena_disable() -> None:
+def zero_arena_end_step() -> None:
+    """the step's gradients have been packed / consumed: backward passes from here on get plain torch.zeros again"""
     _ARENA.active = False
+
+
+zero_arena_disable = zero_arena_end_step
 
 
 def _zeros(n: int, device) -> torch.Tensor:
@@ -1184,63 +1194,3 @@ def aux_image_losses(decoder_out, joint_coord, hand_seg, obj_seg, sigma: float):
     return _AuxImageLosses.apply(decoder_out, joint_coord, hand_seg, obj_seg, sigma)
 
 
-# ---------------------------------------------------------------------------------------------
-# (f4) encoder side: training-mode BatchNorm2d + ReLU (+ residual) on channels-last activations
-# ---------------------------------------------------------------------------------------------
-def _cl_rows(t: torch.Tensor):
-    """(N,C,H,W) channels_last tensor -> its [N*H*W][C] row view (no copy); None if the layout does not allow it"""
-    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
-        return None
-    return t.permute(0, 2, 3, 1)
-
-
-def batchnorm_supported(x: torch.Tensor) -> bool:
-    C = x.shape[1] if x.dim() == 4 else 0
-    c4 = C // 4
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and C % 4 == 0 and 0 < C <= 2048
-            and (256 % c4 == 0 if c4 <= 64 else c4 % 64 == 0)
-            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[0] * x.shape[2] * x.shape[3] > 1)
-
-
-class _BatchNormReLU(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu):
-        from ._lib import lib
-        N, Cn, H, W = x.shape
-        R = N * H * W
-        _chk(x, residual, gamma, beta, running_mean, running_var)
-        if residual is not None:
-            assert residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)
-        y = torch.empty_like(x)                                   # keeps the channels_last strides
-        st = torch.empty(2, Cn, device=x.device, dtype=torch.float32)
-        nb = lib().hoisdf_batchnorm_workspace(R, Cn)
-        ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32)
-        call("hoisdf_batchnorm_relu_fwd", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-             float(momentum), float(eps), int(relu), _p(y), _p(st[0]), _p(st[1]), R, Cn, _p(ws), nb, _st())
-        ctx.save_for_backward(x, y if relu else None, gamma, st)
-        ctx.meta = (R, Cn, bool(relu), residual is not None)
-        ctx.mark_non_differentiable()
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        from ._lib import lib
-        x, y, gamma, st = ctx.saved_tensors
-        R, Cn, relu, has_res = ctx.meta
-        if not dy.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if (has_res and ctx.needs_input_grad[1]) else None
-        need_p = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        dgb = torch.empty(2, Cn, device=x.device, dtype=torch.float32) if need_p else None
-        nb = lib().hoisdf_batchnorm_workspace(R, Cn)
-        ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32)
-        call("hoisdf_batchnorm_relu_bwd", _p(dy), _p(x), _p(y), _p(gamma), _p(st[0]), _p(st[1]), int(relu), _p(dx), _p(dres),
-             _p(dgb[0]) if need_p else None, _p(dgb[1]) if need_p else None, R, Cn, _p(ws), nb, _st())
-        return (dx, dres, dgb[0] if ctx.needs_input_grad[2] else None, dgb[1] if ctx.needs_input_grad[3] else None,
-                None, None, None, None, None)
-
-
-def batchnorm_relu(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=True, residual=None):
-    """y = relu?(BN_train(x) (+ residual)) on channels_last (N,C,H,W) tensors; updates the running statistics in place."""
-    return _BatchNormReLU.apply(x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu)

@@ -401,24 +401,6 @@ typedef struct {
 int hoisdf_adamw_step(const hoisdf_adamw_chunk* chunks, int n_chunks, double lr, double beta1, double beta2,
                       double eps, double weight_decay, long step, float grad_scale, void* stream);
 
-/* ---- (f4) encoder side: training-mode BatchNorm2d + ReLU (+ residual add) on channels-last rows ------------------------
- * reference: nn.BatchNorm2d + nn.ReLU(inplace) (+ `out += identity`) of the CNN (common/nets/resnet.py, layer.py:23-63).
- * x, residual, y: [R = N*H*W][C] (channels-last activations); batch statistics per channel (biased variance for the
- * normalisation; running_var gets the unbiased one, running_* updated with `momentum`, may be NULL).
- *   y = relu?( gamma * (x - mean) * invstd + beta (+ residual) );  mean / invstd [C] are saved for the backward.
- * Backward: g = dy * [y > 0] (relu), dx = gamma * invstd * (g - mean_r(g) - xhat * mean_r(g * xhat)), dresidual = g
- * (optional), dgamma = sum_r g * xhat, dbeta = sum_r g (optional).  Order-fixed (per-block partials merged in block
- * order, no atomics).  workspace: hoisdf_batchnorm_workspace(R, C) bytes.  C: multiple of 4, <= 2048, C/4 a divisor of 256 or
- * a multiple of 64. */
-long hoisdf_batchnorm_workspace(long R, int C);
-int hoisdf_batchnorm_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, int relu, float* y,
-                              float* mean, float* invstd, long R, int C, void* workspace, long workspace_bytes,
-                              void* stream);
-int hoisdf_batchnorm_relu_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean,
-                              const float* invstd, int relu, float* dx, float* dresidual, float* dgamma, float* dbeta,
-                              long R, int C, void* workspace, long workspace_bytes, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -255,13 +255,14 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     assert abs(res["value"] - 8 / (res["ms_per_step"] * 1e-3)) <= 1e-2 * res["value"]     # whole-job samples / max-rank time
 
 
-@pytest.mark.parametrize("gemm", [False, True])
-def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm):
+@pytest.mark.parametrize("gemm,nh,no", [(False, 384, 128), (True, 384, 128), (False, 6144, 2048), (True, 6144, 2048)])
+def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm, nh, no):
     """BASELINE configs[4] ("fp16 MFMA attention"): with the f16-operand attention kernel switched on, the eval
-    forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m.  gemm=True: the linear layers
-    (the dense-lattice SDF query included) in split precision as well (cfg.gemm_split_eval)."""
+    forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m - at 512 points and at
+    configs[4]'s own 6144 + 2048 = 8192 points (g7_e2e_dexycb_n8192, the reference's forward at that size).  gemm=True: the
+    linear layers (the dense-lattice SDF query included) in split precision as well (cfg.gemm_split_eval)."""
     from hoisdf_amd import ops
-    setting, nh, no, bins, b = "dexycb", 384, 128, 64, 1
+    setting, bins, b = "dexycb", 64, 1
     g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
     model, c = build(setting, nh, no, bins)
     pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=2))
