@@ -1,0 +1,375 @@
+// fp32 linear layers EMULATED on the bf16 MFMA pipe ("bf16x3"): forward and grad-input of common/nets/layer.py:168-201
+// (MLP), common/nets/transformer.py:286-302 (in / out projections, feed-forward), main/model.py:56-90 (input MLPs, heads).
+//
+// Every f32 operand is split EXACTLY into three bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significand bits; bf16 has the f32
+// exponent range, so - unlike an f16 hi / lo pair - nothing has to be scaled and nothing is lost: x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), every subtraction exact).  A product x y is accumulated in f32 from six
+// v_mfma_f32_32x32x16_bf16 products, x0y0 + x0y1 + x1y0 + x1y1 + x0y2 + x2y0 (each bf16 x bf16 product is exact in f32); the
+// three dropped terms are <= 2^-24 |x y|, below the rounding of an f32 fused multiply-add.  Against fp64 the result has the
+// error of an f32 GEMM (measured next to the exact-f32 MFMA kernel: tools/ubench/gemm_emu_lab.hip, tests/test_gpu_emu.py),
+// while the bf16 pipe runs 16 x the f32 MFMA rate: 2.67 x after six products.
+//
+//   A (activations x, or dy) is read as f32, k-contiguous, and split on its way into LDS (thread = tile row; the forward's
+//   ReLU / dropout sign bitmap and 1 / keep are applied to dy before the split).  B (the weight) is pre-split ONCE per weight
+//   update into a "slab image": for column tile tn (128 output columns), slab s (16 k), plane p, k-chunk c (8 k), row r the
+//   16 bytes at ((((tn * nslab + s) * 3 + p) * 2 + c) * 128 + r) * 16 - exactly the LDS image of the slab, so staging it is
+//   three fully coalesced 16-byte loads and three ds_write_b128 per thread (hoisdf_linear_emu_prepare; transposed for grad-input).
+//   LDS image of a plane slab: [chunk][row][16 B]: the MFMA fragment read (32 consecutive rows of one chunk per half-wave,
+//   ds_read_b128) and the staging write (consecutive rows) are both bank-conflict free without padding.
+// Tile 256 x 128, 4 waves as 2 x 2, wave tile 128 x 64 = 4 x 2 MFMA blocks (128 accumulators), 16-deep slabs double-buffered
+// in LDS (72 KB), two workgroups per CU (<= 256 VGPRs); one barrier per slab; the next slab is converted / parked and the one
+// after it requested at the top of every slab.  Epilogue = gemm.hip's (bias, ReLU, dropout, 1-bit sign map, accumulate-into,
+// LDS-transposed 16-byte stores).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace hoisdf {
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define MFB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int TM = 256, TN = 128, KS = 16, NT = 256;
+constexpr int WN = TN / 2, NJ = WN / 32;
+constexpr int A_U4 = 3 * 2 * TM, B_U4 = 3 * 2 * TN, STAGE_U4 = A_U4 + B_U4;
+constexpr int NB = B_U4 / NT;
+constexpr unsigned LDS_BYTES = 2u * STAGE_U4 * 16u;        // 73 728
+
+// exact three-way split (native ext vectors only: arrays of HIP's uint4 / float4 structs end up in scratch)
+#define SPLIT1(x, i)                             \
+  do {                                           \
+    const __bf16 a_ = (__bf16)(x);               \
+    const float r1_ = (x) - (float)a_;           \
+    const __bf16 b_ = (__bf16)r1_;               \
+    const float r2_ = r1_ - (float)b_;           \
+    p0[i] = a_; p1[i] = b_; p2[i] = (__bf16)r2_; \
+  } while (0)
+__device__ __forceinline__ void split3x8(const float4 u, const float4 w, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+  SPLIT1(u.x, 0); SPLIT1(u.y, 1); SPLIT1(u.z, 2); SPLIT1(u.w, 3);
+  SPLIT1(w.x, 4); SPLIT1(w.y, 5); SPLIT1(w.z, 6); SPLIT1(w.w, 7);
+}
+
+struct EmuArgs {
+  const float* A; long lda;                 // [M][lda] f32, k-contiguous
+  const u32x4* Bimg;                        // slab image of the weight operand (rows = output columns)
+  float* C; int ldc;
+  const float* bias;
+  const uint32_t* abits; int ldbits; float ascale;      // sign bitmap of A ([M][ceil(K / 32)]) and 1 / keep (grad-input)
+  uint32_t* bits_out; int ldbits_out;
+  int M, N, K;                              // output rows, output columns, contraction length
+  int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
+  int tiles_m, tiles_n, vecC, beta;
+};
+}  // namespace
+
+// ---- weight -> slab image.  transpose = 0: image row n, contraction k = W[n][k] (forward);  1: image row k, contraction
+// n = W[n][k] (grad-input: dx = dy . W).  One thread per (tile, slab, chunk, row): 8 source values -> 3 x 16 bytes.
+__global__ __launch_bounds__(256) void emu_prep_weight_kernel(const float* __restrict__ W, int ldw, int R, int Kc, int transpose,
+                                                              int nslab, long total, u32x4* __restrict__ img) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int r = (int)(idx % TN);
+  const int c = (int)((idx / TN) % 2);
+  const int s = (int)((idx / (2 * TN)) % nslab);
+  const int tn = (int)(idx / ((long)2 * TN * nslab));
+  const int row = tn * TN + r;
+  const int k0 = s * KS + c * 8;
+  float e[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    float v = 0.f;
+    if (row < R && k < Kc) v = transpose ? W[(size_t)k * ldw + row] : W[(size_t)row * ldw + k];
+    e[i] = v;
+  }
+  bf16x8 p0, p1, p2;
+  split3x8(make_float4(e[0], e[1], e[2], e[3]), make_float4(e[4], e[5], e[6], e[7]), p0, p1, p2);
+  const size_t base = ((size_t)(tn * nslab + s) * 3) * 2 * TN;
+  img[base + (0 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p0);
+  img[base + (1 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p1);
+  img[base + (2 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p2);
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nslab = (g.K + KS - 1) / KS;
+  const int last = nslab - 1;
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: thread = row of the A tile (rows past M re-read the last row: their products only reach rows that are never
+  // stored); B image pieces tid + 256 q.  All loads are unconditional (a load behind a branch makes hipcc assume the shorter
+  // queue at the merge and wait for everything): the k tail is handled by clamping the address and zeroing the value.
+  const int arow_i = min(m0 + tid, g.M - 1);
+  const float* arow = g.A + (size_t)arow_i * g.lda;
+  const uint32_t* mrow = MASK ? g.abits + (size_t)arow_i * g.ldbits : nullptr;
+  const u32x4* bsrc = g.Bimg + (size_t)tn * nslab * B_U4 + tid;
+  const int kmax4 = g.K - 4;                       // K is a multiple of 4 (checked by the host)
+  float4 ra[4];
+  u32x4 rb[NB];
+  uint32_t rm = 0xffffffffu;
+#define LOAD_SLAB(sl)                                                                                                  \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                      \
+        ra[q] = *reinterpret_cast<const float4*>(arow + min((sl) * KS + q * 4, kmax4));                                \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) rb[q] = bsrc[(size_t)(sl) * B_U4 + q * NT];                          \
+    if (MASK) rm = mrow[(sl) >> 1];                                                                                    \
+  } while (0)
+#define STORE_SLAB(st, sl)                                                                                             \
+  do {                                                                                                                 \
+    const int krem_ = g.K - (sl) * KS;                      /* valid k in this slab (>= 16 except in the last one) */  \
+    const uint32_t mb_ = MASK ? (rm >> (((sl) & 1) * 16)) : 0xffffu;                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+      float4 v_ = ra[q];                                                                                               \
+      if (MASK) {                                                                                                      \
+        v_.x = ((mb_ >> (4 * q + 0)) & 1u) ? v_.x * g.ascale : 0.f;                                                    \
+        v_.y = ((mb_ >> (4 * q + 1)) & 1u) ? v_.y * g.ascale : 0.f;                                                    \
+        v_.z = ((mb_ >> (4 * q + 2)) & 1u) ? v_.z * g.ascale : 0.f;                                                    \
+        v_.w = ((mb_ >> (4 * q + 3)) & 1u) ? v_.w * g.ascale : 0.f;                                                    \
+      }                                                                                                                \
+      if (4 * q >= krem_) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+      ra[q] = v_;                                                                                                      \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                    \
+      bf16x8 p0, p1, p2;                                                                                               \
+      split3x8(ra[2 * c], ra[2 * c + 1], p0, p1, p2);                                                                  \
+      (st)[(0 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p0);                                                    \
+      (st)[(1 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p1);                                                    \
+      (st)[(2 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p2);                                                    \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) (st)[A_U4 + tid + q * NT] = rb[q];                                   \
+  } while (0)
+
+  LOAD_SLAB(0);
+  STORE_SLAB(lds, 0);
+  LOAD_SLAB(min(1, last));
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    const u32x4* st = lds + (s & 1) * STAGE_U4;
+    u32x4* nx = lds + ((s + 1) & 1) * STAGE_U4;
+    const u32x4* sa = st + wm * 128 + l31;
+    const u32x4* sb = st + A_U4 + wn * WN + l31;
+    bf16x8 b0[NJ], b1[NJ], b2[NJ], a[4];
+#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < NJ; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * TN + j * 32])
+#define RD_A(p) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, sa[((p) * 2 + kh) * TM + i * 32])
+#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
+    RD_B(b0, 0); RD_A(2);
+    // the next slab: registers -> the other stage (masked, converted); the slab after it -> registers (a whole slab of MFMAs
+    // to land).  Pinned here: hipcc otherwise sinks the loads to the end of the loop body.  Past the end the last slab is
+    // simply staged again into the stage nobody reads any more.
+    STORE_SLAB(nx, min(s + 1, last));
+    LOAD_SLAB(min(s + 2, last));
+    __builtin_amdgcn_sched_barrier(0);
+    MM1(b0);                                   // x2 y0            (small terms first)
+    RD_B(b1, 1); RD_A(1);
+    MM1(b1); MM1(b0);                          // x1 y1, x1 y0
+    RD_B(b2, 2); RD_A(0);
+    MM1(b2); MM1(b1); MM1(b0);                 // x0 y2, x0 y1, x0 y0
+    __syncthreads();
+  }
+#undef LOAD_SLAB
+#undef STORE_SLAB
+#undef RD_A
+#undef RD_B
+#undef MM1
+
+  // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); all waves are
+  // past the main loop's last barrier, the staging buffer is free
+  const int rbase = m0 + wm * 128 + 4 * kh;
+  const int cbase = n0 + wn * WN + l31;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = cbase + j * 32;
+    const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bv;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        acc[i][j][r] = v;
+      }
+  }
+  if (g.drop_p > 0.f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        const uint32_t rk = drop_rowkey(g.seed, (uint32_t)row);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j][r] *= drop_scale(rk, (uint32_t)(cbase + j * 32), g.thresh, g.inv_keep);
+      }
+  }
+  const bool full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
+  if (full && g.vecC) {
+    // one row of blocks (32 x 64) per wave at a time through a wave-private LDS slice, read back row-wise: one
+    // global_store_dwordx4 covers four complete 256-byte row segments
+    constexpr int ES = WN + 4;
+    float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int rr = p * 4 + (lane >> 4), cc = (lane & 15) * 4;
+        float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
+        float4* cp = reinterpret_cast<float4*>(g.C + (size_t)(m0 + wm * 128 + i * 32 + rr) * g.ldc + n0 + wn * WN + cc);
+        if (g.beta) {
+          const float4 old = *cp;
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        *cp = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2), col = cbase + j * 32;
+          if (row < g.M && col < g.N) {
+            float* cp = g.C + (size_t)row * g.ldc + col;
+            *cp = g.beta ? *cp + acc[i][j][r] : acc[i][j][r];
+          }
+        }
+  }
+  if (g.bits_out) {
+    // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below: one ballot is two mask words.
+    // Each lane collects the words of "its" rows (lane and lane + 64 of the wave's 128 x 64 sub-tile) and writes them once.
+    uint32_t w00 = 0u, w01 = 0u, w10 = 0u, w11 = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (i & 1) * 32 + (r & 3) + 8 * (r >> 2);      // row within a 64-row half, as held by lanes 0-31
+        const unsigned long long q0 = __ballot(acc[i][0][r] > 0.f);
+        const unsigned long long q1 = __ballot(acc[i][1][r] > 0.f);
+        if (i < 2) {
+          if (lane == rl) { w00 = (uint32_t)q0; w01 = (uint32_t)q1; }
+          if (lane == rl + 4) { w00 = (uint32_t)(q0 >> 32); w01 = (uint32_t)(q1 >> 32); }
+        } else {
+          if (lane == rl) { w10 = (uint32_t)q0; w11 = (uint32_t)q1; }
+          if (lane == rl + 4) { w10 = (uint32_t)(q0 >> 32); w11 = (uint32_t)(q1 >> 32); }
+        }
+      }
+    const int wcol = (n0 + wn * WN) >> 5;
+    const int nvalid = g.N - (n0 + wn * WN);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int row = m0 + wm * 128 + hh * 64 + lane;
+      const uint32_t v0 = hh ? w10 : w00, v1 = hh ? w11 : w01;
+      if (row < g.M) {
+        if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol] = nvalid >= 32 ? v0 : (v0 & ((1u << nvalid) - 1u));
+        if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits_out + wcol + 1] = nvalid >= 64 ? v1 : (v1 & ((1u << (nvalid - 32)) - 1u));
+      }
+    }
+  }
+}
+
+namespace {
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int launch_emu(EmuArgs g, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_kc_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_kc_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_BYTES) != hipSuccess) {
+      set_error("linear_emu: cannot raise the dynamic LDS limit to %u bytes", LDS_BYTES);
+      return HOISDF_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  g.tiles_m = cdiv(g.M, TM);
+  g.tiles_n = cdiv(g.N, TN);
+  g.vecC = al16(g.C) && (g.ldc % 4 == 0);
+  const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
+  if (g.abits) hipLaunchKernelGGL((emu_kc_kernel<true>), grid, block, LDS_BYTES, st, g);
+  else hipLaunchKernelGGL((emu_kc_kernel<false>), grid, block, LDS_BYTES, st, g);
+  return check_launch("linear_emu");
+}
+}  // namespace
+
+}  // namespace hoisdf
+
+using namespace hoisdf;
+
+extern "C" long hoisdf_linear_emu_image_bytes(int rows, int K) {
+  if (rows <= 0 || K <= 0) return 0;
+  return (long)cdiv(rows, TN) * cdiv(K, KS) * B_U4 * 16;
+}
+
+extern "C" int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, int transpose, void* image, void* stream) {
+  HOISDF_REQUIRE(W && image && N > 0 && K > 0 && ldw >= K, HOISDF_ERR_INVALID, "linear_emu_prepare: bad arguments");
+  HOISDF_REQUIRE(al16(image), HOISDF_ERR_INVALID, "linear_emu_prepare: the image must be 16-byte aligned");
+  const int R = transpose ? K : N, Kc = transpose ? N : K;
+  const int nslab = cdiv(Kc, KS);
+  const long total = (long)cdiv(R, TN) * nslab * 2 * TN;
+  hipLaunchKernelGGL(emu_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldw, R, Kc,
+                     transpose, nslab, total, static_cast<u32x4*>(image));
+  return check_launch("linear_emu_prepare");
+}
+
+extern "C" int hoisdf_linear_emu_supported(const float* a, long lda, int Kc) {
+  return a && al16(a) && (lda % 4 == 0) && (Kc % 4 == 0) && Kc >= 4;
+}
+
+extern "C" int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M,
+                                     int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream) {
+  HOISDF_REQUIRE(M == 0 || (x && w_image && y), HOISDF_ERR_INVALID, "linear_fwd_emu: null pointer");
+  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && M < (1L << 31), HOISDF_ERR_INVALID,
+                 "linear_fwd_emu: bad sizes M=%ld N=%d K=%d ldx=%d ldy=%d", M, N, K, ldx, ldy);
+  HOISDF_REQUIRE(drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "linear_fwd_emu: drop_p=%f", drop_p);
+  if (M == 0) return HOISDF_OK;
+  HOISDF_REQUIRE(hoisdf_linear_emu_supported(x, ldx, K), HOISDF_ERR_INVALID,
+                 "linear_fwd_emu: x must be 16-byte aligned with ldx and K multiples of 4 (use hoisdf_linear_fwd otherwise)");
+  EmuArgs g{};
+  g.A = x; g.lda = ldx; g.Bimg = static_cast<const u32x4*>(w_image);
+  g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
+  g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
+  g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
+  return launch_emu(g, as_stream(stream));
+}
+
+extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                                           const void* wt_image, float* dx, int lddx, long M, int N, int K, int accumulate,
+                                           void* stream) {
+  HOISDF_REQUIRE(M == 0 || (dy && wt_image && dx), HOISDF_ERR_INVALID, "linear_bwd_input_emu: null pointer");
+  HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && lddx >= K && M < (1L << 31) && drop_p >= 0.f && drop_p < 1.f,
+                 HOISDF_ERR_INVALID, "linear_bwd_input_emu: bad sizes");
+  if (M == 0) return HOISDF_OK;
+  HOISDF_REQUIRE(hoisdf_linear_emu_supported(dy, lddy, N), HOISDF_ERR_INVALID,
+                 "linear_bwd_input_emu: dy must be 16-byte aligned with lddy and N multiples of 4");
+  EmuArgs g{};
+  // dx[m][k] = sum_n dy[m][n] W[n][k]: A = dy rows (contraction n contiguous), B = the transposed image ([k][n])
+  g.A = dy; g.lda = lddy; g.Bimg = static_cast<const u32x4*>(wt_image);
+  g.abits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
+  g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N;
+  g.inv_keep = 1.f;
+  g.beta = accumulate ? 1 : 0;
+  return launch_emu(g, as_stream(stream));
+}

@@ -300,6 +300,62 @@ def gemm_split() -> bool:
     return _GEMM_SPLIT
 
 
+# ---- fp32 emulated on the bf16 MFMA pipe (csrc/gemm_emu.hip): forward / grad-input of the large linear layers ------------
+_GEMM_EMU = __import__("os").environ.get("HOISDF_GEMM", "emu") != "f32"
+_GEMM_EMU_MIN_ROWS = 2048            # below this a problem is a handful of tiles: latency-bound, stays on the f32 kernel
+_EMU_IMAGES = {}                     # (data_ptr, shape, ld, transpose) -> [image, version key, event, build stream, owner]
+
+
+def set_gemm_emu(on: bool) -> None:
+    """cfg.gemm_emu (default on; HOISDF_GEMM=f32 turns it off): forward and grad-input of the large linear layers as exact
+    three-way bf16 splits of both f32 operands, six bf16 MFMA products per product, f32 accumulation - fp32-equivalent
+    results (include/hoisdf.h hoisdf_linear_fwd_emu) at 1.7x the f32 MFMA kernel.  Off: the exact-f32 MFMA kernel."""
+    global _GEMM_EMU
+    _GEMM_EMU = bool(on)
+
+
+def gemm_emu() -> bool:
+    return _GEMM_EMU
+
+
+def _emu_ok(M: int, a: torch.Tensor, lda: int, contraction: int) -> bool:
+    return (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_MIN_ROWS and contraction % 4 == 0 and lda % 4 == 0
+            and a.data_ptr() % 16 == 0)
+
+
+def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """the bf16x3 slab image of a weight (hoisdf_linear_emu_prepare), cached per (storage, shape, orientation) and rebuilt in
+    place when the weight changed (torch's version counter, or the generation FusedAdamW bumps).  The build is recorded with
+    an event: a consumer on another HIP stream (the object stack runs on a second one) waits for it."""
+    from ._lib import lib
+    N, K = W.shape
+    key = (W.data_ptr(), N, K, W.stride(0), bool(transpose))
+    ver = (_WEIGHT_GEN[0], W._version)
+    cur = torch.cuda.current_stream(W.device)
+    ent = _EMU_IMAGES.get(key)
+    # the entry belongs to ONE tensor object (the parameter, or the parameter a slice views): another tensor that the
+    # allocator later placed at the same address must not hit it
+    base = W._base if W._base is not None else W
+    if ent is not None and ent[4]() is not base:
+        ent[1], ent[4] = None, __import__("weakref").ref(base)
+    if ent is None:
+        nb = lib().hoisdf_linear_emu_image_bytes(K if transpose else N, N if transpose else K)
+        ent = [torch.empty(nb, device=W.device, dtype=torch.uint8), None, None, None, __import__("weakref").ref(base)]
+        if len(_EMU_IMAGES) > 4096:          # weights that came and went (tests): do not grow without bound
+            _EMU_IMAGES.clear()
+        _EMU_IMAGES[key] = ent
+    if ent[1] != ver:
+        if ent[3] is not None and ent[3] != cur:
+            cur.wait_stream(ent[3])          # the previous image's last readers on the other stream
+        call("hoisdf_linear_emu_prepare", _p(W), W.stride(0), N, K, int(transpose), _p(ent[0]), _st())
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        ent[1], ent[2], ent[3] = ver, ev, cur
+    elif ent[3] != cur:
+        cur.wait_event(ent[2])
+    return ent[0]
+
+
 def _split_ok(M: int, N: int, K: int) -> bool:
     return _GEMM_SPLIT and M >= _GEMM_SPLIT_MIN_ROWS and N >= 64 and K >= 64
 
@@ -317,6 +373,10 @@ def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
         call("hoisdf_linear_fwd_split", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _p(ws), nb, _st())
         return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
+    if _emu_ok(M, x2, ldx, K):
+        call("hoisdf_linear_fwd_emu", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
+             float(drop_p), seed, _p(bits), _st())
+        return None
     call("hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p),
          seed, _p(bits), _st())
     return None
@@ -329,6 +389,10 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
         call("hoisdf_linear_bwd_input_split", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
              int(accumulate), _p(ws), nb, _st())
         return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
+    if _emu_ok(M, dy2, lddy, N):
+        call("hoisdf_linear_bwd_input_emu", _p(dy2), lddy, _p(bits), float(p), _p(_emu_image(W, True)), _p(dx), lddx, M, N, K,
+             int(accumulate), _st())
+        return None
     call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
          int(accumulate), _st())
     return None

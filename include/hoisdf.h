@@ -119,6 +119,26 @@ long hoisdf_linear_bwd_weight_workspace(long M, int N, int K);
 int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                              const float* x, int ldx, float* dW, int lddw, float* db, long M, int N,
                              int K, float* workspace, long workspace_floats, void* stream);
+/* ---- fp32 linear layers emulated on the bf16 MFMA pipe ("bf16x3"; cfg.gemm_emu) ------------------------------------------
+ * reference: the same call sites as hoisdf_linear_fwd / hoisdf_linear_bwd_input (common/nets/layer.py:168-201,
+ * common/nets/transformer.py:286-302, main/model.py:56-90).  Same contracts and argument meaning, fp32-equivalent results:
+ * every f32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, no scaling - bf16 has the f32
+ * exponent range) and each product is accumulated in f32 from six bf16 MFMA products (the three dropped cross terms are
+ * <= 2^-24 of the product); error against fp64 = that of the exact-f32 entries (tests/test_gpu_emu.py), not bit-identical
+ * to them (another summation order).  The weight operand is handed over as a pre-split "slab image"
+ * (hoisdf_linear_emu_image_bytes(rows, K) bytes, 16-byte aligned, caller-owned):
+ *   hoisdf_linear_emu_prepare(W, ldw, N, K, 0, image)  -> image for hoisdf_linear_fwd_emu       (rows = N, contraction K)
+ *   hoisdf_linear_emu_prepare(W, ldw, N, K, 1, image)  -> image for hoisdf_linear_bwd_input_emu (rows = K, contraction N)
+ * to be rebuilt whenever W changes (once per optimizer step).  The activation operand must be 16-byte aligned with a leading
+ * dimension and a contraction length that are multiples of 4 (hoisdf_linear_emu_supported); other shapes stay on the f32
+ * entries. */
+long hoisdf_linear_emu_image_bytes(int rows, int K);
+int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, int transpose, void* image, void* stream);
+int hoisdf_linear_emu_supported(const float* a, long lda, int contraction);
+int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
+                          int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);
+int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image,
+                                float* dx, int lddx, long M, int N, int K, int accumulate, void* stream);
 /* ---- split-precision linear layers (opt-in; cfg.gemm_split) -----------------------------------
  * reference: the same call sites as hoisdf_linear_* (common/nets/layer.py:168-201, common/nets/transformer.py:286-302,
  * main/model.py:181-244).  Same contracts and argument meaning as hoisdf_linear_fwd / _bwd_input / _bwd_weight, but the
