@@ -33,3 +33,23 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def pyramid_gradient_close(got, golden_fp32, suffix):
+    """The element-wise stride-32 pyramid gradient of a training fixture is ill-conditioned: ReLU gates whose pre-activation
+    is at rounding level flip with the summation order, and the reference's OWN fp32 value sits 1.0e-3 of the tensor's max away
+    from the fp64 value at the worst element (tools/fp64_truth.py: the pinned CPU oracle run in float64; 0.29254 in fp64,
+    0.29594 in the reference's fp32, 0.29194 from the bf16x3 kernels).  So the check is two-sided: no further from the fp64
+    truth than the reference's fp32 is (1.2e-3 with margin), and within the sum of the two distances of the reference."""
+    got = got.double().cpu()
+    mx = float(golden_fp32.abs().max())
+    err_ref = float((got - golden_fp32.double()).abs().max())
+    assert err_ref <= 2.2e-3 * mx, ("vs the reference's fp32 gradient", err_ref / mx)
+    name = "g8_train_dexycb" + suffix + "_fp64"
+    if os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        g64 = load_golden(name)["grad.pyr.stride32"].double()
+        err64 = float((got - g64).abs().max())
+        ref64 = float((golden_fp32.double() - g64).abs().max())
+        assert err64 <= max(1.2e-3 * mx, 1.2 * ref64), ("vs fp64", err64 / mx, "reference fp32 vs fp64", ref64 / mx)
+    else:
+        assert err_ref <= 1.0e-3 * mx, err_ref / mx

@@ -7,7 +7,7 @@ import random
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, pyramid_gradient_close
 from hoisdf_amd import testing as T
 from hoisdf_amd.config import Config
 
@@ -170,7 +170,7 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
     gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
     gclose(model.linear_handcls.layers[2].weight.grad, g["grad.linear_handcls.layers.2.weight"])
     gclose(model.hand_sdf_decoder.linh0.weight_g.grad, g["grad.hand_sdf_decoder.linh0.weight_g"])
-    gclose(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"])
+    pyramid_gradient_close(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"], suffix)
     gn2 = levels[0].grad.double().norm().item()
     assert abs(gn2 - float(g["grad.pyr.stride2_norm"])) <= 1e-3 * float(g["grad.pyr.stride2_norm"])
 
@@ -440,7 +440,5 @@ def test_train_fwd_bwd_with_split_precision_attention_meets_the_golden_bars(nh, 
             assert abs(gn - float(g[key])) <= 1e-3 * float(g[key]) + 1e-6, (name, gn, float(g[key]))
             n += 1
     assert n > 100
-    err = (levels[4].grad.permute(0, 3, 1, 2)[:, ::16].float().cpu() - g["grad.pyr.stride32"]).abs().max().item()
-    # element-wise pyramid gradient: ill-conditioned (the exact-f32 path sits at 4e-4 of the max at N = 2048); a hi + lo pair
-    # carries 22 bits instead of 24, measured 1.13e-3 with the GEMMs split as well -> bar 1.5e-3 for that mode only
-    assert err <= (1.5e-3 if gemm else 1e-3) * float(g["grad.pyr.stride32"].abs().max())
+    # element-wise pyramid gradient: ill-conditioned, judged against the fp64 value as well as the reference's fp32 one
+    pyramid_gradient_close(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"], suffix)

@@ -238,3 +238,16 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     gclose(Pm["linear_handcls.layers.2.weight"].grad, g["grad.linear_handcls.layers.2.weight"])
     gclose(pyr["stride32"].grad[:, ::16], g["grad.pyr.stride32"])
     close(pyr["stride2"].grad.double().norm().float(), g["grad.pyr.stride2_norm"], rtol=1e-4)
+
+
+def test_fp64_truth_fixture_documents_the_references_own_fp32_distance():
+    """tests/golden/g8_train_dexycb_n2048_fp64.npz = the pinned oracle run in float64 (tools/fp64_truth.py).  The element-wise
+    stride-32 pyramid gradient is ill-conditioned: the REFERENCE's fp32 value sits 1.0e-3 of the tensor's max away from fp64
+    at its worst element, while its total loss agrees to 1e-8 - the yardstick the GPU tests use (conftest.pyramid_gradient_close)."""
+    g = load_golden("g8_train_dexycb_n2048")
+    g64 = load_golden("g8_train_dexycb_n2048_fp64")
+    ref, tru = g["grad.pyr.stride32"].double(), g64["grad.pyr.stride32"].double()
+    mx = float(ref.abs().max())
+    d = float((ref - tru).abs().max()) / mx
+    assert 5e-4 < d < 1.2e-3, d
+    assert abs(float(g64["total"]) - float(g["total"])) <= 1e-7 * abs(float(g["total"]))
