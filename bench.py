@@ -65,6 +65,7 @@ class KernelTimer:
         # algorithmic FLOPs (the six bf16 products per product are not counted)
         "hoisdf_linear_fwd_emu": lambda a: 2.0 * a[6] * a[7] * a[8],
         "hoisdf_linear_bwd_input_emu": lambda a: 2.0 * a[7] * a[8] * a[9],
+        "hoisdf_linear_bwd_weight_emu": lambda a: 2.0 * a[9] * a[10] * a[11],
         "hoisdf_linear_fwd_split": lambda a: 2.0 * a[7] * a[8] * a[9],
         "hoisdf_linear_bwd_input_split": lambda a: 2.0 * a[8] * a[9] * a[10],
         "hoisdf_linear_bwd_weight_split": lambda a: 2.0 * a[9] * a[10] * a[11],
@@ -84,7 +85,7 @@ class KernelTimer:
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20),
              "hoisdf_attention_fwd_split_keep": (9, 11, 13), "hoisdf_attention_bwd_split_kept": (16, 18, 20),
-             "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9),
+             "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
              "hoisdf_linear_fwd_split": (7, 8, 9), "hoisdf_linear_bwd_input_split": (8, 9, 10),
              "hoisdf_linear_bwd_weight_split": (9, 10, 11)}
 
@@ -368,8 +369,8 @@ def main():
         sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's split switch
         fams = {"gemm_f32_kernel (linear fwd + grad-input + grad-weight)":
                     ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if args.gemm == "split" else sq),
-                "emu_kc_kernel (linear fwd + grad-input, fp32 emulated with 3-way bf16 splits, 6 products)":
-                    ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"],
+                "emu_kc_kernel + emu_dw_kernel (linear fwd + grad-input + grad-weight, fp32 emulated with 3-way bf16 splits, 6 products)":
+                    ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu", "hoisdf_linear_bwd_weight_emu"],
                 "attn_fwd_kernel": ["hoisdf_attention_fwd"],
                 "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
                 "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"],

@@ -54,6 +54,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_emu_prepare": [_P, _I, _I, _I, _I, _P, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
+    "hoisdf_linear_bwd_weight_emu": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_linear_fwd_split": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _L, _P],
     "hoisdf_linear_bwd_input_split": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P, _L, _P],
     "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P],
@@ -102,6 +103,7 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),
           "hoisdf_linear_emu_image_bytes": ([_I, _I], C.c_long),
+          "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
           "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long)}

@@ -289,6 +289,228 @@ __global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
   }
 }
 
+
+// ============================================================================================================================
+// grad-weight: dW[n][k] = sum_m dy_eff[m][n] x[m][k], db[n] = sum_m dy_eff[m][n].  The contraction runs over the ROWS of both
+// operands, so each needs its planes transposed ([column][8 consecutive m]): a staging thread loads a 4-column x 8-row patch
+// (8 float4, lanes along the columns: 1 KB contiguous per row), transposes it in registers and writes, per column, the three
+// 16-byte pieces of that column's chunk - no transposed copy of an activation ever goes through HBM.
+// Tile 256 (n) x 256 (k): one 4 x 8 patch per thread covers both operands of a 16-row slab (threads 0-127: dy, 128-255: x);
+// 4 waves as 2 x 2, wave tile 128 x 128 = 4 x 4 MFMA blocks, 256 accumulators (AGPRs), one workgroup per CU; the rows are
+// split over the workgroups (every slice of a tile on one XCD) into partial tiles + an ordered reduce: no atomics.
+// ============================================================================================================================
+namespace {
+constexpr int DT = 256;                                  // tile edge (both n and k)
+constexpr int DW_OP_U4 = 3 * 2 * DT;                     // 16-byte units per operand per stage
+constexpr int DW_STAGE_U4 = 2 * DW_OP_U4;
+constexpr unsigned DW_LDS_BYTES = 2u * DW_STAGE_U4 * 16u;   // 98 304
+
+struct DwArgs {
+  const float* dy; long lddy;
+  const float* x; long ldx;
+  const uint32_t* bits; int ldbits; float ascale;
+  float* C; long c_split_stride;             // partial tiles [split][N][K] (or dW itself when splitk == 1)
+  float* colsum; long colsum_split_stride;   // partial bias gradients [split][N] (or db), may be null
+  int M, N, K;
+  int splitk, m_per_split, tiles_n, tiles_k;
+};
+}  // namespace
+
+template <bool MASK>
+__global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int ntile = g.tiles_n * g.tiles_k;
+  const int bid = blockIdx.x;
+  const int split = (bid & 7) + 8 * (bid / (8 * ntile));      // every slice of one tile on the same XCD (shared L2)
+  const int t = (bid >> 3) % ntile;
+  if (split >= g.splitk) return;
+  const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
+  const int n0 = tn * DT, k0 = tk * DT;
+  const int mbeg = split * g.m_per_split;
+  const int mend = min(g.M, mbeg + g.m_per_split);
+  const int nslab = (mend - mbeg + KS - 1) / KS;
+  const int last = nslab - 1;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging patch of this thread: operand (wave-uniform), column group cg (4 columns), chunk c (8 rows of the slab)
+  const bool isA = tid < 128;
+  const int cg = tid & 63, c = (tid >> 6) & 1;
+  const int col0 = (isA ? n0 : k0) + 4 * cg;
+  const int ncol = isA ? g.N : g.K;                      // multiples of 4 (checked by the host): a patch column group is all in or out
+  const bool col_ok = col0 < ncol;
+  const long ld = isA ? g.lddy : g.ldx;
+  const float* src = (isA ? g.dy : g.x) + (col_ok ? col0 : 0);
+  const uint32_t* bsrc = (MASK && isA) ? g.bits + ((col_ok ? col0 : 0) >> 5) : nullptr;
+  const int bsh = col0 & 31;
+  const bool do_colsum = isA && g.colsum != nullptr && tk == 0;
+  float4 rv[8];
+  uint32_t rm[8];
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#define DW_LOAD(sl)                                                                                                   \
+  do {                                                                                                                \
+    const int mb_ = mbeg + (sl) * KS + c * 8;                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
+      const int m_ = min(mb_ + e, g.M - 1);                                                                           \
+      rv[e] = *reinterpret_cast<const float4*>(src + (size_t)m_ * ld);                                                \
+      if (MASK) rm[e] = isA ? bsrc[(size_t)m_ * g.ldbits] : 0xffffffffu;                                              \
+    }                                                                                                                 \
+  } while (0)
+#define DW_STORE(st, sl)                                                                                              \
+  do {                                                                                                                \
+    const int mb_ = mbeg + (sl) * KS + c * 8;                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
+      float4 v_ = rv[e];                                                                                              \
+      if (MASK && isA) {                                                                                              \
+        const uint32_t nib_ = rm[e] >> bsh;                                                                           \
+        v_.x = (nib_ & 1u) ? v_.x * g.ascale : 0.f;                                                                   \
+        v_.y = (nib_ & 2u) ? v_.y * g.ascale : 0.f;                                                                   \
+        v_.z = (nib_ & 4u) ? v_.z * g.ascale : 0.f;                                                                   \
+        v_.w = (nib_ & 8u) ? v_.w * g.ascale : 0.f;                                                                   \
+      }                                                                                                               \
+      if (mb_ + e >= mend || !col_ok) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+      rv[e] = v_;                                                                                                     \
+    }                                                                                                                 \
+    if (do_colsum) {                                                                                                  \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
+        csum.x += rv[e].x; csum.y += rv[e].y; csum.z += rv[e].z; csum.w += rv[e].w;                                   \
+      }                                                                                                               \
+    }                                                                                                                 \
+    u32x4* dst_ = (st) + (isA ? 0 : DW_OP_U4) + c * DT + 4 * cg;                                                      \
+    bf16x8 p0, p1, p2;                                                                                                \
+    split3x8(make_float4(rv[0].x, rv[1].x, rv[2].x, rv[3].x), make_float4(rv[4].x, rv[5].x, rv[6].x, rv[7].x), p0, p1, p2); \
+    dst_[0] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT] = __builtin_bit_cast(u32x4, p2); \
+    split3x8(make_float4(rv[0].y, rv[1].y, rv[2].y, rv[3].y), make_float4(rv[4].y, rv[5].y, rv[6].y, rv[7].y), p0, p1, p2); \
+    dst_[1] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 1] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 1] = __builtin_bit_cast(u32x4, p2); \
+    split3x8(make_float4(rv[0].z, rv[1].z, rv[2].z, rv[3].z), make_float4(rv[4].z, rv[5].z, rv[6].z, rv[7].z), p0, p1, p2); \
+    dst_[2] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 2] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 2] = __builtin_bit_cast(u32x4, p2); \
+    split3x8(make_float4(rv[0].w, rv[1].w, rv[2].w, rv[3].w), make_float4(rv[4].w, rv[5].w, rv[6].w, rv[7].w), p0, p1, p2); \
+    dst_[3] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 3] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 3] = __builtin_bit_cast(u32x4, p2); \
+  } while (0)
+
+  if (nslab > 0) {
+    DW_LOAD(0);
+    DW_STORE(lds, 0);
+    DW_LOAD(min(1, last));
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    const u32x4* st = lds + (s & 1) * DW_STAGE_U4;
+    u32x4* nx = lds + ((s + 1) & 1) * DW_STAGE_U4;
+    const u32x4* sa = st + wm * 128 + l31;
+    const u32x4* sb = st + DW_OP_U4 + wn * 128 + l31;
+    bf16x8 b0[4], b1[4], b2[4], a[4];
+#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * DT + j * 32])
+#define RD_A(p) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, sa[((p) * 2 + kh) * DT + i * 32])
+#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
+    // long phase first: 48 MFMAs queue up right behind the barrier, the conversion of the next slab follows them.  (Measured
+    // on MI355X, tools/mb_emu.py: pinning only the global loads and letting hipcc spread the conversion over the MFMAs, or an
+    // explicit sched_group_barrier pipeline of 1 MFMA + 6 VALU, are within 2 % of this form.)
+    RD_B(b0, 0); RD_A(0); RD_B(b1, 1); RD_B(b2, 2);
+    MM1(b2); MM1(b1); MM1(b0);                 // x0 y2, x0 y1, x0 y0
+    __builtin_amdgcn_sched_barrier(0);
+    RD_A(1);
+    if (s + 1 < nslab) DW_STORE(nx, s + 1);
+    DW_LOAD(min(s + 2, last));
+    __builtin_amdgcn_sched_barrier(0);
+    MM1(b1); MM1(b0);                          // x1 y1, x1 y0
+    RD_A(2);
+    MM1(b0);                                   // x2 y0
+    __syncthreads();
+  }
+#undef DW_LOAD
+#undef DW_STORE
+#undef RD_A
+#undef RD_B
+#undef MM1
+
+  // bias gradient partial: the two chunk threads of a column group add up through LDS (all waves are past the last barrier)
+  if (g.colsum != nullptr && tk == 0) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (isA) *reinterpret_cast<float4*>(&red[c * DT + 4 * cg]) = csum;
+    __syncthreads();
+    if (tid < DT) {
+      const int n = n0 + tid;
+      if (n < g.N) g.colsum[(size_t)split * g.colsum_split_stride + n] = red[tid] + red[DT + tid];
+    }
+    __syncthreads();
+  }
+
+  // epilogue: one row of four 32 x 32 blocks (32 x 128) at a time through the wave's private LDS slice
+  float* Cb = g.C + (size_t)split * g.c_split_stride;
+  const bool full = (n0 + DT <= g.N) && (k0 + DT <= g.K) && (g.K % 4 == 0);
+  constexpr int ES = 132;
+  float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int rr = p * 2 + kh;
+      const int row = n0 + wm * 128 + i * 32 + rr, col = k0 + wn * 128 + l31 * 4;
+      const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + l31 * 4);
+      if (full) {
+        *reinterpret_cast<float4*>(Cb + (size_t)row * g.K + col) = v;
+      } else if (row < g.N) {
+        float* cp = Cb + (size_t)row * g.K + col;
+        if (col + 0 < g.K) cp[0] = v.x;
+        if (col + 1 < g.K) cp[1] = v.y;
+        if (col + 2 < g.K) cp[2] = v.z;
+        if (col + 3 < g.K) cp[3] = v.w;
+      }
+    }
+  }
+}
+
+// out[i] = sum_s part[s * stride + i], deterministic: a block owns 256 consecutive floats (64 lanes x float4), its 16 waves sum
+// the slices s = w, w + 16, ... in order (16 independent 1 KB streams per block keep the loads in flight) and the 16 partial sums
+// are combined in wave order through LDS.  n must be a multiple of 4 (N * K and N are).
+__global__ __launch_bounds__(1024) void emu_reduce_partials_kernel(const float* __restrict__ part, long stride, int splits,
+                                                                   float* __restrict__ out, long n) {
+  __shared__ float4 red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + lane) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    const float* p = part + i;
+    int k = w;
+    for (; k + 16 < splits; k += 32) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(k + 16) * stride);
+      s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (k < splits) {
+      const float4 u = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
+      s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    float4 t = red[0][lane];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+      const float4 v = red[j][lane];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = t;
+  }
+}
+
 namespace {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -372,4 +594,75 @@ extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint
   g.inv_keep = 1.f;
   g.beta = accumulate ? 1 : 0;
   return launch_emu(g, as_stream(stream));
+}
+
+namespace {
+// row slices for grad-weight: one workgroup per CU (256 slots), >= 8 slabs per slice
+void plan_dw(long M, int N, int K, int& splitk, int& mper) {
+  const int ntile = cdiv(N, DT) * cdiv(K, DT);
+  const int slabs = cdiv(M, KS);
+  int want = ntile >= 256 ? 1 : 256 / ntile;
+  if (want > slabs / 8) want = slabs / 8 > 0 ? slabs / 8 : 1;
+  mper = cdiv(slabs, want) * KS;
+  splitk = cdiv(M, mper);
+}
+}  // namespace
+
+extern "C" long hoisdf_linear_bwd_weight_emu_workspace(long M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int splitk, mper;
+  plan_dw(M, N, K, splitk, mper);
+  if (splitk <= 1) return 0;
+  return (long)splitk * ((long)N * K + N);
+}
+
+extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
+                                            int ldx, float* dW, int lddw, float* db, long M, int N, int K, float* workspace,
+                                            long workspace_floats, void* stream) {
+  HOISDF_REQUIRE(dW && (M == 0 || (dy && x)), HOISDF_ERR_INVALID, "linear_bwd_weight_emu: null pointer");
+  HOISDF_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw == K && M < (1L << 31) && drop_p >= 0.f && drop_p < 1.f,
+                 HOISDF_ERR_INVALID, "linear_bwd_weight_emu: bad sizes (a dense dW, lddw == K, is required)");
+  HOISDF_REQUIRE(al16(dy) && al16(x) && al16(dW) && (lddy % 4 == 0) && (ldx % 4 == 0) && (N % 4 == 0) && (K % 4 == 0),
+                 HOISDF_ERR_INVALID, "linear_bwd_weight_emu: operands must be 16-byte aligned with N, K and leading dims multiples of 4");
+  hipStream_t st = as_stream(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)DW_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)DW_LDS_BYTES) != hipSuccess) {
+      set_error("linear_bwd_weight_emu: cannot raise the dynamic LDS limit to %u bytes", DW_LDS_BYTES);
+      return HOISDF_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  DwArgs g{};
+  g.dy = dy; g.lddy = lddy; g.x = x; g.ldx = ldx;
+  g.bits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
+  g.M = (int)M; g.N = N; g.K = K;
+  g.tiles_n = cdiv(N, DT); g.tiles_k = cdiv(K, DT);
+  plan_dw(M, N, K, g.splitk, g.m_per_split);
+  const long need = g.splitk > 1 ? (long)g.splitk * ((long)N * K + N) : 0;
+  HOISDF_REQUIRE(need == 0 || (workspace && workspace_floats >= need && al16(workspace)), HOISDF_ERR_WORKSPACE,
+                 "linear_bwd_weight_emu: workspace of %ld floats needed", need);
+  if (g.splitk > 1) {
+    g.C = workspace; g.c_split_stride = (long)N * K;
+    g.colsum = db ? workspace + (size_t)g.splitk * N * K : nullptr; g.colsum_split_stride = N;
+  } else {
+    g.C = dW; g.c_split_stride = 0; g.colsum = db; g.colsum_split_stride = 0;
+  }
+  const int ntile = g.tiles_n * g.tiles_k;
+  const dim3 grid((unsigned)(ntile * 8 * cdiv(g.splitk, 8))), block(NT);
+  if (relu_bits) hipLaunchKernelGGL((emu_dw_kernel<true>), grid, block, DW_LDS_BYTES, st, g);
+  else hipLaunchKernelGGL((emu_dw_kernel<false>), grid, block, DW_LDS_BYTES, st, g);
+  if (int rc = check_launch("linear_bwd_weight_emu")) return rc;
+  if (g.splitk > 1) {
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(emu_reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(1024), 0, st, workspace, n, g.splitk, dW, n);
+    if (db)
+      hipLaunchKernelGGL(emu_reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(1024), 0, st,
+                         workspace + (size_t)g.splitk * N * K, (long)N, g.splitk, db, (long)N);
+    return check_launch("linear_bwd_weight_emu reduce");
+  }
+  return HOISDF_OK;
 }

@@ -303,6 +303,7 @@ def gemm_split() -> bool:
 # ---- fp32 emulated on the bf16 MFMA pipe (csrc/gemm_emu.hip): forward / grad-input of the large linear layers ------------
 _GEMM_EMU = __import__("os").environ.get("HOISDF_GEMM", "emu") != "f32"
 _GEMM_EMU_MIN_ROWS = 2048            # below this a problem is a handful of tiles: latency-bound, stays on the f32 kernel
+_GEMM_EMU_DW_MIN_ROWS = 8192         # grad-weight: the contraction runs over the rows (>= 32 slabs per slice at 256 slices)
 _EMU_IMAGES = {}                     # (data_ptr, shape, ld, transpose) -> [image, version key, event, build stream, owner]
 
 
@@ -410,6 +411,16 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
         ws, nb = _split_ws(M, N, K, 2, dW.device)
         call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
              _p(x_scale), _p(dy_scale), _p(ws), nb, _st())
+        return
+    if (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= 64 and N % 4 == 0 and K % 4 == 0
+            and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+            and dW.data_ptr() % 16 == 0 and ((N + 255) // 256) * ((K + 255) // 256) != 3):
+        # (three output tiles - the 768 x 256 in-projection - measured slower than the f32 kernel: 296 vs 240 us, tools/mb_emu.py)
+        from ._lib import lib
+        nws = lib().hoisdf_linear_bwd_weight_emu_workspace(M, N, K)
+        ws = torch.empty(max(nws, 4), device=dW.device, dtype=torch.float32)
+        call("hoisdf_linear_bwd_weight_emu", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
+             _p(ws), nws, _st())
         return
     ws, nws = None, 0
     if deterministic():             # partial tiles + ordered reduce instead of split-k atomics

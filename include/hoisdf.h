@@ -139,6 +139,15 @@ int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const fl
                           int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);
 int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image,
                                 float* dx, int lddx, long M, int N, int K, int accumulate, void* stream);
+/* dW[N][K] = dy_eff[M][N]^T . x[M][K], db[N] = column sums of dy_eff (db may be NULL), same emulation: both activation operands
+ * are split into bf16 triples inside the kernel (a register transpose per 4-column x 8-row patch, no transposed copy through
+ * HBM).  dW (dense: lddw == K) and db are fully OVERWRITTEN; the rows are split over the workgroups into partial tiles in
+ * `workspace` (hoisdf_linear_bwd_weight_emu_workspace(M, N, K) floats, 16-byte aligned) and summed in slice order: no atomics,
+ * run-to-run identical.  N, K, lddy, ldx multiples of 4, 16-byte aligned operands. */
+long hoisdf_linear_bwd_weight_emu_workspace(long M, int N, int K);
+int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx,
+                                 float* dW, int lddw, float* db, long M, int N, int K, float* workspace, long workspace_floats,
+                                 void* stream);
 /* ---- split-precision linear layers (opt-in; cfg.gemm_split) -----------------------------------
  * reference: the same call sites as hoisdf_linear_* (common/nets/layer.py:168-201, common/nets/transformer.py:286-302,
  * main/model.py:181-244).  Same contracts and argument meaning as hoisdf_linear_fwd / _bwd_input / _bwd_weight, but the

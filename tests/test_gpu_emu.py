@@ -82,6 +82,42 @@ def test_emulated_linear_matches_fp64_at_the_exact_kernels_bar(M, N, K, act, p):
         assert_close(dx_acc, gy.double() @ W.detach().double() + 0.25, rel=2e-6, what="dx accumulate")
 
 
+@pytest.mark.parametrize("M,N,K,act,p", [(8192, 256, 256, False, 0.0), (16384, 1024, 256, True, 0.1), (9000, 224, 516, True, 0.0),
+                                         (8192, 768, 256, False, 0.0), (70000, 256, 1024, True, 0.0), (8200, 64, 992, False, 0.0)])
+def test_emulated_grad_weight_matches_fp64(M, N, K, act, p):
+    """hoisdf_linear_bwd_weight_emu (in-kernel transposing split of both activation operands, partial tiles + ordered reduce)
+    through ops.linear's backward: dW, db against fp64 at the exact kernel's 2e-6; ragged M (row tail inside a slab and a short
+    last slice), N / K that are not multiples of 256 (guarded tile edges), ReLU + dropout through the sign bitmap; two runs
+    are bit-identical (no atomics)."""
+    O = ops()
+    O.manual_seed(5)
+    g = torch.Generator().manual_seed(M + N + K)
+    decades = lambda n: torch.pow(10.0, -6.0 * torch.rand(n, 1, generator=g))
+    x = (torch.randn(M, K, generator=g) * decades(M)).to(DEV).requires_grad_(True)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 1e-3).to(DEV).requires_grad_(True)
+    gy = (torch.randn(M, N, generator=g) * decades(M)).to(DEV)
+    gy[::7] = 0.0
+    y = O.linear(x, W, b, act=act, drop_p=p)
+    y.backward(gy)
+    scale = (y.detach() > 0).double() / (1 - p) if act else torch.ones(M, N, device=DEV, dtype=torch.float64)
+    dye = gy.double() * scale
+    assert_close(W.grad, dye.t() @ x.detach().double(), rel=2e-6, what="dW")
+    assert_close(b.grad, dye.sum(0), rel=2e-6, what="db")
+    # determinism + the switch really selects the emulated kernel
+    bits = (y.detach() > 0) if act else None
+    dW1, db1 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    dW2, db2 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    O._gemm_bwd_weight(gy, N, None, 0.0, x.detach(), K, dW1, db1, M, N, K)
+    O._gemm_bwd_weight(gy, N, None, 0.0, x.detach(), K, dW2, db2, M, N, K)
+    assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
+    O.set_gemm_emu(False)
+    dW3, db3 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    O._gemm_bwd_weight(gy, N, None, 0.0, x.detach(), K, dW3, db3, M, N, K)
+    assert not torch.equal(dW1, dW3)
+    assert_close(dW1, dW3, rel=2e-6, what="emulated vs exact-f32 dW")
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 256), (4096, 256, 1024), (4096, 512, 992)])
 def test_emulated_linear_is_no_less_accurate_than_the_exact_f32_kernel(M, N, K):
     """element-wise |err vs fp64| / sum_k |a_k||b_k| of the emulated kernels next to the exact-f32 MFMA kernels AND the vendor's
