@@ -98,7 +98,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
-_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
+_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),

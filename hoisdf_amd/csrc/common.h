@@ -64,6 +64,7 @@ static inline uint32_t drop_threshold(float p) {
 //   to arrive (block_column_sum below, library-owned scratch: deterministic mode is single-stream).
 bool deterministic_mode();
 bool gemm_split_mode();           // hoisdf_set_gemm_split: the contractions INSIDE composite entries (sdf_query) in split precision
+bool gemm_emu_mode();             // hoisdf_set_gemm_emu: ... as fp32 emulated on the bf16 MFMA pipe (default on)
 struct DetScratch {
   float* part;          // [gridDim.x][ncols] partials
   unsigned* ticket;     // arrival counter, zero between launches

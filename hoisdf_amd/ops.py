@@ -313,6 +313,8 @@ def set_gemm_emu(on: bool) -> None:
     results (include/hoisdf.h hoisdf_linear_fwd_emu) at 1.7x the f32 MFMA kernel.  Off: the exact-f32 MFMA kernel."""
     global _GEMM_EMU
     _GEMM_EMU = bool(on)
+    from ._lib import lib
+    lib().hoisdf_set_gemm_emu(int(_GEMM_EMU))            # the layers inside hoisdf_sdf_query_fwd follow
 
 
 def gemm_emu() -> bool:

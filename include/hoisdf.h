@@ -71,6 +71,10 @@ void hoisdf_set_deterministic(int on);
  * together with cfg.gemm_split.  The per-layer entries are chosen by the caller and are not affected. */
 void hoisdf_set_gemm_split(int on);
 int hoisdf_get_gemm_split(void);
+/* the contractions inside composite entries as fp32 emulated on the bf16 MFMA pipe (hoisdf_linear_fwd_emu); default ON
+ * (environment HOISDF_GEMM=f32 or hoisdf_set_gemm_emu(0): the exact-f32 MFMA kernel) */
+void hoisdf_set_gemm_emu(int on);
+int hoisdf_get_gemm_emu(void);
 int hoisdf_get_deterministic(void);
 
 /* ---- K1: pinhole projection + 5-level bilinear gather --------------------------------

@@ -708,15 +708,24 @@ def test_sdf_query_split_precision_layers():
     inputs, _, meta = T.synthetic_batch(B, P, 8, seed=5)
     pts = (inputs["hand_sdf_points"] * 1.2).to(DEV)
     root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
+    keep_emu = O.gemm_emu()
     with torch.no_grad():
-        ref_sdf, ref_raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
-        O.set_gemm_split(True)
+        O.set_gemm_emu(False)
         try:
-            sdf, raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
+            ref_sdf, ref_raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")       # exact-f32 MFMA layers
+            O.set_gemm_split(True)
+            try:
+                sdf, raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
+            finally:
+                O.set_gemm_split(False)
+            O.set_gemm_emu(True)                                   # the default: the six layers as bf16x3-emulated fp32
+            esdf, eraw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
         finally:
-            O.set_gemm_split(False)
+            O.set_gemm_emu(keep_emu)
     assert not torch.equal(raw, ref_raw)                          # the split path really ran
     assert_close(raw, ref_raw, rel=5e-6, what="raw"); assert_close(sdf, ref_sdf, rel=5e-6, what="sdf")
+    assert not torch.equal(eraw, ref_raw)                         # ... and so did the emulated one
+    assert_close(eraw, ref_raw, rel=2e-6, what="emulated raw"); assert_close(esdf, ref_sdf, rel=2e-6, what="emulated sdf")
 
 
 def test_sdf_query_one_call_matches_the_op_chain():
