@@ -54,6 +54,9 @@ class KernelTimer:
         "hoisdf_attention_bwd": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,B,H,Lq,Lk,kv_len,ws,nws): algorithmic QK^T + PV (the 3x split products are not counted)
         "hoisdf_attention_fwd_f16": lambda a: 4.0 * a[8] * a[9] * a[10] * a[12] * 64,
+        # emulated fp32 attention: (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
+        "hoisdf_attention_fwd_emu": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
+        "hoisdf_attention_bwd_emu": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         "hoisdf_attention_fwd_split": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_split": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
@@ -83,6 +86,7 @@ class KernelTimer:
     SHAPE = {"hoisdf_linear_fwd": (7, 8, 9), "hoisdf_linear_bwd_input": (8, 9, 10), "hoisdf_linear_bwd_weight": (9, 10, 11),
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
+             "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
              "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20),
              "hoisdf_attention_fwd_split_keep": (9, 11, 13), "hoisdf_attention_bwd_split_kept": (16, 18, 20),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
@@ -372,6 +376,8 @@ def main():
                 "emu_kc_kernel + emu_dw_kernel (linear fwd + grad-input + grad-weight, fp32 emulated with 3-way bf16 splits, 6 products)":
                     ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu", "hoisdf_linear_bwd_weight_emu"],
                 "attn_fwd_kernel": ["hoisdf_attention_fwd"],
+                "emu_attn_fwd_kernel (+ bf16x3 conversion passes)": ["hoisdf_attention_fwd_emu"],
+                "emu_attn_bwd_kernel (fused dK, dV, dQ; + conversion / delta / dQ reduce passes)": ["hoisdf_attention_bwd_emu"],
                 "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
                 "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"],
                 "gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)":

@@ -79,6 +79,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                              _I, _F, _U64, _P],
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "hoisdf_attention_fwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P],
+    "hoisdf_attention_bwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
+                                 _L, _P],
     "hoisdf_attention_fwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _P],
     "hoisdf_attention_bwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
                                    _U64, _P, _L, _P],
@@ -106,7 +109,9 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_
           "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
-          "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
+          "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long),
+          "hoisdf_attention_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long),
+          "hoisdf_attention_bwd_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
 
 _lib = None
 

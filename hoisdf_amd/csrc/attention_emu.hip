@@ -1,0 +1,684 @@
+// fp32 attention EMULATED on the bf16 MFMA pipe ("bf16x3"), forward + backward for training and evaluation.
+// reference: common/nets/transformer.py:269,286-302 (nn.MultiheadAttention inside the encoder layers), forward + autograd
+// backward.  Every f32 operand of the five contractions (Q, K, V, dO and the in-kernel P, dS) is split EXACTLY into three bf16
+// pieces (8 + 8 + 8 significand bits, bf16 has the f32 exponent range: no scaling) and every product is accumulated in f32
+// from six v_mfma_f32_32x32x16_bf16 products (the three dropped cross terms are <= 2^-24 of the product) - the arithmetic of
+// gemm_emu.hip; softmax state, dropout and the dS algebra stay f32.  Results carry the error of the exact-f32 kernels of
+// attention.hip (tests/test_gpu_emu.py), the contractions run on a pipe that is 16 x faster.
+//
+//   pre-pass  : f32 head slices -> bf16 planes, row-major [bh][Lp][64] and transposed [bh][64][Lp] (Q pre-scaled by
+//               log2(e)/8: softmax in the log2 domain, the LSE convention of attention.hip)
+//   forward   : block = 128 queries (lane = query), streams 32-key tiles of K rows / V^T:  S^T = K.Q^T, O^T += V^T.P^T
+//   backward  : ONE pass, 5 GEMM-equivalents: block = 128 keys (lane = key: K, V fragments and dK, dV accumulators in
+//               registers), streams 32-query tiles of Q / dO rows and Q^T / dO^T:  S = Q.K^T, dP = dO.V^T, dV^T += dO^T.Pd,
+//               dK^T += Q^T.dS; every wave drops its dS block (bf16 triples) into a shared LDS tile T[32 q][128 keys] and then
+//               contracts T with the block's K^T slab over all 128 keys for a 16-wide slice of d (v_mfma_f32_16x16x32_bf16),
+//               so the block's 32 x 64 dQ contribution is complete in registers.  It goes to a per-key-block partial buffer
+//               [kb][bh][q][64]; a reduce pass sums the key blocks in order: no atomics anywhere, run-to-run identical.
+// The dropout mask is the same function of (seed, query, key) as in the f32 kernels.
+#include "common.h"
+
+namespace hoisdf {
+
+namespace {
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int D = 64;
+constexpr int RP = 72;              // bf16 per row of a row-major [32][64] tile in LDS (144 B)
+constexpr int TPH = 36;             // bf16 per row of a transposed [64][32] tile in LDS (72 B: conflict-free 8-byte reads)
+constexpr int ROWS_T = 32 * RP;     // bf16 per row-major plane tile
+constexpr int TRN_T = 64 * TPH;     // bf16 per transposed plane tile
+constexpr float QS2 = 0.125f * 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+#define CR(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+#define MB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// x y accumulated from six products (small terms first): x2y0 + x0y2 + x1y1 + x1y0 + x0y1 + x0y0
+#define MB6(acc, x0, x1, x2, y0, y1, y2) \
+  do {                                   \
+    acc = MB(x2, y0, acc);               \
+    acc = MB(x0, y2, acc);               \
+    acc = MB(x1, y1, acc);               \
+    acc = MB(x1, y0, acc);               \
+    acc = MB(x0, y1, acc);               \
+    acc = MB(x0, y0, acc);               \
+  } while (0)
+
+#define SPLIT1(x, i)                             \
+  do {                                           \
+    const __bf16 a_ = (__bf16)(x);               \
+    const float r1_ = (x) - (float)a_;           \
+    const __bf16 b_ = (__bf16)r1_;               \
+    const float r2_ = r1_ - (float)b_;           \
+    p0[i] = a_; p1[i] = b_; p2[i] = (__bf16)r2_; \
+  } while (0)
+
+struct EmuAttn {
+  // planes (any may be null when a kernel does not use it): [p] = piece 0, 1, 2
+  const __bf16 *q[3], *qt[3];      // Q rows (pre-scaled), Q^T
+  const __bf16 *k[3], *kt[3];      // K rows, K^T
+  const __bf16 *v[3], *vt[3];      // V rows, V^T
+  const __bf16 *d[3], *dt[3];      // dO rows, dO^T
+  const float* lse_in; const float* delta;
+  float* out; float* lse; float* dq_part; float* dk; float* dv;
+  int ldo, ldk, ldv;
+  int B, H, Lq, Lk, Lqp, Lkp, kv_len;
+  float drop_p, inv_keep;
+  uint32_t thresh;
+  uint64_t seed;
+};
+
+__device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
+  const int L = blockIdx.x, slot = L >> 3;        // every tile of a (b, head) on one XCD, as in attention.hip
+  bh = (slot / nx) * 8 + (L & 7);
+  tile = slot % nx;
+  return bh < nbh;
+}
+
+// tile copies global -> registers -> LDS.  Row-major plane tile: 32 rows x 64 bf16, thread -> (row t >> 3, 8 values at
+// (t & 7) * 8).  Transposed plane tile: 64 rows (d) x 32 bf16, thread -> (row t >> 2, 8 values at (t & 3) * 8), stored as two
+// 8-byte halves (rows are 72 B apart).
+__device__ __forceinline__ u32x4 ld_rows(const __bf16* base, size_t row0, int tid) {
+  return *reinterpret_cast<const u32x4*>(base + (row0 + (tid >> 3)) * D + (tid & 7) * 8);
+}
+__device__ __forceinline__ void st_rows(__bf16* lds, const u32x4 v, int tid) {
+  *reinterpret_cast<u32x4*>(lds + (tid >> 3) * RP + (tid & 7) * 8) = v;
+}
+__device__ __forceinline__ u32x4 ld_trn(const __bf16* base, size_t Lp, size_t col0, int tid) {
+  return *reinterpret_cast<const u32x4*>(base + (size_t)(tid >> 2) * Lp + col0 + (tid & 3) * 8);
+}
+__device__ __forceinline__ void st_trn(__bf16* lds, const u32x4 v, int tid) {
+  u32x2* p = reinterpret_cast<u32x2*>(lds + (tid >> 2) * TPH + (tid & 3) * 8);
+  p[0] = u32x2{v.x, v.y};
+  p[1] = u32x2{v.z, v.w};
+}
+// fragment of a transposed tile for k-step jj: the 8 "k" entries held by accumulator registers 8 jj .. 8 jj + 7 of a lane
+// (rows CR(r, h)): two 8-byte reads
+__device__ __forceinline__ bf16x8 frag_trn(const __bf16* tile, int row, int jj, int h) {
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(tile + row * TPH + 16 * jj + 4 * h);
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(tile + row * TPH + 16 * jj + 8 + 4 * h);
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ void split8(const f32x16& s, int jj, float mul, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = s[8 * jj + i] * mul;
+    SPLIT1(x, i);
+  }
+}
+}  // namespace
+
+// ---- conversion pre-pass: f32 [B][L][ld] (head slice) -> three bf16 planes, row-major [bh][Lp][64] and / or transposed
+// [bh][64][Lp]; rows >= L are zero.  One block per (bh, 64-row tile): a thread owns 16 consecutive d of one row (4 threads per
+// row: 256-byte coalesced reads, 128-byte coalesced row-major writes); the transposed copies go through an LDS tile.
+__global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __restrict__ src, int ld, int L, int Lp, int B, int H,
+                                                               float scale, __bf16* __restrict__ r0, __bf16* __restrict__ r1,
+                                                               __bf16* __restrict__ r2, __bf16* __restrict__ t0,
+                                                               __bf16* __restrict__ t1, __bf16* __restrict__ t2) {
+  constexpr int TP = 72;
+  __shared__ __attribute__((aligned(16))) __bf16 tile[3][64 * TP];
+  const int tid = threadIdx.x;
+  const int nb = Lp / 64;
+  const int kb = blockIdx.x % nb, bh = blockIdx.x / nb, b = bh / H, head = bh - b * H;
+  const int r = tid >> 2, dc = (tid & 3) * 16;
+  const int row = kb * 64 + r;
+  const bool valid = row < L;
+  const float* sr = src + ((size_t)b * L + (valid ? row : 0)) * ld + head * D + dc;
+  bf16x8 pa[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float4 u = valid ? *reinterpret_cast<const float4*>(sr + 8 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w = valid ? *reinterpret_cast<const float4*>(sr + 8 * i + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    u.x *= scale; u.y *= scale; u.z *= scale; u.w *= scale;
+    w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
+    bf16x8 p0, p1, p2;
+    SPLIT1(u.x, 0); SPLIT1(u.y, 1); SPLIT1(u.z, 2); SPLIT1(u.w, 3);
+    SPLIT1(w.x, 4); SPLIT1(w.y, 5); SPLIT1(w.z, 6); SPLIT1(w.w, 7);
+    pa[i][0] = p0; pa[i][1] = p1; pa[i][2] = p2;
+  }
+  if (r0) {
+    const size_t o = ((size_t)bh * Lp + row) * D + dc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<bf16x8*>(r0 + o + 8 * i) = pa[i][0];
+      *reinterpret_cast<bf16x8*>(r1 + o + 8 * i) = pa[i][1];
+      *reinterpret_cast<bf16x8*>(r2 + o + 8 * i) = pa[i][2];
+    }
+  }
+  if (t0) {                                                // block-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        tile[0][(dc + 8 * i + e) * TP + r] = pa[i][0][e];
+        tile[1][(dc + 8 * i + e) * TP + r] = pa[i][1][e];
+        tile[2][(dc + 8 * i + e) * TP + r] = pa[i][2][e];
+      }
+    __syncthreads();
+    const int d = tid >> 2, rc = (tid & 3) * 16;           // 16 consecutive rows of d-row d
+    const size_t o = ((size_t)bh * D + d) * Lp + kb * 64 + rc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<u32x4*>(t0 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[0][d * TP + rc + 8 * i]);
+      *reinterpret_cast<u32x4*>(t1 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[1][d * TP + rc + 8 * i]);
+      *reinterpret_cast<u32x4*>(t2 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[2][d * TP + rc + 8 * i]);
+    }
+  }
+}
+
+// ============================================================================================================================
+// forward: block = 128 queries (lane = query), streams 32-key tiles of K rows (3 planes) and V^T (3 planes)
+// ============================================================================================================================
+__global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
+  constexpr int BUF = 3 * ROWS_T + 3 * TRN_T;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  int qtile, bh;
+  if (!emu_block((a.Lq + 127) / 128, a.B * a.H, qtile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int qrow = qtile * 128 + wave * 32 + c;
+  const __bf16* kp[3] = {a.k[0] + (size_t)bh * a.Lkp * D, a.k[1] + (size_t)bh * a.Lkp * D, a.k[2] + (size_t)bh * a.Lkp * D};
+  const __bf16* vp[3] = {a.vt[0] + (size_t)bh * D * a.Lkp, a.vt[1] + (size_t)bh * D * a.Lkp, a.vt[2] + (size_t)bh * D * a.Lkp};
+
+  bf16x8 qf[4][3];                        // Q^T fragments: k-step j <-> d = 16 j + 8 h .. + 7 of the lane's query
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const __bf16* s = a.q[p] + ((size_t)bh * a.Lqp + qrow) * D;       // qrow < Lqp always (padded with zero rows)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j][p] = *reinterpret_cast<const bf16x8*>(s + 16 * j + 8 * h);
+  }
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
+  float m = -INFINITY, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+
+  const int ntiles = (a.kv_len + 31) / 32;
+  u32x4 r0, r1, r2, r3, r4, r5;
+#define FWD_LOAD(kt)                                   \
+  do {                                                 \
+    r0 = ld_rows(kp[0], (size_t)(kt) * 32, tid);       \
+    r1 = ld_rows(kp[1], (size_t)(kt) * 32, tid);       \
+    r2 = ld_rows(kp[2], (size_t)(kt) * 32, tid);       \
+    r3 = ld_trn(vp[0], a.Lkp, (size_t)(kt) * 32, tid); \
+    r4 = ld_trn(vp[1], a.Lkp, (size_t)(kt) * 32, tid); \
+    r5 = ld_trn(vp[2], a.Lkp, (size_t)(kt) * 32, tid); \
+  } while (0)
+#define FWD_STORE(buf)                                 \
+  do {                                                 \
+    st_rows((buf), r0, tid);                           \
+    st_rows((buf) + ROWS_T, r1, tid);                  \
+    st_rows((buf) + 2 * ROWS_T, r2, tid);              \
+    st_trn((buf) + 3 * ROWS_T, r3, tid);               \
+    st_trn((buf) + 3 * ROWS_T + TRN_T, r4, tid);       \
+    st_trn((buf) + 3 * ROWS_T + 2 * TRN_T, r5, tid);   \
+  } while (0)
+  FWD_LOAD(0);
+  FWD_STORE(lds);
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    FWD_LOAD(min(kt + 1, ntiles - 1));              // unconditional (past the end the last tile is re-read and dropped)
+    const __bf16* K0 = lds + cur * BUF;
+    const __bf16* V0 = K0 + 3 * ROWS_T;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(&K0[c * RP + 16 * j + 8 * h]);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(&K0[ROWS_T + c * RP + 16 * j + 8 * h]);
+      const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(&K0[2 * ROWS_T + c * RP + 16 * j + 8 * h]);
+      MB6(s, k0, k1, k2, qf[j][0], qf[j][1], qf[j][2]);
+    }
+    if (kt == ntiles - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + CR(r, h) >= a.kv_len) s[r] = -INFINITY;
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(s[r] - mn);
+      ps += p;
+      s[r] = p;
+    }
+    lsum = lsum * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    if (a.drop_p > 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= drop_scale(rowkey, (uint32_t)(kt * 32 + CR(r, h)), a.thresh, a.inv_keep);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      bf16x8 p0, p1, p2;
+      split8(s, jj, 1.f, p0, p1, p2);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 v0 = frag_trn(V0, dt * 32 + c, jj, h);
+        const bf16x8 v1 = frag_trn(V0 + TRN_T, dt * 32 + c, jj, h);
+        const bf16x8 v2 = frag_trn(V0 + 2 * TRN_T, dt * 32 + c, jj, h);
+        MB6(o[dt], v0, v1, v2, p0, p1, p2);
+      }
+    }
+    if (kt + 1 < ntiles) FWD_STORE(lds + (cur ^ 1) * BUF);
+    __syncthreads();
+  }
+#undef FWD_LOAD
+#undef FWD_STORE
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (qrow < a.Lq) {
+    const float inv = 1.f / ltot;
+    float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * h) =
+            make_float4(o[t][4 * g + 0] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
+  }
+}
+
+
+// ============================================================================================================================
+// backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys (lane = key), one workgroup per CU (the
+// register file holds K, V fragments, the dK, dV accumulators and a whole prefetched query tile: > 256 registers per lane).
+// LDS (134 KB): the 32-query tile as Q / dO row planes and Q^T / dO^T planes, the block's K^T slab, the dS tile T.
+// ============================================================================================================================
+namespace {
+constexpr int KTP = 136;                       // bf16 per row of the K^T slab [64 d][128 keys] and of T [32 q][128 keys] (272 B)
+constexpr int BWD_QR = 0, BWD_DR = 3 * ROWS_T, BWD_QT = 6 * ROWS_T, BWD_DT = 6 * ROWS_T + 3 * TRN_T;
+constexpr int BWD_KT = 6 * ROWS_T + 6 * TRN_T;
+constexpr int BWD_TS = BWD_KT + 3 * 64 * KTP;
+constexpr int BWD_BF16 = BWD_TS + 3 * 32 * KTP;
+constexpr unsigned BWD_LDS_BYTES = BWD_BF16 * 2u + 64u * 4u;
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void emu_attn_bwd_kernel(EmuAttn a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  float* Ls = reinterpret_cast<float*>(lds + BWD_BF16);      // lse[32] (log2 domain), then delta[32]
+  float* Es = Ls + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  int ktile, bh;
+  const int nkb = (a.Lk + 127) / 128;
+  if (!emu_block(nkb, a.B * a.H, ktile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int key = ktile * 128 + wave * 32 + c;
+  const bool kvalid = key < a.kv_len;
+  const bool block_active = ktile * 128 < a.kv_len;
+  const int nq = block_active ? (a.Lq + 31) / 32 : 0;
+
+  // resident fragments of this lane's key: K and V rows (B operands of S and dP), k-step j <-> d = 16 j + 8 h .. + 7
+  bf16x8 kf[4][3], vf[4][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const size_t ro = ((size_t)bh * a.Lkp + key) * D;          // key < Lkp always (padded with zero rows)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kf[j][p] = *reinterpret_cast<const bf16x8*>(a.k[p] + ro + 16 * j + 8 * h);
+      vf[j][p] = *reinterpret_cast<const bf16x8*>(a.v[p] + ro + 16 * j + 8 * h);
+    }
+  }
+  // the block's K^T slab: 3 planes x [64 d][128 keys]; thread -> (d = tid >> 2, 32 keys at (tid & 3) * 32): 4 x 16 bytes
+  if (nq > 0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const __bf16* src = a.kt[p] + ((size_t)bh * D + (tid >> 2)) * a.Lkp + ktile * 128 + (tid & 3) * 32;
+      __bf16* dst = lds + BWD_KT + p * 64 * KTP + (tid >> 2) * KTP + (tid & 3) * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + 8 * i) = *reinterpret_cast<const u32x4*>(src + 8 * i);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
+
+  // staging registers: the whole next query tile (12 plane tiles of 4 KB: one 16-byte piece per thread each) + lse / delta
+  u32x4 sq[3], sd[3], sqt[3], sdt[3];
+  float rl = INFINITY, re = 0.f;
+  const size_t rowbase = (size_t)bh * a.Lqp * D, trnbase = (size_t)bh * D * a.Lqp;
+#define BWD_LOAD(QTI_)                                                                 \
+  do {                                                                               \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                  \
+      sq[p] = ld_rows(a.q[p] + rowbase, (size_t)(QTI_) * 32, tid);                     \
+      sd[p] = ld_rows(a.d[p] + rowbase, (size_t)(QTI_) * 32, tid);                     \
+      sqt[p] = ld_trn(a.qt[p] + trnbase, a.Lqp, (size_t)(QTI_) * 32, tid);             \
+      sdt[p] = ld_trn(a.dt[p] + trnbase, a.Lqp, (size_t)(QTI_) * 32, tid);             \
+    }                                                                                \
+    if (tid < 32) {                                                                  \
+      const int q_ = (QTI_) * 32 + tid;                                                \
+      rl = q_ < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q_] : INFINITY;                  \
+      re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                        \
+    }                                                                                \
+  } while (0)
+  if (nq > 0) BWD_LOAD(0);
+
+  const int l16 = lane & 15, kq = lane >> 4;
+  float* part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
+  for (int qt = 0; qt < nq; ++qt) {
+    __syncthreads();                       // the previous tile's readers are done (also orders the K^T slab)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      st_rows(lds + BWD_QR + p * ROWS_T, sq[p], tid);
+      st_rows(lds + BWD_DR + p * ROWS_T, sd[p], tid);
+      st_trn(lds + BWD_QT + p * TRN_T, sqt[p], tid);
+      st_trn(lds + BWD_DT + p * TRN_T, sdt[p], tid);
+    }
+    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+    BWD_LOAD(min(qt + 1, nq - 1));         // unconditional prefetch (lands during the MFMAs below)
+    // S[q][key] = Qs.K^T and dP[q][key] = dO.V^T: rows = the tile's queries, column = this lane's key
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = c * RP + 16 * j + 8 * h;
+      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + o);
+      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + ROWS_T + o);
+      const bf16x8 q2 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + 2 * ROWS_T + o);
+      const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + o);
+      const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + ROWS_T + o);
+      const bf16x8 d2 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + 2 * ROWS_T + o);
+      MB6(s, q0, q1, q2, kf[j][0], kf[j][1], kf[j][2]);
+      MB6(dp, d0, d1, d2, vf[j][0], vf[j][1], vf[j][2]);
+    }
+    // s <- Pd (dropped probabilities), dp <- dS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = CR(r, h);
+      const float p = kvalid ? __builtin_amdgcn_exp2f(s[r] - Ls[qi]) : 0.f;
+      float dsc = 1.f;
+      if (a.drop_p > 0.f)
+        dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
+      s[r] = p * dsc;
+      dp[r] = p * (dp[r] * dsc - Es[qi]);
+    }
+    // dV^T[d][key] += dO^T[d][q] . Pd[q][key];  dK^T[d][key] += Qs^T[d][q] . dS[q][key];  dS also goes to T as bf16 triples
+    __bf16* Tw = lds + BWD_TS + wave * 32 + c;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      bf16x8 p0, p1, p2, g0, g1, g2;
+      split8(s, jj, 1.f, p0, p1, p2);
+      {
+        bf16x8 &p0_ = g0, &p1_ = g1, &p2_ = g2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = dp[8 * jj + i];
+          const __bf16 a_ = (__bf16)x;
+          const float r1_ = x - (float)a_;
+          const __bf16 b_ = (__bf16)r1_;
+          const float r2_ = r1_ - (float)b_;
+          p0_[i] = a_; p1_[i] = b_; p2_[i] = (__bf16)r2_;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int qi = CR(8 * jj + i, h);
+        Tw[qi * KTP] = g0[i];
+        Tw[32 * KTP + qi * KTP] = g1[i];
+        Tw[64 * KTP + qi * KTP] = g2[i];
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 o0 = frag_trn(lds + BWD_DT, dt * 32 + c, jj, h);
+        const bf16x8 o1 = frag_trn(lds + BWD_DT + TRN_T, dt * 32 + c, jj, h);
+        const bf16x8 o2 = frag_trn(lds + BWD_DT + 2 * TRN_T, dt * 32 + c, jj, h);
+        const bf16x8 t0 = frag_trn(lds + BWD_QT, dt * 32 + c, jj, h);
+        const bf16x8 t1 = frag_trn(lds + BWD_QT + TRN_T, dt * 32 + c, jj, h);
+        const bf16x8 t2 = frag_trn(lds + BWD_QT + 2 * TRN_T, dt * 32 + c, jj, h);
+        MB6(dv[dt], o0, o1, o2, p0, p1, p2);
+        MB6(dk[dt], t0, t1, t2, g0, g1, g2);
+      }
+    }
+    __syncthreads();                       // T is complete
+    // dQ[q][16 w .. 16 w + 15] = sum over the block's 128 keys of dS[q][key] K[key][d]   (16x16x32 MFMA: lane l supplies
+    // A[row l % 16][8 (l / 16) ..] and B[8 (l / 16) ..][col l % 16], holds C[rows 4 (l / 16) .. + 3][col l % 16])
+    {
+      f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+      const __bf16* tp = lds + BWD_TS + l16 * KTP + 8 * kq;
+      const __bf16* kp = lds + BWD_KT + (wave * 16 + l16) * KTP + 8 * kq;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bf16x8 x0[3], x1[3], y[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          x0[p] = *reinterpret_cast<const bf16x8*>(tp + p * 32 * KTP + 32 * t);
+          x1[p] = *reinterpret_cast<const bf16x8*>(tp + p * 32 * KTP + 16 * KTP + 32 * t);
+          y[p] = *reinterpret_cast<const bf16x8*>(kp + p * 64 * KTP + 32 * t);
+        }
+#define MQ(acc, xa, xb, xc)                                                          \
+  do {                                                                               \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xc, y[0], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[2], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, y[1], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, y[0], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[1], acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[0], acc, 0, 0, 0);           \
+  } while (0)
+        MQ(q0, x0[0], x0[1], x0[2]);
+        MQ(q1, x1[0], x1[1], x1[2]);
+#undef MQ
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qa = qt * 32 + 4 * kq + i, qb = qa + 16;
+        if (qa < a.Lq) part[(size_t)qa * D + wave * 16 + l16] = q0[i];
+        if (qb < a.Lq) part[(size_t)qb * D + wave * 16 + l16] = q1[i];
+      }
+    }
+  }
+#undef BWD_LOAD
+  if (key < a.Lk) {
+    float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
+    float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
+        *reinterpret_cast<float4*>(pk + 32 * t + 8 * g + 4 * h) =
+            make_float4(dk[t][4 * g + 0] * LN2, dk[t][4 * g + 1] * LN2, dk[t][4 * g + 2] * LN2, dk[t][4 * g + 3] * LN2);
+        *reinterpret_cast<float4*>(pv + 32 * t + 8 * g + 4 * h) =
+            make_float4(dv[t][4 * g + 0], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
+      }
+  }
+}
+
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]  (f32; 16 lanes per (q, head))
+__global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __restrict__ o, int ldo, const float* __restrict__ dout,
+                                                             int lddo, float* __restrict__ delta, int B, int H, int Lq) {
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  if (g >= (long)B * Lq * H) return;
+  const int head = (int)(g % H);
+  const long bq = g / H;
+  const int q = (int)(bq % Lq), b = (int)(bq / Lq);
+  const float4 x = *reinterpret_cast<const float4*>(o + ((size_t)b * Lq + q) * ldo + head * D + l16 * 4);
+  const float4 y = *reinterpret_cast<const float4*>(dout + ((size_t)b * Lq + q) * lddo + head * D + l16 * 4);
+  float s = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+  if (l16 == 0) delta[((size_t)b * H + head) * Lq + q] = s;
+}
+
+// dq[b][q][head * 64 + d] = 0.125 * sum_kb part[kb][bh][q][d] in key-block order (one float4 per thread)
+__global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __restrict__ part, int nkb, float* __restrict__ dq,
+                                                                 int ldq, int B, int H, int Lq) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // (bh, q, d / 4)
+  const long n = (long)B * H * Lq * 16;
+  if (i >= n) return;
+  const int d4 = (int)(i & 15);
+  const long bq = i >> 4;
+  const int q = (int)(bq % Lq);
+  const int bh = (int)(bq / Lq), b = bh / H, head = bh - b * H;
+  const size_t stride = (size_t)B * H * Lq * D;
+  const float* p = part + ((size_t)bh * Lq + q) * D + d4 * 4;
+  float4 s = *reinterpret_cast<const float4*>(p);
+  for (int k = 1; k < nkb; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dq + ((size_t)b * Lq + q) * ldq + head * D + d4 * 4) =
+      make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+}
+
+}  // namespace hoisdf
+
+using namespace hoisdf;
+
+namespace {
+inline long pad128(long L) { return (L + 127) / 128 * 128; }
+inline size_t plane_elems(int B, int H, long Lp) { return (size_t)B * H * Lp * 64; }
+
+// one tensor's planes inside a workspace: rows r[3] then transposed t[3] (either group may be absent)
+struct Planes { __bf16 *r[3], *t[3]; };
+inline Planes carve(__bf16*& w, size_t n, bool rows, bool trn) {
+  Planes p{};
+  for (int i = 0; i < 3; ++i) { p.r[i] = rows ? w : nullptr; if (rows) w += n; }
+  for (int i = 0; i < 3; ++i) { p.t[i] = trn ? w : nullptr; if (trn) w += n; }
+  return p;
+}
+int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, const Planes& p, hipStream_t st) {
+  const long nblk = (long)B * H * (Lp / 64);
+  hipLaunchKernelGGL(emu_attn_convert_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, p.r[0], p.r[1],
+                     p.r[2], p.t[0], p.t[1], p.t[2]);
+  return check_launch("attention_emu_convert");
+}
+int check_emu(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, int B, int H, int Lq, int Lk, int kv_len,
+              float drop_p, const char* who) {
+  HOISDF_REQUIRE(q && k && v, HOISDF_ERR_INVALID, "%s: null pointer", who);
+  HOISDF_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && kv_len > 0 && kv_len <= Lk, HOISDF_ERR_INVALID,
+                 "%s: bad sizes B=%d H=%d Lq=%d Lk=%d kv_len=%d", who, B, H, Lq, Lk, kv_len);
+  HOISDF_REQUIRE(ldq >= H * 64 && ldk >= H * 64 && ldv >= H * 64 && ((ldq | ldk | ldv) & 3) == 0 &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0,
+                 HOISDF_ERR_INVALID, "%s: leading dims must be multiples of 4 and >= H*64, pointers 16-byte aligned", who);
+  HOISDF_REQUIRE(drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "%s: drop_p=%f", who, drop_p);
+  return HOISDF_OK;
+}
+}  // namespace
+
+// mode 0: forward only (Q rows, K rows, V^T).  mode 2: forward that keeps every plane the backward needs (Q, K, V rows + transposed).
+extern "C" long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int mode) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  const size_t q = plane_elems(B, H, pad128(Lq)), k = plane_elems(B, H, pad128(Lk));
+  const size_t planes = mode == 0 ? 3 * q + 6 * k : 6 * q + 12 * k;
+  return (long)(planes * sizeof(__bf16));
+}
+
+extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                        int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
+                                        uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
+  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
+  HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
+                 HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
+  const long need = hoisdf_attention_emu_workspace(B, H, Lq, Lk, keep ? 2 : 0);
+  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_fwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
+  const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
+  hipStream_t st = as_stream(stream);
+  __bf16* w = reinterpret_cast<__bf16*>(workspace);
+  const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
+  // layout (kept form): [Q rows, Q^T | K rows, K^T | V rows, V^T]; forward-only form: [Q rows | K rows | V^T]
+  const Planes pq = carve(w, nq, true, keep != 0);
+  const Planes pk = carve(w, nk, true, keep != 0);
+  const Planes pv = carve(w, nk, keep != 0, true);
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
+  EmuAttn a{};
+  for (int i = 0; i < 3; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
+  a.out = o; a.lse = lse; a.ldo = ldo;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
+  hipLaunchKernelGGL(emu_attn_fwd_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
+  return check_launch("attention_fwd_emu");
+}
+
+// backward workspace: dO rows + dO^T (6 planes) + the dQ partials [ceil(kv_len / 128)][B H][Lq][64] f32
+//   (+ Q, K, V planes when the forward did not keep them: kept == 0)
+extern "C" long hoisdf_attention_bwd_emu_workspace(int B, int H, int Lq, int Lk, int kept) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  const size_t q = plane_elems(B, H, pad128(Lq)), k = plane_elems(B, H, pad128(Lk));
+  size_t bytes = 6 * q * sizeof(__bf16) + (size_t)cdiv(Lk, 128) * B * H * Lq * 64 * sizeof(float);
+  if (!kept) bytes += (6 * q + 12 * k) * sizeof(__bf16);
+  return (long)bytes;
+}
+
+extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                        int ldo, const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk,
+                                        float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
+                                        const void* fwd_workspace, void* workspace, long workspace_bytes, void* stream) {
+  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_bwd_emu")) return rc;
+  HOISDF_REQUIRE(o && dout && lse && delta && dq && dk && dv && workspace, HOISDF_ERR_INVALID, "attention_bwd_emu: null pointer");
+  HOISDF_REQUIRE(ldo >= H * 64 && lddo >= H * 64 && ((ldo | lddo) & 3) == 0 &&
+                     (((uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)workspace |
+                       (uintptr_t)fwd_workspace) & 15) == 0,
+                 HOISDF_ERR_INVALID, "attention_bwd_emu: bad leading dims / alignment");
+  const long need = hoisdf_attention_bwd_emu_workspace(B, H, Lq, Lk, fwd_workspace ? 1 : 0);
+  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_bwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)BWD_LDS_BYTES) != hipSuccess) {
+      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", BWD_LDS_BYTES);
+      return HOISDF_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
+  hipStream_t st = as_stream(stream);
+  const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
+  __bf16* w = reinterpret_cast<__bf16*>(workspace);
+  const Planes pd = carve(w, nq, true, true);
+  float* part = reinterpret_cast<float*>(w);
+  w += (size_t)cdiv(Lk, 128) * B * H * Lq * 64 * 2;                 // (float = 2 bf16 slots)
+  Planes pq, pk, pv;
+  if (fwd_workspace) {          // the planes hoisdf_attention_fwd_emu(keep = 1) left for the same q, k, v
+    __bf16* f = reinterpret_cast<__bf16*>(const_cast<void*>(fwd_workspace));
+    pq = carve(f, nq, true, true); pk = carve(f, nk, true, true); pv = carve(f, nk, true, true);
+  } else {
+    pq = carve(w, nq, true, true); pk = carve(w, nk, true, true); pv = carve(w, nk, true, true);
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
+  }
+  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, pd, st)) return rc;
+  const long ng = (long)B * Lq * H;
+  hipLaunchKernelGGL(emu_attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, o, ldo, dout, lddo, delta, B, H, Lq);
+  if (int rc = check_launch("attention_emu_delta")) return rc;
+  EmuAttn a{};
+  for (int i = 0; i < 3; ++i) {
+    a.q[i] = pq.r[i]; a.qt[i] = pq.t[i]; a.k[i] = pk.r[i]; a.kt[i] = pk.t[i]; a.v[i] = pv.r[i];
+    a.d[i] = pd.r[i]; a.dt[i] = pd.t[i];
+  }
+  a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
+  a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
+  hipLaunchKernelGGL(emu_attn_bwd_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), BWD_LDS_BYTES, st, a);
+  if (int rc = check_launch("attention_bwd_emu")) return rc;
+  const long n4 = (long)B * H * Lq * 16;
+  hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
+                     B, H, Lq);
+  return check_launch("attention_bwd_emu dq reduce");
+}

@@ -93,6 +93,7 @@ def zero_arena_begin_step(device) -> None:
     buffer that is cleared with a single memset.  See _ZeroArena for the validity contract."""
     _ARENA.begin_step(torch.device(device))
     _SPLIT_PLANES.clear()          # kept attention planes of graphs that never ran their backward
+    _EMU_PLANES.clear()
 
 
 def zero_arena_end_step() -> None:
@@ -758,8 +759,28 @@ def set_attention_split(on: bool) -> None:
     _ATTENTION_SPLIT = bool(on)
 
 
-def _use_split(Lq: int) -> bool:
-    return _ATTENTION_SPLIT and Lq >= 32            # the 17-query decoder attention keeps its own f32 kernels
+_ATTENTION_EMU = __import__("os").environ.get("HOISDF_ATTENTION", "emu") != "f32"
+
+
+def set_attention_emu(on: bool) -> None:
+    """cfg.attention_emu (default on; HOISDF_ATTENTION=f32 turns it off): the large attention calls (forward with dropout + LSE,
+    fused one-pass backward) as fp32 emulated on the bf16 MFMA pipe - exact three-way bf16 splits of Q, K, V, dO, P and dS, six
+    products per product, f32 accumulation / softmax (csrc/attention_emu.hip).  fp32-equivalent results, no atomics.  Off: the
+    exact-f32 MFMA kernels of csrc/attention.hip."""
+    global _ATTENTION_EMU
+    _ATTENTION_EMU = bool(on)
+
+
+def attention_emu() -> bool:
+    return _ATTENTION_EMU
+
+
+def _use_split(Lq: int) -> int:
+    """attention kernel family for a call with Lq queries: 0 = exact-f32 MFMA, 1 = f16 hi + lo split (opt-in), 2 = bf16x3
+    emulated fp32 (default).  The 17-query decoder attention keeps its own f32 kernels."""
+    if Lq < 32:
+        return 0
+    return 1 if _ATTENTION_SPLIT else (2 if _ATTENTION_EMU else 0)
 
 
 # forward workspaces whose Q / K / V planes the matching backward reuses (hoisdf_attention_fwd_split_keep /
@@ -816,6 +837,68 @@ def _attn_bwd_split(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
          _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
 
 
+_EMU_PLANES = {}
+
+
+def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False):
+    """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it"""
+    from ._lib import lib
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    for t, L in ((q, Lq), (k, Lk), (v, Lk)):
+        assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
+    keep = keep and _SPLIT_KEEP
+    nbytes = lib().hoisdf_attention_emu_workspace(B, H, Lq, Lk, 2 if keep else 0)
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    call("hoisdf_attention_fwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk,
+         kv_len, float(drop_p), seed, _p(ws), nbytes, int(keep), _st())
+    if keep:
+        if len(_EMU_PLANES) >= 64:
+            _EMU_PLANES.clear()
+        _EMU_PLANES[_planes_key(q, k, v, H, kv_len)] = ws
+    return o, lse
+
+
+def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
+    from ._lib import lib
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    kept = _EMU_PLANES.pop(_planes_key(q, k, v, H, kv_len), None)
+    nbytes = lib().hoisdf_attention_bwd_emu_workspace(B, H, Lq, Lk, int(kept is not None))
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    if kept is not None:
+        kept.record_stream(torch.cuda.current_stream(q.device))
+    call("hoisdf_attention_bwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E, _p(lse),
+         _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _st())
+
+
+_ATTN_BWD_EMU = __import__("os").environ.get("HOISDF_ATTN_BWD", "") == "emu"
+
+
+def _emu_bwd() -> bool:
+    """the fused emulated backward (one workgroup per CU: K, V fragments, dK / dV accumulators and a prefetched query tile need
+    > 256 registers per lane) measures 3.4 ms against 3.1 ms for the exact-f32 fused kernel at B = 32, S = 2048
+    (tools/mb_attn_emu.py), so by default only the FORWARD runs emulated (0.93 vs 1.35 ms).  The emulated backward is the
+    order-fixed one (no atomics): it replaces the f32 two-kernel form in deterministic mode, and HOISDF_ATTN_BWD=emu selects it."""
+    return _ATTN_BWD_EMU or deterministic()
+
+
+def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False):
+    if mode == 2:
+        return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=keep and _emu_bwd())
+    if mode == 1:
+        return _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed, keep=keep)
+    return _attn_fwd(q, k, v, H, kv_len, drop_p, seed)
+
+
+def _attn_bwd_mode(mode, *a):
+    return (_attn_bwd_emu if (mode == 2 and _emu_bwd()) else (_attn_bwd_split if mode == 1 else _attn_bwd))(*a)
+
+
 class _AttentionSelf(torch.autograd.Function):
     """qkv (B,L,3E): the packed in-projection output [q | k | v]."""
 
@@ -825,8 +908,8 @@ class _AttentionSelf(torch.autograd.Function):
         _chk(qkv)
         E = qkv.shape[2] // 3
         split = _use_split(qkv.shape[1])
-        fwd = (lambda *a: _attn_fwd_split(*a, keep=any(ctx.needs_input_grad))) if split else _attn_fwd
-        o, lse = fwd(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        o, lse = _attn_fwd_mode(split, qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, kv_len, drop_p, seed,
+                                keep=any(ctx.needs_input_grad))
         ctx.save_for_backward(qkv, o, lse)
         ctx.meta = (H, kv_len, float(drop_p), seed, split)
         return o
@@ -837,9 +920,8 @@ class _AttentionSelf(torch.autograd.Function):
         H, kv_len, drop_p, seed, split = ctx.meta
         E = qkv.shape[2] // 3
         d = torch.empty_like(qkv)
-        (_attn_bwd_split if split else _attn_bwd)(
-            qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do.contiguous(), d[:, :, :E],
-            d[:, :, E:2 * E], d[:, :, 2 * E:], H, kv_len, drop_p, seed)
+        _attn_bwd_mode(split, qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], o, lse, do.contiguous(), d[:, :, :E],
+                       d[:, :, E:2 * E], d[:, :, 2 * E:], H, kv_len, drop_p, seed)
         return d, None, None, None, None
 
 
@@ -852,8 +934,7 @@ class _AttentionCross(torch.autograd.Function):
         _chk(q, kv)
         E = q.shape[2]
         split = _use_split(q.shape[1])
-        o, lse = (_attn_fwd_split(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed, keep=any(ctx.needs_input_grad)) if split else
-                  _attn_fwd(q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed))
+        o, lse = _attn_fwd_mode(split, q, kv[:, :, :E], kv[:, :, E:], H, kv_len, drop_p, seed, keep=any(ctx.needs_input_grad))
         ctx.save_for_backward(q, kv, o, lse)
         ctx.meta = (H, kv_len, float(drop_p), seed, split)
         return o
@@ -865,8 +946,8 @@ class _AttentionCross(torch.autograd.Function):
         E = q.shape[2]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        (_attn_bwd_split if split else _attn_bwd)(q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), dq,
-                                                  dkv[:, :, :E], dkv[:, :, E:], H, kv_len, drop_p, seed)
+        _attn_bwd_mode(split, q, kv[:, :, :E], kv[:, :, E:], o, lse, do.contiguous(), dq, dkv[:, :, :E], dkv[:, :, E:], H, kv_len,
+                       drop_p, seed)
         return dq, dkv, None, None, None, None
 
 
@@ -1056,8 +1137,7 @@ class _EncoderLayer(torch.autograd.Function):
             # gradient-free eval with cfg.attention_f16_eval: the f16-operand kernel (no LSE: nothing is saved for a backward)
             o, lse = _attn_fwd_f16(q, k, v, H, S), None
         else:
-            o, lse = (_attn_fwd_split(q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad)) if split else
-                      _attn_fwd(q, k, v, H, S, p, s_attn))
+            o, lse = _attn_fwd_mode(split, q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad))
         M = B * nq
         a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
         xq2 = xq.view(M, E)
@@ -1128,7 +1208,7 @@ class _EncoderLayer(torch.autograd.Function):
         do = torch.empty(M, E, device=dev)
         _lin_bwd_input(da, None, 0.0, w_out, do, False)
         _lin_bwd_weight(da, None, 0.0, o.view(M, E), dw_out, db_out)
-        bwd = _attn_bwd_split if split else _attn_bwd
+        bwd = lambda *a_: _attn_bwd_mode(split, *a_)
         do3 = do.view(B, nq, E)
         if full:
             qkv3 = qs.view(B, S, 3 * E)

@@ -313,6 +313,26 @@ int hoisdf_attention_fwd_f16(const float* q, int ldq, const float* k, int ldk, c
                              float* o, int ldo, int B, int H, int Lq, int Lk, int kv_len, void* workspace,
                              long workspace_bytes, void* stream);
 
+/* ---- fp32 attention emulated on the bf16 MFMA pipe ("bf16x3"; cfg.attention_emu, default) -------------------------------
+ * reference: nn.MultiheadAttention inside the encoder layers (common/nets/transformer.py:269,286-302), forward + autograd
+ * backward.  Same contracts, argument meaning, LSE convention (log2 domain) and dropout mask as hoisdf_attention_fwd / _bwd;
+ * every contraction (QK^T, PV, dO V^T, dO^T P, Q^T dS, dS K) takes both f32 operands as exact bf16 triples and six bf16 MFMA
+ * products per product with f32 accumulation (the arithmetic of hoisdf_linear_fwd_emu); softmax, dropout and the dS algebra stay
+ * f32.  fp32-equivalent results (tests/test_gpu_emu.py), not bit-identical to the f32 entries.
+ *   forward : workspace = hoisdf_attention_emu_workspace(B, H, Lq, Lk, keep ? 2 : 0) bytes, 16-byte aligned; keep = 1 leaves every
+ *             Q / K / V plane the backward needs in it (pass it on as fwd_workspace).
+ *   backward: ONE fused pass (dK, dV, dQ; 5 GEMM-equivalents), dQ through per-key-block partials summed in order - no atomics,
+ *             run-to-run identical.  workspace = hoisdf_attention_bwd_emu_workspace(B, H, Lq, Lk, fwd_workspace != NULL) bytes.
+ *             dq, dk, dv are fully overwritten (leading dimensions ldq, ldk, ldv of q, k, v). */
+long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int mode);
+int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                             float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
+                             long workspace_bytes, int keep, void* stream);
+long hoisdf_attention_bwd_emu_workspace(int B, int H, int Lq, int Lk, int kept);
+int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                             const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                             int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
+                             void* workspace, long workspace_bytes, void* stream);
 /* ---- split-precision attention for training (opt-in: cfg.attention_split) -----------------------------------------
  * Same contract as hoisdf_attention_fwd / _bwd (streaming softmax, keys >= kv_len masked, dropout mask = the same
  * function of (seed, query, key), LSE in the log2 domain), but every contraction runs on the 16-bit MFMA pipe with f16

@@ -201,3 +201,87 @@ def test_emulated_image_cache_follows_weight_updates_and_owners():
     diff = (bits_e ^ bits_f)
     n_diff = sum(bin(int(v) & 0xffffffff).count("1") for v in diff[diff != 0].cpu().tolist())
     assert n_diff <= 4, n_diff                                        # only elements within rounding of zero may differ
+
+
+def _ref_attn64(q, k, v, H, kv=None):
+    B, Lq, E = q.shape
+    qh, kh, vh = (t.view(t.shape[0], t.shape[1], H, 64).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) / 8.0
+    if kv is not None:
+        s[..., kv:] = -float("inf")
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+
+
+@pytest.mark.parametrize("B,Lq,Lk,kv", [(2, 2048, 2048, 2048), (2, 300, 300, 230), (1, 1536, 2048, 1536), (3, 33, 700, 700),
+                                        (1, 512, 2048, 2048)])
+def test_emulated_attention_is_as_accurate_as_the_exact_f32_kernels(B, Lq, Lk, kv):
+    """csrc/attention_emu.hip (bf16x3 forward + fused one-pass backward) against float64 softmax attention, next to the exact-f32
+    MFMA kernels on the same inputs: output, dq, dk, dv within the f32 kernels' own bars (2e-5 / 5e-5 of the tensor's max) and
+    no further from fp64 than 1.5 x the exact kernels' distance; masked keys get exactly zero gradients; two backward runs are
+    bit-identical (no atomics)."""
+    O = ops()
+    E, H = 256, 4
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B, Lq, E, generator=g)
+    kvt = torch.randn(B, Lk, 2 * E, generator=g)
+    go = torch.randn(B, Lq, E, generator=g)
+    q64, kv64 = q.double().requires_grad_(True), kvt.double().requires_grad_(True)
+    ref = _ref_attn64(q64, kv64[..., :E], kv64[..., E:], H, kv)
+    ref.backward(go.double())
+
+    import hoisdf_amd.ops as OO
+    keep_bwd = OO._ATTN_BWD_EMU
+    OO._ATTN_BWD_EMU = True                                         # the fused emulated backward (default: forward only)
+
+    def run(emu):
+        O.set_attention_emu(emu)
+        qg, kg = q.to(DEV).requires_grad_(True), kvt.to(DEV).requires_grad_(True)
+        o = O.attention_cross(qg, kg, H, kv)
+        o.backward(go.to(DEV))
+        return o.detach(), qg.grad, kg.grad
+    keep = O.attention_emu()
+    try:
+        oe, dqe, dkve = run(True)
+        oe2, dqe2, dkve2 = run(True)
+        of, dqf, dkvf = run(False)
+    finally:
+        O.set_attention_emu(keep)
+        OO._ATTN_BWD_EMU = keep_bwd
+    assert not torch.equal(oe, of)                                  # the switch selected other kernels
+    assert torch.equal(oe, oe2) and torch.equal(dqe, dqe2) and torch.equal(dkve, dkve2)      # deterministic
+    for name, ge, gf, r, rel in (("out", oe, of, ref, 2e-5), ("dq", dqe, dqf, q64.grad, 5e-5), ("dkv", dkve, dkvf, kv64.grad, 5e-5)):
+        assert_close(ge, r, rel=rel, what="emulated " + name)
+        mx = float(r.abs().max())
+        ee = float((ge.double().cpu() - r).abs().max()) / mx
+        ef = float((gf.double().cpu() - r).abs().max()) / mx
+        assert ee <= 1.5 * ef + 2e-7, (name, ee, ef)
+    if kv < Lk:
+        assert float(dkve[:, kv:].abs().max()) == 0.0
+
+
+def test_emulated_attention_dropout_mask_is_the_f32_kernels_mask():
+    """same (seed, query, key) hash as attention.hip: with dropout on, the emulated forward / backward agree with the exact-f32
+    kernels to rounding (the SAME elements are dropped), and the backward is the adjoint of the forward in V (same mask)."""
+    O = ops()
+    import hoisdf_amd.ops as OO
+    B, L, E, H, p = 2, 256, 256, 4, 0.2
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(B, L, 3 * E, generator=g).to(DEV)
+    go = torch.randn(B, L, E, generator=g).to(DEV)
+    seed = 424242
+    keep = O.attention_emu()
+    keep_bwd = OO._ATTN_BWD_EMU
+    OO._ATTN_BWD_EMU = True
+    res = []
+    try:
+        for emu in (True, False):
+            O.set_attention_emu(emu)
+            x = qkv.clone().requires_grad_(True)
+            o = OO._AttentionSelf.apply(x, H, L, p, seed)
+            o.backward(go)
+            res.append((o.detach(), x.grad))
+    finally:
+        O.set_attention_emu(keep)
+        OO._ATTN_BWD_EMU = keep_bwd
+    assert_close(res[0][0], res[1][0], rel=2e-5, what="dropout out")
+    assert_close(res[0][1], res[1][1], rel=5e-5, what="dropout dqkv")
