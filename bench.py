@@ -32,7 +32,11 @@ sys.path.insert(0, REPO)
 
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (no sparsity)
-TRAFFIC_FILE = "r02_pmc_traffic.json"
+# the arithmetic type of the headline line: every contraction is fp32 - either the exact-f32 MFMA or (default for the large
+# linear layers and the attention forward) fp32 emulated with EXACT 3-way bf16 operand splits, 6 products, f32 accumulation:
+# error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
+DTYPE_F32 = "f32"
+PMC_FILE = "r03_pmc.json"
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
 
@@ -151,12 +155,13 @@ def main():
     ap.add_argument("--aten-report", action="store_true",
                     help="after the warm-up, run one extra step under torch.profiler and print the ATen ops by name and input "
                          "shape (stderr): where the glue launches come from")
-    ap.add_argument("--gemm", choices=("f32", "split"), default="f32",
-                    help="training linear layers: f32 = exact-f32 MFMA GEMM (the headline line); split = f16 hi+lo operands, "
-                         "3 products per contraction (csrc/gemm_split.hip; part of the second, separately labelled line)")
-    ap.add_argument("--attention", choices=("f32", "split"), default="f32",
-                    help="training attention: f32 = exact-f32 MFMA kernels (the headline line); split = f16 hi+lo operands, "
-                         "3 products per contraction on the 16-bit MFMA pipe (a second, separately labelled line)")
+    ap.add_argument("--gemm", choices=("emu", "f32", "split"), default="emu",
+                    help="linear layers: emu = fp32 emulated on the bf16 MFMA pipe (exact 3-way bf16 operand splits, 6 products, f32 "
+                         "accumulation: fp32-equivalent, the default); f32 = the exact-f32 MFMA GEMM; split = f16 hi+lo operands, "
+                         "3 products (22-bit operands: a separately labelled second line)")
+    ap.add_argument("--attention", choices=("emu", "f32", "split"), default="emu",
+                    help="attention: emu = forward emulated like --gemm emu (the backward stays on the exact-f32 fused kernel unless "
+                         "HOISDF_ATTN_BWD=emu); f32 = exact-f32 MFMA kernels; split = f16 hi+lo operands (second line)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 32, [3]: 16, [4]: 8 / max(2, gpus))")
     ap.add_argument("--n-hand", type=int, default=None)
     ap.add_argument("--n-obj", type=int, default=None)
@@ -221,6 +226,10 @@ def main():
     cfg.attention_split = train and args.attention == "split"
     cfg.gemm_split = train and args.gemm == "split"
     cfg.gemm_split_eval = (not train) and args.gemm == "split"
+    cfg.gemm_emu = args.gemm == "emu"
+    cfg.attention_emu = args.attention == "emu"
+    ops.set_gemm_emu(cfg.gemm_emu)
+    ops.set_attention_emu(cfg.attention_emu)
     torch.manual_seed(0)           # identical initial weights on every rank
     model = get_model("train" if train else "test", cfg=cfg).to(dev).train(train)
     if args.channels_last:
@@ -355,7 +364,7 @@ def main():
                   f"samples/sec, inference (BASELINE configs[{args.config}])",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if (args.config != 4 and args.attention == "f32" and args.gemm == "f32") else
+        "dtype": DTYPE_F32 if (args.config != 4 and args.attention != "split" and args.gemm != "split") else
                  ("f32 (attention" + (" and linear-layer" if args.gemm == "split" else "") +
                   " contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax)"
                   if (args.config == 4 or args.attention == "split") else
@@ -365,67 +374,101 @@ def main():
                    "global_batch": world * args.batch, "points": args.n_hand + args.n_obj,
                    "parallelism": f"dp{world}", ("final_loss" if train else "checksum"): float(last.detach())},
     }
+    res["config"]["arithmetic"] = {
+        "linear_layers": {"emu": "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate",
+                          "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[args.gemm],
+        "attention": {"emu": "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel"
+                             + (" (HOISDF_ATTN_BWD=emu: emulated)" if os.environ.get("HOISDF_ATTN_BWD") == "emu" else ""),
+                      "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[
+                          "split" if args.attention == "split" else ("f32" if (args.attention == "f32" or args.config == 4) else "emu")],
+        "accuracy_evidence": "tests/test_gpu_emu.py, tools/emu_accuracy.py: error vs fp64 <= the exact-f32 kernels' and hipBLASLt fp32's"}
     if timer is not None:
         ks = timer.summary()
         if args.shape_report:
             print("\n".join(timer.by_shape(timed_steps)), file=sys.stderr)
-        # kernel families = device kernels: the three linear entry points are ONE kernel template (gemm_f32_kernel)
-        sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's split switch
-        fams = {"gemm_f32_kernel (linear fwd + grad-input + grad-weight)":
-                    ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if args.gemm == "split" else sq),
-                "emu_kc_kernel + emu_dw_kernel (linear fwd + grad-input + grad-weight, fp32 emulated with 3-way bf16 splits, 6 products)":
-                    ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu", "hoisdf_linear_bwd_weight_emu"],
-                "attn_fwd_kernel": ["hoisdf_attention_fwd"],
-                "emu_attn_fwd_kernel (+ bf16x3 conversion passes)": ["hoisdf_attention_fwd_emu"],
-                "emu_attn_bwd_kernel (fused dK, dV, dQ; + conversion / delta / dQ reduce passes)": ["hoisdf_attention_bwd_emu"],
-                "attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)": ["hoisdf_attention_bwd"],
-                "attn_fwd_f16_kernel (+ operand split pass)": ["hoisdf_attention_fwd_f16"],
-                "gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)":
-                    ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] +
-                    (sq if args.gemm == "split" else []),
-                "split_fwd_kernel (+ conversion passes)": ["hoisdf_attention_fwd_split", "hoisdf_attention_fwd_split_keep"],
-                "split_bwd_dkv + split_bwd_dq (+ conversion passes)": ["hoisdf_attention_bwd_split",
-                                                                       "hoisdf_attention_bwd_split_kept"]}
+        # kernel families = device kernels (a family = the C entries that launch the same kernel template), each priced against
+        # the MFMA roof of the arithmetic it runs:
+        #   f32    exact-f32 MFMA kernels: 157.3 TFLOP/s
+        #   emu    fp32 emulated with 3-way bf16 splits: six bf16 products per product -> 2500 / 6 TFLOP/s of fp32-equivalent work
+        #   split  f16 hi + lo pairs (opt-in second line): three f16 products per product -> 2500 / 3
+        sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's emulation / split switch
+        sq_emu = args.gemm != "split" and bool(_lib.lib().hoisdf_get_gemm_emu())
+        FAMS = [
+            ("attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)", ["hoisdf_attention_bwd"], "f32"),
+            ("attn_fwd_kernel", ["hoisdf_attention_fwd"], "f32"),
+            ("gemm_f32_kernel (linear fwd + grad-input + grad-weight)",
+             ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if (args.gemm == "split" or sq_emu) else sq), "f32"),
+            ("emu_kc_kernel (linear fwd + grad-input)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
+            ("emu_dw_kernel (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
+            ("emu_attn_fwd_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
+            ("emu_attn_bwd_kernel (fused dK, dV, dQ; + conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
+            ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
+            ("gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)",
+             ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] + (sq if args.gemm == "split" else []), "split"),
+            ("split_fwd_kernel (+ conversion passes)", ["hoisdf_attention_fwd_split", "hoisdf_attention_fwd_split_keep"], "split"),
+            ("split_bwd_dkv + split_bwd_dq (+ conversion passes)", ["hoisdf_attention_bwd_split", "hoisdf_attention_bwd_split_kept"], "split"),
+        ]
+        PEAK = {"f32": (PEAK_F32_TFLOPS, "f32 MFMA peak (= f32 vector peak), MI355X_MICROARCH.md:41"),
+                "emu": (round(PEAK_F16_TFLOPS / 6.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product (MI355X_MICROARCH.md:42)"),
+                "split": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense f16 MFMA peak 2500 TFLOP/s / 3 products per product")}
         agg = {}
-        for fam, members in fams.items():
+        for fam, members, cls in FAMS:
             ms = sum(ks[m]["total_ms"] for m in members if m in ks)
             if ms > 0:
                 gf = sum(ks[m]["gflop"] for m in members if m in ks)
                 n = sum(ks[m]["launches"] for m in members if m in ks)
-                agg[fam] = dict(total_ms=ms, gflop=gf, launches=n, tflops=gf / ms, members=[m for m in members if m in ks])
+                agg[fam] = dict(total_ms=ms, gflop=gf, launches=n, tflops=gf / ms, members=[m for m in members if m in ks], cls=cls)
         dom = max(agg, key=lambda f: agg[f]["total_ms"])
         d = agg[dom]
-        f16 = "f16" in dom or "split" in dom
-        peak = PEAK_F16_TFLOPS if f16 else PEAK_F32_TFLOPS
+        peak, peak_note = PEAK[d["cls"]]
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": round(d["tflops"] / peak, 4), "traffic": None,
+                           "peak_note": peak_note,
                            "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
                            "launches_per_step": d["launches"] / timed_steps,
                            "ms_per_step": round(d["total_ms"] / timed_steps, 3),
                            "algorithmic_gflop_per_launch": round(d["gflop"] / d["launches"], 3),
                            "events_on_steps": f"{timed_steps} of {args.steps} (those steps single-stream)"}
-        if f16:
-            res["roofline"]["peak_note"] = ("dense f16 MFMA peak; the kernel issues 3 f16 products per algorithmic "
-                                            "product (hi+lo split), so 1/3 is the ceiling of this formulation")
-        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate
-        # passes; tools/pmc_attn.py / tools/pmc_gemm.py at the bench shapes; summaries in profiles/).  Collected per
-        # round at the largest shape of the family, not inside this run (PMC needs rocprofv3 around the process).
+        # PMC evidence (rocprofv3 --pmc, separate passes per counter group, tools/pmc_collect.sh -> profiles/<PMC_FILE>): a list of
+        # records keyed by (C entry, shape), never merged across shapes.  The record of the dominant family's entry at the shape
+        # with the most time in this run is quoted: HBM bytes per launch (FETCH_SIZE x 2 [gfx950] + WRITE_SIZE), MFMA-busy fraction
+        # and the effective clock under that kernel; the achieved HBM rate uses THIS run's HIP-event duration at that shape.
         try:
-            tr = json.load(open(os.path.join(REPO, "profiles", TRAFFIC_FILE)))
-            knames = {"hoisdf_attention_bwd": ["hoisdf::attn_delta_kernel", "hoisdf::attn_bwd_fused_kernel"],
-                      "hoisdf_attention_fwd": ["hoisdf::attn_fwd_kernel"],
-                      "hoisdf_linear_fwd": ["hoisdf::gemm_f32_kernel<true, true, false, false>"]}
-            m0 = d["members"][0]
-            if m0 in knames and all(k in tr for k in knames[m0]):
-                res["roofline"]["traffic"] = int(sum(tr[k]["hbm_bytes_per_launch"] for k in knames[m0]))
-                # north_star asks for HBM GB/s next to the MFMA fraction: PMC bytes of that launch / its measured duration
-                res["roofline"]["hbm_gbps"] = round(res["roofline"]["traffic"] / (timer.largest_launch_us(m0) * 1e-6) / 1e9, 1)
-                res["roofline"]["hbm_peak_gbps"] = 8000.0
-                res["roofline"]["traffic_note"] = (f"PMC bytes (profiles/{TRAFFIC_FILE}) of one launch at the largest shape of "
-                                                   "this family (self-attention B=32,S=2048 / linear fwd 49152x1024x992)")
-        except Exception:
-            pass
+            pmc = json.load(open(os.path.join(REPO, "profiles", PMC_FILE)))
+            by_shape = {}
+            for m in d["members"]:
+                for s0, e0, fl0, shape in timer.records.get(m, []):
+                    a0 = by_shape.setdefault((m, shape), [0, 0.0])
+                    a0[0] += 1
+                    a0[1] += s0.elapsed_time(e0)
+            for (m, shape), (cnt, ms) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+                rec = [r for r in pmc if r["entry"] == m and tuple(r["shape"]) == tuple(shape) and "hbm_bytes_per_launch" in r]
+                if rec:
+                    r0 = rec[0]
+                    us = 1e3 * ms / cnt
+                    res["roofline"]["traffic"] = int(r0["hbm_bytes_per_launch"])
+                    res["roofline"]["traffic_record"] = {"file": f"profiles/{PMC_FILE}", "case": r0["case"], "entry": m, "shape": list(shape),
+                                                         "launch_us_this_run": round(us, 1)}
+                    res["roofline"]["hbm_gbps"] = round(r0["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
+                    res["roofline"]["hbm_peak_gbps"] = 8000.0
+                    if "mfma_busy" in r0:
+                        res["roofline"]["mfma_busy"] = r0["mfma_busy"]
+                        res["roofline"]["effective_clock_ghz"] = r0["effective_clock_ghz"]
+                    break
+        except Exception as ex:                 # the PMC file is evidence, not a dependency of the measurement
+            res["roofline"]["traffic_note"] = f"no PMC record: {ex}"
+        res["families"] = [{"kernel": fam, "arithmetic": v["cls"], "ms_per_step": round(v["total_ms"] / timed_steps, 3),
+                            "launches_per_step": v["launches"] / timed_steps, "achieved_tflops": round(v["tflops"], 2),
+                            "peak_tflops": PEAK[v["cls"]][0], "frac": round(v["tflops"] / PEAK[v["cls"]][0], 4)}
+                           for fam, v in sorted(agg.items(), key=lambda kv: -kv[1]["total_ms"])]
+        tot_ms = sum(v["total_ms"] for v in agg.values())
+        tot_gf = sum(v["gflop"] for v in agg.values())
+        # the whole HIP hot path's MFMA-shaped work: algorithmic TFLOP per step / the HIP-event time of those launches
+        res["hot_path"] = {"algorithmic_tflop_per_step": round(tot_gf / timed_steps / 1e3, 3),
+                           "mfma_kernel_ms_per_step": round(tot_ms / timed_steps, 3),
+                           "tflops": round(tot_gf / tot_ms, 2) if tot_ms > 0 else 0.0,
+                           "tflops_over_the_whole_step": round(tot_gf / timed_steps / 1e3 / (ms_per_step * 1e-3), 2)}
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),
                               "launches_per_step": v["launches"] / timed_steps, "avg_us": round(v["avg_us"], 2)}
                           for n, v in ks.items()}

@@ -397,6 +397,10 @@ class Model(nn.Module):
         ops.set_attention_f16_eval(bool(getattr(c, "attention_f16_eval", False)) and mode != "train")
         ops.set_attention_split(bool(getattr(c, "attention_split", False)) and mode == "train")
         ops.set_gemm_split(bool(getattr(c, "gemm_split", False)) if mode == "train" else bool(getattr(c, "gemm_split_eval", False)))
+        if getattr(c, "gemm_emu", None) is not None:
+            ops.set_gemm_emu(bool(c.gemm_emu))
+        if getattr(c, "attention_emu", None) is not None:
+            ops.set_attention_emu(bool(c.attention_emu))
         loss, out = self.hot_path(pyr, inputs, targets, meta_info, mode, epoch_cnt, batch_ratio)
         if mode == "train" or c.dataset == "dexycb":                                   # :404-422 aux image losses
             out["joint_heatmap_out"] = decoder_out[:, 0]

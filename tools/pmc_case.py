@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""PMC driver: ONE launch family at ONE shape per process (run under `rocprofv3 --pmc ...`), so that a counter row can be keyed
+by (C entry, shape) without guessing.  usage: pmc_case.py <case>;  `pmc_case.py --list` prints the case names."""
+import sys, os, math
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+CASES = {
+    # name: (C entry, kernel substring, shape)
+    "attn_bwd_f32_32x2048x2048": ("hoisdf_attention_bwd", "attn_bwd_fused_kernel", (32, 2048, 2048)),
+    "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd_kernel", (32, 2048, 2048)),
+    "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd_kernel", (32, 2048, 2048)),
+    "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu", "emu_kc_kernel<false>", (65536, 1024, 256)),
+    "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu", "emu_kc_kernel<false>", (65536, 256, 1024)),
+    "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu", "emu_kc_kernel<true>", (65536, 1024, 256)),
+    "linear_bwd_weight_emu_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw_kernel<true>", (65536, 1024, 256)),
+    "linear_fwd_f32_65536x1024x256": ("hoisdf_linear_fwd", "gemm_f32_kernel<true, true, false, false>", (65536, 1024, 256)),
+}
+if __name__ == "__main__":
+    if sys.argv[1] == "--list":
+        print(" ".join(CASES)); sys.exit(0)
+    import torch
+    from hoisdf_amd import ops as O
+    case = sys.argv[1]
+    entry, _, shape = CASES[case]
+    dev = "cuda"
+    if "attn" in case:
+        B, Lq, Lk = shape
+        E, H, p = 256, 4, 0.1
+        q = torch.randn(B, Lq, E, device=dev); kv = torch.randn(B, Lk, 2 * E, device=dev); do = torch.randn(B, Lq, E, device=dev)
+        k, v = kv[:, :, :E], kv[:, :, E:]
+        dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+        o, lse = O._attn_fwd(q, k, v, H, Lk, p, 1234)
+        for _ in range(3):
+            if entry == "hoisdf_attention_bwd":
+                O._attn_bwd(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, Lk, p, 1234)
+            elif entry == "hoisdf_attention_fwd_emu":
+                O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, keep=False)
+            else:
+                O._attn_bwd_emu(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, Lk, p, 1234)
+    else:
+        M, N, K = shape
+        x = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / math.sqrt(K); b = torch.randn(N, device=dev)
+        dy = torch.randn(M, N, device=dev)
+        y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+        bits = torch.empty(M, (N + 31) // 32, dtype=torch.int32, device=dev)
+        O.set_gemm_emu("_emu" in case)
+        O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.0, 0, bits)
+        for _ in range(3):
+            if "linear_fwd" in case:
+                O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.0, 0, bits)
+            elif "bwd_input" in case:
+                O._gemm_bwd_input(dy, N, bits, 0.0, W, dx, K, M, N, K, 0)
+            else:
+                O._gemm_bwd_weight(dy, N, bits, 0.0, x, K, dW, db, M, N, K)
+    torch.cuda.synchronize()

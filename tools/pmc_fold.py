@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Fold the per-case PMC CSVs of tools/pmc_collect.sh into ONE json list keyed by (C entry, kernel, shape) - never merged across
+shapes.  HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE are in KB, FETCH_SIZE counts 128-byte requests in
+64-byte units on gfx950 (x2).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x per-XCD active cycles), effective clock =
+per-XCD active cycles / kernel duration (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  usage: pmc_fold.py <dir> > out.json"""
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_case import CASES
+
+
+def rows(path, kernel_sub):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if kernel_sub in r["Kernel_Name"]:
+                out.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return out
+
+
+def main():
+    d = sys.argv[1]
+    res = []
+    for case, (entry, ksub, shape) in CASES.items():
+        f = rows(os.path.join(d, f"{case}.pass1.csv"), ksub)
+        w = rows(os.path.join(d, f"{case}.pass2.csv"), ksub)
+        b = rows(os.path.join(d, f"{case}.pass3.csv"), ksub)
+        if not (f or w or b):
+            continue
+        mean = lambda xs, i: sum(x[i] for x in xs) / len(xs)
+        e = {"case": case, "entry": entry, "kernel": ksub, "shape": list(shape)}
+        if "FETCH_SIZE" in f:
+            e["fetch_bytes"] = mean(f["FETCH_SIZE"], 0) * 1024 * 2
+        if "WRITE_SIZE" in w:
+            e["write_bytes"] = mean(w["WRITE_SIZE"], 0) * 1024
+        if "fetch_bytes" in e and "write_bytes" in e:
+            e["hbm_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
+        if "GRBM_GUI_ACTIVE" in b and "SQ_VALU_MFMA_BUSY_CYCLES" in b:
+            act = mean(b["GRBM_GUI_ACTIVE"], 0) / 8.0
+            dur_ns = mean(b["GRBM_GUI_ACTIVE"], 1)
+            e["mfma_busy"] = round(mean(b["SQ_VALU_MFMA_BUSY_CYCLES"], 0) / (1024.0 * act), 4)
+            e["effective_clock_ghz"] = round(act / dur_ns, 3)
+            e["duration_us_under_pmc"] = round(dur_ns / 1e3, 1)
+        res.append(e)
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
