@@ -333,6 +333,58 @@ def main():
         dt = float(t)
     assert torch.isfinite(last), "non-finite loss"
 
+    # ---- communication diagnostics (every rank takes part, rank 0 reports; outside the timed region) -----------------------
+    comm = None
+    if use_dist and train:
+        import torch.distributed as dist
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world, f"{int(ones.item())} ranks joined the job, expected {world}"
+        # (a) exposed communication: how long the compute stream stalls in reducer.finish() (outstanding bucket all-reduces +
+        #     the unused-parameter bookkeeping) over three extra steps
+        exposed = []
+        for _ in range(3):
+            reducer.zero_grad()
+            out = model(inputs, targets, meta, "train", epoch_cnt, 0.1)
+            total = sum(v.mean() * LOSS_WEIGHTS.get(k, 1.0) for k, v in out.items() if "_out" not in k)
+            total.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.finish()
+            e1.record()
+            opt.step()
+            torch.cuda.synchronize()
+            exposed.append(e0.elapsed_time(e1))
+        # (b) every bucket's all-reduce on its own (nothing else on the device): latency / bus bandwidth of the collective itself
+        per_bucket = []
+        for flat in reducer.buckets:
+            torch.cuda.synchronize(); dist.barrier()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            nbytes = flat.numel() * 4
+            ms = sorted(ts)[1]
+            per_bucket.append({"mbytes": round(nbytes / 2 ** 20, 1), "ms": round(ms, 3),
+                               "busbw_gbps": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if world > 1 else None})
+        t = torch.tensor([sorted(exposed)[1]], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = "unknown"
+        comm = {"backend": dist.get_backend(), "rccl_version": ver, "world": world, "ranks_joined": world,
+                "gradient_mbytes": round(reducer.total_bytes() / 2 ** 20, 1), "buckets": per_bucket,
+                "exposed_ms_per_step_max_over_ranks": round(float(t), 3),
+                "all_reduce_ms_sum": round(sum(b["ms"] for b in per_bucket), 3),
+                "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+        if rank == 0:
+            print(f"[comm] {json.dumps(comm)}", file=sys.stderr)
+
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -472,6 +524,8 @@ def main():
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),
                               "launches_per_step": v["launches"] / timed_steps, "avg_us": round(v["avg_us"], 2)}
                           for n, v in ks.items()}
+    if comm is not None:
+        res["comm"] = comm
     if world == 1 and not args.no_cpu_baseline:
         from oracle.cpu_step import time_cpu_baseline
         threads = min(args.cpu_threads, os.cpu_count() or 1)

@@ -298,6 +298,41 @@ def test_c_host_allreduce():
     assert out.returncode == 0 and "allreduce ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_c_host_allreduce_two_ranks_file_rendezvous():
+    """libhoisdf_rccl.so with TWO ranks and a file rendezvous of the 256-byte token (the id-exchange path a launcher without
+    torch uses).  Both ranks must end up with the same token.  With two GPUs the all-reduce itself is checked; on a one-GPU box
+    RCCL refuses (or stalls on) two ranks on one device - then the token plumbing is what this test pins, and the processes are
+    ended after a short wait."""
+    import os
+    import subprocess
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = "/tmp/hoisdf_test_allreduce_w2"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", os.path.join(repo, "tests", "c", "test_allreduce_world2.c"), "-I",
+                    os.path.join(repo, "include"), "-L", os.path.join(repo, "hoisdf_amd"), "-lhoisdf_rccl",
+                    "-Wl,-rpath," + os.path.join(repo, "hoisdf_amd"), "-o", exe], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "id.bin")
+        procs = [subprocess.Popen([exe, str(r), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+                 for r in (0, 1)]
+        outs = []
+        for p in procs:
+            try:
+                o, e = p.communicate(timeout=90)
+            except subprocess.TimeoutExpired:           # two ranks on one device: RCCL waits for a peer it cannot place
+                p.kill()
+                o, e = p.communicate()
+                o += "init refused: timeout\n"
+            outs.append((p.returncode, o, e))
+    ids = [[l for l in o.splitlines() if l.startswith("id ")] for _, o, _ in outs]
+    assert all(len(i) == 1 for i in ids) and ids[0] == ids[1], outs              # the token reached rank 1 intact
+    if torch.cuda.device_count() >= 2:
+        assert all(rc == 0 and "allreduce ok" in o for rc, o, _ in outs), outs
+    else:
+        assert all("allreduce ok" in o or "init refused" in o for _, o, _ in outs), outs
+
+
 def test_c_host_linear():
     """A plain C program links libhoisdf_hip.so through include/hoisdf.h only (no Python, no torch types)."""
     import os
