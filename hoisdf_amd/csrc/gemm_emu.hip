@@ -316,8 +316,13 @@ struct DwArgs {
 };
 }  // namespace
 
-template <bool MASK>
-__global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
+// DTK = tile width along k: 256 (wave tile 128 x 128, 256 accumulators, one workgroup per CU) or 128 (wave tile 128 x 64, two
+// workgroups per CU: the conversion phase of one overlaps the MFMAs of the other; x patches on wave 2 only, wave 3 stages nothing)
+template <bool MASK, int DTK>
+__global__ __launch_bounds__(NT, DTK == 256 ? 1 : 2) void emu_dw_kernel(DwArgs g) {
+  constexpr int NJ = DTK / 64;                         // 32-column blocks per wave along k
+  constexpr int WK = DTK / 2;                          // wave tile width along k
+  constexpr int A_U4 = 3 * 2 * DT, STAGE = A_U4 + 3 * 2 * DTK;
   extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -328,26 +333,27 @@ __global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
   const int t = (bid >> 3) % ntile;
   if (split >= g.splitk) return;
   const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
-  const int n0 = tn * DT, k0 = tk * DT;
+  const int n0 = tn * DT, k0 = tk * DTK;
   const int mbeg = split * g.m_per_split;
   const int mend = min(g.M, mbeg + g.m_per_split);
   const int nslab = (mend - mbeg + KS - 1) / KS;
   const int last = nslab - 1;
 
-  f32x16 acc[4][4];
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging patch of this thread: operand (wave-uniform), column group cg (4 columns), chunk c (8 rows of the slab)
   const bool isA = tid < 128;
-  const int cg = tid & 63, c = (tid >> 6) & 1;
+  const bool stager = DTK == 256 || tid < 192;          // (wave-uniform)
+  const int cg = (isA || DTK == 256) ? (tid & 63) : (tid & 31), c = (isA || DTK == 256) ? ((tid >> 6) & 1) : ((tid >> 5) & 1);
   const int col0 = (isA ? n0 : k0) + 4 * cg;
   const int ncol = isA ? g.N : g.K;                      // multiples of 4 (checked by the host): a patch column group is all in or out
-  const bool col_ok = col0 < ncol;
+  const bool col_ok = stager && col0 < ncol;
   const long ld = isA ? g.lddy : g.ldx;
   const float* src = (isA ? g.dy : g.x) + (col_ok ? col0 : 0);
   const uint32_t* bsrc = (MASK && isA) ? g.bits + ((col_ok ? col0 : 0) >> 5) : nullptr;
@@ -385,19 +391,20 @@ __global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
         csum.x += rv[e].x; csum.y += rv[e].y; csum.z += rv[e].z; csum.w += rv[e].w;                                   \
       }                                                                                                               \
     }                                                                                                                 \
-    u32x4* dst_ = (st) + (isA ? 0 : DW_OP_U4) + c * DT + 4 * cg;                                                      \
+    const int rs_ = isA ? DT : DTK;                          /* rows per (plane, chunk) region of this operand */      \
+    u32x4* dst_ = (st) + (isA ? 0 : A_U4) + c * rs_ + 4 * cg;                                                         \
     bf16x8 p0, p1, p2;                                                                                                \
     split3x8(make_float4(rv[0].x, rv[1].x, rv[2].x, rv[3].x), make_float4(rv[4].x, rv[5].x, rv[6].x, rv[7].x), p0, p1, p2); \
-    dst_[0] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT] = __builtin_bit_cast(u32x4, p2); \
+    dst_[0] = __builtin_bit_cast(u32x4, p0); dst_[2 * rs_] = __builtin_bit_cast(u32x4, p1); dst_[4 * rs_] = __builtin_bit_cast(u32x4, p2); \
     split3x8(make_float4(rv[0].y, rv[1].y, rv[2].y, rv[3].y), make_float4(rv[4].y, rv[5].y, rv[6].y, rv[7].y), p0, p1, p2); \
-    dst_[1] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 1] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 1] = __builtin_bit_cast(u32x4, p2); \
+    dst_[1] = __builtin_bit_cast(u32x4, p0); dst_[2 * rs_ + 1] = __builtin_bit_cast(u32x4, p1); dst_[4 * rs_ + 1] = __builtin_bit_cast(u32x4, p2); \
     split3x8(make_float4(rv[0].z, rv[1].z, rv[2].z, rv[3].z), make_float4(rv[4].z, rv[5].z, rv[6].z, rv[7].z), p0, p1, p2); \
-    dst_[2] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 2] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 2] = __builtin_bit_cast(u32x4, p2); \
+    dst_[2] = __builtin_bit_cast(u32x4, p0); dst_[2 * rs_ + 2] = __builtin_bit_cast(u32x4, p1); dst_[4 * rs_ + 2] = __builtin_bit_cast(u32x4, p2); \
     split3x8(make_float4(rv[0].w, rv[1].w, rv[2].w, rv[3].w), make_float4(rv[4].w, rv[5].w, rv[6].w, rv[7].w), p0, p1, p2); \
-    dst_[3] = __builtin_bit_cast(u32x4, p0); dst_[2 * DT + 3] = __builtin_bit_cast(u32x4, p1); dst_[4 * DT + 3] = __builtin_bit_cast(u32x4, p2); \
+    dst_[3] = __builtin_bit_cast(u32x4, p0); dst_[2 * rs_ + 3] = __builtin_bit_cast(u32x4, p1); dst_[4 * rs_ + 3] = __builtin_bit_cast(u32x4, p2); \
   } while (0)
 
-  if (nslab > 0) {
+  if (nslab > 0 && stager) {
     DW_LOAD(0);
     DW_STORE(lds, 0);
     DW_LOAD(min(1, last));
@@ -405,14 +412,14 @@ __global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
   __syncthreads();
 
   for (int s = 0; s < nslab; ++s) {
-    const u32x4* st = lds + (s & 1) * DW_STAGE_U4;
-    u32x4* nx = lds + ((s + 1) & 1) * DW_STAGE_U4;
+    const u32x4* st = lds + (s & 1) * STAGE;
+    u32x4* nx = lds + ((s + 1) & 1) * STAGE;
     const u32x4* sa = st + wm * 128 + l31;
-    const u32x4* sb = st + DW_OP_U4 + wn * 128 + l31;
-    bf16x8 b0[4], b1[4], b2[4], a[4];
-#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < 4; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * DT + j * 32])
+    const u32x4* sb = st + A_U4 + wn * WK + l31;
+    bf16x8 b0[NJ], b1[NJ], b2[NJ], a[4];
+#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < NJ; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * DTK + j * 32])
 #define RD_A(p) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, sa[((p) * 2 + kh) * DT + i * 32])
-#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
+#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
     // long phase first: 48 MFMAs queue up right behind the barrier, the conversion of the next slab follows them.  (Measured
     // on MI355X, tools/mb_emu.py: pinning only the global loads and letting hipcc spread the conversion over the MFMAs, or an
     // explicit sched_group_barrier pipeline of 1 MFMA + 6 VALU, are within 2 % of this form.)
@@ -420,8 +427,10 @@ __global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
     MM1(b2); MM1(b1); MM1(b0);                 // x0 y2, x0 y1, x0 y0
     __builtin_amdgcn_sched_barrier(0);
     RD_A(1);
-    if (s + 1 < nslab) DW_STORE(nx, s + 1);
-    DW_LOAD(min(s + 2, last));
+    if (stager) {
+      if (s + 1 < nslab) DW_STORE(nx, s + 1);
+      DW_LOAD(min(s + 2, last));
+    }
     __builtin_amdgcn_sched_barrier(0);
     MM1(b1); MM1(b0);                          // x1 y1, x1 y0
     RD_A(2);
@@ -446,22 +455,23 @@ __global__ __launch_bounds__(NT, 1) void emu_dw_kernel(DwArgs g) {
     __syncthreads();
   }
 
-  // epilogue: one row of four 32 x 32 blocks (32 x 128) at a time through the wave's private LDS slice
+  // epilogue: one row of 32 x 32 blocks (32 x WK) at a time through the wave's private LDS slice
   float* Cb = g.C + (size_t)split * g.c_split_stride;
-  const bool full = (n0 + DT <= g.N) && (k0 + DT <= g.K) && (g.K % 4 == 0);
-  constexpr int ES = 132;
+  const bool full = (n0 + DT <= g.N) && (k0 + DTK <= g.K) && (g.K % 4 == 0);
+  constexpr int ES = WK + 4;
+  constexpr int LPR = WK / 4, RPI = 64 / LPR;          // lanes per row (one float4 each), rows per wave instruction
   float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int rr = p * 2 + kh;
-      const int row = n0 + wm * 128 + i * 32 + rr, col = k0 + wn * 128 + l31 * 4;
-      const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + l31 * 4);
+    for (int p = 0; p < 32 / RPI; ++p) {
+      const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
+      const int row = n0 + wm * 128 + i * 32 + rr, col = k0 + wn * WK + cc;
+      const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
       if (full) {
         *reinterpret_cast<float4*>(Cb + (size_t)row * g.K + col) = v;
       } else if (row < g.N) {
@@ -598,10 +608,21 @@ extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint
 
 namespace {
 // row slices for grad-weight: one workgroup per CU (256 slots), >= 8 slabs per slice
+// k-tile width: 256 (one workgroup per CU), or 128 (two per CU) when the 256-wide tiling leaves three tiles or fewer - there the
+// narrow form packs the last wave of slices better (measured, tools/mb_emu.py: 768 x 256 107 vs 89 TF-eq, 256 x 256 103 vs 98;
+// level elsewhere).  HOISDF_EMU_DW_TILE=128 / 256 forces one form.
+int dw_tile(int N, int K) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("HOISDF_EMU_DW_TILE"); const int v = e ? atoi(e) : 0; forced = (v == 128 || v == 256) ? v : 0; }
+  if (forced) return forced;
+  return cdiv(N, DT) * cdiv(K, 256) <= 3 ? 128 : 256;
+}
 void plan_dw(long M, int N, int K, int& splitk, int& mper) {
-  const int ntile = cdiv(N, DT) * cdiv(K, DT);
+  const int dtk = dw_tile(N, K);
+  const int ntile = cdiv(N, DT) * cdiv(K, dtk);
   const int slabs = cdiv(M, KS);
-  int want = ntile >= 256 ? 1 : 256 / ntile;
+  const int slots = dtk == 256 ? 256 : 512;
+  int want = ntile >= slots ? 1 : slots / ntile;
   if (want > slabs / 8) want = slabs / 8 > 0 ? slabs / 8 : 1;
   mper = cdiv(slabs, want) * KS;
   splitk = cdiv(M, mper);
@@ -627,11 +648,12 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   hipStream_t st = as_stream(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)DW_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)DW_LDS_BYTES) != hipSuccess) {
-      set_error("linear_bwd_weight_emu: cannot raise the dynamic LDS limit to %u bytes", DW_LDS_BYTES);
+    bool ok = true;
+#define DW_ATTR(M_, T_) ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(emu_dw_kernel<M_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2u * (3 * 2 * DT + 3 * 2 * T_) * 16u)) == hipSuccess
+    DW_ATTR(false, 256); DW_ATTR(true, 256); DW_ATTR(false, 128); DW_ATTR(true, 128);
+#undef DW_ATTR
+    if (!ok) {
+      set_error("linear_bwd_weight_emu: cannot raise the dynamic LDS limit");
       return HOISDF_ERR_LAUNCH;
     }
     attr_set = true;
@@ -640,7 +662,8 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   g.dy = dy; g.lddy = lddy; g.x = x; g.ldx = ldx;
   g.bits = relu_bits; g.ldbits = (N + 31) / 32; g.ascale = 1.f / (1.f - drop_p);
   g.M = (int)M; g.N = N; g.K = K;
-  g.tiles_n = cdiv(N, DT); g.tiles_k = cdiv(K, DT);
+  const int dtk = dw_tile(N, K);
+  g.tiles_n = cdiv(N, DT); g.tiles_k = cdiv(K, dtk);
   plan_dw(M, N, K, g.splitk, g.m_per_split);
   const long need = g.splitk > 1 ? (long)g.splitk * ((long)N * K + N) : 0;
   HOISDF_REQUIRE(need == 0 || (workspace && workspace_floats >= need && al16(workspace)), HOISDF_ERR_WORKSPACE,
@@ -653,8 +676,14 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   }
   const int ntile = g.tiles_n * g.tiles_k;
   const dim3 grid((unsigned)(ntile * 8 * cdiv(g.splitk, 8))), block(NT);
-  if (relu_bits) hipLaunchKernelGGL((emu_dw_kernel<true>), grid, block, DW_LDS_BYTES, st, g);
-  else hipLaunchKernelGGL((emu_dw_kernel<false>), grid, block, DW_LDS_BYTES, st, g);
+  const unsigned lb = 2u * (3 * 2 * DT + 3 * 2 * dtk) * 16u;
+  if (dtk == 256) {
+    if (relu_bits) hipLaunchKernelGGL((emu_dw_kernel<true, 256>), grid, block, lb, st, g);
+    else hipLaunchKernelGGL((emu_dw_kernel<false, 256>), grid, block, lb, st, g);
+  } else {
+    if (relu_bits) hipLaunchKernelGGL((emu_dw_kernel<true, 128>), grid, block, lb, st, g);
+    else hipLaunchKernelGGL((emu_dw_kernel<false, 128>), grid, block, lb, st, g);
+  }
   if (int rc = check_launch("linear_bwd_weight_emu")) return rc;
   if (g.splitk > 1) {
     const long n = (long)N * K;

@@ -417,8 +417,7 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
         return
     if (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= 64 and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
-            and dW.data_ptr() % 16 == 0 and ((N + 255) // 256) * ((K + 255) // 256) != 3):
-        # (three output tiles - the 768 x 256 in-projection - measured slower than the f32 kernel: 296 vs 240 us, tools/mb_emu.py)
+            and dW.data_ptr() % 16 == 0):
         from ._lib import lib
         nws = lib().hoisdf_linear_bwd_weight_emu_workspace(M, N, K)
         ws = torch.empty(max(nws, 4), device=dW.device, dtype=torch.float32)

@@ -725,8 +725,9 @@ def test_sdf_query_split_precision_layers():
     assert not torch.equal(raw, ref_raw)                          # the split path really ran
     assert_close(raw, ref_raw, rel=5e-6, what="raw"); assert_close(sdf, ref_sdf, rel=5e-6, what="sdf")
     assert not torch.equal(eraw, ref_raw)                         # ... and so did the emulated one
-    # (two fp32-class implementations through six chained layers: their roundings differ, measured 2.3e-6 of the range)
-    assert_close(eraw, ref_raw, rel=5e-6, what="emulated raw"); assert_close(esdf, ref_sdf, rel=5e-6, what="emulated sdf")
+    # (two fp32-class implementations through six chained layers: their roundings differ - measured 2.3e-6 of the raw range and,
+    # run to run with the exact path's split-k atomics, 4e-6 .. 7e-6 of the clamped field's 0.15)
+    assert_close(eraw, ref_raw, rel=5e-6, what="emulated raw"); assert_close(esdf, ref_sdf, rel=1e-5, what="emulated sdf")
 
 
 def test_sdf_query_one_call_matches_the_op_chain():
