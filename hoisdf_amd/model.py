@@ -340,8 +340,8 @@ class Model(nn.Module):
             obj_rot = self.linear_obj_rot(obj_enc)                                         # (L,B,no,3)
             obj_trans = self.linear_obj_rel_trans(obj_enc)
 
-        # ---- MANO head + its losses + the object pose losses: ~200 tiny kernels, on the second stream under the big
-        # vote-head GEMMs of the ambient stream
+        # ---- MANO head (two launches: ground truth, predictions + fused losses) + the object pose losses, on the second
+        # stream under the big vote-head GEMMs of the ambient stream
         pred_m = gt_m = None
         side_made = []
         with on_side():

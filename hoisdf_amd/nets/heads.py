@@ -1,9 +1,10 @@
 """Vote aggregation + losses (reference common/nets/loss.py:23-171) and the MANO head
 (common/nets/mano_head.py:185-278).
 
-``JointvoteLoss`` produces ``hand_joints_out`` through the HIP vote kernel (K12).  The three
-scalar losses around it and the MANO head are a16 / a15 rows of SURVEY.md section 8 - negligible
-work that stays in PyTorch (runs on the GPU through ATen).
+``JointvoteLoss`` produces ``hand_joints_out`` through the HIP vote kernel (K12, its three reductions fused).
+The MANO head (a16 / f3) is one HIP kernel forward and one backward for all L*B hands with the four ManoLoss
+squared-error sums fused (csrc/mano.hip); the PyTorch chain in ``ManoHead`` remains for MANO layers that are not
+``nets.mano.ManoLayer`` or carry a hand mean.
 """
 from __future__ import annotations
 
@@ -49,6 +50,12 @@ class ManoLoss(nn.Module):
         self.lv, self.lj, self.lp, self.ls = lambda_verts3d, lambda_joints3d, lambda_manopose, lambda_manoshape
 
     def forward(self, preds, gts):
+        if "loss_sums" in preds:                          # the MANO-head kernel already reduced the four squared errors per hand
+            s = preds["loss_sums"].sum(0)
+            n = preds["loss_sums"].shape[0]
+            return (s[0] * (self.lv / (n * 2334)), s[1] * (self.lj / (n * 63)), s[2] * (self.lp / (n * 144)),
+                    s[3] * (self.ls / (n * 10)), None, None)
+
         def mse(a, b):
             return F.mse_loss(a, b.unsqueeze(0).expand(a.shape))
         return (self.lv * mse(preds["verts3d"], gts["verts3d"]), self.lj * mse(preds["joints3d"], gts["joints3d"]),
@@ -129,8 +136,24 @@ class ManoHead(nn.Module):
         return self.forward_batch_first(pose6d.permute(0, 2, 1, 3), shape, mano_params)
 
     def forward_batch_first(self, pose6d, shape, mano_params=None):
-        from .mano import axis_angle_to_matrix
+        from .mano import axis_angle_to_matrix, ManoLayer
         L, B, N, C = pose6d.shape
+        assets = self.mano_layer.kernel_assets() if (pose6d.is_cuda and isinstance(self.mano_layer, ManoLayer)) else None
+        if assets is not None:
+            # one HIP launch for the predictions (+ one for the ground truth): csrc/mano.hip.  The torch chain below stays for
+            # MANO layers that are not this package's (get_model takes any module with manopth's interface) or carry a hand mean.
+            gt = pack = None
+            if mano_params is not None:
+                mp = mano_params.contiguous().float()
+                gv, gj, gr = ops.mano_gt(mp, assets)
+                gt = {"verts3d": gv, "joints3d": gj, "mano_shape": mp[:, self.mano_pose_size:], "mano_pose": gr}
+                pack = (gv, gj, gr, mp[:, self.mano_pose_size:])
+            verts, joints, R, sums = ops.mano_head(pose6d.reshape(L * B, N, C), shape.reshape(L * B, 10), assets, pack)
+            pred = {"verts3d": verts.view(L, B, -1, 3), "joints3d": joints.view(L, B, -1, 3), "mano_pose": R.view(L, B, N, 3, 3),
+                    "mano_shape": shape.reshape(L, B, 10)}
+            if sums is not None:
+                pred["loss_sums"] = sums                  # (L*B, 4) squared-error sums of the four ManoLoss terms
+            return pred, gt
         R = rot6d_to_matrix(pose6d.reshape(L * B * N, C))
         pose = matrix_to_axis_angle(R).reshape(-1, self.mano_pose_size)
         betas = shape.reshape(-1, 10)

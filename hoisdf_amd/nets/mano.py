@@ -1,7 +1,10 @@
-"""MANO hand model layer (linear blend skinning) in plain PyTorch.
+"""MANO hand model layer (linear blend skinning): the module with manopth's interface and buffers.
 
-Scope: SURVEY.md section 8 row a16 / (f3) - "stays PyTorch": 4*B hands per step, negligible
-work.  It sits between the HIP hot path (which produces the 6D pose and shape parameters) and
+Scope: SURVEY.md section 8 row a16 / (f3).  On the GPU the head (nets/heads.py ManoHead) runs this layer's
+maths inside one HIP kernel per direction (csrc/mano.hip, reading this module's buffers through
+``kernel_assets``); ``forward`` below is the same layer in plain PyTorch - the module's public manopth-style
+call, the fp64 reference of tests/test_gpu_mano.py, and the path a layer with a non-zero hand mean takes.
+It sits between the HIP hot path (which produces the 6D pose and shape parameters) and
 the reported vertex / joint coordinates.  The licensed MANO_RIGHT.pkl asset is not available
 offline, so ``synthetic_assets`` builds a MANO-*shaped* random asset with the same buffer names
 and shapes the reference registers (manopth/manopth/manolayer.py:72-101) - checkpoints that
@@ -71,6 +74,24 @@ class ManoLayer(nn.Module):
         self.register_buffer("_tip_idx", torch.tensor(_TIP_VERTS, dtype=torch.long), persistent=False)
         self.register_buffer("_joint_idx", torch.tensor(_JOINT_ORDER, dtype=torch.long), persistent=False)
         self.center_idx = center_idx
+        self._kernel_assets = None                      # ((versions, pointers), assets tuple) of the HIP MANO-head kernels
+
+    def kernel_assets(self):
+        """The asset tuple ops.mano_head / ops.mano_gt take - (transposed blend-shape image, v_template, J_regressor,
+        skinning weights, hands_mean) - or None when the one-kernel head does not apply: tensors not on a GPU, a centre
+        joint other than the wrist, or a non-zero hand mean (the reference builds the layer with flat_hand_mean=True,
+        main/model.py:735-742; the kernel's backward relies on it).  Rebuilt when a buffer is reloaded or moved."""
+        bufs = (self.th_shapedirs, self.th_posedirs, self.th_v_template, self.th_J_regressor, self.th_weights, self.th_hands_mean)
+        key = tuple((b._version, b.data_ptr()) for b in bufs)
+        if self._kernel_assets is None or self._kernel_assets[0] != key:
+            assets = None
+            if self.th_shapedirs.is_cuda and self.center_idx == 0 and not bool(self.th_hands_mean.ne(0).any()):
+                from .. import ops
+                f = lambda t: t.contiguous().float()
+                assets = (ops.mano_dirs_image(self.th_shapedirs, self.th_posedirs), f(self.th_v_template).view(-1),
+                          f(self.th_J_regressor), f(self.th_weights), f(self.th_hands_mean).view(-1))
+            self._kernel_assets = (key, assets)
+        return self._kernel_assets[1]
 
     def forward(self, th_pose_coeffs: torch.Tensor, th_betas: torch.Tensor):
         B = th_pose_coeffs.shape[0]

@@ -1312,6 +1312,86 @@ def vote_loss(off, cls, pts, gt_mm, radius: float):
 
 
 # ---------------------------------------------------------------------------------------------
+# (f3) MANO head: 6D pose -> rotations -> MANO layer -> vertices / joints (+ the four ManoLoss sums), one kernel each way
+# ---------------------------------------------------------------------------------------------
+def mano_dirs_image(shapedirs, posedirs):
+    """th_shapedirs (778,3,10) + th_posedirs (778,3,135) -> the transposed [145][2334] table image the kernels read."""
+    shapedirs, posedirs = shapedirs.contiguous().float(), posedirs.contiguous().float()
+    _chk(shapedirs, posedirs)
+    assert shapedirs.shape == (778, 3, 10) and posedirs.shape == (778, 3, 135)
+    from ._lib import lib
+    image = torch.empty(lib().hoisdf_mano_dirs_image_floats(), device=shapedirs.device, dtype=torch.float32)
+    call("hoisdf_mano_prepare", _p(shapedirs), _p(posedirs), _p(image), _st())
+    return image
+
+
+def _mano_gt_args(gt):
+    if gt is None:
+        return (None, None, None, None, 0, 0)
+    gv, gj, gr, gshape = gt                       # gshape: (Bg, >= 10) view with unit inner stride (mano_param[:, 48:])
+    assert gshape.stride(1) == 1 and gv.is_contiguous() and gj.is_contiguous() and gr.is_contiguous()
+    return (_p(gv), _p(gj), _p(gr), _p(gshape), gshape.stride(0), gv.shape[0])
+
+
+class _ManoHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose6d, betas, assets, gt):
+        pose6d, betas = pose6d.contiguous(), betas.contiguous()
+        _chk(pose6d, betas)
+        H = pose6d.shape[0]
+        assert pose6d.shape == (H, 16, 6) and betas.shape == (H, 10)
+        dev = pose6d.device
+        verts = torch.empty(H, 778, 3, device=dev, dtype=torch.float32)
+        joints = torch.empty(H, 21, 3, device=dev, dtype=torch.float32)
+        rot = torch.empty(H, 16, 3, 3, device=dev, dtype=torch.float32)
+        sums = torch.empty(H, 4, device=dev, dtype=torch.float32) if gt is not None else None
+        image, tmpl, jreg, w, mean = assets
+        call("hoisdf_mano_head_fwd", _p(pose6d), 96, 0, _p(betas), 10, H, _p(image), _p(tmpl), _p(jreg), _p(w), _p(mean),
+             *_mano_gt_args(gt), _p(verts), _p(joints), _p(rot), _p(sums), _st())
+        ctx.save_for_backward(pose6d, betas)
+        ctx.assets, ctx.gt = assets, gt
+        ctx.set_materialize_grads(False)
+        return verts, joints, rot, sums             # sums is None without ground truth
+
+    @staticmethod
+    def backward(ctx, g_verts, g_joints, g_rot, g_sums):
+        pose6d, betas = ctx.saved_tensors
+        H = pose6d.shape[0]
+        gs = [None if g is None else g.contiguous() for g in (g_sums if ctx.gt is not None else None, g_verts, g_joints, g_rot)]
+        d_pose, d_betas = torch.empty_like(pose6d), torch.empty_like(betas)
+        image, tmpl, jreg, w, mean = ctx.assets
+        call("hoisdf_mano_head_bwd", _p(pose6d), _p(betas), H, _p(image), _p(tmpl), _p(jreg), _p(w), _p(mean),
+             *_mano_gt_args(ctx.gt), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), _p(d_pose), _p(d_betas), _st())
+        return d_pose, d_betas, None, None
+
+
+def mano_head(pose6d, betas, assets, gt=None):
+    """(f3) mano_head.py:232-250 + manolayer.py:111-276 in one launch: pose6d (H,16,6), betas (H,10) -> verts (H,778,3) and
+    joints (H,21,3) in metres (wrist-centred), rot (H,16,3,3) = the Gram-Schmidt rotations, and, with
+    gt = (gt_verts, gt_joints, gt_rot, gt_shape) of Bg hands (hand h pairs with h % Bg), sums (H,4) = squared-error sums of
+    (verts, joints, rot, betas).  assets = (dirs_image, v_template, J_regressor, weights, hands_mean) - hands_mean must be zero."""
+    return _ManoHead.apply(pose6d, betas, assets, gt)
+
+
+def mano_gt(mano_param, assets):
+    """the ground-truth hands of mano_head.py:252-276: mano_param (B, 58) = 48 axis-angle coefficients + 10 betas ->
+    verts (B,778,3), joints (B,21,3) in metres, rot (B,16,3,3).  No gradient."""
+    mano_param = mano_param.contiguous().float()
+    _chk(mano_param)
+    B = mano_param.shape[0]
+    assert mano_param.shape[1] == 58
+    dev = mano_param.device
+    verts = torch.empty(B, 778, 3, device=dev, dtype=torch.float32)
+    joints = torch.empty(B, 21, 3, device=dev, dtype=torch.float32)
+    rot = torch.empty(B, 16, 3, 3, device=dev, dtype=torch.float32)
+    image, tmpl, jreg, w, mean = assets
+    betas = mano_param[:, 48:]
+    call("hoisdf_mano_head_fwd", _p(mano_param), 58, 1, _p(betas), 58, B, _p(image), _p(tmpl), _p(jreg), _p(w), _p(mean),
+         None, None, None, None, 0, 0, _p(verts), _p(joints), _p(rot), None, _st())
+    return verts, joints, rot
+
+
+# ---------------------------------------------------------------------------------------------
 # (f4) auxiliary image losses of the encoder outputs
 # ---------------------------------------------------------------------------------------------
 class _AuxImageLosses(torch.autograd.Function):

@@ -421,6 +421,40 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
                          const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
                          int B, int P, int J, void* stream);
 
+/* ---- (f3) MANO head ---------------------------------------------------------------------------------------------
+ * reference: common/nets/mano_head.py:12-278 (6D -> rotation -> quaternion -> axis-angle, the head), manopth/manopth/
+ * manolayer.py:111-276 (the layer as main/model.py:735-742 configures it: use_pca=False, flat_hand_mean=True,
+ * center_idx=0, side right), common/nets/loss.py:81-171 (ManoLoss: four MSE terms).  One workgroup per hand.
+ *
+ * hoisdf_mano_prepare: the layer's blend-shape tables th_shapedirs [778][3][10] and th_posedirs [778][3][135] transposed
+ *   into one image [145][2334] (hoisdf_mano_dirs_image_floats() floats) - build it once per set of assets.
+ * hoisdf_mano_head_fwd, for `hands` hands:
+ *   mode 0 (predictions): pose = 6D rotations [hands][16][6] (row stride ldpose >= 96), betas [hands][>= 10];
+ *   mode 1 (ground truth): pose = axis-angle MANO coefficients [hands][>= 48] as the dataset stores them (mano_param[:, :48]:
+ *     the head subtracts hands_mean from [3:48] and the layer adds it back; rot = Rodrigues of the mean-free coefficients);
+ *   v_template [778][3], j_regressor [16][778], weights [778][16] (16-byte aligned), hands_mean [45];
+ *   outputs in metres, centred on the wrist: verts [hands][778][3], joints [hands][21][3] (the reference's 21-joint order),
+ *   rot [hands][16][3][3] (mode 0: the Gram-Schmidt rotations = pred mano_pose).
+ *   With gt_verts != NULL (mode 0) hand h is compared with ground-truth hand h % gt_hands and
+ *   loss_sums [hands][4] = sum of squared errors of (verts, joints, rot, betas) - the reference's four ManoLoss terms are
+ *   lambda_i * sum_h loss_sums[h][i] / (hands * {2334, 63, 144, 10}).
+ * hoisdf_mano_head_bwd (mode 0 inputs again; nothing is saved between the calls): upstream gradients g_loss_sums
+ *   [hands][4], g_verts, g_joints, g_rot (each may be NULL = zero) -> d_pose6d [hands][16][6], d_betas [hands][10].
+ *   hands_mean must be zero (flat_hand_mean=True): the backward applies the layer's rotation gradient to the 6D rotation
+ *   directly, which is exact only then (csrc/mano.hip header). */
+long hoisdf_mano_dirs_image_floats(void);
+int hoisdf_mano_prepare(const float* shapedirs, const float* posedirs, float* image, void* stream);
+int hoisdf_mano_head_fwd(const float* pose, int ldpose, int mode, const float* betas, int ldbetas, int hands,
+                         const float* dirs_image, const float* v_template, const float* j_regressor, const float* weights,
+                         const float* hands_mean, const float* gt_verts, const float* gt_joints, const float* gt_rot,
+                         const float* gt_shape, int ldgt_shape, int gt_hands, float* verts, float* joints, float* rot,
+                         float* loss_sums, void* stream);
+int hoisdf_mano_head_bwd(const float* pose6d, const float* betas, int hands, const float* dirs_image, const float* v_template,
+                         const float* j_regressor, const float* weights, const float* hands_mean, const float* gt_verts,
+                         const float* gt_joints, const float* gt_rot, const float* gt_shape, int ldgt_shape, int gt_hands,
+                         const float* g_loss_sums, const float* g_verts, const float* g_joints, const float* g_rot,
+                         float* d_pose6d, float* d_betas, void* stream);
+
 /* ---- (f4) auxiliary image losses of the encoder outputs ---------------------------------------------------
  * reference: main/model.py:128-143 (render_gaussian_heatmap) and :404-422 (MSELoss / BCELoss with reduction none).
  * dec = decoder_out (B, 3, H, W) [heat-map, hand seg, object seg] with element strides (sb, sc, sh, sw) - NCHW or
