@@ -40,6 +40,27 @@ class SdfWeights(C.Structure):
                 ("dec_w3", C.c_void_p), ("dec_b3", C.c_void_p), ("dec_w4", C.c_void_p), ("dec_b4", C.c_void_p)]
 
 
+class EncoderLayerDesc(C.Structure):
+    """include/hoisdf.h hoisdf_encoder_layer_desc"""
+    _fields_ = [("B", C.c_int), ("S", C.c_int), ("E", C.c_int), ("F", C.c_int), ("H", C.c_int), ("n_query", C.c_int),
+                ("n_inter", C.c_int), ("eps", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64 * 4), ("attention", C.c_int),
+                ("attention_bwd_emulated", C.c_int), ("training", C.c_int)]
+
+
+_ENC_W = ("w_in", "b_in", "w_out", "b_out", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "g3", "be3")
+_ENC_IMG = ("img_in", "img_in_q", "img_in_kv", "img_out", "img_1", "img_2")
+
+
+class EncoderLayerWeights(C.Structure):
+    """include/hoisdf.h hoisdf_encoder_layer_weights"""
+    _fields_ = [(n, C.c_void_p) for n in _ENC_W + _ENC_IMG + tuple(n.replace("img_", "img_t_") for n in _ENC_IMG)]
+
+
+class EncoderLayerGrads(C.Structure):
+    """include/hoisdf.h hoisdf_encoder_layer_grads"""
+    _fields_ = [("d" + n, C.c_void_p) for n in _ENC_W]
+
+
 _P, _I, _L, _F, _U64, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_double
 _PYR = C.POINTER(Pyramid)
 _SDFW = C.POINTER(SdfWeights)
@@ -95,6 +116,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_layernorm_rows_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
     "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "hoisdf_encoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
+    "hoisdf_encoder_layer_bwd": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P],
     "hoisdf_mano_prepare": [_P, _P, _P, _P],
     "hoisdf_mano_head_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "hoisdf_mano_head_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -106,6 +129,8 @@ SIGNATURES: Dict[str, List] = {
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
+          "hoisdf_encoder_layer_saved_bytes": ([_P], C.c_long),
+          "hoisdf_encoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),

@@ -1234,10 +1234,108 @@ class _EncoderLayer(torch.autograd.Function):
         return (dx, None, None, None, dw_in, db_in, dw_out, db_out, dg1, dbe1, dw1, db1, dw2, db2, dg2, dbe2, dg3, dbe3, None, None)
 
 
+class _EncoderLayerC(torch.autograd.Function):
+    """The same layer through the coarse C entries hoisdf_encoder_layer_fwd / _bwd (csrc/layers.hip): the chain of
+    ``_EncoderLayer`` issued by the library itself - one C-ABI call, one saved-activation buffer and one scratch buffer per
+    direction instead of ~15 calls and ~20 allocations.  Same kernels in the same order, same dropout seeds."""
+
+    @staticmethod
+    def _images(w, names, transpose, rows_q, rows_s, E, full):
+        """cached bf16x3 images of the weights the library would otherwise rebuild in its workspace on every call"""
+        if not _GEMM_EMU:
+            return
+        w_in, w_out, w1, w2 = names
+        sfx = "img_t_" if transpose else "img_"
+        big_q, big_s = rows_q >= _GEMM_EMU_MIN_ROWS, rows_s >= _GEMM_EMU_MIN_ROWS
+        if full and big_s:
+            setattr(w, sfx + "in", _emu_image(w_in, transpose).data_ptr())
+        if not full:
+            if big_q:
+                setattr(w, sfx + "in_q", _emu_image(w_in[:E], transpose).data_ptr())
+            if big_s:
+                setattr(w, sfx + "in_kv", _emu_image(w_in[E:], transpose).data_ptr())
+        if big_q:
+            setattr(w, sfx + "out", _emu_image(w_out, transpose).data_ptr())
+            setattr(w, sfx + "1", _emu_image(w1, transpose).data_ptr())
+            setattr(w, sfx + "2", _emu_image(w2, transpose).data_ptr())
+
+    @staticmethod
+    def forward(ctx, x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps, n_inter=None):
+        from ._lib import lib, EncoderLayerDesc, EncoderLayerWeights
+        x = x.contiguous()
+        params = (w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3)
+        _chk(x, *params)
+        assert all(t.is_contiguous() for t in params)
+        B, S, E = x.shape
+        nq = S if (n_query is None or n_query >= S) else int(n_query)
+        ni = nq if (n_inter is None or n_inter >= nq) else int(n_inter)
+        d = EncoderLayerDesc(B=B, S=S, E=E, F=w1.shape[0], H=H, n_query=nq, n_inter=ni, eps=eps, drop_p=p,
+                             attention=2 if _use_split(nq) == 2 else 0, attention_bwd_emulated=int(_emu_bwd() and _SPLIT_KEEP),
+                             training=int(any(ctx.needs_input_grad)))
+        for i in range(4):                                     # attention, after out-projection, FFN hidden, after the FFN
+            d.seed[i] = next_seed() if p > 0 else 0
+        w = EncoderLayerWeights(**{n: t.data_ptr() for n, t in zip(_ENC_W_NAMES, params)})
+        _EncoderLayerC._images(w, (w_in, w_out, w1, w2), False, B * nq, B * S, E, nq == S)
+        dp, wp = C.addressof(d), C.addressof(w)
+        n_saved = lib().hoisdf_encoder_layer_saved_bytes(dp) if d.training else 0
+        n_ws = lib().hoisdf_encoder_layer_workspace_bytes(dp, 0)
+        dev = x.device
+        saved = torch.empty(n_saved, device=dev, dtype=torch.uint8) if n_saved else None
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        x2 = torch.empty(B, nq, E, device=dev)
+        y = torch.empty(B, ni, E, device=dev)
+        call("hoisdf_encoder_layer_fwd", _p(x), wp, dp, _p(x2), _p(y), _p(saved), n_saved, _p(ws), n_ws, _st())
+        ctx.save_for_backward(x, x2, saved, *params)
+        ctx.desc = d
+        return x2, y
+
+    @staticmethod
+    def backward(ctx, g_x2, g_y):
+        from ._lib import lib, EncoderLayerWeights, EncoderLayerGrads
+        x, x2, saved, *params = ctx.saved_tensors
+        w_in, _, w_out, _, _, _, w1, _, w2 = params[:9]
+        d = ctx.desc
+        B, S, E, F, nq = d.B, d.S, d.E, d.F, d.n_query
+        dev = x.device
+        sizes = [3 * E * E, 3 * E, E * E, E, E, E, F * E, F, E * F, E, E, E, E, E]     # one zero slice for all parameter gradients
+        buf = _zeros(sum(sizes), dev)
+        parts, off = [], 0
+        for n in sizes:
+            parts.append(buf[off:off + n])
+            off += n
+        G = EncoderLayerGrads(**{"d" + n: t.data_ptr() for n, t in zip(_ENC_W_NAMES, parts)})
+        w = EncoderLayerWeights(**{n: t.data_ptr() for n, t in zip(_ENC_W_NAMES, params)})
+        _EncoderLayerC._images(w, (w_in, w_out, w1, w2), True, B * nq, B * S, E, nq == S)
+        dp = C.addressof(d)
+        n_ws = lib().hoisdf_encoder_layer_workspace_bytes(dp, 1)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        dx = torch.empty(B, S, E, device=dev)
+        gx2 = None if g_x2 is None else g_x2.contiguous()
+        gy = None if g_y is None else g_y.contiguous()
+        call("hoisdf_encoder_layer_bwd", _p(x), _p(x2), C.addressof(w), dp, _p(saved), saved.numel(), _p(gx2), _p(gy), _p(dx),
+             C.addressof(G), _p(ws), n_ws, _st())
+        shaped = [parts[0].view(3 * E, E), parts[1], parts[2].view(E, E), parts[3], parts[4], parts[5], parts[6].view(F, E), parts[7],
+                  parts[8].view(E, F)] + parts[9:]
+        return (dx, None, None, None, *shaped, None, None)
+
+
+_ENC_W_NAMES = ("w_in", "b_in", "w_out", "b_out", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "g3", "be3")
+_ENCODER_LAYER_C = __import__("os").environ.get("HOISDF_ENCODER_LAYER", "c") != "ops"
+
+
+def _coarse_layer_ok(p, x, *weights) -> bool:
+    """the C entry covers the default arithmetic; the opt-in split / f16 modes and bench.py's per-call event timing (which
+    brackets the individual C-ABI calls from Python) take the op-by-op node"""
+    from . import _lib
+    return (_ENCODER_LAYER_C and not _GEMM_SPLIT and not _ATTENTION_SPLIT and _lib._timer is None
+            and not _use_f16(p, x, *weights))
+
+
 def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps=1e-5,
                   n_inter=None):
     """-> (x2 (B, n_query|S, E) = the layer output, y = inter_norm(x2) (B, n_inter|n_query|S, E): rows < n_inter only)"""
-    return _EncoderLayer.apply(x, n_query, float(p), int(H), w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3,
+    fn = _EncoderLayerC if _coarse_layer_ok(float(p), x, w_in, w_out, w1, w2) else _EncoderLayer
+    return fn.apply(x, n_query, float(p), int(H), w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3,
                                be3, float(eps), n_inter)
 
 

@@ -396,6 +396,53 @@ int hoisdf_layernorm_rows_bwd(const float* dy, const float* x, const float* gamm
                               const float* dx_add, float* dx, float* dgamma, float* dbeta, long groups, int rows_per_group,
                               int take, int D, void* stream);
 
+/* ---- one transformer encoder layer per call (SURVEY.md section 8(b) coarse entries) ---------------------------------
+ * reference: common/nets/transformer.py:286-302 (TransformerEncoderLayer.forward_post: self-attention, out-projection,
+ * residual + dropout + LayerNorm, FFN linear1 -> ReLU -> dropout -> linear2, residual + dropout + LayerNorm) and the
+ * stack's inter_norm of each layer output (:117-131).  Host-side chains of the per-op entries above on the caller's stream.
+ * x [B][S][E] (dense).  Rows < n_query of every sample are produced: x_out [B][n_query][E]; with weights.g3 the
+ * inter_norm of rows < n_inter goes to y_out [B][n_inter][E].  Keys / values always come from all S rows.
+ * Arithmetic: linear layers follow hoisdf_set_gemm_emu (default: fp32 emulated on the bf16 pipe from 2048 rows up; the
+ * img_* fields may carry hoisdf_linear_emu_prepare images of the weights (img_t_*: transpose = 1) - a NULL image is built
+ * in the workspace on every call); attention as desc.attention says.  Split-precision / f16 modes are not offered here.
+ * saved: hoisdf_encoder_layer_saved_bytes(desc) bytes the backward re-reads (training = 1); workspace:
+ * hoisdf_encoder_layer_workspace_bytes(desc, 0 | 1) bytes of scratch (sized for the case that every image is built).
+ * Backward: g_x_out / g_y = gradients of the two outputs (either may be NULL, not both); dx [B][S][E] is overwritten; the
+ * parameter gradients must be zero on entry and hold the gradient on return. */
+typedef struct hoisdf_encoder_layer_desc {
+  int B, S, E, F, H;            /* batch, tokens per sample, model width (multiple of 4 and of H), FFN width, heads */
+  int n_query;                  /* <= 0 or >= S: all rows */
+  int n_inter;                  /* <= 0 or >= n_query: all produced rows */
+  float eps, drop_p;
+  uint64_t seed[4];             /* dropout streams: attention, after out-projection, FFN hidden, after the FFN */
+  int attention;                /* 0: exact-f32 kernels; 2: emulated-fp32 forward (hoisdf_attention_fwd_emu) */
+  int attention_bwd_emulated;   /* with attention == 2: the order-fixed emulated backward instead of the f32 fused one */
+  int training;                 /* 0: nothing is saved (saved may be NULL), hoisdf_encoder_layer_bwd cannot follow */
+} hoisdf_encoder_layer_desc;
+typedef struct hoisdf_encoder_layer_weights {
+  const float *w_in, *b_in;     /* [3E][E], [3E]: packed q | k | v in-projection */
+  const float *w_out, *b_out;   /* [E][E], [E] */
+  const float *g1, *be1;        /* norm1 */
+  const float *w1, *b1;         /* [F][E], [F] */
+  const float *w2, *b2;         /* [E][F], [E] */
+  const float *g2, *be2;        /* norm2 */
+  const float *g3, *be3;        /* inter_norm of the stack; NULL: no y_out */
+  const void *img_in, *img_in_q, *img_in_kv, *img_out, *img_1, *img_2;              /* optional (see above); _q = rows [0, E), _kv = rows [E, 3E) */
+  const void *img_t_in, *img_t_in_q, *img_t_in_kv, *img_t_out, *img_t_1, *img_t_2;
+} hoisdf_encoder_layer_weights;
+typedef struct hoisdf_encoder_layer_grads {
+  float *dw_in, *db_in, *dw_out, *db_out, *dg1, *dbe1, *dw1, *db1, *dw2, *db2, *dg2, *dbe2, *dg3, *dbe3;
+} hoisdf_encoder_layer_grads;
+long hoisdf_encoder_layer_saved_bytes(const hoisdf_encoder_layer_desc* desc);
+long hoisdf_encoder_layer_workspace_bytes(const hoisdf_encoder_layer_desc* desc, int backward_pass);
+int hoisdf_encoder_layer_fwd(const float* x, const hoisdf_encoder_layer_weights* weights, const hoisdf_encoder_layer_desc* desc,
+                             float* x_out, float* y_out, void* saved, long saved_bytes, void* workspace, long workspace_bytes,
+                             void* stream);
+int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, const hoisdf_encoder_layer_weights* weights,
+                             const hoisdf_encoder_layer_desc* desc, const void* saved, long saved_bytes, const float* g_x_out,
+                             const float* g_y, float* dx, const hoisdf_encoder_layer_grads* grads, void* workspace,
+                             long workspace_bytes, void* stream);
+
 /* ---- K12: vote aggregation ----------------------------------------------------------------
  * reference: common/nets/loss.py:31-56.  off [L][B][P][J*3], cls [L][B][P][J] (batch-first
  * rows), pts [B][P][3].  joints[l][b][j] = sum_p softmax_p(cls)[p] * (pts[p] + off[p][j]).

@@ -346,6 +346,41 @@ def test_c_host_linear():
     assert out.returncode == 0 and "c host ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_c_host_encoder_layer(tmp_path):
+    """A plain C host runs one transformer encoder layer through the coarse entries hoisdf_encoder_layer_fwd / _bwd on values
+    dumped from fixture g5 (the reference's TransformerEncoderLayer output + the stack's inter_norm), then checks the
+    backward against a finite difference - tests/c/test_encoder_layer_host.c."""
+    import os
+    import struct
+    import subprocess
+    import numpy as np
+    g = load_golden("g5_transformer")
+    pre = "hand_transformer.encoder."
+    names = ["layers.0.self_attn.in_proj_weight", "layers.0.self_attn.in_proj_bias", "layers.0.self_attn.out_proj.weight",
+             "layers.0.self_attn.out_proj.bias", "layers.0.norm1.weight", "layers.0.norm1.bias", "layers.0.linear1.weight",
+             "layers.0.linear1.bias", "layers.0.linear2.weight", "layers.0.linear2.bias", "layers.0.norm2.weight",
+             "layers.0.norm2.bias", "inter_norm.weight", "inter_norm.bias"]
+    E, F = 256, 1024
+    shapes = [(3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,), (E,), (E,), (E,), (E,)]
+    src = g["src"].permute(1, 0, 2).contiguous()                       # fixture is (S, B, E); the entry takes (B, S, E)
+    Bn, S, _ = src.shape
+    path = str(tmp_path / "enc_layer.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5i", Bn, S, E, F, 4))
+        f.write(src.numpy().astype("<f4").tobytes())
+        for n, sh in zip(names, shapes):
+            f.write(T.det_param(pre + n, sh).numpy().astype("<f4").tobytes())
+        f.write(g["enc_layer0"].permute(1, 0, 2).contiguous().numpy().astype("<f4").tobytes())
+        f.write(g["inter"][0].permute(1, 0, 2).contiguous().numpy().astype("<f4").tobytes())
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = "/tmp/hoisdf_test_encoder_layer_host"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", os.path.join(repo, "tests", "c", "test_encoder_layer_host.c"), "-I",
+                    os.path.join(repo, "include"), "-L", os.path.join(repo, "hoisdf_amd"), "-lhoisdf_hip",
+                    "-Wl,-rpath," + os.path.join(repo, "hoisdf_amd"), "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "c host encoder layer ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_graft_entry_smoke():
     """the driver's smoke(): tiny eval forward vs the oracle + one train forward/backward"""
     import __graft_entry__ as g

@@ -851,3 +851,41 @@ def test_attention_split_cross_shapes():
     assert_close(kg.grad, kvt.grad, rel=5e-5, what="split cross dkv")
 
 
+
+
+@pytest.mark.parametrize("B,S,nq,ni,p", [(2, 64, None, None, 0.0), (4, 1024, None, 768, 0.1), (4, 1024, 768, 768, 0.1), (3, 100, 40, 17, 0.1)])
+def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p):
+    """hoisdf_encoder_layer_fwd / _bwd (one C-ABI call per direction, csrc/layers.hip) against the op-by-op autograd node:
+    the same kernels in the same order with the same dropout seeds - forward bit-identical; gradients equal up to the float
+    atomics of the f32 attention backward / small split-k grad-weights (2e-5 of each tensor's scale)."""
+    O = ops()
+    E, F, H = 256, 1024, 4
+    names = ["w_in", "b_in", "w_out", "b_out", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "g3", "be3"]
+    shapes = [(3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,), (E,), (E,), (E,), (E,)]
+    x0 = rnd(B, S, E, seed=11)
+    P0 = [rnd(*s, seed=20 + i) * (1.0 / math.sqrt(s[-1]) if len(s) == 2 else 0.1) + (1.0 if n in ("g1", "g2", "g3") else 0.0)
+          for i, (n, s) in enumerate(zip(names, shapes))]
+    nqe = S if nq is None else nq
+    nie = nqe if ni is None else ni
+    gx2, gy = rnd(B, nqe, E, seed=5).to(DEV), rnd(B, nie, E, seed=6).to(DEV)
+    res = {}
+    keep = O._ENCODER_LAYER_C
+    try:
+        for coarse in (True, False):
+            O._ENCODER_LAYER_C = coarse
+            O.manual_seed(1234)
+            x = x0.to(DEV).requires_grad_(True)
+            P = [t.to(DEV).requires_grad_(True) for t in P0]
+            picked = O._EncoderLayerC if O._coarse_layer_ok(p, x, P[0], P[2], P[6], P[8]) else O._EncoderLayer
+            assert (picked is O._EncoderLayerC) == coarse
+            x2, y = O.encoder_layer(x, nq, p, H, *P, eps=1e-5, n_inter=ni)
+            ((x2 * gx2).sum() + (y * gy).sum()).backward()
+            res[coarse] = [x2.detach(), y.detach(), x.grad] + [t.grad for t in P]
+    finally:
+        O._ENCODER_LAYER_C = keep
+    if B * nqe >= 2048:
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    else:       # a few-tile exact-f32 GEMM splits its k range over workgroups and adds with float atomics: order-dependent last bits
+        assert_close(res[True][0], res[False][0], rel=2e-6, what="x2"); assert_close(res[True][1], res[False][1], rel=2e-6, what="y")
+    for what, a, b in zip(["dx"] + ["d" + n for n in names], res[True][2:], res[False][2:]):
+        assert_close(a, b, rel=2e-5, what=what)
