@@ -116,6 +116,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_layernorm_rows_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
     "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "hoisdf_sdf_infer_count": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
+    "hoisdf_sdf_infer": [_PYR, _P, _P, _P, _F, _I, _I, _P, _P, _I, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P],
     "hoisdf_encoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
     "hoisdf_encoder_layer_bwd": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P],
     "hoisdf_mano_prepare": [_P, _P, _P, _P],
@@ -129,6 +131,7 @@ SIGNATURES: Dict[str, List] = {
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
+          "hoisdf_sdf_infer_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_encoder_layer_saved_bytes": ([_P], C.c_long),
           "hoisdf_encoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),

@@ -116,3 +116,92 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   if (rc) return rc;
   return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
 }
+
+// ---- sdf_infer (main/model.py:246-355) as two calls: count the lattice survivors (one device -> host read of B integers, which
+// sizes everything else), then lattice fill -> SDF query -> top-k by |sdf| -> gather of the selected points / values / encodings ----
+namespace hoisdf {
+namespace {
+inline long up256(long b) { return (b + 255) & ~255L; }
+}  // namespace
+}  // namespace hoisdf
+
+extern "C" int hoisdf_sdf_infer_count(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n, int B,
+                                      int32_t* counts_device, int32_t* counts_host, long* n_rows, void* stream) {
+  HOISDF_REQUIRE(center && cam_intr && bbox && counts_device && counts_host && n_rows && B > 0 && bins_n > 0, HOISDF_ERR_INVALID,
+                 "sdf_infer_count: bad arguments");
+  if (int rc = hoisdf_lattice_count(center, cam_intr, bbox, scale, bins_n, B, counts_device, stream)) return rc;
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(counts_host, counts_device, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    set_error("sdf_infer_count: reading the counts back failed: %s", hipGetErrorString(hipGetLastError()));
+    return HOISDF_ERR_LAUNCH;
+  }
+  long n = 0;
+  for (int b = 0; b < B; ++b) n += counts_host[b];
+  *n_rows = n;
+  return HOISDF_OK;
+}
+
+extern "C" long hoisdf_sdf_infer_workspace(long n_rows, int B, int C) {
+  if (n_rows < 0 || B <= 0 || C <= 0) return -1;
+  // offsets [B] | points [n][3] | sample_idx [n] | lattice_idx [n] | sdf [n] | raw [n] | pe [n][30] | sel [B][k <= n] | query workspace
+  return up256(4L * B) + up256(12 * n_rows) + 2 * up256(4 * n_rows) + 2 * up256(4 * n_rows) + up256(120 * n_rows) + up256(4 * n_rows) +
+         up256(hoisdf_sdf_query_workspace(n_rows, C, 1)) + 256;
+}
+
+extern "C" int hoisdf_sdf_infer(const hoisdf_pyramid* pyr, const float* center, const float* cam_intr, const float* bbox, float scale,
+                                int bins_n, int B, const int32_t* counts_device, const int32_t* counts_host, int num_points, int img_h,
+                                int img_w, const hoisdf_sdf_weights* w, float clamp, float drop_p, uint64_t seed, float* points_out,
+                                float* sdf_out, float* pe_out, void* workspace, long workspace_bytes, void* stream) {
+  HOISDF_REQUIRE(pyr && center && cam_intr && bbox && counts_device && counts_host && w && points_out && sdf_out && workspace && B > 0 &&
+                     num_points > 0,
+                 HOISDF_ERR_INVALID, "sdf_infer: bad arguments");
+  long n = 0;
+  for (int b = 0; b < B; ++b) {
+    // the reference indexes the first num_points of the sorted survivors and fails on a short sample (main/model.py:348)
+    HOISDF_REQUIRE(counts_host[b] >= num_points, HOISDF_ERR_INVALID,
+                   "sdf_infer: sample %d has only %d lattice points inside its bbox, fewer than num_points=%d", b, counts_host[b], num_points);
+    n += counts_host[b];
+  }
+  const long need = hoisdf_sdf_infer_workspace(n, B, w->C);
+  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "sdf_infer: workspace of %ld bytes, need %ld", workspace_bytes, need);
+  char* p = static_cast<char*>(workspace);
+  auto take = [&](long bytes) { char* r = p; p += up256(bytes); return r; };
+  int32_t* offsets = reinterpret_cast<int32_t*>(take(4L * B));
+  float* pts = reinterpret_cast<float*>(take(12 * n));
+  int32_t* sidx = reinterpret_cast<int32_t*>(take(4 * n));
+  int32_t* lidx = reinterpret_cast<int32_t*>(take(4 * n));
+  float* sdf = reinterpret_cast<float*>(take(4 * n));
+  float* raw = reinterpret_cast<float*>(take(4 * n));
+  float* pe = reinterpret_cast<float*>(take(120 * n));
+  int32_t* sel = reinterpret_cast<int32_t*>(take(4L * B * num_points));
+  const long qbytes = hoisdf_sdf_query_workspace(n, w->C, 1);
+  void* qws = take(0);
+  hipStream_t st = as_stream(stream);
+  // exclusive prefix of the counts: B integers, staged through a small pinned-or-pageable host array (async copy from a stack
+  // buffer would race with its lifetime: synchronous copy, B * 4 bytes)
+  {
+    int32_t* off_h = static_cast<int32_t*>(malloc(sizeof(int32_t) * B));
+    HOISDF_REQUIRE(off_h, HOISDF_ERR_LAUNCH, "sdf_infer: out of host memory");
+    int32_t acc = 0;
+    for (int b = 0; b < B; ++b) { off_h[b] = acc; acc += counts_host[b]; }
+    const hipError_t e = hipMemcpyAsync(offsets, off_h, sizeof(int32_t) * B, hipMemcpyHostToDevice, st);
+    const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
+    free(off_h);
+    HOISDF_REQUIRE(e2 == hipSuccess, HOISDF_ERR_LAUNCH, "sdf_infer: uploading the offsets failed: %s", hipGetErrorString(e2));
+  }
+  int rc = hoisdf_lattice_fill(center, cam_intr, bbox, scale, bins_n, B, offsets, pts, sidx, lidx, stream);
+  if (rc) return rc;
+  rc = hoisdf_sdf_query_fwd(pyr, pts, sidx, n, 1, center, cam_intr, scale, img_h, img_w, nullptr, nullptr, w, clamp, drop_p, seed, sdf, raw, pe,
+                            nullptr, qws, qbytes, stream);
+  if (rc) return rc;
+  rc = hoisdf_select_smallest_abs(raw, offsets, counts_device, B, num_points, sel, stream);
+  if (rc) return rc;
+  const long ns = (long)B * num_points;
+  rc = hoisdf_gather_rows(pts, 3, sel, ns, 3, points_out, 3, stream);
+  if (rc) return rc;
+  rc = hoisdf_gather_rows(sdf, 1, sel, ns, 1, sdf_out, 1, stream);
+  if (rc) return rc;
+  if (pe_out) rc = hoisdf_gather_rows(pe, 30, sel, ns, 30, pe_out, 30, stream);
+  return rc;
+}

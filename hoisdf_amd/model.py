@@ -186,18 +186,14 @@ class Model(nn.Module):
         c = self.cfg
         pyr = self._pyramid(feature_pyramid)
         B = center_joint.shape[0]
-        pts, sidx, _lidx, counts, offsets, counts_dev = ops.lattice_candidates(center_joint, cam_intr, bbox,
-                                                                              sdf_scale, c.bins_n)
-        short = [b for b, n in enumerate(counts) if n < num_points]
-        if short:
-            raise ValueError(
-                f"sdf_infer({type}): sample {short[0]} has only {counts[short[0]]} lattice points inside its "
-                f"bbox, fewer than num_points={num_points} (the reference fails at main/model.py:348)")
-        sdf, raw, pe, _ = self._sdf_query(pyr, pts, center_joint, cam_intr, sdf_scale, type, sample_idx=sidx)
-        sel = ops.select_smallest_abs(raw, offsets, counts_dev, num_points)
-        pose_points = ops.gather_rows(pts, sel).view(B, num_points, 3)
-        pose_sdf = ops.gather_rows(sdf, sel).view(B, num_points, 1)
-        pose_pe = ops.gather_rows(pe, sel).view(B, num_points, -1)
+        dec = self.hand_sdf_decoder if type == "hand" else self.obj_sdf_decoder
+        try:
+            pose_points, pose_sdf, pose_pe = ops.sdf_infer(self._query_weights(type), pyr, center_joint, cam_intr, bbox, sdf_scale,
+                                                           c.bins_n, num_points, c.ClampingDistance, c.input_img_shape,
+                                                           dec.dropout_prob if dec.training else 0.0)
+        except ValueError as e:
+            raise ValueError(str(e).replace("sdf_infer:", f"sdf_infer({type}):")) from None
+        pose_sdf = pose_sdf.unsqueeze(-1)
         return pose_points, pose_sdf, pose_pe, None
 
     def render_gaussian_heatmap(self, joint_coord):

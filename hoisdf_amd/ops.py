@@ -667,6 +667,40 @@ def lattice_candidates(center, cam_intr, bbox, scale: float, bins_n: int):
     return pts, sidx, lidx, counts_h.tolist(), offsets, counts
 
 
+@torch.no_grad()
+def sdf_infer(weights: SdfQueryWeights, pyr: "PyramidNHWC", center, cam_intr, bbox, scale: float, bins_n: int, num_points: int,
+              clamp: float, img_hw=(256, 256), drop_p: float = 0.0):
+    """hoisdf_sdf_infer_count + hoisdf_sdf_infer (main/model.py:246-355 in two C-ABI calls): -> points (B,k,3), sdf (B,k),
+    posenc (B,k,30) of the k = num_points lattice survivors with the smallest |sdf| per sample.  Raises ValueError when a
+    sample has fewer than num_points survivors (the reference fails at main/model.py:348)."""
+    from ._lib import lib, HoisdfError
+    B = center.shape[0]
+    dev = center.device
+    center, cam_intr, bbox = center.contiguous(), cam_intr.contiguous(), bbox.contiguous()
+    _chk(center, cam_intr, bbox)
+    counts = torch.empty(B, device=dev, dtype=torch.int32)
+    counts_h = (C.c_int32 * B)()
+    n = C.c_long(0)
+    call("hoisdf_sdf_infer_count", _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts), C.addressof(counts_h),
+         C.addressof(n), _st())
+    short = [b for b in range(B) if counts_h[b] < num_points]
+    if short:
+        raise ValueError(f"sdf_infer: sample {short[0]} has only {counts_h[short[0]]} lattice points inside its bbox, fewer "
+                         f"than num_points={num_points} (the reference fails at main/model.py:348)")
+    w = weights.get()
+    assert w.C == pyr.C
+    nbytes = lib().hoisdf_sdf_infer_workspace(n.value, B, w.C)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    pts = torch.empty(B, num_points, 3, device=dev)
+    sdf = torch.empty(B, num_points, device=dev)
+    pe = torch.empty(B, num_points, 30, device=dev)
+    s = pyr.struct()
+    call("hoisdf_sdf_infer", C.byref(s), _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts),
+         C.addressof(counts_h), num_points, img_hw[0], img_hw[1], C.byref(w), float(clamp), float(drop_p),
+         next_seed() if drop_p > 0 else 0, _p(pts), _p(sdf), _p(pe), _p(ws), nbytes, _st())
+    return pts, sdf, pe
+
+
 def select_smallest_abs(sdf_raw, offsets, counts, k: int):
     """K6: (B,k) int32 row indices of the k smallest |sdf_raw| per sample, ascending."""
     B = offsets.shape[0]

@@ -258,6 +258,24 @@ int hoisdf_select_smallest_abs(const float* sdf_raw, const int32_t* offsets, con
 /* out[r][0:width] = src[sel[r]][0:width] */
 int hoisdf_gather_rows(const float* src, int lds, const int32_t* sel, long n_sel, int width,
                        float* out, int ldo, void* stream);
+/* ---- sdf_infer in two calls (SURVEY.md section 8(b) `hoisdf_sdf_infer`) ----------------------------------------------
+ * reference: Model.sdf_infer (main/model.py:246-355): dense sheared lattice inside the bbox -> SDF of every survivor ->
+ * the num_points survivors of every sample with the smallest |sdf| (ascending) -> their points (scaled frame), clamped
+ * SDF values and positional encodings.
+ * hoisdf_sdf_infer_count: survivors per sample into counts_device [B] and counts_host [B] (ONE device -> host read, the
+ *   stream is synchronised), *n_rows = their total.  The caller sizes the workspace with
+ *   hoisdf_sdf_infer_workspace(n_rows, B, C) and calls
+ * hoisdf_sdf_infer: lattice fill -> hoisdf_sdf_query_fwd -> hoisdf_select_smallest_abs -> hoisdf_gather_rows; a sample
+ *   with fewer than num_points survivors is refused (the reference raises at main/model.py:348).
+ *   points_out [B][num_points][3], sdf_out [B][num_points], pe_out [B][num_points][30] (optional). */
+int hoisdf_sdf_infer_count(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n, int B,
+                           int32_t* counts_device, int32_t* counts_host, long* n_rows, void* stream);
+long hoisdf_sdf_infer_workspace(long n_rows, int B, int C);
+int hoisdf_sdf_infer(const hoisdf_pyramid* pyr, const float* center, const float* cam_intr, const float* bbox, float scale,
+                     int bins_n, int B, const int32_t* counts_device, const int32_t* counts_host, int num_points, int img_h,
+                     int img_w, const hoisdf_sdf_weights* w, float clamp, float drop_p, uint64_t seed, float* points_out,
+                     float* sdf_out, float* pe_out, void* workspace, long workspace_bytes, void* stream);
+
 /* ---- (f2) dataset-side SDF sample selection on the device ------------------------------------------------
  * reference: data/dexycb.py:514-546 (np.random.choice without replacement of num_samp_hand / num_samp_obj rows of
  * the frame's sdf_processed array, and - training - of the rows with |sdf| < points_filter_dist).

@@ -853,11 +853,16 @@ def test_attention_split_cross_shapes():
 
 
 
-@pytest.mark.parametrize("B,S,nq,ni,p", [(2, 64, None, None, 0.0), (4, 1024, None, 768, 0.1), (4, 1024, 768, 768, 0.1), (3, 100, 40, 17, 0.1)])
-def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p):
+@pytest.mark.parametrize("B,S,nq,ni,p,det", [(2, 64, None, None, 0.0, True), (4, 1024, None, 768, 0.1, False), (4, 1024, 768, 768, 0.1, False),
+                                             (3, 100, 40, 17, 0.1, True), (4, 1024, 768, 768, 0.1, True)])
+def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p, det):
     """hoisdf_encoder_layer_fwd / _bwd (one C-ABI call per direction, csrc/layers.hip) against the op-by-op autograd node:
-    the same kernels in the same order with the same dropout seeds - forward bit-identical; gradients equal up to the float
-    atomics of the f32 attention backward / small split-k grad-weights (2e-5 of each tensor's scale)."""
+    the same kernels in the same order with the same dropout seeds.  Few-tile exact-f32 GEMMs split their k range and add
+    with float atomics, so two runs of EITHER path differ in the last bits - and a last-bit change of a pre-activation at zero
+    flips its ReLU gate (tools/dbg_enc2.py: one bitmap word, 1e-2 of the gradient's scale, 66 of 400 identical op-chain
+    runs).  The small shapes therefore run in deterministic mode (order-fixed reductions, emulated attention backward - which
+    also puts that branch of the entry under test) and everything must be bit-identical; the large shapes run the default
+    mode: forward bit-identical, gradients to 2e-5 of each tensor's scale."""
     O = ops()
     E, F, H = 256, 1024, 4
     names = ["w_in", "b_in", "w_out", "b_out", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "g3", "be3"]
@@ -869,7 +874,8 @@ def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p):
     nie = nqe if ni is None else ni
     gx2, gy = rnd(B, nqe, E, seed=5).to(DEV), rnd(B, nie, E, seed=6).to(DEV)
     res = {}
-    keep = O._ENCODER_LAYER_C
+    keep, keep_det = O._ENCODER_LAYER_C, O.deterministic()
+    O.set_deterministic(det)
     try:
         for coarse in (True, False):
             O._ENCODER_LAYER_C = coarse
@@ -883,9 +889,10 @@ def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p):
             res[coarse] = [x2.detach(), y.detach(), x.grad] + [t.grad for t in P]
     finally:
         O._ENCODER_LAYER_C = keep
-    if B * nqe >= 2048:
-        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
-    else:       # a few-tile exact-f32 GEMM splits its k range over workgroups and adds with float atomics: order-dependent last bits
-        assert_close(res[True][0], res[False][0], rel=2e-6, what="x2"); assert_close(res[True][1], res[False][1], rel=2e-6, what="y")
+        O.set_deterministic(keep_det)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for what, a, b in zip(["dx"] + ["d" + n for n in names], res[True][2:], res[False][2:]):
-        assert_close(a, b, rel=2e-5, what=what)
+        if det:
+            assert torch.equal(a, b), what
+        else:
+            assert_close(a, b, rel=2e-5, what=what)
