@@ -120,7 +120,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_sdf_infer": [_PYR, _P, _P, _P, _F, _I, _I, _P, _P, _I, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P],
     "hoisdf_encoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
     "hoisdf_encoder_layer_bwd": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P],
-    "hoisdf_mano_prepare": [_P, _P, _P, _P],
+    "hoisdf_mano_prepare": [_P, _P, _P, _P, _P],
     "hoisdf_mano_head_fwd": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "hoisdf_mano_head_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "hoisdf_vote_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -19,8 +19,10 @@
 namespace hoisdf {
 namespace {
 
-constexpr int MV = 778, MVC = 2334, MJ = 16, MPM = 135, MB = 10, MJT = 21, MNT = 256;
+constexpr int MV = 778, MVC = 2334, MJ = 16, MPM = 135, MB = 10, MJT = 21;
+constexpr int MNT = 1024, MNW = MNT / 64;   // 16 waves a hand: the phases are chains of L2-latency loads, more waves = more of them in flight
 constexpr int MDIRS = MB + MPM;                 // rows of the transposed direction image
+constexpr long MWT_OFF = (long)MDIRS * MVC;     // ... followed by the skinning weights transposed [16][778]
 
 __constant__ int c_tip[5] = {745, 317, 444, 556, 673};
 __constant__ int c_order[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
@@ -54,7 +56,7 @@ struct ManoLds {
   float pm[MPM + 1];
   float beta[MB + 2];
   float cat[MJT * 3];   // 16 joint positions + 5 finger tips, before the reordering
-  float red[64];
+  float red[MNW * 4];
 };
 
 __device__ __forceinline__ void rodrigues(const float t[3], float* R) {     // mano_head.py:12-52 / rodrigues_layer.py:43-54
@@ -102,7 +104,7 @@ __device__ __forceinline__ void rotation_to_axis_angle(const float b1[3], const 
   for (int i = 0; i < 3; ++i) if (aa[i] != aa[i]) aa[i] = 0.f;
 }
 
-// the forward of one hand into LDS (all 256 threads); leaves s.raw (uncentred vertices), s.cat, and everything before them
+// the forward of one hand into LDS (all threads of the workgroup); leaves s.raw (uncentred vertices), s.cat, and everything before them
 __device__ void mano_forward(const ManoArgs& a, int h, ManoLds& s) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < MJ) {
@@ -246,7 +248,11 @@ __global__ __launch_bounds__(MNT) void mano_head_fwd_kernel(ManoArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { part[i] = wave_sum(part[i]); if (lane == 0) s.red[wave * 4 + i] = part[i]; }
     __syncthreads();
-    if (tid < 4) a.sums[(size_t)h * 4 + tid] = ((s.red[tid] + s.red[4 + tid]) + s.red[8 + tid]) + s.red[12 + tid];
+    if (tid < 4) {
+      float t = 0.f;
+      for (int wv = 0; wv < MNW; ++wv) t += s.red[wv * 4 + tid];      // wave order: fixed
+      a.sums[(size_t)h * 4 + tid] = t;
+    }
   }
 }
 
@@ -280,7 +286,11 @@ __global__ __launch_bounds__(MNT) void mano_head_bwd_kernel(ManoArgs a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) { cs[c] = wave_sum(cs[c]); if (lane == 0) s.red[wave * 4 + c] = cs[c]; }
   __syncthreads();
-  if (tid < 3) gcat[tid] -= ((s.red[tid] + s.red[4 + tid]) + s.red[8 + tid]) + s.red[12 + tid];
+  if (tid < 3) {
+    float t = 0.f;
+    for (int wv = 0; wv < MNW; ++wv) t += s.red[wv * 4 + tid];
+    gcat[tid] -= t;
+  }
   if (tid >= 64 && tid < 64 + 15) { const int k = tid - 64; s.raw[c_tip[k / 3] * 3 + k % 3] += gcat[MJ * 3 + k]; }   // finger tips are vertices
   __syncthreads();
   // skinning backward, vertex side: d posed vertex = T_R^T g
@@ -304,13 +314,16 @@ __global__ __launch_bounds__(MNT) void mano_head_bwd_kernel(ManoArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) s.vs[v * 3 + c] = T[c] * g0 + T[3 + c] * g1 + T[6 + c] * g2;
   }
-  // ... transform side: dA[j][r][c] = sum_v w[v][j] g[v][r] [vp_v ; 1][c]
-  if (tid < MJ * 12) {
-    const int j = tid / 12, e = tid - j * 12, r = e >> 2, c = e & 3;
+  // ... transform side: dA[j][r][c] = sum_v w[v][j] g[v][r] [vp_v ; 1][c] - a wave per output, lanes across the vertices
+  // (transposed weights: coalesced), 12 outputs a wave
+  for (int o = wave; o < MJ * 12; o += MNW) {
+    const int j = o / 12, e = o - j * 12, r = e >> 2, c = e & 3;
+    const float* wt = a.dirs + MWT_OFF + (size_t)j * MV;
     float acc = 0.f;
-    if (c < 3) { for (int v = 0; v < MV; ++v) acc += a.weights[v * MJ + j] * (s.raw[v * 3 + r] * s.vp[v * 3 + c]); }
-    else       { for (int v = 0; v < MV; ++v) acc += a.weights[v * MJ + j] * s.raw[v * 3 + r]; }
-    dA[tid] = acc;
+    if (c < 3) { for (int v = lane; v < MV; v += 64) acc += wt[v] * (s.raw[v * 3 + r] * s.vp[v * 3 + c]); }
+    else       { for (int v = lane; v < MV; v += 64) acc += wt[v] * s.raw[v * 3 + r]; }
+    acc = wave_sum(acc);
+    if (lane == 0) dA[o] = acc;
   }
   __syncthreads();
   // A = [G_R | G_t - G_R J]  ->  dG, dJ ; joint positions are the translations
@@ -455,11 +468,15 @@ __global__ __launch_bounds__(MNT) void mano_head_bwd_kernel(ManoArgs a) {
 }
 
 __global__ void mano_transpose_dirs_kernel(const float* __restrict__ shapedirs, const float* __restrict__ posedirs,
-                                           float* __restrict__ image) {
+                                           const float* __restrict__ weights, float* __restrict__ image) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= MDIRS * MVC) return;
-  const int k = i / MVC, vc = i - k * MVC;
-  image[i] = k < MB ? shapedirs[vc * MB + k] : posedirs[vc * MPM + (k - MB)];
+  if (i < MDIRS * MVC) {
+    const int k = i / MVC, vc = i - k * MVC;
+    image[i] = k < MB ? shapedirs[vc * MB + k] : posedirs[vc * MPM + (k - MB)];
+  } else if (i < MDIRS * MVC + MJ * MV) {
+    const int t = i - MDIRS * MVC, j = t / MV, v = t - j * MV;
+    image[i] = weights[v * MJ + j];
+  }
 }
 
 }  // namespace
@@ -467,12 +484,12 @@ __global__ void mano_transpose_dirs_kernel(const float* __restrict__ shapedirs, 
 
 using namespace hoisdf;
 
-extern "C" long hoisdf_mano_dirs_image_floats(void) { return (long)MDIRS * MVC; }
+extern "C" long hoisdf_mano_dirs_image_floats(void) { return (long)MDIRS * MVC + (long)MJ * MV; }
 
-extern "C" int hoisdf_mano_prepare(const float* shapedirs, const float* posedirs, float* image, void* stream) {
-  HOISDF_REQUIRE(shapedirs && posedirs && image, HOISDF_ERR_INVALID, "mano_prepare: null pointer");
-  hipLaunchKernelGGL(mano_transpose_dirs_kernel, dim3((unsigned)cdiv((long)MDIRS * MVC, 256)), dim3(256), 0, as_stream(stream), shapedirs,
-                     posedirs, image);
+extern "C" int hoisdf_mano_prepare(const float* shapedirs, const float* posedirs, const float* weights, float* image, void* stream) {
+  HOISDF_REQUIRE(shapedirs && posedirs && weights && image, HOISDF_ERR_INVALID, "mano_prepare: null pointer");
+  hipLaunchKernelGGL(mano_transpose_dirs_kernel, dim3((unsigned)cdiv(hoisdf_mano_dirs_image_floats(), 256)), dim3(256), 0, as_stream(stream),
+                     shapedirs, posedirs, weights, image);
   return check_launch("mano_prepare");
 }
 

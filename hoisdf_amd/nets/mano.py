@@ -88,7 +88,7 @@ class ManoLayer(nn.Module):
             if self.th_shapedirs.is_cuda and self.center_idx == 0 and not bool(self.th_hands_mean.ne(0).any()):
                 from .. import ops
                 f = lambda t: t.contiguous().float()
-                assets = (ops.mano_dirs_image(self.th_shapedirs, self.th_posedirs), f(self.th_v_template).view(-1),
+                assets = (ops.mano_dirs_image(self.th_shapedirs, self.th_posedirs, self.th_weights), f(self.th_v_template).view(-1),
                           f(self.th_J_regressor), f(self.th_weights), f(self.th_hands_mean).view(-1))
             self._kernel_assets = (key, assets)
         return self._kernel_assets[1]

@@ -1446,14 +1446,15 @@ def vote_loss(off, cls, pts, gt_mm, radius: float):
 # ---------------------------------------------------------------------------------------------
 # (f3) MANO head: 6D pose -> rotations -> MANO layer -> vertices / joints (+ the four ManoLoss sums), one kernel each way
 # ---------------------------------------------------------------------------------------------
-def mano_dirs_image(shapedirs, posedirs):
-    """th_shapedirs (778,3,10) + th_posedirs (778,3,135) -> the transposed [145][2334] table image the kernels read."""
-    shapedirs, posedirs = shapedirs.contiguous().float(), posedirs.contiguous().float()
-    _chk(shapedirs, posedirs)
-    assert shapedirs.shape == (778, 3, 10) and posedirs.shape == (778, 3, 135)
+def mano_dirs_image(shapedirs, posedirs, weights):
+    """th_shapedirs (778,3,10) + th_posedirs (778,3,135) + th_weights (778,16) -> the transposed table image the kernels read
+    ([145][2334] directions, then [16][778] skinning weights)."""
+    shapedirs, posedirs, weights = shapedirs.contiguous().float(), posedirs.contiguous().float(), weights.contiguous().float()
+    _chk(shapedirs, posedirs, weights)
+    assert shapedirs.shape == (778, 3, 10) and posedirs.shape == (778, 3, 135) and weights.shape == (778, 16)
     from ._lib import lib
     image = torch.empty(lib().hoisdf_mano_dirs_image_floats(), device=shapedirs.device, dtype=torch.float32)
-    call("hoisdf_mano_prepare", _p(shapedirs), _p(posedirs), _p(image), _st())
+    call("hoisdf_mano_prepare", _p(shapedirs), _p(posedirs), _p(weights), _p(image), _st())
     return image
 
 

@@ -492,7 +492,8 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
  * center_idx=0, side right), common/nets/loss.py:81-171 (ManoLoss: four MSE terms).  One workgroup per hand.
  *
  * hoisdf_mano_prepare: the layer's blend-shape tables th_shapedirs [778][3][10] and th_posedirs [778][3][135] transposed
- *   into one image [145][2334] (hoisdf_mano_dirs_image_floats() floats) - build it once per set of assets.
+ *   into one image [145][2334], followed by th_weights [778][16] transposed (hoisdf_mano_dirs_image_floats() floats in
+ *   all) - build it once per set of assets.
  * hoisdf_mano_head_fwd, for `hands` hands:
  *   mode 0 (predictions): pose = 6D rotations [hands][16][6] (row stride ldpose >= 96), betas [hands][>= 10];
  *   mode 1 (ground truth): pose = axis-angle MANO coefficients [hands][>= 48] as the dataset stores them (mano_param[:, :48]:
@@ -508,7 +509,7 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
  *   hands_mean must be zero (flat_hand_mean=True): the backward applies the layer's rotation gradient to the 6D rotation
  *   directly, which is exact only then (csrc/mano.hip header). */
 long hoisdf_mano_dirs_image_floats(void);
-int hoisdf_mano_prepare(const float* shapedirs, const float* posedirs, float* image, void* stream);
+int hoisdf_mano_prepare(const float* shapedirs, const float* posedirs, const float* weights, float* image, void* stream);
 int hoisdf_mano_head_fwd(const float* pose, int ldpose, int mode, const float* betas, int ldbetas, int hands,
                          const float* dirs_image, const float* v_template, const float* j_regressor, const float* weights,
                          const float* hands_mean, const float* gt_verts, const float* gt_joints, const float* gt_rot,
