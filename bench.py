@@ -160,8 +160,8 @@ def main():
                          "accumulation: fp32-equivalent, the default); f32 = the exact-f32 MFMA GEMM; split = f16 hi+lo operands, "
                          "3 products (22-bit operands: a separately labelled second line)")
     ap.add_argument("--attention", choices=("emu", "f32", "split"), default="emu",
-                    help="attention: emu = forward emulated like --gemm emu (the backward stays on the exact-f32 fused kernel unless "
-                         "HOISDF_ATTN_BWD=emu); f32 = exact-f32 MFMA kernels; split = f16 hi+lo operands (second line)")
+                    help="attention: emu = forward and backward emulated like --gemm emu (HOISDF_ATTN_BWD=f32 keeps the exact-f32 fused "
+                         "backward); f32 = exact-f32 MFMA kernels; split = f16 hi+lo operands (second line)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 32, [3]: 16, [4]: 8 / max(2, gpus))")
     ap.add_argument("--n-hand", type=int, default=None)
     ap.add_argument("--n-obj", type=int, default=None)
@@ -434,8 +434,9 @@ def main():
     res["config"]["arithmetic"] = {
         "linear_layers": {"emu": "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate",
                           "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[args.gemm],
-        "attention": {"emu": "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel"
-                             + (" (HOISDF_ATTN_BWD=emu: emulated)" if os.environ.get("HOISDF_ATTN_BWD") == "emu" else ""),
+        "attention": {"emu": "forward and backward emulated fp32 (as the linear layers; the 17-query decoder attention exact-f32)"
+                             if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
+                             "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
                       "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[
                           "split" if args.attention == "split" else ("f32" if (args.attention == "f32" or args.config == 4) else "emu")],
         "accuracy_evidence": "tests/test_gpu_emu.py, tools/emu_accuracy.py: error vs fp64 <= the exact-f32 kernels' and hipBLASLt fp32's"}
@@ -458,7 +459,7 @@ def main():
             ("emu_kc_kernel (linear fwd + grad-input)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
             ("emu_dw_kernel (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
             ("emu_attn_fwd_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
-            ("emu_attn_bwd_kernel (fused dK, dV, dQ; + conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
+            ("emu_attn_bwd16_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
             ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
             ("gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)",
              ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] + (sq if args.gemm == "split" else []), "split"),

@@ -16,6 +16,8 @@
 //               so the block's 32 x 64 dQ contribution is complete in registers.  It goes to a per-key-block partial buffer
 //               [kb][bh][q][64]; a reduce pass sums the key blocks in order: no atomics anywhere, run-to-run identical.
 // The dropout mask is the same function of (seed, query, key) as in the f32 kernels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -506,6 +508,242 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd_kernel(EmuAttn a) {
   }
 }
 
+// ============================================================================================================================
+// backward, second form: the same one-pass algorithm with HALF the per-lane state, so two waves fit a SIMD.  Block = 128 keys,
+// 8 waves, wave = 16 keys (lane l: key l % 16, k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16:
+//   S, dP   [32 q x 16 keys]  = two 16 x 16 tiles, A = Q / dO rows from LDS, B = the lane's K / V fragments (registers)
+//   dV^T, dK^T [64 d x 16 keys] = four tiles each, A = dO^T / Q^T from LDS, B = Pd / dS straight from the S / dP registers
+//             (a lane holds q = 16 qh + 4 g + i: the transposed tiles are stored with the queries permuted to that order)
+//   dQ      [32 q x 64 d]     = eight 16 x 16 tiles, one per wave, A = the dS tile T (LDS), B = the block's K^T slab (LDS)
+// 16-byte LDS reads are serviced in groups of 16 lanes {0-3, 12-15, 20-27}, ...: rows 0-3 / 12-15 of one k-group together with
+// rows 4-11 of the next - no row pitch is conflict-free for that, so every tile is XOR-swizzled by row (functions below).
+// ============================================================================================================================
+namespace {
+constexpr int B2_ROWS = 32 * 64;               // bf16 per row-major plane tile [32 q][64 d], 128-byte rows, 8 chunks of 16 B
+constexpr int B2_TRN = 64 * 32;                // bf16 per transposed plane tile [64 d][32 q-slots], 64-byte rows, 4 chunks
+constexpr int B2_KT = 64 * 128;                // bf16 per K^T plane [64 d][128 keys], 256-byte rows, 16 chunks
+constexpr int B2_T = 32 * 128;                 // bf16 per dS plane [32 q][128 keys]
+constexpr int B2_QR = 0, B2_DR = 3 * B2_ROWS, B2_QT = 6 * B2_ROWS, B2_DT = 6 * B2_ROWS + 3 * B2_TRN;
+constexpr int B2_KTO = 6 * B2_ROWS + 6 * B2_TRN, B2_TS = B2_KTO + 3 * B2_KT, B2_BF16 = B2_TS + 3 * B2_T;
+constexpr unsigned B2_LDS_BYTES = B2_BF16 * 2u + 64u * 4u;
+// element offsets (bf16) of the 16-byte chunk `ch` of row `r`
+__device__ __forceinline__ int b2_rows_off(int r, int ch) { return r * 64 + ((ch ^ ((r >> 1) & 7)) << 3); }
+// (64-byte rows: rows r, r + 4, r + 8, r + 12 share their banks; the table f = [0, 2, 3, 1] of (r >> 2) & 3 separates them for both
+// chunk values a lane group mixes)
+__device__ __forceinline__ int b2_trn_off(int r, int ch) { return r * 32 + ((ch ^ ((0x78 >> (((r >> 2) & 3) * 2)) & 3)) << 3); }
+__device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((ch ^ (r & 15)) << 3); }
+#define MF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a_), (b_), (c_), 0, 0, 0)
+#define MF6(acc, x0, x1, x2, y0, y1, y2) \
+  do {                                   \
+    acc = MF16(x2, y0, acc);             \
+    acc = MF16(x0, y2, acc);             \
+    acc = MF16(x1, y1, acc);             \
+    acc = MF16(x1, y0, acc);             \
+    acc = MF16(x0, y1, acc);             \
+    acc = MF16(x0, y0, acc);             \
+  } while (0)
+}  // namespace
+
+__global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  float* Ls = reinterpret_cast<float*>(lds + B2_BF16);       // lse[32] (log2 domain), then delta[32]
+  float* Es = Ls + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  int ktile, bh;
+  const int nkb = (a.Lk + 127) / 128;
+  if (!emu_block(nkb, a.B * a.H, ktile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int key = ktile * 128 + wave * 16 + l16;
+  const bool kvalid = key < a.kv_len;
+  const int nq = ktile * 128 < a.kv_len ? (a.Lq + 31) / 32 : 0;
+
+  // resident B operands of S / dP: this lane's key, d = 32 ks + 8 g .. + 7
+  bf16x8 kf[2][3], vf[2][3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const size_t ro = ((size_t)bh * a.Lkp + key) * D;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks][p] = *reinterpret_cast<const bf16x8*>(a.k[p] + ro + 32 * ks + 8 * g);
+      vf[ks][p] = *reinterpret_cast<const bf16x8*>(a.v[p] + ro + 32 * ks + 8 * g);
+    }
+  }
+  // the block's K^T slab: 3 planes x [64 d][128 keys] = 3 x 1024 chunks, two per thread and plane
+  if (nq > 0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int id = tid + 512 * i, d = id >> 4, ch = id & 15;
+        *reinterpret_cast<u32x4*>(lds + B2_KTO + p * B2_KT + b2_wide_off(d, ch)) =
+            *reinterpret_cast<const u32x4*>(a.kt[p] + ((size_t)bh * D + d) * a.Lkp + ktile * 128 + ch * 8);
+      }
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // staging: threads 0-255 carry the six row-major plane tiles (Q, dO), threads 256-511 the six transposed ones
+  const bool rows_half = tid < 256;
+  const int tt = tid & 255;
+  u32x4 sg[6];
+  float rl = INFINITY, re = 0.f;
+  const size_t rowbase = (size_t)bh * a.Lqp * D, trnbase = (size_t)bh * D * a.Lqp;
+#define B2_LOAD(QTI_)                                                                                                  \
+  do {                                                                                                                 \
+    if (rows_half) {                                                                                                   \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
+        sg[p] = *reinterpret_cast<const u32x4*>(a.q[p] + rowbase + ((size_t)(QTI_) * 32 + (tt >> 3)) * D + (tt & 7) * 8);     \
+        sg[3 + p] = *reinterpret_cast<const u32x4*>(a.d[p] + rowbase + ((size_t)(QTI_) * 32 + (tt >> 3)) * D + (tt & 7) * 8); \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
+        sg[p] = *reinterpret_cast<const u32x4*>(a.qt[p] + trnbase + (size_t)(tt >> 2) * a.Lqp + (size_t)(QTI_) * 32 + (tt & 3) * 8);     \
+        sg[3 + p] = *reinterpret_cast<const u32x4*>(a.dt[p] + trnbase + (size_t)(tt >> 2) * a.Lqp + (size_t)(QTI_) * 32 + (tt & 3) * 8); \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (tid < 32) {                                                                                                    \
+      const int q_ = (QTI_) * 32 + tid;                                                                                \
+      rl = q_ < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q_] : INFINITY;                                                    \
+      re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                                                          \
+    }                                                                                                                  \
+  } while (0)
+  if (nq > 0) B2_LOAD(0);
+
+  // transposed staging: a thread's 8 consecutive queries q0 .. q0 + 7 (q0 = 8 (tt & 3)) land in two 8-byte halves of the permuted
+  // row: slot(q) = 8 ((q & 15) >> 2) + 4 (q >> 4) + (q & 3)
+  const int trow = tt >> 2, tq0 = (tt & 3) * 8;
+  const int tslot0 = 8 * ((tq0 & 15) >> 2) + 4 * (tq0 >> 4), tslot1 = tslot0 + 8;
+  float* part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
+  const int qh_o = wave >> 2, dt_o = wave & 3;          // this wave's dQ output tile
+  for (int qt = 0; qt < nq; ++qt) {
+    __syncthreads();                       // the previous tile's readers are done (also orders the K^T slab)
+    if (rows_half) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        *reinterpret_cast<u32x4*>(lds + B2_QR + p * B2_ROWS + b2_rows_off(tt >> 3, tt & 7)) = sg[p];
+        *reinterpret_cast<u32x4*>(lds + B2_DR + p * B2_ROWS + b2_rows_off(tt >> 3, tt & 7)) = sg[3 + p];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        __bf16* tq = lds + B2_QT + p * B2_TRN;
+        __bf16* td = lds + B2_DT + p * B2_TRN;
+        *reinterpret_cast<u32x2*>(tq + b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7)) = u32x2{sg[p].x, sg[p].y};
+        *reinterpret_cast<u32x2*>(tq + b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7)) = u32x2{sg[p].z, sg[p].w};
+        *reinterpret_cast<u32x2*>(td + b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7)) = u32x2{sg[3 + p].x, sg[3 + p].y};
+        *reinterpret_cast<u32x2*>(td + b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7)) = u32x2{sg[3 + p].z, sg[3 + p].w};
+      }
+    }
+    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
+    __syncthreads();
+    B2_LOAD(min(qt + 1, nq - 1));          // unconditional prefetch (lands during the MFMAs below)
+    // S[q][key] = Qs.K^T, dP[q][key] = dO.V^T
+    f32x4 s[2], dp[2];
+    // (the six products of BOTH k-steps in order of magnitude - x2 y0, x0 y2, x1 y1 | x1 y0, x0 y1 | x0 y0 - so that no small
+    // term is added to an accumulator that already holds a leading one)
+#define B2_SDP(acc, TILE, BF)                                                                                         \
+  do {                                                                                                                \
+    const int o0_ = b2_rows_off(16 * qh + l16, g), o1_ = b2_rows_off(16 * qh + l16, 4 + g);                            \
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + o0_);                                            \
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + B2_ROWS + o0_);                                  \
+    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + 2 * B2_ROWS + o0_);                              \
+    const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + o1_);                                            \
+    const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + B2_ROWS + o1_);                                  \
+    const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + 2 * B2_ROWS + o1_);                              \
+    f32x4 t_ = {0.f, 0.f, 0.f, 0.f};                                                                                  \
+    t_ = MF16(a2, BF[0][0], t_); t_ = MF16(c2, BF[1][0], t_);                                                          \
+    t_ = MF16(a0, BF[0][2], t_); t_ = MF16(c0, BF[1][2], t_);                                                          \
+    t_ = MF16(a1, BF[0][1], t_); t_ = MF16(c1, BF[1][1], t_);                                                          \
+    t_ = MF16(a1, BF[0][0], t_); t_ = MF16(c1, BF[1][0], t_);                                                          \
+    t_ = MF16(a0, BF[0][1], t_); t_ = MF16(c0, BF[1][1], t_);                                                          \
+    t_ = MF16(a0, BF[0][0], t_); t_ = MF16(c0, BF[1][0], t_);                                                          \
+    acc = t_;                                                                                                         \
+  } while (0)
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      B2_SDP(s[qh], B2_QR, kf);
+      B2_SDP(dp[qh], B2_DR, vf);
+    }
+#undef B2_SDP
+    // Pd and dS for the lane's 8 (query, key) pairs, split into bf16 triples; dS also goes to the shared tile T
+    bf16x8 p0, p1, p2, g0, g1, g2;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qi = 16 * qh + 4 * g + i, e = 4 * qh + i;
+        const float pr = kvalid ? __builtin_amdgcn_exp2f(s[qh][i] - Ls[qi]) : 0.f;
+        float dsc = 1.f;
+        if (a.drop_p > 0.f)
+          dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
+        const float pd = pr * dsc;
+        const float ds = pr * (dp[qh][i] * dsc - Es[qi]);
+        {
+          const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
+          p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;
+        }
+        {
+          const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
+          g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;
+          __bf16* tw = lds + B2_TS + b2_wide_off(qi, 2 * wave + (l16 >> 3)) + (l16 & 7);
+          tw[0] = a_; tw[B2_T] = b_; tw[2 * B2_T] = (__bf16)r2_;
+        }
+      }
+    // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Qs^T[d][q] . dS[q][key]   (one k-step: the 32 queries)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int o = b2_trn_off(16 * dt + l16, g);
+      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + o);
+      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + B2_TRN + o);
+      const bf16x8 o2 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + 2 * B2_TRN + o);
+      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + o);
+      const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + B2_TRN + o);
+      const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + 2 * B2_TRN + o);
+      MF6(dv[dt], o0, o1, o2, p0, p1, p2);
+      MF6(dk[dt], t0, t1, t2, g0, g1, g2);
+    }
+    __syncthreads();                       // T is complete
+    // dQ tile of this wave: rows 16 qh_o .., columns 16 dt_o .. : sum over the block's 128 keys
+    {
+      // three accumulators by magnitude class (the four k-steps' leading terms must not swamp the later steps' small ones)
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, mid = {0.f, 0.f, 0.f, 0.f}, big = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ot = b2_wide_off(16 * qh_o + l16, 4 * ks + g), ok = b2_wide_off(16 * dt_o + l16, 4 * ks + g);
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + ot);
+        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + B2_T + ot);
+        const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + 2 * B2_T + ot);
+        const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + ok);
+        const bf16x8 y1 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + B2_KT + ok);
+        const bf16x8 y2 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + 2 * B2_KT + ok);
+        acc = MF16(x2, y0, acc); acc = MF16(x0, y2, acc); acc = MF16(x1, y1, acc);
+        mid = MF16(x1, y0, mid); mid = MF16(x0, y1, mid);
+        big = MF16(x0, y0, big);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = (acc[i] + mid[i]) + big[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qt * 32 + 16 * qh_o + 4 * g + i;
+        if (q < a.Lq) part[(size_t)q * D + 16 * dt_o + l16] = acc[i];
+      }
+    }
+  }
+#undef B2_LOAD
+  if (key < a.Lk) {
+    float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
+    float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
+      *reinterpret_cast<float4*>(pk + 16 * dt + 4 * g) = make_float4(dk[dt][0] * LN2, dk[dt][1] * LN2, dk[dt][2] * LN2, dk[dt][3] * LN2);
+      *reinterpret_cast<float4*>(pv + 16 * dt + 4 * g) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+    }
+  }
+}
+
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]  (f32; 16 lanes per (q, head))
 __global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __restrict__ o, int ldo, const float* __restrict__ dout,
                                                              int lddo, float* __restrict__ delta, int B, int H, int Lq) {
@@ -638,8 +876,13 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   const long need = hoisdf_attention_bwd_emu_workspace(B, H, Lq, Lk, fwd_workspace ? 1 : 0);
   HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_bwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
   static bool attr_set = false;
+  static int form = 16;                 // HOISDF_ATTN_BWD_FORM=32: the first form (4 waves x 32 keys, one wave per SIMD)
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const char* e = getenv("HOISDF_ATTN_BWD_FORM");
+    if (e && atoi(e) == 32) form = 32;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B2_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BWD_LDS_BYTES) != hipSuccess) {
       set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", BWD_LDS_BYTES);
       return HOISDF_ERR_LAUNCH;
@@ -675,7 +918,8 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  hipLaunchKernelGGL(emu_attn_bwd_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), BWD_LDS_BYTES, st, a);
+  if (form == 16) hipLaunchKernelGGL(emu_attn_bwd16_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(emu_attn_bwd_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), BWD_LDS_BYTES, st, a);
   if (int rc = check_launch("attention_bwd_emu")) return rc;
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,

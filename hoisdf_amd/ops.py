@@ -909,14 +909,14 @@ def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
          _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _st())
 
 
-_ATTN_BWD_EMU = __import__("os").environ.get("HOISDF_ATTN_BWD", "") == "emu"
+_ATTN_BWD_EMU = __import__("os").environ.get("HOISDF_ATTN_BWD", "emu") != "f32"
 
 
 def _emu_bwd() -> bool:
-    """the fused emulated backward (one workgroup per CU: K, V fragments, dK / dV accumulators and a prefetched query tile need
-    > 256 registers per lane) measures 3.4 ms against 3.1 ms for the exact-f32 fused kernel at B = 32, S = 2048
-    (tools/mb_attn_emu.py), so by default only the FORWARD runs emulated (0.93 vs 1.35 ms).  The emulated backward is the
-    order-fixed one (no atomics): it replaces the f32 two-kernel form in deterministic mode, and HOISDF_ATTN_BWD=emu selects it."""
+    """Emulated attention calls run their backward emulated as well (default; HOISDF_ATTN_BWD=f32 keeps the exact-f32 fused
+    backward next to the emulated forward): the 8-wave form of csrc/attention_emu.hip (16 keys per wave, two waves per SIMD)
+    measures 2.47 ms against 3.07 ms for the f32 kernel at B = 32, S = 2048 (tools/mb_attn_emu.py; the first, one-wave-per-SIMD
+    form was 3.4 ms).  It is order-fixed (no atomics), so it is also what deterministic mode uses."""
     return _ATTN_BWD_EMU or deterministic()
 
 
