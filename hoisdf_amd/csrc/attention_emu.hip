@@ -544,6 +544,7 @@ __device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((c
   } while (0)
 }  // namespace
 
+template <bool DROP>
 __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   float* Ls = reinterpret_cast<float*>(lds + B2_BF16);       // lse[32] (log2 domain), then delta[32]
@@ -584,61 +585,75 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  // staging: threads 0-255 carry the six row-major plane tiles (Q, dO), threads 256-511 the six transposed ones
+  // staging: threads 0-255 carry the six row-major plane tiles (Q, dO), threads 256-511 the six transposed ones; every thread
+  // walks six running pointers (one 16-byte piece of each of its tiles), advanced by one query tile per iteration
   const bool rows_half = tid < 256;
   const int tt = tid & 255;
   u32x4 sg[6];
   float rl = INFINITY, re = 0.f;
-  const size_t rowbase = (size_t)bh * a.Lqp * D, trnbase = (size_t)bh * D * a.Lqp;
+  const __bf16* gp[6];
+  {
+    const size_t rowoff = (size_t)bh * a.Lqp * D + (size_t)(tt >> 3) * D + (tt & 7) * 8;
+    const size_t trnoff = (size_t)bh * D * a.Lqp + (size_t)(tt >> 2) * a.Lqp + (tt & 3) * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      gp[p] = rows_half ? a.q[p] + rowoff : a.qt[p] + trnoff;
+      gp[3 + p] = rows_half ? a.d[p] + rowoff : a.dt[p] + trnoff;
+    }
+  }
+  const int tstride = rows_half ? 32 * D : 32;          // elements per query tile along this thread's pointers
 #define B2_LOAD(QTI_)                                                                                                  \
   do {                                                                                                                 \
-    if (rows_half) {                                                                                                   \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
-        sg[p] = *reinterpret_cast<const u32x4*>(a.q[p] + rowbase + ((size_t)(QTI_) * 32 + (tt >> 3)) * D + (tt & 7) * 8);     \
-        sg[3 + p] = *reinterpret_cast<const u32x4*>(a.d[p] + rowbase + ((size_t)(QTI_) * 32 + (tt >> 3)) * D + (tt & 7) * 8); \
-      }                                                                                                                \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
-        sg[p] = *reinterpret_cast<const u32x4*>(a.qt[p] + trnbase + (size_t)(tt >> 2) * a.Lqp + (size_t)(QTI_) * 32 + (tt & 3) * 8);     \
-        sg[3 + p] = *reinterpret_cast<const u32x4*>(a.dt[p] + trnbase + (size_t)(tt >> 2) * a.Lqp + (size_t)(QTI_) * 32 + (tt & 3) * 8); \
-      }                                                                                                                \
-    }                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) sg[i] = *reinterpret_cast<const u32x4*>(gp[i]);                      \
     if (tid < 32) {                                                                                                    \
       const int q_ = (QTI_) * 32 + tid;                                                                                \
       rl = q_ < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q_] : INFINITY;                                                    \
       re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                                                          \
     }                                                                                                                  \
   } while (0)
-  if (nq > 0) B2_LOAD(0);
-
-  // transposed staging: a thread's 8 consecutive queries q0 .. q0 + 7 (q0 = 8 (tt & 3)) land in two 8-byte halves of the permuted
-  // row: slot(q) = 8 ((q & 15) >> 2) + 4 (q >> 4) + (q & 3)
+#define B2_ADVANCE()                                                                                                   \
+  do { _Pragma("unroll") for (int i = 0; i < 6; ++i) gp[i] += tstride; } while (0)
+  // LDS destinations of the staged pieces.  Transposed tiles: a thread's 8 consecutive queries q0 .. q0 + 7 (q0 = 8 (tt & 3))
+  // land in two 8-byte halves of the permuted row: slot(q) = 8 ((q & 15) >> 2) + 4 (q >> 4) + (q & 3)
   const int trow = tt >> 2, tq0 = (tt & 3) * 8;
   const int tslot0 = 8 * ((tq0 & 15) >> 2) + 4 * (tq0 >> 4), tslot1 = tslot0 + 8;
+  const int st_rows_o = b2_rows_off(tt >> 3, tt & 7);
+  const int st_t0 = b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7), st_t1 = b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7);
+#define B2_STAGE()                                                                                                     \
+  do {                                                                                                                 \
+    if (rows_half) {                                                                                                   \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
+        *reinterpret_cast<u32x4*>(lds + B2_QR + p * B2_ROWS + st_rows_o) = sg[p];                                      \
+        *reinterpret_cast<u32x4*>(lds + B2_DR + p * B2_ROWS + st_rows_o) = sg[3 + p];                                  \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
+        *reinterpret_cast<u32x2*>(lds + B2_QT + p * B2_TRN + st_t0) = u32x2{sg[p].x, sg[p].y};                         \
+        *reinterpret_cast<u32x2*>(lds + B2_QT + p * B2_TRN + st_t1) = u32x2{sg[p].z, sg[p].w};                         \
+        *reinterpret_cast<u32x2*>(lds + B2_DT + p * B2_TRN + st_t0) = u32x2{sg[3 + p].x, sg[3 + p].y};                 \
+        *reinterpret_cast<u32x2*>(lds + B2_DT + p * B2_TRN + st_t1) = u32x2{sg[3 + p].z, sg[3 + p].w};                 \
+      }                                                                                                                \
+    }                                                                                                                  \
+    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }                                                                      \
+  } while (0)
   float* part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
   const int qh_o = wave >> 2, dt_o = wave & 3;          // this wave's dQ output tile
+  // where this lane's dS values go in the shared tile T: row q = 16 qh + 4 g + i, key column 16 wave + l16 (swizzled chunk)
+  int tw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tw[i] = B2_TS + (4 * g + i) * 128 + ((((2 * wave + (l16 >> 3)) ^ (4 * g)) ^ i) << 3) + (l16 & 7);
+  // two barriers per query tile: [S, dP, softmax, T, dV, dK of tile t] | X | [stage tile t + 1, prefetch t + 2, dQ of tile t] | Y
+  if (nq > 0) {
+    B2_LOAD(0);
+    B2_STAGE();
+    if (nq > 1) B2_ADVANCE();
+    B2_LOAD(min(1, nq - 1));
+  }
+  __syncthreads();                         // tile 0 and the K^T slab are in LDS
   for (int qt = 0; qt < nq; ++qt) {
-    __syncthreads();                       // the previous tile's readers are done (also orders the K^T slab)
-    if (rows_half) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        *reinterpret_cast<u32x4*>(lds + B2_QR + p * B2_ROWS + b2_rows_off(tt >> 3, tt & 7)) = sg[p];
-        *reinterpret_cast<u32x4*>(lds + B2_DR + p * B2_ROWS + b2_rows_off(tt >> 3, tt & 7)) = sg[3 + p];
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        __bf16* tq = lds + B2_QT + p * B2_TRN;
-        __bf16* td = lds + B2_DT + p * B2_TRN;
-        *reinterpret_cast<u32x2*>(tq + b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7)) = u32x2{sg[p].x, sg[p].y};
-        *reinterpret_cast<u32x2*>(tq + b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7)) = u32x2{sg[p].z, sg[p].w};
-        *reinterpret_cast<u32x2*>(td + b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7)) = u32x2{sg[3 + p].x, sg[3 + p].y};
-        *reinterpret_cast<u32x2*>(td + b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7)) = u32x2{sg[3 + p].z, sg[3 + p].w};
-      }
-    }
-    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
-    __syncthreads();
-    B2_LOAD(min(qt + 1, nq - 1));          // unconditional prefetch (lands during the MFMAs below)
+    // the lane's eight queries' statistics (two 16-byte reads each, in flight under the MFMAs)
+    const f32x4 ls0 = *reinterpret_cast<const f32x4*>(Ls + 4 * g), ls1 = *reinterpret_cast<const f32x4*>(Ls + 16 + 4 * g);
+    const f32x4 es0 = *reinterpret_cast<const f32x4*>(Es + 4 * g), es1 = *reinterpret_cast<const f32x4*>(Es + 16 + 4 * g);
     // S[q][key] = Qs.K^T, dP[q][key] = dO.V^T
     f32x4 s[2], dp[2];
     // (the six products of BOTH k-steps in order of magnitude - x2 y0, x0 y2, x1 y1 | x1 y0, x0 y1 | x0 y0 - so that no small
@@ -674,12 +689,14 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int qi = 16 * qh + 4 * g + i, e = 4 * qh + i;
-        const float pr = kvalid ? __builtin_amdgcn_exp2f(s[qh][i] - Ls[qi]) : 0.f;
+        const float lsv = qh ? ls1[i] : ls0[i], esv = qh ? es1[i] : es0[i];
+        const float pe = __builtin_amdgcn_exp2f(s[qh][i] - lsv);
+        const float pr = kvalid ? pe : 0.f;
         float dsc = 1.f;
-        if (a.drop_p > 0.f)
+        if (DROP)
           dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
         const float pd = pr * dsc;
-        const float ds = pr * (dp[qh][i] * dsc - Es[qi]);
+        const float ds = pr * (dp[qh][i] * dsc - esv);
         {
           const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
           p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;
@@ -687,8 +704,8 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
         {
           const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
           g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;
-          __bf16* tw = lds + B2_TS + b2_wide_off(qi, 2 * wave + (l16 >> 3)) + (l16 & 7);
-          tw[0] = a_; tw[B2_T] = b_; tw[2 * B2_T] = (__bf16)r2_;
+          __bf16* tp = lds + tw[i] + qh * (16 * 128);
+          tp[0] = a_; tp[B2_T] = b_; tp[2 * B2_T] = (__bf16)r2_;
         }
       }
     // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Qs^T[d][q] . dS[q][key]   (one k-step: the 32 queries)
@@ -704,7 +721,10 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
       MF6(dv[dt], o0, o1, o2, p0, p1, p2);
       MF6(dk[dt], t0, t1, t2, g0, g1, g2);
     }
-    __syncthreads();                       // T is complete
+    __syncthreads();                       // X: T is complete, nobody reads the staged tile any more
+    if (qt + 1 < nq) B2_STAGE();           // tile t + 1 (in registers since the previous iteration) goes to LDS under the dQ MFMAs
+    if (qt + 2 < nq) B2_ADVANCE();
+    B2_LOAD(min(qt + 2, nq - 1));          // unconditional prefetch
     // dQ tile of this wave: rows 16 qh_o .., columns 16 dt_o .. : sum over the block's 128 keys
     {
       // three accumulators by magnitude class (the four k-steps' leading terms must not swamp the later steps' small ones)
@@ -730,8 +750,11 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
         if (q < a.Lq) part[(size_t)q * D + 16 * dt_o + l16] = acc[i];
       }
     }
+    __syncthreads();                       // Y: tile t + 1 is visible, T may be overwritten
   }
 #undef B2_LOAD
+#undef B2_ADVANCE
+#undef B2_STAGE
   if (key < a.Lk) {
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
@@ -880,7 +903,9 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   if (!attr_set) {
     const char* e = getenv("HOISDF_ATTN_BWD_FORM");
     if (e && atoi(e) == 32) form = 32;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B2_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)B2_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)BWD_LDS_BYTES) != hipSuccess) {
@@ -918,7 +943,8 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  if (form == 16) hipLaunchKernelGGL(emu_attn_bwd16_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
+  if (form == 16 && drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd16_kernel<true>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
+  else if (form == 16) hipLaunchKernelGGL(emu_attn_bwd16_kernel<false>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
   else hipLaunchKernelGGL(emu_attn_bwd_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), BWD_LDS_BYTES, st, a);
   if (int rc = check_launch("attention_bwd_emu")) return rc;
   const long n4 = (long)B * H * Lq * 16;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from hoisdf_amd import ops
 dev = "cuda"
-def timeit(fn, iters=5, warm=2):
+def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
