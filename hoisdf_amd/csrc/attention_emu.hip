@@ -9,12 +9,12 @@
 //   pre-pass  : f32 head slices -> bf16 planes, row-major [bh][Lp][64] and transposed [bh][64][Lp] (Q pre-scaled by
 //               log2(e)/8: softmax in the log2 domain, the LSE convention of attention.hip)
 //   forward   : block = 128 queries (lane = query), streams 32-key tiles of K rows / V^T:  S^T = K.Q^T, O^T += V^T.P^T
-//   backward  : ONE pass, 5 GEMM-equivalents: block = 128 keys (lane = key: K, V fragments and dK, dV accumulators in
-//               registers), streams 32-query tiles of Q / dO rows and Q^T / dO^T:  S = Q.K^T, dP = dO.V^T, dV^T += dO^T.Pd,
-//               dK^T += Q^T.dS; every wave drops its dS block (bf16 triples) into a shared LDS tile T[32 q][128 keys] and then
-//               contracts T with the block's K^T slab over all 128 keys for a 16-wide slice of d (v_mfma_f32_16x16x32_bf16),
-//               so the block's 32 x 64 dQ contribution is complete in registers.  It goes to a per-key-block partial buffer
-//               [kb][bh][q][64]; a reduce pass sums the key blocks in order: no atomics anywhere, run-to-run identical.
+//   backward  : ONE pass, 5 GEMM-equivalents: block = 128 keys in 8 waves of 16 (lane = key: K, V fragments and dK, dV
+//               accumulators in registers), streams 32-query tiles of Q / dO rows and Q^T / dO^T:  S = Q.K^T, dP = dO.V^T,
+//               dV^T += dO^T.Pd, dK^T += Q^T.dS; every wave drops its dS block (bf16 triples) into a shared LDS tile
+//               T[32 q][128 keys], and each wave then contracts T with the block's K^T slab over all 128 keys for one 16 x 16
+//               tile of the block's 32 x 64 dQ contribution.  It goes to a per-key-block partial buffer [kb][bh][q][64]; a
+//               reduce pass sums the key blocks in order: no atomics anywhere, run-to-run identical.
 // The dropout mask is the same function of (seed, query, key) as in the f32 kernels.
 #include <stdlib.h>
 
@@ -301,216 +301,10 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 
 
 // ============================================================================================================================
-// backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys (lane = key), one workgroup per CU (the
-// register file holds K, V fragments, the dK, dV accumulators and a whole prefetched query tile: > 256 registers per lane).
-// LDS (134 KB): the 32-query tile as Q / dO row planes and Q^T / dO^T planes, the block's K^T slab, the dS tile T.
-// ============================================================================================================================
-namespace {
-constexpr int KTP = 136;                       // bf16 per row of the K^T slab [64 d][128 keys] and of T [32 q][128 keys] (272 B)
-constexpr int BWD_QR = 0, BWD_DR = 3 * ROWS_T, BWD_QT = 6 * ROWS_T, BWD_DT = 6 * ROWS_T + 3 * TRN_T;
-constexpr int BWD_KT = 6 * ROWS_T + 6 * TRN_T;
-constexpr int BWD_TS = BWD_KT + 3 * 64 * KTP;
-constexpr int BWD_BF16 = BWD_TS + 3 * 32 * KTP;
-constexpr unsigned BWD_LDS_BYTES = BWD_BF16 * 2u + 64u * 4u;
-}  // namespace
-
-__global__ __launch_bounds__(256, 1) void emu_attn_bwd_kernel(EmuAttn a) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-  float* Ls = reinterpret_cast<float*>(lds + BWD_BF16);      // lse[32] (log2 domain), then delta[32]
-  float* Es = Ls + 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, c = lane & 31;
-  int ktile, bh;
-  const int nkb = (a.Lk + 127) / 128;
-  if (!emu_block(nkb, a.B * a.H, ktile, bh)) return;
-  const int b = bh / a.H, head = bh - b * a.H;
-  const int key = ktile * 128 + wave * 32 + c;
-  const bool kvalid = key < a.kv_len;
-  const bool block_active = ktile * 128 < a.kv_len;
-  const int nq = block_active ? (a.Lq + 31) / 32 : 0;
-
-  // resident fragments of this lane's key: K and V rows (B operands of S and dP), k-step j <-> d = 16 j + 8 h .. + 7
-  bf16x8 kf[4][3], vf[4][3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const size_t ro = ((size_t)bh * a.Lkp + key) * D;          // key < Lkp always (padded with zero rows)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      kf[j][p] = *reinterpret_cast<const bf16x8*>(a.k[p] + ro + 16 * j + 8 * h);
-      vf[j][p] = *reinterpret_cast<const bf16x8*>(a.v[p] + ro + 16 * j + 8 * h);
-    }
-  }
-  // the block's K^T slab: 3 planes x [64 d][128 keys]; thread -> (d = tid >> 2, 32 keys at (tid & 3) * 32): 4 x 16 bytes
-  if (nq > 0) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const __bf16* src = a.kt[p] + ((size_t)bh * D + (tid >> 2)) * a.Lkp + ktile * 128 + (tid & 3) * 32;
-      __bf16* dst = lds + BWD_KT + p * 64 * KTP + (tid >> 2) * KTP + (tid & 3) * 32;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + 8 * i) = *reinterpret_cast<const u32x4*>(src + 8 * i);
-    }
-  }
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[t][r] = 0.f; dv[t][r] = 0.f; }
-
-  // staging registers: the whole next query tile (12 plane tiles of 4 KB: one 16-byte piece per thread each) + lse / delta
-  u32x4 sq[3], sd[3], sqt[3], sdt[3];
-  float rl = INFINITY, re = 0.f;
-  const size_t rowbase = (size_t)bh * a.Lqp * D, trnbase = (size_t)bh * D * a.Lqp;
-#define BWD_LOAD(QTI_)                                                                 \
-  do {                                                                               \
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                  \
-      sq[p] = ld_rows(a.q[p] + rowbase, (size_t)(QTI_) * 32, tid);                     \
-      sd[p] = ld_rows(a.d[p] + rowbase, (size_t)(QTI_) * 32, tid);                     \
-      sqt[p] = ld_trn(a.qt[p] + trnbase, a.Lqp, (size_t)(QTI_) * 32, tid);             \
-      sdt[p] = ld_trn(a.dt[p] + trnbase, a.Lqp, (size_t)(QTI_) * 32, tid);             \
-    }                                                                                \
-    if (tid < 32) {                                                                  \
-      const int q_ = (QTI_) * 32 + tid;                                                \
-      rl = q_ < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q_] : INFINITY;                  \
-      re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                        \
-    }                                                                                \
-  } while (0)
-  if (nq > 0) BWD_LOAD(0);
-
-  const int l16 = lane & 15, kq = lane >> 4;
-  float* part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
-  for (int qt = 0; qt < nq; ++qt) {
-    __syncthreads();                       // the previous tile's readers are done (also orders the K^T slab)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      st_rows(lds + BWD_QR + p * ROWS_T, sq[p], tid);
-      st_rows(lds + BWD_DR + p * ROWS_T, sd[p], tid);
-      st_trn(lds + BWD_QT + p * TRN_T, sqt[p], tid);
-      st_trn(lds + BWD_DT + p * TRN_T, sdt[p], tid);
-    }
-    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }
-    __syncthreads();
-    BWD_LOAD(min(qt + 1, nq - 1));         // unconditional prefetch (lands during the MFMAs below)
-    // S[q][key] = Qs.K^T and dP[q][key] = dO.V^T: rows = the tile's queries, column = this lane's key
-    f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int o = c * RP + 16 * j + 8 * h;
-      const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + o);
-      const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + ROWS_T + o);
-      const bf16x8 q2 = *reinterpret_cast<const bf16x8*>(lds + BWD_QR + 2 * ROWS_T + o);
-      const bf16x8 d0 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + o);
-      const bf16x8 d1 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + ROWS_T + o);
-      const bf16x8 d2 = *reinterpret_cast<const bf16x8*>(lds + BWD_DR + 2 * ROWS_T + o);
-      MB6(s, q0, q1, q2, kf[j][0], kf[j][1], kf[j][2]);
-      MB6(dp, d0, d1, d2, vf[j][0], vf[j][1], vf[j][2]);
-    }
-    // s <- Pd (dropped probabilities), dp <- dS
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = CR(r, h);
-      const float p = kvalid ? __builtin_amdgcn_exp2f(s[r] - Ls[qi]) : 0.f;
-      float dsc = 1.f;
-      if (a.drop_p > 0.f)
-        dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
-      s[r] = p * dsc;
-      dp[r] = p * (dp[r] * dsc - Es[qi]);
-    }
-    // dV^T[d][key] += dO^T[d][q] . Pd[q][key];  dK^T[d][key] += Qs^T[d][q] . dS[q][key];  dS also goes to T as bf16 triples
-    __bf16* Tw = lds + BWD_TS + wave * 32 + c;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      bf16x8 p0, p1, p2, g0, g1, g2;
-      split8(s, jj, 1.f, p0, p1, p2);
-      {
-        bf16x8 &p0_ = g0, &p1_ = g1, &p2_ = g2;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float x = dp[8 * jj + i];
-          const __bf16 a_ = (__bf16)x;
-          const float r1_ = x - (float)a_;
-          const __bf16 b_ = (__bf16)r1_;
-          const float r2_ = r1_ - (float)b_;
-          p0_[i] = a_; p1_[i] = b_; p2_[i] = (__bf16)r2_;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int qi = CR(8 * jj + i, h);
-        Tw[qi * KTP] = g0[i];
-        Tw[32 * KTP + qi * KTP] = g1[i];
-        Tw[64 * KTP + qi * KTP] = g2[i];
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 o0 = frag_trn(lds + BWD_DT, dt * 32 + c, jj, h);
-        const bf16x8 o1 = frag_trn(lds + BWD_DT + TRN_T, dt * 32 + c, jj, h);
-        const bf16x8 o2 = frag_trn(lds + BWD_DT + 2 * TRN_T, dt * 32 + c, jj, h);
-        const bf16x8 t0 = frag_trn(lds + BWD_QT, dt * 32 + c, jj, h);
-        const bf16x8 t1 = frag_trn(lds + BWD_QT + TRN_T, dt * 32 + c, jj, h);
-        const bf16x8 t2 = frag_trn(lds + BWD_QT + 2 * TRN_T, dt * 32 + c, jj, h);
-        MB6(dv[dt], o0, o1, o2, p0, p1, p2);
-        MB6(dk[dt], t0, t1, t2, g0, g1, g2);
-      }
-    }
-    __syncthreads();                       // T is complete
-    // dQ[q][16 w .. 16 w + 15] = sum over the block's 128 keys of dS[q][key] K[key][d]   (16x16x32 MFMA: lane l supplies
-    // A[row l % 16][8 (l / 16) ..] and B[8 (l / 16) ..][col l % 16], holds C[rows 4 (l / 16) .. + 3][col l % 16])
-    {
-      f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
-      const __bf16* tp = lds + BWD_TS + l16 * KTP + 8 * kq;
-      const __bf16* kp = lds + BWD_KT + (wave * 16 + l16) * KTP + 8 * kq;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        bf16x8 x0[3], x1[3], y[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          x0[p] = *reinterpret_cast<const bf16x8*>(tp + p * 32 * KTP + 32 * t);
-          x1[p] = *reinterpret_cast<const bf16x8*>(tp + p * 32 * KTP + 16 * KTP + 32 * t);
-          y[p] = *reinterpret_cast<const bf16x8*>(kp + p * 64 * KTP + 32 * t);
-        }
-#define MQ(acc, xa, xb, xc)                                                          \
-  do {                                                                               \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xc, y[0], acc, 0, 0, 0);           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[2], acc, 0, 0, 0);           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, y[1], acc, 0, 0, 0);           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, y[0], acc, 0, 0, 0);           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[1], acc, 0, 0, 0);           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, y[0], acc, 0, 0, 0);           \
-  } while (0)
-        MQ(q0, x0[0], x0[1], x0[2]);
-        MQ(q1, x1[0], x1[1], x1[2]);
-#undef MQ
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qa = qt * 32 + 4 * kq + i, qb = qa + 16;
-        if (qa < a.Lq) part[(size_t)qa * D + wave * 16 + l16] = q0[i];
-        if (qb < a.Lq) part[(size_t)qb * D + wave * 16 + l16] = q1[i];
-      }
-    }
-  }
-#undef BWD_LOAD
-  if (key < a.Lk) {
-    float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
-    float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
-        *reinterpret_cast<float4*>(pk + 32 * t + 8 * g + 4 * h) =
-            make_float4(dk[t][4 * g + 0] * LN2, dk[t][4 * g + 1] * LN2, dk[t][4 * g + 2] * LN2, dk[t][4 * g + 3] * LN2);
-        *reinterpret_cast<float4*>(pv + 32 * t + 8 * g + 4 * h) =
-            make_float4(dv[t][4 * g + 0], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
-      }
-  }
-}
-
-// ============================================================================================================================
-// backward, second form: the same one-pass algorithm with HALF the per-lane state, so two waves fit a SIMD.  Block = 128 keys,
-// 8 waves, wave = 16 keys (lane l: key l % 16, k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16:
+// backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys, 8 waves, wave = 16 keys (lane l: key l % 16,
+// k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16 - 16-wide tiles keep the per-lane state (K, V fragments,
+// dK, dV accumulators) under 256 registers, so two waves share a SIMD (a first form with 32 keys per wave on 32x32x16 tiles
+// needed > 400 registers, ran one wave per SIMD and took 3.4 ms where this one takes 2.35 ms at B = 32, S = 2048):
 //   S, dP   [32 q x 16 keys]  = two 16 x 16 tiles, A = Q / dO rows from LDS, B = the lane's K / V fragments (registers)
 //   dV^T, dK^T [64 d x 16 keys] = four tiles each, A = dO^T / Q^T from LDS, B = Pd / dS straight from the S / dP registers
 //             (a lane holds q = 16 qh + 4 g + i: the transposed tiles are stored with the queries permuted to that order)
@@ -899,17 +693,12 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   const long need = hoisdf_attention_bwd_emu_workspace(B, H, Lq, Lk, fwd_workspace ? 1 : 0);
   HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_bwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
   static bool attr_set = false;
-  static int form = 16;                 // HOISDF_ATTN_BWD_FORM=32: the first form (4 waves x 32 keys, one wave per SIMD)
   if (!attr_set) {
-    const char* e = getenv("HOISDF_ATTN_BWD_FORM");
-    if (e && atoi(e) == 32) form = 32;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)B2_LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)B2_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)BWD_LDS_BYTES) != hipSuccess) {
-      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", BWD_LDS_BYTES);
+                            (int)B2_LDS_BYTES) != hipSuccess) {
+      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", B2_LDS_BYTES);
       return HOISDF_ERR_LAUNCH;
     }
     attr_set = true;
@@ -943,9 +732,8 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  if (form == 16 && drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd16_kernel<true>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
-  else if (form == 16) hipLaunchKernelGGL(emu_attn_bwd16_kernel<false>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(emu_attn_bwd_kernel, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(256), BWD_LDS_BYTES, st, a);
+  if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd16_kernel<true>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(emu_attn_bwd16_kernel<false>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
   if (int rc = check_launch("attention_bwd_emu")) return rc;
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
