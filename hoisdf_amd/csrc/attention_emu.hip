@@ -6,13 +6,14 @@
 // gemm_emu.hip; softmax state, dropout and the dS algebra stay f32.  Results carry the error of the exact-f32 kernels of
 // attention.hip (tests/test_gpu_emu.py), the contractions run on a pipe that is 16 x faster.
 //
-//   pre-pass  : f32 head slices -> bf16 planes, row-major [bh][Lp][64] and transposed [bh][64][Lp] (Q pre-scaled by
+//   pre-pass  : f32 head slices -> bf16 planes, row-major [bh][Lp][64] and (V only) transposed [bh][64][Lp] (Q pre-scaled by
 //               log2(e)/8: softmax in the log2 domain, the LSE convention of attention.hip)
 //   forward   : block = 128 queries (lane = query), streams 32-key tiles of K rows / V^T:  S^T = K.Q^T, O^T += V^T.P^T
 //   backward  : ONE pass, 5 GEMM-equivalents: block = 128 keys in 8 waves of 16 (lane = key: K, V fragments and dK, dV
-//               accumulators in registers), streams 32-query tiles of Q / dO rows and Q^T / dO^T:  S = Q.K^T, dP = dO.V^T,
+//               accumulators in registers), streams 32-query tiles of Q / dO rows (the transposed fragments come out of the
+//               same tiles through ds_read_b64_tr_b16):  S = Q.K^T, dP = dO.V^T,
 //               dV^T += dO^T.Pd, dK^T += Q^T.dS; every wave drops its dS block (bf16 triples) into a shared LDS tile
-//               T[32 q][128 keys], and each wave then contracts T with the block's K^T slab over all 128 keys for one 16 x 16
+//               T[32 q][128 keys], and each wave then contracts T with the block's K rows over all 128 keys for one 16 x 16
 //               tile of the block's 32 x 64 dQ contribution.  It goes to a per-key-block partial buffer [kb][bh][q][64]; a
 //               reduce pass sums the key blocks in order: no atomics anywhere, run-to-run identical.
 // The dropout mask is the same function of (seed, query, key) as in the f32 kernels.
@@ -61,10 +62,10 @@ constexpr float LN2 = 0.6931471805599453f;
 
 struct EmuAttn {
   // planes (any may be null when a kernel does not use it): [p] = piece 0, 1, 2
-  const __bf16 *q[3], *qt[3];      // Q rows (pre-scaled), Q^T
-  const __bf16 *k[3], *kt[3];      // K rows, K^T
-  const __bf16 *v[3], *vt[3];      // V rows, V^T
-  const __bf16 *d[3], *dt[3];      // dO rows, dO^T
+  const __bf16 *q[3];              // Q rows (pre-scaled)
+  const __bf16 *k[3];              // K rows
+  const __bf16 *v[3], *vt[3];      // V rows (backward), V^T (forward)
+  const __bf16 *d[3];              // dO rows
   const float* lse_in; const float* delta;
   float* out; float* lse; float* dq_part; float* dk; float* dv;
   int ldo, ldk, ldv;
@@ -300,31 +301,8 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 }
 
 
-// ============================================================================================================================
-// backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys, 8 waves, wave = 16 keys (lane l: key l % 16,
-// k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16 - 16-wide tiles keep the per-lane state (K, V fragments,
-// dK, dV accumulators) under 256 registers, so two waves share a SIMD (a first form with 32 keys per wave on 32x32x16 tiles
-// needed > 400 registers, ran one wave per SIMD and took 3.4 ms where this one takes 2.35 ms at B = 32, S = 2048):
-//   S, dP   [32 q x 16 keys]  = two 16 x 16 tiles, A = Q / dO rows from LDS, B = the lane's K / V fragments (registers)
-//   dV^T, dK^T [64 d x 16 keys] = four tiles each, A = dO^T / Q^T from LDS, B = Pd / dS straight from the S / dP registers
-//             (a lane holds q = 16 qh + 4 g + i: the transposed tiles are stored with the queries permuted to that order)
-//   dQ      [32 q x 64 d]     = eight 16 x 16 tiles, one per wave, A = the dS tile T (LDS), B = the block's K^T slab (LDS)
-// 16-byte LDS reads are serviced in groups of 16 lanes {0-3, 12-15, 20-27}, ...: rows 0-3 / 12-15 of one k-group together with
-// rows 4-11 of the next - no row pitch is conflict-free for that, so every tile is XOR-swizzled by row (functions below).
-// ============================================================================================================================
 namespace {
-constexpr int B2_ROWS = 32 * 64;               // bf16 per row-major plane tile [32 q][64 d], 128-byte rows, 8 chunks of 16 B
-constexpr int B2_TRN = 64 * 32;                // bf16 per transposed plane tile [64 d][32 q-slots], 64-byte rows, 4 chunks
-constexpr int B2_KT = 64 * 128;                // bf16 per K^T plane [64 d][128 keys], 256-byte rows, 16 chunks
-constexpr int B2_T = 32 * 128;                 // bf16 per dS plane [32 q][128 keys]
-constexpr int B2_QR = 0, B2_DR = 3 * B2_ROWS, B2_QT = 6 * B2_ROWS, B2_DT = 6 * B2_ROWS + 3 * B2_TRN;
-constexpr int B2_KTO = 6 * B2_ROWS + 6 * B2_TRN, B2_TS = B2_KTO + 3 * B2_KT, B2_BF16 = B2_TS + 3 * B2_T;
-constexpr unsigned B2_LDS_BYTES = B2_BF16 * 2u + 64u * 4u;
-// element offsets (bf16) of the 16-byte chunk `ch` of row `r`
-__device__ __forceinline__ int b2_rows_off(int r, int ch) { return r * 64 + ((ch ^ ((r >> 1) & 7)) << 3); }
-// (64-byte rows: rows r, r + 4, r + 8, r + 12 share their banks; the table f = [0, 2, 3, 1] of (r >> 2) & 3 separates them for both
-// chunk values a lane group mixes)
-__device__ __forceinline__ int b2_trn_off(int r, int ch) { return r * 32 + ((ch ^ ((0x78 >> (((r >> 2) & 3) * 2)) & 3)) << 3); }
+// element offset (bf16) of the 16-byte chunk `ch` of row `r` of a [rows][128] tile (256-byte rows, 16 chunks)
 __device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((ch ^ (r & 15)) << 3); }
 #define MF16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a_), (b_), (c_), 0, 0, 0)
 #define MF6(acc, x0, x1, x2, y0, y1, y2) \
@@ -338,11 +316,54 @@ __device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((c
   } while (0)
 }  // namespace
 
+// ============================================================================================================================
+// backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys, 8 waves, wave = 16 keys (lane l: key l % 16,
+// k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16 - 16-wide tiles keep the per-lane state (K, V fragments 48
+// registers, dK, dV accumulators 32) under 256 registers, so two waves share a SIMD (a first form with 32 keys per wave on
+// 32x32x16 tiles needed > 400 registers, ran one wave per SIMD and took 3.4 ms where this one takes 2.3 ms at B = 32, S = 2048):
+//   S, dP      [32 q x 16 keys] = two 16 x 16 tiles, A = Q / dO rows from LDS, B = the lane's K / V fragments (registers)
+//   dV^T, dK^T [64 d x 16 keys] = four tiles each, A = dO^T / Q^T fragments, B = Pd / dS straight from the S / dP accumulator
+//              registers (a lane holds q = 16 qh + 4 g + i: k-slot 8 g + i <-> q = 4 g + i, 8 g + 4 + i <-> q = 16 + 4 g + i)
+//   dQ         [32 q x 64 d]    = eight 16 x 16 tiles, one per wave, A = the dS tile T (LDS, written by all waves), B = K^T fragments
+// The two waves of a SIMD do not run the same phase at the same time: waves 0-3 ("early") and 4-7 ("late", one half-step behind;
+// wave w and w + 4 share a SIMD) alternate two half-steps, separated by workgroup barriers (a lock-step variant of the same
+// kernel - all eight waves in phase, transposed operand tiles staged separately - measured 2.36 ms against 2.29):
+//     X(t): S / dP of query tile t  +  dQ of tile t - 2 (early) or t - 1 (late)          [MFMA only]
+//     Y(t): softmax / splits of tile t (dS -> T[t & 1])  ->  dV / dK of tile t           [VALU, then MFMA]
+// so that in every half-step one wave of each SIMD issues MFMAs while the other runs its VALU phase.  That needs tile t + 1 staged
+// while tile t is still being read and dS tiles of two query tiles alive: both double-buffered - which fits 160 KB only because
+// the TRANSPOSED operand fragments (dO^T / Q^T for dV / dK, K^T for dQ) are no longer staged as separate tiles but read from the
+// row-major tiles with ds_read_b64_tr_b16 (within 16 lanes: lane 4 r + c supplies the address of columns 4 c .. 4 c + 3 of row r,
+// lane j receives [row0[j], row1[j], row2[j], row3[j]] - measured, tools/ubench/ds_tr_probe.hip).  LDS: Q / dO row tiles 2 x 24 KB,
+// T 2 x 24 KB, the block's K rows 48 KB.  The early waves' 256 threads stage everything.
+// ============================================================================================================================
+namespace {
+constexpr int B3_ROWS = 32 * 64;                 // bf16 per plane tile [32 q][64 d]
+constexpr int B3_ST = 6 * B3_ROWS;               // one staging buffer: Q planes 0-2, dO planes 0-2
+constexpr int B3_T = 32 * 128;                   // bf16 per dS plane [32 q][128 keys]
+constexpr int B3_TB = 3 * B3_T;
+constexpr int B3_KS = 128 * 64;                  // bf16 per K plane [128 keys][64 d]
+constexpr int B3_TS0 = 2 * B3_ST, B3_KS0 = B3_TS0 + 2 * B3_TB, B3_BF16 = B3_KS0 + 3 * B3_KS;
+constexpr unsigned B3_LDS_BYTES = B3_BF16 * 2u + 2u * 64u * 4u;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+// 16-byte chunk `ch` of row `r`.  Row tiles: chunk ^ (r & 6) serves both the 16-byte reads of S / dP (lane groups mix rows 0-3 /
+// 12-15 at one chunk with rows 4-11 at the next) and the transpose reads (32 lanes = 8 consecutive rows x 32 bytes: rows of equal
+// parity share their banks and must land in different chunk pairs).  K rows: the transpose reads of dQ take rows {0-3, 8-11} /
+// {4-7, 12-15} of every 16 together, so bits 1 and 3 of the row select the chunk pair.
+__device__ __forceinline__ int b3_rows_off(int r, int ch) { return r * 64 + ((ch ^ (r & 6)) << 3); }
+__device__ __forceinline__ int b3_ks_off(int r, int ch) { return r * 64 + ((ch ^ ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2))) << 3); }
+__device__ __forceinline__ bf16x8 b3_tr8(const __bf16* lo, const __bf16* hi) {
+  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lo));
+  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(hi));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+}  // namespace
+
 template <bool DROP>
-__global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
+__global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-  float* Ls = reinterpret_cast<float*>(lds + B2_BF16);       // lse[32] (log2 domain), then delta[32]
-  float* Es = Ls + 32;
+  float* stats = reinterpret_cast<float*>(lds + B3_BF16);       // [2][lse 32 (log2 domain) | delta 32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   int ktile, bh;
@@ -352,6 +373,8 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
   const int key = ktile * 128 + wave * 16 + l16;
   const bool kvalid = key < a.kv_len;
   const int nq = ktile * 128 < a.kv_len ? (a.Lq + 31) / 32 : 0;
+  const bool early = wave < 4;
+  const int lag = early ? 0 : 1;
 
   // resident B operands of S / dP: this lane's key, d = 32 ks + 8 g .. + 7
   bf16x8 kf[2][3], vf[2][3];
@@ -364,39 +387,33 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
       vf[ks][p] = *reinterpret_cast<const bf16x8*>(a.v[p] + ro + 32 * ks + 8 * g);
     }
   }
-  // the block's K^T slab: 3 planes x [64 d][128 keys] = 3 x 1024 chunks, two per thread and plane
+  // the block's K rows: 3 planes x [128 keys][64 d] = 3 x 1024 chunks, two per thread and plane
   if (nq > 0) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int id = tid + 512 * i, d = id >> 4, ch = id & 15;
-        *reinterpret_cast<u32x4*>(lds + B2_KTO + p * B2_KT + b2_wide_off(d, ch)) =
-            *reinterpret_cast<const u32x4*>(a.kt[p] + ((size_t)bh * D + d) * a.Lkp + ktile * 128 + ch * 8);
+        const int id = tid + 512 * i, r = id >> 3, ch = id & 7;
+        *reinterpret_cast<u32x4*>(lds + B3_KS0 + p * B3_KS + b3_ks_off(r, ch)) =
+            *reinterpret_cast<const u32x4*>(a.k[p] + ((size_t)bh * a.Lkp + ktile * 128 + r) * D + ch * 8);
       }
   }
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { dk[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  // staging: threads 0-255 carry the six row-major plane tiles (Q, dO), threads 256-511 the six transposed ones; every thread
-  // walks six running pointers (one 16-byte piece of each of its tiles), advanced by one query tile per iteration
-  const bool rows_half = tid < 256;
+  // staging (early waves only: thread -> row tid >> 3, chunk tid & 7 of each of the six plane tiles), running pointers
   const int tt = tid & 255;
   u32x4 sg[6];
   float rl = INFINITY, re = 0.f;
   const __bf16* gp[6];
   {
     const size_t rowoff = (size_t)bh * a.Lqp * D + (size_t)(tt >> 3) * D + (tt & 7) * 8;
-    const size_t trnoff = (size_t)bh * D * a.Lqp + (size_t)(tt >> 2) * a.Lqp + (tt & 3) * 8;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      gp[p] = rows_half ? a.q[p] + rowoff : a.qt[p] + trnoff;
-      gp[3 + p] = rows_half ? a.d[p] + rowoff : a.dt[p] + trnoff;
-    }
+    for (int p = 0; p < 3; ++p) { gp[p] = a.q[p] + rowoff; gp[3 + p] = a.d[p] + rowoff; }
   }
-  const int tstride = rows_half ? 32 * D : 32;          // elements per query tile along this thread's pointers
-#define B2_LOAD(QTI_)                                                                                                  \
+  const int st_o = b3_rows_off(tt >> 3, tt & 7);
+#define B3_LOAD(QTI_)                                                                                                  \
   do {                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 6; ++i) sg[i] = *reinterpret_cast<const u32x4*>(gp[i]);                      \
     if (tid < 32) {                                                                                                    \
@@ -405,150 +422,153 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd16_kernel(EmuAttn a) {
       re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                                                          \
     }                                                                                                                  \
   } while (0)
-#define B2_ADVANCE()                                                                                                   \
-  do { _Pragma("unroll") for (int i = 0; i < 6; ++i) gp[i] += tstride; } while (0)
-  // LDS destinations of the staged pieces.  Transposed tiles: a thread's 8 consecutive queries q0 .. q0 + 7 (q0 = 8 (tt & 3))
-  // land in two 8-byte halves of the permuted row: slot(q) = 8 ((q & 15) >> 2) + 4 (q >> 4) + (q & 3)
-  const int trow = tt >> 2, tq0 = (tt & 3) * 8;
-  const int tslot0 = 8 * ((tq0 & 15) >> 2) + 4 * (tq0 >> 4), tslot1 = tslot0 + 8;
-  const int st_rows_o = b2_rows_off(tt >> 3, tt & 7);
-  const int st_t0 = b2_trn_off(trow, tslot0 >> 3) + (tslot0 & 7), st_t1 = b2_trn_off(trow, tslot1 >> 3) + (tslot1 & 7);
-#define B2_STAGE()                                                                                                     \
+#define B3_ADVANCE() do { _Pragma("unroll") for (int i = 0; i < 6; ++i) gp[i] += 32 * D; } while (0)
+#define B3_STAGE(BUF_)                                                                                                 \
   do {                                                                                                                 \
-    if (rows_half) {                                                                                                   \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
-        *reinterpret_cast<u32x4*>(lds + B2_QR + p * B2_ROWS + st_rows_o) = sg[p];                                      \
-        *reinterpret_cast<u32x4*>(lds + B2_DR + p * B2_ROWS + st_rows_o) = sg[3 + p];                                  \
-      }                                                                                                                \
-    } else {                                                                                                           \
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                                  \
-        *reinterpret_cast<u32x2*>(lds + B2_QT + p * B2_TRN + st_t0) = u32x2{sg[p].x, sg[p].y};                         \
-        *reinterpret_cast<u32x2*>(lds + B2_QT + p * B2_TRN + st_t1) = u32x2{sg[p].z, sg[p].w};                         \
-        *reinterpret_cast<u32x2*>(lds + B2_DT + p * B2_TRN + st_t0) = u32x2{sg[3 + p].x, sg[3 + p].y};                 \
-        *reinterpret_cast<u32x2*>(lds + B2_DT + p * B2_TRN + st_t1) = u32x2{sg[3 + p].z, sg[3 + p].w};                 \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (tid < 32) { Ls[tid] = rl; Es[tid] = re; }                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                      \
+      *reinterpret_cast<u32x4*>(lds + (BUF_) * B3_ST + i * B3_ROWS + st_o) = sg[i];                                    \
+    if (tid < 32) { stats[(BUF_) * 64 + tid] = rl; stats[(BUF_) * 64 + 32 + tid] = re; }                              \
   } while (0)
   float* part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
   const int qh_o = wave >> 2, dt_o = wave & 3;          // this wave's dQ output tile
-  // where this lane's dS values go in the shared tile T: row q = 16 qh + 4 g + i, key column 16 wave + l16 (swizzled chunk)
+  // where this lane's dS values go in a T buffer: row q = 16 qh + 4 g + i, key column 16 wave + l16 (swizzled chunk)
   int tw[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tw[i] = B2_TS + (4 * g + i) * 128 + ((((2 * wave + (l16 >> 3)) ^ (4 * g)) ^ i) << 3) + (l16 & 7);
-  // two barriers per query tile: [S, dP, softmax, T, dV, dK of tile t] | X | [stage tile t + 1, prefetch t + 2, dQ of tile t] | Y
-  if (nq > 0) {
-    B2_LOAD(0);
-    B2_STAGE();
-    if (nq > 1) B2_ADVANCE();
-    B2_LOAD(min(1, nq - 1));
+  for (int i = 0; i < 4; ++i) tw[i] = (4 * g + i) * 128 + ((((2 * wave + (l16 >> 3)) ^ (4 * g)) ^ i) << 3) + (l16 & 7);
+  // transpose-read addresses: row 4 g + (l16 >> 2) (+ 16), columns 4 (l16 & 3) .. + 3 of a 16-column block
+  const int trq = 4 * g + (l16 >> 2), trc = l16 & 3;
+  if (nq > 0 && early) {
+    B3_LOAD(0);
+    B3_STAGE(0);
+    if (nq > 1) B3_ADVANCE();
+    B3_LOAD(min(1, nq - 1));
   }
-  __syncthreads();                         // tile 0 and the K^T slab are in LDS
-  for (int qt = 0; qt < nq; ++qt) {
-    // the lane's eight queries' statistics (two 16-byte reads each, in flight under the MFMAs)
-    const f32x4 ls0 = *reinterpret_cast<const f32x4*>(Ls + 4 * g), ls1 = *reinterpret_cast<const f32x4*>(Ls + 16 + 4 * g);
-    const f32x4 es0 = *reinterpret_cast<const f32x4*>(Es + 4 * g), es1 = *reinterpret_cast<const f32x4*>(Es + 16 + 4 * g);
-    // S[q][key] = Qs.K^T, dP[q][key] = dO.V^T
-    f32x4 s[2], dp[2];
-    // (the six products of BOTH k-steps in order of magnitude - x2 y0, x0 y2, x1 y1 | x1 y0, x0 y1 | x0 y0 - so that no small
-    // term is added to an accumulator that already holds a leading one)
-#define B2_SDP(acc, TILE, BF)                                                                                         \
-  do {                                                                                                                \
-    const int o0_ = b2_rows_off(16 * qh + l16, g), o1_ = b2_rows_off(16 * qh + l16, 4 + g);                            \
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + o0_);                                            \
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + B2_ROWS + o0_);                                  \
-    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + 2 * B2_ROWS + o0_);                              \
-    const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + o1_);                                            \
-    const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + B2_ROWS + o1_);                                  \
-    const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(lds + (TILE) + 2 * B2_ROWS + o1_);                              \
-    f32x4 t_ = {0.f, 0.f, 0.f, 0.f};                                                                                  \
-    t_ = MF16(a2, BF[0][0], t_); t_ = MF16(c2, BF[1][0], t_);                                                          \
-    t_ = MF16(a0, BF[0][2], t_); t_ = MF16(c0, BF[1][2], t_);                                                          \
-    t_ = MF16(a1, BF[0][1], t_); t_ = MF16(c1, BF[1][1], t_);                                                          \
-    t_ = MF16(a1, BF[0][0], t_); t_ = MF16(c1, BF[1][0], t_);                                                          \
-    t_ = MF16(a0, BF[0][1], t_); t_ = MF16(c0, BF[1][1], t_);                                                          \
-    t_ = MF16(a0, BF[0][0], t_); t_ = MF16(c0, BF[1][0], t_);                                                          \
-    acc = t_;                                                                                                         \
+  __syncthreads();                         // tile 0 and the K rows are in LDS
+  f32x4 s[2], dp[2];
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) { s[qh] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qh] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int nhalf = nq > 0 ? 2 * nq + 3 : 0;
+  for (int hs = 0; hs < nhalf; ++hs) {
+    const int kk = hs - lag;
+    if (kk >= 0) {
+      const int t = kk >> 1;
+      if (!(kk & 1)) {
+        // ---------------- X(t): S / dP of tile t, dQ of an older tile -------------------------------------------------------
+        if (t < nq) {
+          const __bf16* ST = lds + (t & 1) * B3_ST;
+          // (the six products of BOTH k-steps in order of magnitude - x2 y0, x0 y2, x1 y1 | x1 y0, x0 y1 | x0 y0)
+#define B3_SDP(acc, TILE, BF)                                                                                          \
+  do {                                                                                                                 \
+    const int o0_ = b3_rows_off(16 * qh + l16, g), o1_ = b3_rows_off(16 * qh + l16, 4 + g);                             \
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + o0_);                                             \
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + B3_ROWS + o0_);                                   \
+    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + 2 * B3_ROWS + o0_);                               \
+    const bf16x8 c0 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + o1_);                                             \
+    const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + B3_ROWS + o1_);                                   \
+    const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(ST + (TILE) + 2 * B3_ROWS + o1_);                               \
+    f32x4 t_ = {0.f, 0.f, 0.f, 0.f};                                                                                   \
+    t_ = MF16(a2, BF[0][0], t_); t_ = MF16(c2, BF[1][0], t_);                                                           \
+    t_ = MF16(a0, BF[0][2], t_); t_ = MF16(c0, BF[1][2], t_);                                                           \
+    t_ = MF16(a1, BF[0][1], t_); t_ = MF16(c1, BF[1][1], t_);                                                           \
+    t_ = MF16(a1, BF[0][0], t_); t_ = MF16(c1, BF[1][0], t_);                                                           \
+    t_ = MF16(a0, BF[0][1], t_); t_ = MF16(c0, BF[1][1], t_);                                                           \
+    t_ = MF16(a0, BF[0][0], t_); t_ = MF16(c0, BF[1][0], t_);                                                           \
+    acc = t_;                                                                                                          \
   } while (0)
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-      B2_SDP(s[qh], B2_QR, kf);
-      B2_SDP(dp[qh], B2_DR, vf);
-    }
-#undef B2_SDP
-    // Pd and dS for the lane's 8 (query, key) pairs, split into bf16 triples; dS also goes to the shared tile T
-    bf16x8 p0, p1, p2, g0, g1, g2;
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qi = 16 * qh + 4 * g + i, e = 4 * qh + i;
-        const float lsv = qh ? ls1[i] : ls0[i], esv = qh ? es1[i] : es0[i];
-        const float pe = __builtin_amdgcn_exp2f(s[qh][i] - lsv);
-        const float pr = kvalid ? pe : 0.f;
-        float dsc = 1.f;
-        if (DROP)
-          dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qt * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
-        const float pd = pr * dsc;
-        const float ds = pr * (dp[qh][i] * dsc - esv);
-        {
-          const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
-          p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;
+          for (int qh = 0; qh < 2; ++qh) {
+            B3_SDP(s[qh], 0, kf);
+            B3_SDP(dp[qh], 3 * B3_ROWS, vf);
+          }
+#undef B3_SDP
         }
-        {
-          const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
-          g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;
-          __bf16* tp = lds + tw[i] + qh * (16 * 128);
-          tp[0] = a_; tp[B2_T] = b_; tp[2 * B2_T] = (__bf16)r2_;
+        const int td = t - 2 + lag;
+        if (td >= 0 && td < nq) {
+          // dQ tile of this wave for query tile td: rows 16 qh_o .., columns 16 dt_o ..: sum over the block's 128 keys
+          const __bf16* TS = lds + B3_TS0 + (td & 1) * B3_TB;
+          const __bf16* KS = lds + B3_KS0;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, mid = {0.f, 0.f, 0.f, 0.f}, big = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int ot = b2_wide_off(16 * qh_o + l16, 4 * ks + g);
+            const int r0 = 32 * ks + 8 * g + (l16 >> 2);
+            const int k0 = b3_ks_off(r0, 2 * dt_o + (trc >> 1)) + (trc & 1) * 4, k1 = b3_ks_off(r0 + 4, 2 * dt_o + (trc >> 1)) + (trc & 1) * 4;
+            const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(TS + ot);
+            const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(TS + B3_T + ot);
+            const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(TS + 2 * B3_T + ot);
+            const bf16x8 y0 = b3_tr8(KS + k0, KS + k1);
+            const bf16x8 y1 = b3_tr8(KS + B3_KS + k0, KS + B3_KS + k1);
+            const bf16x8 y2 = b3_tr8(KS + 2 * B3_KS + k0, KS + 2 * B3_KS + k1);
+            acc = MF16(x2, y0, acc); acc = MF16(x0, y2, acc); acc = MF16(x1, y1, acc);
+            mid = MF16(x1, y0, mid); mid = MF16(x0, y1, mid);
+            big = MF16(x0, y0, big);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int q = td * 32 + 16 * qh_o + 4 * g + i;
+            if (q < a.Lq) part[(size_t)q * D + 16 * dt_o + l16] = (acc[i] + mid[i]) + big[i];
+          }
+        }
+      } else {
+        // ---------------- Y(t): stage tile t + 1 (early), softmax of tile t, dV / dK of tile t ---------------------------------
+        if (early && t + 1 < nq) {
+          B3_STAGE((t + 1) & 1);
+          if (t + 2 < nq) B3_ADVANCE();
+          B3_LOAD(min(t + 2, nq - 1));
+        }
+        if (t < nq) {
+          const float* st = stats + (t & 1) * 64;
+          const f32x4 ls0 = *reinterpret_cast<const f32x4*>(st + 4 * g), ls1 = *reinterpret_cast<const f32x4*>(st + 16 + 4 * g);
+          const f32x4 es0 = *reinterpret_cast<const f32x4*>(st + 32 + 4 * g), es1 = *reinterpret_cast<const f32x4*>(st + 48 + 4 * g);
+          __bf16* TW = lds + B3_TS0 + (t & 1) * B3_TB;
+          bf16x8 p0, p1, p2, g0, g1, g2;
+#pragma unroll
+          for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int qi = 16 * qh + 4 * g + i, e = 4 * qh + i;
+              const float lsv = qh ? ls1[i] : ls0[i], esv = qh ? es1[i] : es0[i];
+              const float pe = __builtin_amdgcn_exp2f(s[qh][i] - lsv);
+              const float pr = kvalid ? pe : 0.f;
+              float dsc = 1.f;
+              if (DROP)
+                dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + t * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
+              const float pd = pr * dsc;
+              const float ds = pr * (dp[qh][i] * dsc - esv);
+              {
+                const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
+                p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;
+              }
+              {
+                const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
+                g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;
+                __bf16* tp = TW + tw[i] + qh * (16 * 128);
+                tp[0] = a_; tp[B3_T] = b_; tp[2 * B3_T] = (__bf16)r2_;
+              }
+            }
+          // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Qs^T[d][q] . dS[q][key]: the transposed fragments come out
+          // of the row tiles through the transpose read (k-slots 8 g + i <-> q = 4 g + i, 8 g + 4 + i <-> q = 16 + 4 g + i)
+          const __bf16* ST = lds + (t & 1) * B3_ST;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const int o0 = b3_rows_off(trq, 2 * dt + (trc >> 1)) + (trc & 1) * 4, o1 = b3_rows_off(trq + 16, 2 * dt + (trc >> 1)) + (trc & 1) * 4;
+            const bf16x8 t0 = b3_tr8(ST + o0, ST + o1);
+            const bf16x8 t1 = b3_tr8(ST + B3_ROWS + o0, ST + B3_ROWS + o1);
+            const bf16x8 t2 = b3_tr8(ST + 2 * B3_ROWS + o0, ST + 2 * B3_ROWS + o1);
+            const bf16x8 o0_ = b3_tr8(ST + 3 * B3_ROWS + o0, ST + 3 * B3_ROWS + o1);
+            const bf16x8 o1_ = b3_tr8(ST + 4 * B3_ROWS + o0, ST + 4 * B3_ROWS + o1);
+            const bf16x8 o2_ = b3_tr8(ST + 5 * B3_ROWS + o0, ST + 5 * B3_ROWS + o1);
+            MF6(dv[dt], o0_, o1_, o2_, p0, p1, p2);
+            MF6(dk[dt], t0, t1, t2, g0, g1, g2);
+          }
         }
       }
-    // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Qs^T[d][q] . dS[q][key]   (one k-step: the 32 queries)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int o = b2_trn_off(16 * dt + l16, g);
-      const bf16x8 o0 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + o);
-      const bf16x8 o1 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + B2_TRN + o);
-      const bf16x8 o2 = *reinterpret_cast<const bf16x8*>(lds + B2_DT + 2 * B2_TRN + o);
-      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + o);
-      const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + B2_TRN + o);
-      const bf16x8 t2 = *reinterpret_cast<const bf16x8*>(lds + B2_QT + 2 * B2_TRN + o);
-      MF6(dv[dt], o0, o1, o2, p0, p1, p2);
-      MF6(dk[dt], t0, t1, t2, g0, g1, g2);
     }
-    __syncthreads();                       // X: T is complete, nobody reads the staged tile any more
-    if (qt + 1 < nq) B2_STAGE();           // tile t + 1 (in registers since the previous iteration) goes to LDS under the dQ MFMAs
-    if (qt + 2 < nq) B2_ADVANCE();
-    B2_LOAD(min(qt + 2, nq - 1));          // unconditional prefetch
-    // dQ tile of this wave: rows 16 qh_o .., columns 16 dt_o .. : sum over the block's 128 keys
-    {
-      // three accumulators by magnitude class (the four k-steps' leading terms must not swamp the later steps' small ones)
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, mid = {0.f, 0.f, 0.f, 0.f}, big = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ot = b2_wide_off(16 * qh_o + l16, 4 * ks + g), ok = b2_wide_off(16 * dt_o + l16, 4 * ks + g);
-        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + ot);
-        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + B2_T + ot);
-        const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(lds + B2_TS + 2 * B2_T + ot);
-        const bf16x8 y0 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + ok);
-        const bf16x8 y1 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + B2_KT + ok);
-        const bf16x8 y2 = *reinterpret_cast<const bf16x8*>(lds + B2_KTO + 2 * B2_KT + ok);
-        acc = MF16(x2, y0, acc); acc = MF16(x0, y2, acc); acc = MF16(x1, y1, acc);
-        mid = MF16(x1, y0, mid); mid = MF16(x0, y1, mid);
-        big = MF16(x0, y0, big);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = (acc[i] + mid[i]) + big[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = qt * 32 + 16 * qh_o + 4 * g + i;
-        if (q < a.Lq) part[(size_t)q * D + 16 * dt_o + l16] = acc[i];
-      }
-    }
-    __syncthreads();                       // Y: tile t + 1 is visible, T may be overwritten
+    __syncthreads();
   }
-#undef B2_LOAD
-#undef B2_ADVANCE
-#undef B2_STAGE
+#undef B3_LOAD
+#undef B3_ADVANCE
+#undef B3_STAGE
   if (key < a.Lk) {
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
@@ -634,11 +654,11 @@ int check_emu(const void* q, const void* k, const void* v, int ldq, int ldk, int
 }
 }  // namespace
 
-// mode 0: forward only (Q rows, K rows, V^T).  mode 2: forward that keeps every plane the backward needs (Q, K, V rows + transposed).
+// mode 0: forward only (Q rows, K rows, V^T).  mode 2: forward that also leaves the V rows the backward needs (Q rows, K rows, V rows, V^T).
 extern "C" long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int mode) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
   const size_t q = plane_elems(B, H, pad128(Lq)), k = plane_elems(B, H, pad128(Lk));
-  const size_t planes = mode == 0 ? 3 * q + 6 * k : 6 * q + 12 * k;
+  const size_t planes = mode == 0 ? 3 * q + 6 * k : 3 * q + 9 * k;
   return (long)(planes * sizeof(__bf16));
 }
 
@@ -654,9 +674,9 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   hipStream_t st = as_stream(stream);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
-  // layout (kept form): [Q rows, Q^T | K rows, K^T | V rows, V^T]; forward-only form: [Q rows | K rows | V^T]
-  const Planes pq = carve(w, nq, true, keep != 0);
-  const Planes pk = carve(w, nk, true, keep != 0);
+  // layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only form: [Q rows | K rows | V^T]
+  const Planes pq = carve(w, nq, true, false);
+  const Planes pk = carve(w, nk, true, false);
   const Planes pv = carve(w, nk, keep != 0, true);
   if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
   if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
@@ -670,13 +690,13 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   return check_launch("attention_fwd_emu");
 }
 
-// backward workspace: dO rows + dO^T (6 planes) + the dQ partials [ceil(kv_len / 128)][B H][Lq][64] f32
-//   (+ Q, K, V planes when the forward did not keep them: kept == 0)
+// backward workspace: dO rows (3 planes) + the dQ partials [ceil(Lk / 128)][B H][Lq][64] f32
+//   (+ Q, K, V row planes when the forward did not keep them: kept == 0)
 extern "C" long hoisdf_attention_bwd_emu_workspace(int B, int H, int Lq, int Lk, int kept) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
   const size_t q = plane_elems(B, H, pad128(Lq)), k = plane_elems(B, H, pad128(Lk));
-  size_t bytes = 6 * q * sizeof(__bf16) + (size_t)cdiv(Lk, 128) * B * H * Lq * 64 * sizeof(float);
-  if (!kept) bytes += (6 * q + 12 * k) * sizeof(__bf16);
+  size_t bytes = 3 * q * sizeof(__bf16) + (size_t)cdiv(Lk, 128) * B * H * Lq * 64 * sizeof(float);
+  if (!kept) bytes += (3 * q + 6 * k) * sizeof(__bf16);
   return (long)bytes;
 }
 
@@ -694,11 +714,11 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_bwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)B2_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)B2_LDS_BYTES) != hipSuccess) {
-      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", B2_LDS_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_stag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B3_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd_stag_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)B3_LDS_BYTES) != hipSuccess) {
+      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", B3_LDS_BYTES);
       return HOISDF_ERR_LAUNCH;
     }
     attr_set = true;
@@ -707,15 +727,15 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   hipStream_t st = as_stream(stream);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
-  const Planes pd = carve(w, nq, true, true);
+  const Planes pd = carve(w, nq, true, false);
   float* part = reinterpret_cast<float*>(w);
   w += (size_t)cdiv(Lk, 128) * B * H * Lq * 64 * 2;                 // (float = 2 bf16 slots)
   Planes pq, pk, pv;
   if (fwd_workspace) {          // the planes hoisdf_attention_fwd_emu(keep = 1) left for the same q, k, v
     __bf16* f = reinterpret_cast<__bf16*>(const_cast<void*>(fwd_workspace));
-    pq = carve(f, nq, true, true); pk = carve(f, nk, true, true); pv = carve(f, nk, true, true);
+    pq = carve(f, nq, true, false); pk = carve(f, nk, true, false); pv = carve(f, nk, true, true);
   } else {
-    pq = carve(w, nq, true, true); pk = carve(w, nk, true, true); pv = carve(w, nk, true, true);
+    pq = carve(w, nq, true, false); pk = carve(w, nk, true, false); pv = carve(w, nk, true, false);
     if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
     if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
     if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
@@ -726,14 +746,14 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   if (int rc = check_launch("attention_emu_delta")) return rc;
   EmuAttn a{};
   for (int i = 0; i < 3; ++i) {
-    a.q[i] = pq.r[i]; a.qt[i] = pq.t[i]; a.k[i] = pk.r[i]; a.kt[i] = pk.t[i]; a.v[i] = pv.r[i];
-    a.d[i] = pd.r[i]; a.dt[i] = pd.t[i];
+    a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.v[i] = pv.r[i]; a.d[i] = pd.r[i];
   }
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd16_kernel<true>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(emu_attn_bwd16_kernel<false>, dim3(cdiv(Lk, 128) * 8 * cdiv(B * H, 8)), dim3(512), B2_LDS_BYTES, st, a);
+  const dim3 grid(cdiv(Lk, 128) * 8 * cdiv(B * H, 8));
+  if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<true>, grid, dim3(512), B3_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<false>, grid, dim3(512), B3_LDS_BYTES, st, a);
   if (int rc = check_launch("attention_bwd_emu")) return rc;
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
