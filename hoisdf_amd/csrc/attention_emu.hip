@@ -406,23 +406,24 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
   const int tt = tid & 255;
   u32x4 sg[6];
   float rl = INFINITY, re = 0.f;
-  const __bf16* gp[6];
-  {
-    const size_t rowoff = (size_t)bh * a.Lqp * D + (size_t)(tt >> 3) * D + (tt & 7) * 8;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) { gp[p] = a.q[p] + rowoff; gp[3 + p] = a.d[p] + rowoff; }
-  }
+  // (uniform plane bases + one 32-bit element offset per thread: the loads take the scalar-base form, no 64-bit pointers in VGPRs)
+  const size_t rowbase = (size_t)bh * a.Lqp * D;
+  const __bf16* qb0 = a.q[0] + rowbase; const __bf16* qb1 = a.q[1] + rowbase; const __bf16* qb2 = a.q[2] + rowbase;
+  const __bf16* db0 = a.d[0] + rowbase; const __bf16* db1 = a.d[1] + rowbase; const __bf16* db2 = a.d[2] + rowbase;
+  unsigned goff = (unsigned)((tt >> 3) * D + (tt & 7) * 8);      // < 2^31 elements per (b, head): Lqp * 64
   const int st_o = b3_rows_off(tt >> 3, tt & 7);
 #define B3_LOAD(QTI_)                                                                                                  \
   do {                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) sg[i] = *reinterpret_cast<const u32x4*>(gp[i]);                      \
+    sg[0] = *reinterpret_cast<const u32x4*>(qb0 + goff); sg[1] = *reinterpret_cast<const u32x4*>(qb1 + goff);          \
+    sg[2] = *reinterpret_cast<const u32x4*>(qb2 + goff); sg[3] = *reinterpret_cast<const u32x4*>(db0 + goff);          \
+    sg[4] = *reinterpret_cast<const u32x4*>(db1 + goff); sg[5] = *reinterpret_cast<const u32x4*>(db2 + goff);          \
     if (tid < 32) {                                                                                                    \
       const int q_ = (QTI_) * 32 + tid;                                                                                \
       rl = q_ < a.Lq ? a.lse_in[(size_t)bh * a.Lq + q_] : INFINITY;                                                    \
       re = q_ < a.Lq ? a.delta[(size_t)bh * a.Lq + q_] : 0.f;                                                          \
     }                                                                                                                  \
   } while (0)
-#define B3_ADVANCE() do { _Pragma("unroll") for (int i = 0; i < 6; ++i) gp[i] += 32 * D; } while (0)
+#define B3_ADVANCE() do { goff += 32 * D; } while (0)
 #define B3_STAGE(BUF_)                                                                                                 \
   do {                                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                      \
@@ -447,6 +448,33 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
   f32x4 s[2], dp[2];
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh) { s[qh] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qh] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  bf16x8 p0, p1, p2, g0, g1, g2;           // Pd and dS of the lane's 8 (query, key) pairs as bf16 triples: element 4 qh + i
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { p0[e] = p1[e] = p2[e] = g0[e] = g1[e] = g2[e] = (__bf16)0.f; }
+  // softmax / dropout / dS algebra + the two exact three-way splits for the four queries 16 QH + 4 g + i of tile T_ (statistics in ST_)
+#define B3_SOFTMAX(QH, T_, ST_)                                                                                        \
+  do {                                                                                                                 \
+    const f32x4 lsq = *reinterpret_cast<const f32x4*>((ST_) + 16 * (QH) + 4 * g);                                      \
+    const f32x4 esq = *reinterpret_cast<const f32x4*>((ST_) + 32 + 16 * (QH) + 4 * g);                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+      const int qi = 16 * (QH) + 4 * g + i, e = 4 * (QH) + i;                                                          \
+      const float pe = __builtin_amdgcn_exp2f(s[QH][i] - lsq[i]);                                                      \
+      const float pr = kvalid ? pe : 0.f;                                                                              \
+      float dsc = 1.f;                                                                                                 \
+      if (DROP)                                                                                                        \
+        dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + (T_) * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep); \
+      const float pd = pr * dsc;                                                                                       \
+      const float ds = pr * (dp[QH][i] * dsc - esq[i]);                                                                \
+      {                                                                                                                \
+        const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_; \
+        p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;                                                                   \
+      }                                                                                                                \
+      {                                                                                                                \
+        const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_; \
+        g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;                                                                   \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
   const int nhalf = nq > 0 ? 2 * nq + 3 : 0;
   for (int hs = 0; hs < nhalf; ++hs) {
     const int kk = hs - lag;
@@ -481,6 +509,9 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
             B3_SDP(dp[qh], 3 * B3_ROWS, vf);
           }
 #undef B3_SDP
+          // the first half of the tile's VALU work already here, under this wave's own remaining MFMAs (the other half and the
+          // T stores follow in Y): balances the two half-steps
+          B3_SOFTMAX(0, t, stats + (t & 1) * 64);
         }
         const int td = t - 2 + lag;
         if (td >= 0 && td < nq) {
@@ -517,34 +548,14 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
           B3_LOAD(min(t + 2, nq - 1));
         }
         if (t < nq) {
-          const float* st = stats + (t & 1) * 64;
-          const f32x4 ls0 = *reinterpret_cast<const f32x4*>(st + 4 * g), ls1 = *reinterpret_cast<const f32x4*>(st + 16 + 4 * g);
-          const f32x4 es0 = *reinterpret_cast<const f32x4*>(st + 32 + 4 * g), es1 = *reinterpret_cast<const f32x4*>(st + 48 + 4 * g);
+          B3_SOFTMAX(1, t, stats + (t & 1) * 64);
           __bf16* TW = lds + B3_TS0 + (t & 1) * B3_TB;
-          bf16x8 p0, p1, p2, g0, g1, g2;
 #pragma unroll
           for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int qi = 16 * qh + 4 * g + i, e = 4 * qh + i;
-              const float lsv = qh ? ls1[i] : ls0[i], esv = qh ? es1[i] : es0[i];
-              const float pe = __builtin_amdgcn_exp2f(s[qh][i] - lsv);
-              const float pr = kvalid ? pe : 0.f;
-              float dsc = 1.f;
-              if (DROP)
-                dsc = drop_scale(drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + t * 32) + (uint32_t)qi), (uint32_t)key, a.thresh, a.inv_keep);
-              const float pd = pr * dsc;
-              const float ds = pr * (dp[qh][i] * dsc - esv);
-              {
-                const __bf16 a_ = (__bf16)pd; const float r1_ = pd - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
-                p0[e] = a_; p1[e] = b_; p2[e] = (__bf16)r2_;
-              }
-              {
-                const __bf16 a_ = (__bf16)ds; const float r1_ = ds - (float)a_; const __bf16 b_ = (__bf16)r1_; const float r2_ = r1_ - (float)b_;
-                g0[e] = a_; g1[e] = b_; g2[e] = (__bf16)r2_;
-                __bf16* tp = TW + tw[i] + qh * (16 * 128);
-                tp[0] = a_; tp[B3_T] = b_; tp[2 * B3_T] = (__bf16)r2_;
-              }
+              __bf16* tp = TW + tw[i] + qh * (16 * 128);
+              tp[0] = g0[4 * qh + i]; tp[B3_T] = g1[4 * qh + i]; tp[2 * B3_T] = g2[4 * qh + i];
             }
           // dV^T[d][key] += dO^T[d][q] . Pd[q][key] ;  dK^T[d][key] += Qs^T[d][q] . dS[q][key]: the transposed fragments come out
           // of the row tiles through the transpose read (k-slots 8 g + i <-> q = 4 g + i, 8 g + 4 + i <-> q = 16 + 4 g + i)
@@ -569,6 +580,7 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
 #undef B3_LOAD
 #undef B3_ADVANCE
 #undef B3_STAGE
+#undef B3_SOFTMAX
   if (key < a.Lk) {
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
