@@ -56,6 +56,26 @@ class EncoderLayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _ENC_W + _ENC_IMG + tuple(n.replace("img_", "img_t_") for n in _ENC_IMG)]
 
 
+class DecoderLayerDesc(C.Structure):
+    """include/hoisdf.h hoisdf_decoder_layer_desc"""
+    _fields_ = [("B", C.c_int), ("Q", C.c_int), ("S", C.c_int), ("E", C.c_int), ("F", C.c_int), ("H", C.c_int), ("kv_len", C.c_int),
+                ("eps", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64 * 6), ("training", C.c_int)]
+
+
+_DEC_W = ("sa_w_in", "sa_b_in", "sa_w_out", "sa_b_out", "ca_w_in", "ca_b_in", "ca_w_out", "ca_b_out", "w1", "b1", "w2", "b2",
+          "g1", "be1", "g2", "be2", "g3", "be3", "g4", "be4")
+
+
+class DecoderLayerWeights(C.Structure):
+    """include/hoisdf.h hoisdf_decoder_layer_weights"""
+    _fields_ = [(n, C.c_void_p) for n in _DEC_W + ("img_ca_kv", "img_t_ca_kv")]
+
+
+class DecoderLayerGrads(C.Structure):
+    """include/hoisdf.h hoisdf_decoder_layer_grads"""
+    _fields_ = [("d" + n, C.c_void_p) for n in _DEC_W]
+
+
 class EncoderLayerGrads(C.Structure):
     """include/hoisdf.h hoisdf_encoder_layer_grads"""
     _fields_ = [("d" + n, C.c_void_p) for n in _ENC_W]
@@ -118,6 +138,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "hoisdf_sdf_infer_count": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "hoisdf_sdf_infer": [_PYR, _P, _P, _P, _F, _I, _I, _P, _P, _I, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P],
+    "hoisdf_decoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
+    "hoisdf_decoder_layer_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P],
     "hoisdf_encoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
     "hoisdf_encoder_layer_bwd": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _P],
     "hoisdf_mano_prepare": [_P, _P, _P, _P, _P],
@@ -132,6 +154,8 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
           "hoisdf_sdf_infer_workspace": ([_L, _I, _I], C.c_long),
+          "hoisdf_decoder_layer_saved_bytes": ([_P], C.c_long),
+          "hoisdf_decoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_encoder_layer_saved_bytes": ([_P], C.c_long),
           "hoisdf_encoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),

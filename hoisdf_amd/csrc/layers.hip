@@ -333,3 +333,232 @@ extern "C" int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, cons
   if (rc == HOISDF_ERR_WORKSPACE) set_error("encoder_layer_bwd: workspace (%ld bytes) too small", workspace_bytes);
   return rc;
 }
+
+// ============================================================================================================================
+// one transformer DECODER layer per call (common/nets/transformer.py:366-395, TransformerDecoderLayer.forward_post as the hand
+// stack uses it: Q = 17 MANO queries per sample, masked self-attention over the queries with q = k = tgt + query_pos, v = tgt;
+// cross-attention of tgt + query_pos over the first kv_len rows of the encoder memory; FFN; three post-norms; + the stack's norm
+// of the layer output, :150-163).  The per-op entries in the order nets/blocks.py issues them.
+// ============================================================================================================================
+namespace hoisdf {
+namespace {
+
+// out[b][q][:] = a[b][q][:] + p[q][:]
+__global__ void add_bcast_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ p, int rows_p, int E4, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long per = (long)rows_p * E4;
+  const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(p)[i % per];
+  reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+// dp[q][:] += sum_b (g1[b][q][:] + g2[b][q][:])   (one thread per (q, 4 columns), samples in order: fixed summation order)
+__global__ void sum_bcast_grad_kernel(float* __restrict__ dp, const float* __restrict__ g1, const float* __restrict__ g2, int B, int rows_p, int E4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows_p * E4) return;
+  float4 acc = reinterpret_cast<float4*>(dp)[i];
+  for (int b = 0; b < B; ++b) {
+    const float4 x = reinterpret_cast<const float4*>(g1)[(long)b * rows_p * E4 + i], y = reinterpret_cast<const float4*>(g2)[(long)b * rows_p * E4 + i];
+    acc.x += x.x + y.x; acc.y += x.y + y.y; acc.z += x.z + y.z; acc.w += x.w + y.w;
+  }
+  reinterpret_cast<float4*>(dp)[i] = acc;
+}
+
+struct DGeo { int B, Q, S, E, F, H, kv; long M, Ms; float eps, p; };
+int dgeometry(const hoisdf_decoder_layer_desc* d, DGeo& g) {
+  HOISDF_REQUIRE(d, HOISDF_ERR_INVALID, "decoder_layer: null descriptor");
+  HOISDF_REQUIRE(d->B > 0 && d->Q > 0 && d->Q <= 64 && d->S > 0 && d->E > 0 && d->F > 0 && d->H > 0 && d->E % d->H == 0 && d->E % 4 == 0 &&
+                     d->F % 4 == 0 && d->kv_len > 0 && d->kv_len <= d->S,
+                 HOISDF_ERR_INVALID, "decoder_layer: bad sizes B=%d Q=%d S=%d E=%d F=%d H=%d kv_len=%d", d->B, d->Q, d->S, d->E, d->F, d->H, d->kv_len);
+  HOISDF_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, HOISDF_ERR_INVALID, "decoder_layer: drop_p=%f", d->drop_p);
+  g.B = d->B; g.Q = d->Q; g.S = d->S; g.E = d->E; g.F = d->F; g.H = d->H; g.kv = d->kv_len;
+  g.M = (long)d->B * d->Q; g.Ms = (long)d->B * d->S; g.eps = d->eps; g.p = d->drop_p;
+  return HOISDF_OK;
+}
+struct DSaved {
+  float *tq1, *qk, *v, *probs, *o1, *a1, *x1, *tq2, *q2, *kv, *o2, *lse2, *a2, *x2, *h, *f, *st; uint32_t* bits;
+};
+void dcarve(const DGeo& g, Bump& b, DSaved& s) {
+  const long M = g.M; const int E = g.E;
+  s.tq1 = b.floats(M * E); s.qk = b.floats(M * 2 * E); s.v = b.floats(M * E); s.probs = b.floats((long)g.B * g.H * g.Q * g.Q);
+  s.o1 = b.floats(M * E); s.a1 = b.floats(M * E); s.x1 = b.floats(M * E); s.tq2 = b.floats(M * E); s.q2 = b.floats(M * E);
+  s.kv = b.floats(g.Ms * 2 * E); s.o2 = b.floats(M * E); s.lse2 = b.floats((long)g.B * g.H * g.Q); s.a2 = b.floats(M * E);
+  s.x2 = b.floats(M * E); s.h = b.floats(M * g.F); s.bits = static_cast<uint32_t*>(b.take(M * ((g.F + 31) / 32) * 4)); s.f = b.floats(M * E);
+  s.st = b.floats(8 * M);
+}
+int add_bcast(float* out, const float* a, const float* p, const DGeo& g, hipStream_t st) {
+  const long total = g.M * (g.E / 4);
+  hipLaunchKernelGGL(add_bcast_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, out, a, p, g.Q, g.E / 4, total);
+  return check_launch("decoder_layer add");
+}
+
+int dforward(const float* tgt, const float* memory, const float* qpos, const uint8_t* mask, const hoisdf_decoder_layer_weights* w,
+             const hoisdf_decoder_layer_desc* d, const DGeo& g, float* out, float* y_out, Bump& saved, Bump& ws, bool dry, void* stream) {
+  Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
+  DSaved s;
+  dcarve(g, d->training ? saved : ws, s);
+  const int E = g.E, F = g.F;
+  const long M = g.M;
+  float* st = s.st;
+  // masked self-attention over the queries
+  if (!dry && c.ok()) c.rc = add_bcast(s.tq1, tgt, qpos, g, c.st);
+  lin_fwd(c, s.tq1, E, w->sa_w_in, E, nullptr, w->sa_b_in, s.qk, 2 * E, M, 2 * E, E, 0, 0.f, 0, nullptr);
+  lin_fwd(c, tgt, E, w->sa_w_in + (size_t)2 * E * E, E, nullptr, w->sa_b_in ? w->sa_b_in + 2 * E : nullptr, s.v, E, M, E, E, 0, 0.f, 0, nullptr);
+  if (!dry && c.ok())
+    c.rc = hoisdf_attention_small_fwd(s.qk, 2 * E, s.qk + E, 2 * E, s.v, E, mask, s.o1, E, s.probs, g.B, g.H, g.Q, g.Q, g.p, d->seed[0], stream);
+  lin_fwd(c, s.o1, E, w->sa_w_out, E, nullptr, w->sa_b_out, s.a1, E, M, E, E, 0, 0.f, 0, nullptr);
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_fwd(tgt, s.a1, w->g1, w->be1, s.x1, st, st + M, M, E, g.eps, g.p, d->seed[1], stream);
+  // cross-attention over the encoder memory (keys < kv_len)
+  if (!dry && c.ok()) c.rc = add_bcast(s.tq2, s.x1, qpos, g, c.st);
+  lin_fwd(c, s.tq2, E, w->ca_w_in, E, nullptr, w->ca_b_in, s.q2, E, M, E, E, 0, 0.f, 0, nullptr);
+  lin_fwd(c, memory, E, w->ca_w_in + (size_t)E * E, E, w->img_ca_kv, w->ca_b_in ? w->ca_b_in + E : nullptr, s.kv, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr);
+  if (!dry && c.ok())
+    c.rc = hoisdf_attention_fwd(s.q2, E, s.kv, 2 * E, s.kv + E, 2 * E, s.o2, E, s.lse2, g.B, g.H, g.Q, g.S, g.kv, g.p, d->seed[2], stream);
+  lin_fwd(c, s.o2, E, w->ca_w_out, E, nullptr, w->ca_b_out, s.a2, E, M, E, E, 0, 0.f, 0, nullptr);
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_fwd(s.x1, s.a2, w->g2, w->be2, s.x2, st + 2 * M, st + 3 * M, M, E, g.eps, g.p, d->seed[3], stream);
+  // FFN
+  lin_fwd(c, s.x2, E, w->w1, E, nullptr, w->b1, s.h, F, M, F, E, 1, g.p, d->seed[4], s.bits);
+  lin_fwd(c, s.h, F, w->w2, F, nullptr, w->b2, s.f, E, M, E, F, 0, 0.f, 0, nullptr);
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_fwd(s.x2, s.f, w->g3, w->be3, out, st + 4 * M, st + 5 * M, M, E, g.eps, g.p, d->seed[5], stream);
+  if (w->g4 && !dry && c.ok()) c.rc = hoisdf_add_layernorm_fwd(out, nullptr, w->g4, w->be4, y_out, st + 6 * M, st + 7 * M, M, E, g.eps, 0.f, 0, stream);
+  return c.rc;
+}
+
+int dbackward(const float* tgt, const float* memory, const uint8_t* mask, const float* out, const hoisdf_decoder_layer_weights* w,
+              const hoisdf_decoder_layer_desc* d, const DGeo& g, Bump& saved, const float* g_out, const float* g_y, float* d_tgt, float* d_memory,
+              int accumulate_memory, float* d_qpos, const hoisdf_decoder_layer_grads* G, Bump& ws, bool dry, void* stream) {
+  Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
+  DSaved s;
+  dcarve(g, saved, s);
+  (void)mask;
+  const int E = g.E, F = g.F;
+  const long M = g.M, Ms = g.Ms;
+  const float* st = s.st;
+  const float* dx3 = g_out;
+  if (g_y && w->g4) {
+    float* t = ws.floats(M * E);
+    if (!dry && c.ok()) {
+      if (!t) c.rc = HOISDF_ERR_WORKSPACE;
+      else c.rc = hoisdf_add_layernorm_bwd(g_y, out, nullptr, w->g4, st + 6 * M, st + 7 * M, g_out, t, nullptr, G->dg4, G->dbe4, M, E, 0.f, 0, stream);
+    }
+    dx3 = t;
+  }
+  float* dx2 = ws.floats(M * E); float* df = ws.floats(M * E); float* dh = ws.floats(M * F);
+  float* dx1 = ws.floats(M * E); float* da2 = ws.floats(M * E); float* do2 = ws.floats(M * E); float* dq2 = ws.floats(M * E);
+  float* dkv = ws.floats(Ms * 2 * E); float* delta = ws.floats((long)g.B * g.H * g.Q); float* dtq2 = ws.floats(M * E);
+  float* da1 = ws.floats(M * E); float* do1 = ws.floats(M * E); float* dqk = ws.floats(M * 2 * E); float* dv = ws.floats(M * E);
+  float* dtq1 = ws.floats(M * E);
+  if (!dry && (!dx2 || !df || !dh || !dx1 || !da2 || !do2 || !dq2 || !dkv || !delta || !dtq2 || !da1 || !do1 || !dqk || !dv || !dtq1)) {
+    set_error("decoder_layer_bwd: workspace too small");
+    return HOISDF_ERR_WORKSPACE;
+  }
+  if (!dry && !dx3) { set_error("decoder_layer_bwd: no upstream gradient (g_out and g_y both null)"); return HOISDF_ERR_INVALID; }
+  // FFN + norm3
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_bwd(dx3, s.x2, s.f, w->g3, st + 4 * M, st + 5 * M, nullptr, dx2, df, G->dg3, G->dbe3, M, E, g.p, d->seed[5], stream);
+  lin_bwd_input(c, df, E, nullptr, 0.f, w->w2, F, nullptr, dh, F, M, E, F, 0);
+  lin_bwd_weight(c, df, E, nullptr, 0.f, s.h, F, G->dw2, G->db2, M, E, F);
+  lin_bwd_input(c, dh, F, s.bits, g.p, w->w1, E, nullptr, dx2, E, M, F, E, 1);
+  lin_bwd_weight(c, dh, F, s.bits, g.p, s.x2, E, G->dw1, G->db1, M, F, E);
+  // cross-attention + norm2
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_bwd(dx2, s.x1, s.a2, w->g2, st + 2 * M, st + 3 * M, nullptr, dx1, da2, G->dg2, G->dbe2, M, E, g.p, d->seed[3], stream);
+  lin_bwd_input(c, da2, E, nullptr, 0.f, w->ca_w_out, E, nullptr, do2, E, M, E, E, 0);
+  lin_bwd_weight(c, da2, E, nullptr, 0.f, s.o2, E, G->dca_w_out, G->dca_b_out, M, E, E);
+  if (!dry && c.ok())
+    c.rc = hoisdf_attention_bwd(s.q2, E, s.kv, 2 * E, s.kv + E, 2 * E, s.o2, E, do2, E, s.lse2, delta, dq2, dkv, dkv + E, g.B, g.H, g.Q, g.S, g.kv, g.p,
+                                d->seed[2], stream);
+  lin_bwd_input(c, dq2, E, nullptr, 0.f, w->ca_w_in, E, nullptr, dtq2, E, M, E, E, 0);
+  lin_bwd_weight(c, dq2, E, nullptr, 0.f, s.tq2, E, G->dca_w_in, G->dca_b_in, M, E, E);
+  lin_bwd_input(c, dkv, 2 * E, nullptr, 0.f, w->ca_w_in + (size_t)E * E, E, w->img_t_ca_kv, d_memory, E, Ms, 2 * E, E, accumulate_memory ? 1 : 0);
+  lin_bwd_weight(c, dkv, 2 * E, nullptr, 0.f, memory, E, G->dca_w_in + (size_t)E * E, G->dca_b_in ? G->dca_b_in + E : nullptr, Ms, 2 * E, E);
+  if (!dry && c.ok()) c.rc = rows_copy_add(dx1, M * E, dtq2, M * E, 1, (int)M, E, 1, c.st);          // x1 also fed tq2 = x1 + query_pos
+  // self-attention + norm1
+  if (!dry && c.ok()) c.rc = hoisdf_add_layernorm_bwd(dx1, tgt, s.a1, w->g1, st, st + M, nullptr, d_tgt, da1, G->dg1, G->dbe1, M, E, g.p, d->seed[1], stream);
+  lin_bwd_input(c, da1, E, nullptr, 0.f, w->sa_w_out, E, nullptr, do1, E, M, E, E, 0);
+  lin_bwd_weight(c, da1, E, nullptr, 0.f, s.o1, E, G->dsa_w_out, G->dsa_b_out, M, E, E);
+  if (!dry && c.ok()) {
+    // (the small backward accumulates dK / dV over the queries with atomics: zeroed here)
+    if (hipMemsetAsync(dqk, 0, sizeof(float) * M * 2 * E, c.st) != hipSuccess || hipMemsetAsync(dv, 0, sizeof(float) * M * E, c.st) != hipSuccess) {
+      set_error("decoder_layer_bwd: clearing the self-attention gradients failed");
+      return HOISDF_ERR_LAUNCH;
+    }
+    c.rc = hoisdf_attention_small_bwd(s.qk, 2 * E, s.qk + E, 2 * E, s.v, E, s.probs, do1, E, dqk, dqk + E, dv, g.B, g.H, g.Q, g.Q, g.p, d->seed[0], stream);
+  }
+  lin_bwd_input(c, dqk, 2 * E, nullptr, 0.f, w->sa_w_in, E, nullptr, dtq1, E, M, 2 * E, E, 0);
+  lin_bwd_weight(c, dqk, 2 * E, nullptr, 0.f, s.tq1, E, G->dsa_w_in, G->dsa_b_in, M, 2 * E, E);
+  lin_bwd_input(c, dv, E, nullptr, 0.f, w->sa_w_in + (size_t)2 * E * E, E, nullptr, d_tgt, E, M, E, E, 1);
+  lin_bwd_weight(c, dv, E, nullptr, 0.f, tgt, E, G->dsa_w_in + (size_t)2 * E * E, G->dsa_b_in ? G->dsa_b_in + 2 * E : nullptr, M, E, E);
+  if (!dry && c.ok()) c.rc = rows_copy_add(d_tgt, M * E, dtq1, M * E, 1, (int)M, E, 1, c.st);        // tgt also fed tq1 = tgt + query_pos
+  if (d_qpos && !dry && c.ok()) {
+    hipLaunchKernelGGL(sum_bcast_grad_kernel, dim3((unsigned)cdiv((long)g.Q * (E / 4), 256)), dim3(256), 0, c.st, d_qpos, dtq1, dtq2, g.B, g.Q, E / 4);
+    c.rc = check_launch("decoder_layer query_pos gradient");
+  }
+  if (c.ok() && !dry && ws.overflow) { set_error("decoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
+  return c.rc;
+}
+
+}  // namespace
+}  // namespace hoisdf
+
+extern "C" long hoisdf_decoder_layer_saved_bytes(const hoisdf_decoder_layer_desc* d) {
+  DGeo g;
+  if (dgeometry(d, g) != HOISDF_OK) return -1;
+  Bump b(nullptr, 0); DSaved s;
+  dcarve(g, b, s);
+  return b.off + 256;
+}
+
+extern "C" long hoisdf_decoder_layer_workspace_bytes(const hoisdf_decoder_layer_desc* d, int backward_pass) {
+  DGeo g;
+  if (dgeometry(d, g) != HOISDF_OK) return -1;
+  hoisdf_decoder_layer_weights w{};
+  hoisdf_decoder_layer_grads G{};
+  float dummy = 0.f;
+  w.g4 = &dummy;
+  Bump saved(nullptr, 0), ws(nullptr, 0);
+  if (backward_pass) (void)dbackward(nullptr, nullptr, nullptr, nullptr, &w, d, g, saved, &dummy, &dummy, nullptr, nullptr, 0, nullptr, &G, ws, true, nullptr);
+  else (void)dforward(nullptr, nullptr, nullptr, nullptr, &w, d, g, nullptr, nullptr, saved, ws, true, nullptr);
+  return ws.off + 256;
+}
+
+extern "C" int hoisdf_decoder_layer_fwd(const float* tgt, const float* memory, const float* query_pos, const uint8_t* tgt_mask,
+                                        const hoisdf_decoder_layer_weights* w, const hoisdf_decoder_layer_desc* d, float* out, float* y_out,
+                                        void* saved, long saved_bytes, void* workspace, long workspace_bytes, void* stream) {
+  DGeo g;
+  if (int rc = dgeometry(d, g)) return rc;
+  HOISDF_REQUIRE(tgt && memory && query_pos && tgt_mask && w && out && w->sa_w_in && w->sa_w_out && w->ca_w_in && w->ca_w_out && w->w1 && w->w2 &&
+                     w->g1 && w->be1 && w->g2 && w->be2 && w->g3 && w->be3,
+                 HOISDF_ERR_INVALID, "decoder_layer_fwd: null pointer");
+  HOISDF_REQUIRE(!w->g4 || (w->be4 && y_out), HOISDF_ERR_INVALID, "decoder_layer_fwd: the stack norm needs be4 and y_out");
+  HOISDF_REQUIRE(!d->training || saved, HOISDF_ERR_WORKSPACE, "decoder_layer_fwd: training needs the saved buffer (hoisdf_decoder_layer_saved_bytes)");
+  HOISDF_REQUIRE(al16(tgt) && al16(memory) && al16(query_pos) && al16(out) && al16(saved) && al16(workspace), HOISDF_ERR_INVALID,
+                 "decoder_layer_fwd: buffers must be 16-byte aligned");
+  static char none;
+  Bump sv(saved, saved_bytes), ws(workspace, workspace_bytes);
+  if (!sv.base) { sv.base = &none; sv.cap = 0; }
+  if (!ws.base) { ws.base = &none; ws.cap = 0; }
+  int rc = dforward(tgt, memory, query_pos, tgt_mask, w, d, g, out, y_out, sv, ws, false, stream);
+  if (rc == HOISDF_OK && (sv.overflow || ws.overflow)) rc = HOISDF_ERR_WORKSPACE;
+  if (rc == HOISDF_ERR_WORKSPACE) set_error("decoder_layer_fwd: workspace (%ld bytes) or saved buffer (%ld bytes) too small", workspace_bytes, saved_bytes);
+  return rc;
+}
+
+extern "C" int hoisdf_decoder_layer_bwd(const float* tgt, const float* memory, const uint8_t* tgt_mask, const float* out,
+                                        const hoisdf_decoder_layer_weights* w, const hoisdf_decoder_layer_desc* d, const void* saved, long saved_bytes,
+                                        const float* g_out, const float* g_y, float* d_tgt, float* d_memory, int accumulate_memory,
+                                        float* d_query_pos, const hoisdf_decoder_layer_grads* grads, void* workspace, long workspace_bytes,
+                                        void* stream) {
+  DGeo g;
+  if (int rc = dgeometry(d, g)) return rc;
+  HOISDF_REQUIRE(tgt && memory && out && w && saved && d_tgt && d_memory && grads && workspace, HOISDF_ERR_INVALID, "decoder_layer_bwd: null pointer");
+  HOISDF_REQUIRE(grads->dsa_w_in && grads->dsa_b_in && grads->dsa_w_out && grads->dsa_b_out && grads->dca_w_in && grads->dca_b_in && grads->dca_w_out &&
+                     grads->dca_b_out && grads->dw1 && grads->db1 && grads->dw2 && grads->db2 && grads->dg1 && grads->dbe1 && grads->dg2 &&
+                     grads->dbe2 && grads->dg3 && grads->dbe3 && (!w->g4 || !g_y || (grads->dg4 && grads->dbe4)),
+                 HOISDF_ERR_INVALID, "decoder_layer_bwd: every parameter gradient buffer is required (zero-filled)");
+  HOISDF_REQUIRE(d->training, HOISDF_ERR_INVALID, "decoder_layer_bwd: the forward call must have run with training = 1");
+  HOISDF_REQUIRE(al16(tgt) && al16(memory) && al16(d_tgt) && al16(d_memory) && al16(saved) && al16(workspace) && al16(d_query_pos), HOISDF_ERR_INVALID,
+                 "decoder_layer_bwd: buffers must be 16-byte aligned");
+  Bump sv(const_cast<void*>(saved), saved_bytes), ws(workspace, workspace_bytes);
+  int rc = dbackward(tgt, memory, tgt_mask, out, w, d, g, sv, g_out, g_y, d_tgt, d_memory, accumulate_memory, d_query_pos, grads, ws, false, stream);
+  if (rc == HOISDF_OK && sv.overflow) rc = HOISDF_ERR_WORKSPACE;
+  if (rc == HOISDF_ERR_WORKSPACE) set_error("decoder_layer_bwd: workspace (%ld bytes) or saved buffer too small", workspace_bytes);
+  return rc;
+}

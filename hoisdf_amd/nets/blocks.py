@@ -224,10 +224,25 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, memory, query_embed, tgt_mask_u8, kv_len):
         B = memory.shape[0]
+        n = self.norm
+        l0 = self.layers[0]
+        if FUSED_LAYER_NODES and memory.is_cuda and ops.decoder_layer_ok(l0.p if l0.training else 0.0, memory, query_embed, l0.linear1.weight):
+            # one C-ABI call per layer and direction (csrc/layers.hip hoisdf_decoder_layer_fwd / _bwd)
+            x = torch.zeros(B, query_embed.shape[0], query_embed.shape[1], device=memory.device)
+            outs = []
+            for l in self.layers:
+                sa, ca = l.self_attn, l.multihead_attn
+                x, y = ops.decoder_layer(x, memory, query_embed, tgt_mask_u8, kv_len, l.p if l.training else 0.0, sa.num_heads, l.norm1.eps,
+                                         sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                         ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias,
+                                         l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                                         l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias, l.norm3.weight, l.norm3.bias,
+                                         n.weight, n.bias)
+                outs.append(y)
+            return torch.stack(outs)
         qpos = query_embed.unsqueeze(0).expand(B, -1, -1).contiguous()
         x = torch.zeros_like(qpos)
         outs = []
-        n = self.norm
         for layer in self.layers:
             x = layer(x, memory, qpos, tgt_mask_u8, kv_len)
             outs.append(ops.add_layernorm(x, None, n.weight, n.bias, n.eps))

@@ -1373,6 +1373,85 @@ def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w
                                be3, float(eps), n_inter)
 
 
+class _DecoderLayerC(torch.autograd.Function):
+    """common/nets/transformer.py:366-395 (decoder layer, post-norm) + the decoder stack's norm of the layer output through the
+    coarse C entries hoisdf_decoder_layer_fwd / _bwd (csrc/layers.hip): one call per direction instead of ~20 / ~45."""
+
+    @staticmethod
+    def forward(ctx, tgt, memory, query_pos, mask_u8, kv_len, p, H, eps, *params):
+        from ._lib import lib, DecoderLayerDesc, DecoderLayerWeights, _DEC_W
+        tgt, memory, query_pos = tgt.contiguous(), memory.contiguous(), query_pos.contiguous()
+        _chk(tgt, memory, query_pos, *params)
+        assert len(params) == len(_DEC_W) and all(t.is_contiguous() for t in params) and mask_u8.dtype == torch.uint8
+        B, Q, E = tgt.shape
+        S = memory.shape[1]
+        F = params[8].shape[0]
+        d = DecoderLayerDesc(B=B, Q=Q, S=S, E=E, F=F, H=H, kv_len=int(kv_len), eps=eps, drop_p=p, training=int(any(ctx.needs_input_grad)))
+        for i in range(6):
+            d.seed[i] = next_seed() if p > 0 else 0
+        w = DecoderLayerWeights(**{n: t.data_ptr() for n, t in zip(_DEC_W, params)})
+        ca_w_in = params[4]
+        if _GEMM_EMU and B * S >= _GEMM_EMU_MIN_ROWS:
+            w.img_ca_kv = _emu_image(ca_w_in[E:], False).data_ptr()
+        dp = C.addressof(d)
+        n_saved = lib().hoisdf_decoder_layer_saved_bytes(dp) if d.training else 0
+        n_ws = lib().hoisdf_decoder_layer_workspace_bytes(dp, 0)
+        dev = tgt.device
+        saved = torch.empty(n_saved, device=dev, dtype=torch.uint8) if n_saved else None
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        out = torch.empty(B, Q, E, device=dev)
+        y = torch.empty(B, Q, E, device=dev)
+        call("hoisdf_decoder_layer_fwd", _p(tgt), _p(memory), _p(query_pos), _p(mask_u8), C.addressof(w), dp, _p(out), _p(y), _p(saved),
+             n_saved, _p(ws), n_ws, _st())
+        ctx.save_for_backward(tgt, memory, mask_u8, out, saved, *params)
+        ctx.desc = d
+        return out, y
+
+    @staticmethod
+    def backward(ctx, g_out, g_y):
+        from ._lib import lib, DecoderLayerWeights, DecoderLayerGrads, _DEC_W
+        tgt, memory, mask_u8, out, saved, *params = ctx.saved_tensors
+        d = ctx.desc
+        B, Q, S, E = d.B, d.Q, d.S, d.E
+        dev = tgt.device
+        sizes = [t.numel() for t in params]
+        buf = _zeros(sum(sizes) + Q * E, dev)                     # one zero slice: every parameter gradient + d query_pos
+        parts, off = [], 0
+        for t, n in zip(params, sizes):
+            parts.append(buf[off:off + n].view(t.shape))
+            off += n
+        d_qpos = buf[off:off + Q * E].view(Q, E)
+        G = DecoderLayerGrads(**{"d" + n: t.data_ptr() for n, t in zip(_DEC_W, parts)})
+        w = DecoderLayerWeights(**{n: t.data_ptr() for n, t in zip(_DEC_W, params)})
+        if _GEMM_EMU and B * S >= _GEMM_EMU_MIN_ROWS:
+            w.img_t_ca_kv = _emu_image(params[4][E:], True).data_ptr()
+        dp = C.addressof(d)
+        n_ws = lib().hoisdf_decoder_layer_workspace_bytes(dp, 1)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        d_tgt = torch.empty(B, Q, E, device=dev)
+        d_mem = torch.empty(B, S, E, device=dev)
+        go = None if g_out is None else g_out.contiguous()
+        gy = None if g_y is None else g_y.contiguous()
+        call("hoisdf_decoder_layer_bwd", _p(tgt), _p(memory), _p(mask_u8), _p(out), C.addressof(w), dp, _p(saved), saved.numel(), _p(go), _p(gy),
+             _p(d_tgt), _p(d_mem), 0, _p(d_qpos), C.addressof(G), _p(ws), n_ws, _st())
+        return (d_tgt, d_mem, d_qpos, None, None, None, None, None, *parts)
+
+
+_DECODER_LAYER_C = __import__("os").environ.get("HOISDF_DECODER_LAYER", "c") != "ops"
+
+
+def decoder_layer_ok(p, *tensors) -> bool:
+    """as _coarse_layer_ok: default arithmetic only, and not while bench.py brackets the individual calls"""
+    from . import _lib
+    return (_DECODER_LAYER_C and not _GEMM_SPLIT and not _ATTENTION_SPLIT and _lib._timer is None and not _use_f16(p, *tensors))
+
+
+def decoder_layer(tgt, memory, query_pos, mask_u8, kv_len, p, H, eps, *params):
+    """-> (out (B,Q,E), y = the decoder stack's norm of out).  params in the order of _lib._DEC_W (self_attn in / out projection,
+    multihead_attn in / out projection, linear1, linear2, norm1..3, stack norm); query_pos (Q,E) is broadcast over the batch."""
+    return _DecoderLayerC.apply(tgt, memory, query_pos, mask_u8, int(kv_len), float(p), int(H), float(eps), *params)
+
+
 # ---------------------------------------------------------------------------------------------
 # votes
 # ---------------------------------------------------------------------------------------------

@@ -461,6 +461,45 @@ int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, const hoisdf_en
                              const float* g_y, float* dx, const hoisdf_encoder_layer_grads* grads, void* workspace,
                              long workspace_bytes, void* stream);
 
+/* ---- one transformer decoder layer per call ---------------------------------------------------------------------------
+ * reference: common/nets/transformer.py:366-395 (TransformerDecoderLayer.forward_post) as the hand stack runs it, and the
+ * decoder stack's norm of every layer output (:150-163).  tgt [B][Q][E] (Q <= 64 MANO queries), memory [B][S][E] (the encoder
+ * output; only keys < kv_len are attended = the memory mask of common/utils/misc.py:34-47), query_pos [Q][E] (broadcast over
+ * the batch, added to the queries / keys of the self-attention and the queries of the cross-attention), tgt_mask [Q][Q]
+ * uint8 (1 = masked).  out [B][Q][E]; with weights.g4, y_out = the stack norm of out.  Buffers and arithmetic as for the
+ * encoder layer (the 17-query attention kernels are exact f32; the memory's K / V projection follows hoisdf_set_gemm_emu).
+ * Backward: d_tgt is overwritten; d_memory is overwritten or (accumulate_memory = 1: the memory feeds every decoder layer)
+ * added to; d_query_pos [Q][E] (may be NULL) is ADDED to; parameter gradients zero on entry. */
+typedef struct hoisdf_decoder_layer_desc {
+  int B, Q, S, E, F, H, kv_len;
+  float eps, drop_p;
+  uint64_t seed[6];             /* dropout streams: self-attention, after its out-projection, cross-attention, after its
+                                   out-projection, FFN hidden, after the FFN */
+  int training;
+} hoisdf_decoder_layer_desc;
+typedef struct hoisdf_decoder_layer_weights {
+  const float *sa_w_in, *sa_b_in, *sa_w_out, *sa_b_out;      /* self_attn: [3E][E], [3E], [E][E], [E] */
+  const float *ca_w_in, *ca_b_in, *ca_w_out, *ca_b_out;      /* multihead_attn */
+  const float *w1, *b1, *w2, *b2;                            /* [F][E], [F], [E][F], [E] */
+  const float *g1, *be1, *g2, *be2, *g3, *be3;               /* norm1..3 */
+  const float *g4, *be4;                                     /* the stack's norm; NULL: no y_out */
+  const void *img_ca_kv, *img_t_ca_kv;                       /* optional bf16x3 images of ca_w_in rows [E, 3E) (and transposed) */
+} hoisdf_decoder_layer_weights;
+typedef struct hoisdf_decoder_layer_grads {
+  float *dsa_w_in, *dsa_b_in, *dsa_w_out, *dsa_b_out, *dca_w_in, *dca_b_in, *dca_w_out, *dca_b_out, *dw1, *db1, *dw2, *db2,
+      *dg1, *dbe1, *dg2, *dbe2, *dg3, *dbe3, *dg4, *dbe4;
+} hoisdf_decoder_layer_grads;
+long hoisdf_decoder_layer_saved_bytes(const hoisdf_decoder_layer_desc* desc);
+long hoisdf_decoder_layer_workspace_bytes(const hoisdf_decoder_layer_desc* desc, int backward_pass);
+int hoisdf_decoder_layer_fwd(const float* tgt, const float* memory, const float* query_pos, const uint8_t* tgt_mask,
+                             const hoisdf_decoder_layer_weights* weights, const hoisdf_decoder_layer_desc* desc, float* out,
+                             float* y_out, void* saved, long saved_bytes, void* workspace, long workspace_bytes, void* stream);
+int hoisdf_decoder_layer_bwd(const float* tgt, const float* memory, const uint8_t* tgt_mask, const float* out,
+                             const hoisdf_decoder_layer_weights* weights, const hoisdf_decoder_layer_desc* desc, const void* saved,
+                             long saved_bytes, const float* g_out, const float* g_y, float* d_tgt, float* d_memory,
+                             int accumulate_memory, float* d_query_pos, const hoisdf_decoder_layer_grads* grads, void* workspace,
+                             long workspace_bytes, void* stream);
+
 /* ---- K12: vote aggregation ----------------------------------------------------------------
  * reference: common/nets/loss.py:31-56.  off [L][B][P][J*3], cls [L][B][P][J] (batch-first
  * rows), pts [B][P][3].  joints[l][b][j] = sum_p softmax_p(cls)[p] * (pts[p] + off[p][j]).

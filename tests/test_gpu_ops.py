@@ -896,3 +896,46 @@ def test_coarse_encoder_layer_entry_equals_the_op_chain(B, S, nq, ni, p, det):
             assert torch.equal(a, b), what
         else:
             assert_close(a, b, rel=2e-5, what=what)
+
+
+@pytest.mark.parametrize("B,S,kv,p", [(2, 64, 48, 0.0), (3, 700, 600, 0.1), (4, 2048, 1536, 0.1)])
+def test_coarse_decoder_layer_entry_equals_the_op_chain(B, S, kv, p):
+    """hoisdf_decoder_layer_fwd / _bwd (csrc/layers.hip) against the op-by-op decoder stack of nets/blocks.py: same kernels, same
+    dropout seeds.  Deterministic mode (order-fixed kernels): forward bit-identical; the gradients differ only by the order in which
+    the branches of a multi-consumer tensor are added (autograd's accumulation order vs the entry's epilogue adds): 1e-5 of scale."""
+    from hoisdf_amd.nets import blocks as BL
+    O = ops()
+    torch.manual_seed(3)
+    dec = BL.TransformerDecoder(256, 4, 2, 1024, p).to(DEV).train()
+    for prm in dec.parameters():
+        if prm.dim() > 1:
+            torch.nn.init.xavier_uniform_(prm)
+        else:
+            torch.nn.init.normal_(prm, 1.0 if prm.shape[0] == 256 and prm.abs().max() > 0.5 else 0.0, 0.1)
+    Q = 17
+    mask = (torch.rand(Q, Q) < 0.2)
+    mask[torch.arange(Q), torch.arange(Q)] = False
+    mask_u8 = mask.to(torch.uint8).to(DEV)
+    mem0, qe0 = rnd(B, S, 256, seed=8), rnd(Q, 256, seed=9) * 0.5
+    g = rnd(2, B, Q, 256, seed=10).to(DEV)
+    res = {}
+    keep, keep_det = O._DECODER_LAYER_C, O.deterministic()
+    O.set_deterministic(True)
+    try:
+        for coarse in (True, False):
+            O._DECODER_LAYER_C = coarse
+            O.manual_seed(77)
+            mem = mem0.to(DEV).requires_grad_(True)
+            qe = qe0.to(DEV).requires_grad_(True)
+            dec.zero_grad(set_to_none=True)
+            assert O.decoder_layer_ok(p, mem, qe) == coarse
+            hs = dec(mem, qe, mask_u8, kv)
+            (hs * g).sum().backward()
+            res[coarse] = [hs.detach(), mem.grad.clone(), qe.grad.clone()] + [prm.grad.clone() for prm in dec.parameters()]
+    finally:
+        O._DECODER_LAYER_C = keep
+        O.set_deterministic(keep_det)
+    assert torch.equal(res[True][0], res[False][0])
+    names = ["d memory", "d query_embed"] + ["d " + n for n, _ in dec.named_parameters()]
+    for what, a, b in zip(names, res[True][1:], res[False][1:]):
+        assert_close(a, b, rel=1e-5, what=what)
