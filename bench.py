@@ -459,7 +459,7 @@ def main():
             ("emu_kc_kernel (linear fwd + grad-input)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
             ("emu_dw_kernel (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
             ("emu_attn_fwd_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
-            ("emu_attn_bwd16_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
+            ("emu_attn_bwd_stag_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
             ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
             ("gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)",
              ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] + (sq if args.gemm == "split" else []), "split"),
