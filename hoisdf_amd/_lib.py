@@ -81,6 +81,15 @@ class EncoderLayerGrads(C.Structure):
     _fields_ = [("d" + n, C.c_void_p) for n in _ENC_W]
 
 
+_SDF_G = ("d_sdfin_w0", "d_sdfin_b0", "d_sdfin_w1", "d_sdfin_b1", "d_dec_w0", "d_dec_b0", "d_dec_w1", "d_dec_b1", "d_dec_w2", "d_dec_b2",
+          "d_dec_w3", "d_dec_b3", "d_dec_w4", "d_dec_b4")
+
+
+class SdfWeightGrads(C.Structure):
+    """include/hoisdf.h hoisdf_sdf_weight_grads"""
+    _fields_ = [(n, C.c_void_p) for n in _SDF_G]
+
+
 _P, _I, _L, _F, _U64, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_double
 _PYR = C.POINTER(Pyramid)
 _SDFW = C.POINTER(SdfWeights)
@@ -136,6 +145,8 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_layernorm_rows_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
     "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "hoisdf_sdf_query_train_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P, _L, _P],
+    "hoisdf_sdf_query_bwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _SDFW, _F, _F, _P, _L, _P, _P, _P, _L, _P],
     "hoisdf_sdf_infer_count": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
     "hoisdf_sdf_infer": [_PYR, _P, _P, _P, _F, _I, _I, _P, _P, _I, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P],
     "hoisdf_decoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
@@ -154,6 +165,8 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
           "hoisdf_sdf_infer_workspace": ([_L, _I, _I], C.c_long),
+          "hoisdf_sdf_query_train_saved_bytes": ([_L, _I], C.c_long),
+          "hoisdf_sdf_query_train_workspace_bytes": ([_L, _I, _I], C.c_long),
           "hoisdf_decoder_layer_saved_bytes": ([_P], C.c_long),
           "hoisdf_decoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_encoder_layer_saved_bytes": ([_P], C.c_long),

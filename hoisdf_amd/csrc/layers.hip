@@ -7,30 +7,10 @@
 // on the bf16 MFMA pipe (hoisdf_linear_*_emu; hoisdf_set_gemm_emu(0) / HOISDF_GEMM=f32: the exact-f32 kernels), attention as
 // the descriptor says.  The opt-in reduced-operand modes (split precision, f16 eval attention) are not offered here.
 // hoisdf_amd/ops.py's encoder_layer autograd node is a thin wrapper of these two calls.
-#include "common.h"
+#include "chain.h"
 
 namespace hoisdf {
 namespace {
-
-constexpr long EMU_MIN_ROWS = 2048;      // below: a handful of tiles, latency-bound - the exact-f32 kernel
-constexpr long EMU_DW_MIN_ROWS = 8192;   // grad-weight contracts over the rows: >= 32 slabs per slice at 256 slices
-
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// bump allocator over a caller buffer; with base == nullptr it only measures
-struct Bump {
-  char* base; long cap; long off = 0; bool overflow = false;
-  Bump(void* b, long c) : base(static_cast<char*>(b)), cap(c) {}
-  void* take(long bytes) {
-    off = (off + 255) & ~255L;
-    const long at = off;
-    off += bytes;
-    if (!base) return nullptr;
-    if (off > cap) { overflow = true; return nullptr; }
-    return base + at;
-  }
-  float* floats(long n) { return static_cast<float*>(take(n * 4)); }
-};
 
 // dst[g][r][:] (group stride dst_gs floats) (+)= src[g][r][:] (group stride src_gs) for r < rows, E floats a row (E % 4 == 0)
 __global__ void rows_copy_add_kernel(float* __restrict__ dst, long dst_gs, const float* __restrict__ src, long src_gs, int rows, int E4,
@@ -49,78 +29,6 @@ int rows_copy_add(float* dst, long dst_gs, const float* src, long src_gs, int gr
   if (total == 0) return HOISDF_OK;
   hipLaunchKernelGGL(rows_copy_add_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, dst, dst_gs, src, src_gs, rows, E / 4, total, add);
   return check_launch("encoder_layer rows copy/add");
-}
-
-struct Ctx {
-  hipStream_t st; void* stream;
-  Bump* ws;
-  bool dry;          // measuring pass: no launches
-  bool emu;          // library mode at entry
-  int rc = HOISDF_OK;
-  bool ok() const { return rc == HOISDF_OK; }
-};
-
-bool emu_rows(const Ctx& c, long M, const float* a, long lda, int contraction) {
-  // (dry pass: pointers are null - assume aligned, which the real pass then checks again; the workspace is an upper bound)
-  return c.emu && M >= EMU_MIN_ROWS && contraction % 4 == 0 && lda % 4 == 0 && (c.dry || al16(a));
-}
-const void* image_of(Ctx& c, const void* given, const float* W, int ldw, int N, int K, int transpose) {
-  if (given) return given;
-  void* img = c.ws->take(hoisdf_linear_emu_image_bytes(transpose ? K : N, transpose ? N : K));
-  if (c.dry) return nullptr;
-  if (!img) { c.rc = HOISDF_ERR_WORKSPACE; return nullptr; }
-  c.rc = hoisdf_linear_emu_prepare(W, ldw, N, K, transpose, img, c.stream);
-  return img;
-}
-void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const void* img, const float* b, float* y, int ldy, long M, int N,
-             int K, int act, float p, uint64_t seed, uint32_t* bits) {
-  if (!c.ok()) return;
-  if (emu_rows(c, M, x, ldx, K)) {
-    const void* im = image_of(c, img, W, ldw, N, K, 0);
-    if (c.dry || !c.ok()) return;
-    c.rc = hoisdf_linear_fwd_emu(x, ldx, im, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
-    return;
-  }
-  if (c.dry) return;
-  c.rc = hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
-}
-void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* W, int ldw, const void* img_t, float* dx,
-                   int lddx, long M, int N, int K, int accumulate) {
-  if (!c.ok()) return;
-  if (!bits) p = 0.f;
-  if (emu_rows(c, M, dy, lddy, N)) {
-    const void* im = image_of(c, img_t, W, ldw, N, K, 1);
-    if (c.dry || !c.ok()) return;
-    c.rc = hoisdf_linear_bwd_input_emu(dy, lddy, bits, p, im, dx, lddx, M, N, K, accumulate, c.stream);
-    return;
-  }
-  if (c.dry) return;
-  c.rc = hoisdf_linear_bwd_input(dy, lddy, bits, p, W, ldw, dx, lddx, M, N, K, accumulate, c.stream);
-}
-// dW / db zero on entry (the exact-f32 kernel accumulates, the emulated one overwrites)
-void lin_bwd_weight(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* x, int ldx, float* dW, float* db, long M,
-                    int N, int K) {
-  if (!c.ok()) return;
-  if (!bits) p = 0.f;
-  const bool emu = c.emu && M >= EMU_DW_MIN_ROWS && (N < K ? N : K) >= 64 && N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 &&
-                   (c.dry || (al16(dy) && al16(x) && al16(dW)));
-  if (emu) {
-    const long nws = hoisdf_linear_bwd_weight_emu_workspace(M, N, K);
-    float* w = c.ws->floats(nws > 4 ? nws : 4);   // (scratch of consecutive calls is not recycled: earlier launches may still read theirs)
-    if (!c.dry) {
-      if (!w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-      c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K, db, M, N, K, w, nws, c.stream);
-    }
-    return;
-  }
-  long nws = 0; float* w = nullptr;
-  if (deterministic_mode()) {
-    nws = hoisdf_linear_bwd_weight_workspace(M, N, K);
-    if (nws > 0) w = c.ws->floats(nws);
-    if (!c.dry && nws > 0 && !w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-  }
-  if (c.dry) return;
-  c.rc = hoisdf_linear_bwd_weight(dy, lddy, bits, p, x, ldx, dW, K, db, M, N, K, w, nws, c.stream);
 }
 
 struct Geo {

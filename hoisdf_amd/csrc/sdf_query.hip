@@ -205,3 +205,134 @@ extern "C" int hoisdf_sdf_infer(const hoisdf_pyramid* pyr, const float* center, 
   if (pe_out) rc = hoisdf_gather_rows(pe, 30, sel, ns, 30, pe_out, 30, stream);
   return rc;
 }
+
+// ============================================================================================================================
+// The TRAINING-time SDF query (main/model.py:181-244 sdf_forward with gradients: the two SDF-loss queries of a step) as one
+// call per direction: the dataflow of hoisdf_sdf_query_fwd with the ReLU / dropout sign bitmaps and the activations the backward
+// needs kept in a caller-provided `saved` buffer, and hoisdf_sdf_query_bwd = head -> decoder layers 3..0 (the skip
+// concatenation's gradient is the layer-2 input gradient itself: layer 0's input gradient is accumulated into its x0 columns)
+// -> linear_sdfin -> scatter-add into the pyramid gradient.  Weights: the folded hoisdf_sdf_weights of the forward-only entry;
+// the gradients come back in the same (padded) layouts.
+// ============================================================================================================================
+#include "chain.h"
+
+namespace {
+struct TrainSaved { float *feat, *ha, *cat, *h0, *h2, *h3, *raw; uint32_t *ba, *bf, *b0, *b1, *b2, *b3; };
+inline long bits_words(int N) { return (N + 31) / 32; }
+void train_carve(long n, int C, Bump& b, TrainSaved& s) {
+  s.feat = b.floats(n * C); s.ha = b.floats(n * HID0); s.cat = b.floats(n * CAT_LD); s.h0 = b.floats(n * HID0); s.h2 = b.floats(n * HID0);
+  s.h3 = b.floats(n * HID0); s.raw = b.floats(n);
+  s.ba = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.bf = static_cast<uint32_t*>(b.take(n * bits_words(LAT) * 4));
+  s.b0 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b1 = static_cast<uint32_t*>(b.take(n * bits_words(H1 + 1) * 4));
+  s.b2 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b3 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4));
+}
+}  // namespace
+
+extern "C" long hoisdf_sdf_query_train_saved_bytes(long n_rows, int C) {
+  if (n_rows <= 0 || C <= 0) return 0;
+  Bump b(nullptr, 0); TrainSaved s;
+  train_carve(n_rows, C, b, s);
+  return b.off + 256;
+}
+
+static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n, int rps, const float* center,
+                             const float* cam_intr, float scale, int img_h, int img_w, const hoisdf_sdf_weights* w, float clamp, float drop_p,
+                             uint64_t seed, float* sdf, float* pe, float* cam_out, Bump& saved, Bump& ws, bool dry, void* stream) {
+  Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
+  TrainSaved s;
+  const int C = w ? w->C : 1;
+  train_carve(n, C, saved, s);
+  if (!dry) {
+    c.rc = hoisdf_project_gather_fwd(pyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, s.feat, C, cam_out, nullptr, stream);
+    if (c.ok()) c.rc = hipMemsetAsync(s.cat, 0, sizeof(float) * n * CAT_LD, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;   // pad columns
+  }
+  float* x0 = dry ? nullptr : s.cat + X0_COL;
+  // linear_sdfin: C -> 512 -> 256, ReLU after both (main/model.py:63-69)
+  lin_fwd(c, s.feat, C, w->sdfin_w0, C, nullptr, w->sdfin_b0, s.ha, HID0, n, HID0, C, 1, 0.f, 0, s.ba);
+  lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, nullptr, w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf);
+  if (!dry && c.ok()) c.rc = hoisdf_posenc_fwd(points, n, s.cat, CAT_LD, X0_COL + LAT, pe, stream);
+  // decoder (common/nets/sdf_net.py:87-122); layer i draws dropout stream seed + i
+  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, nullptr, w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0);
+  lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, nullptr, w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1);
+  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, nullptr, w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2);
+  lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, nullptr, w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3);
+  if (!dry && c.ok()) c.rc = hoisdf_sdf_head_fwd(s.h3, HID0, w->dec_w4, w->dec_b4, s.raw, sdf, n, HID0, clamp, stream);
+  return c.rc;
+}
+
+static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* points, const int32_t* sample_idx, long n, int rps, const float* center,
+                              const float* cam_intr, float scale, int img_h, int img_w, const hoisdf_sdf_weights* w, float clamp, float drop_p,
+                              const float* d_sdf, const hoisdf_sdf_weight_grads* G, Bump& saved, Bump& ws, bool dry, void* stream) {
+  Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
+  TrainSaved s;
+  const int C = w ? w->C : 1;
+  train_carve(n, C, saved, s);
+  float* dh3 = ws.floats(n * HID0); float* dh2 = ws.floats(n * HID0); float* dcat = ws.floats(n * CAT_LD); float* dh0 = ws.floats(n * HID0);
+  float* dha = ws.floats(n * HID0); float* dfeat = ws.floats(n * (long)C);
+  if (!dry && (!dh3 || !dh2 || !dcat || !dh0 || !dha || !dfeat)) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
+  if (!dry) c.rc = hoisdf_sdf_head_bwd(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, stream);
+  lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, nullptr, dh2, HID0, n, HID0, HID0, 0);
+  lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0);
+  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, nullptr, dcat, CAT_LD, n, HID0, CAT_LD, 0);
+  lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD);
+  lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, nullptr, dh0, HID0, n, H1 + 1, HID0, 0);
+  lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0);
+  // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is dense [512][289]
+  float* dx0 = dry ? nullptr : dcat + X0_COL;
+  const float* x0 = dry ? nullptr : s.cat + X0_COL;
+  lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, nullptr, dx0, CAT_LD, n, HID0, X0, 1);
+  lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0);
+  // linear_sdfin: its output sits in x0[:, 0:256] (positional encoding / xyz columns carry no gradient)
+  lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, nullptr, dha, HID0, n, LAT, HID0, 0);
+  lin_bwd_weight(c, dx0, CAT_LD, s.bf, 0.f, s.ha, HID0, G->d_sdfin_w1, G->d_sdfin_b1, n, LAT, HID0);
+  lin_bwd_input(c, dha, HID0, s.ba, 0.f, w->sdfin_w0, C, nullptr, dfeat, C, n, HID0, C, 0);
+  lin_bwd_weight(c, dha, HID0, s.ba, 0.f, s.feat, C, G->d_sdfin_w0, G->d_sdfin_b0, n, HID0, C);
+  if (!dry && c.ok() && dpyr)
+    c.rc = hoisdf_project_gather_bwd(dpyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, dfeat, C, stream);
+  if (c.ok() && !dry && ws.overflow) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
+  return c.rc;
+}
+
+extern "C" long hoisdf_sdf_query_train_workspace_bytes(long n_rows, int C, int backward_pass) {
+  if (n_rows <= 0 || C <= 0) return 0;
+  hoisdf_sdf_weights w{}; w.C = C; w.dec_ld0 = X0;
+  hoisdf_sdf_weight_grads G{};
+  Bump saved(nullptr, 0), ws(nullptr, 0);
+  if (backward_pass) (void)sdf_train_backward(nullptr, nullptr, nullptr, n_rows, 1, nullptr, nullptr, 1.f, 1, 1, &w, 0.f, 0.f, nullptr, &G, saved, ws, true, nullptr);
+  else (void)sdf_train_forward(nullptr, nullptr, nullptr, n_rows, 1, nullptr, nullptr, 1.f, 1, 1, &w, 0.f, 0.f, 0, nullptr, nullptr, nullptr, saved, ws, true, nullptr);
+  return ws.off + 256;
+}
+
+extern "C" int hoisdf_sdf_query_train_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                                          const float* center, const float* cam_intr, float scale, int img_h, int img_w,
+                                          const hoisdf_sdf_weights* w, float clamp, float drop_p, uint64_t seed, float* sdf, float* pe,
+                                          float* cam_out, void* saved, long saved_bytes, void* workspace, long workspace_bytes, void* stream) {
+  HOISDF_REQUIRE(pyr && points && w && sdf && saved && workspace && center && cam_intr, HOISDF_ERR_INVALID, "sdf_query_train_fwd: null pointer");
+  HOISDF_REQUIRE(n_rows > 0 && n_rows < (1L << 31) && w->C > 0 && w->C % 4 == 0 && w->dec_ld0 >= X0, HOISDF_ERR_INVALID, "sdf_query_train_fwd: bad sizes");
+  HOISDF_REQUIRE(drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "sdf_query_train_fwd: drop_p=%f", drop_p);
+  HOISDF_REQUIRE(saved_bytes >= hoisdf_sdf_query_train_saved_bytes(n_rows, w->C), HOISDF_ERR_WORKSPACE, "sdf_query_train_fwd: saved buffer of %ld bytes, need %ld",
+                 saved_bytes, hoisdf_sdf_query_train_saved_bytes(n_rows, w->C));
+  Bump sv(saved, saved_bytes), ws(workspace, workspace_bytes);
+  int rc = sdf_train_forward(pyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w, w, clamp, drop_p, seed, sdf, pe, cam_out,
+                             sv, ws, false, stream);
+  if (rc == HOISDF_OK && (sv.overflow || ws.overflow)) rc = HOISDF_ERR_WORKSPACE;
+  if (rc == HOISDF_ERR_WORKSPACE) set_error("sdf_query_train_fwd: workspace (%ld bytes) too small", workspace_bytes);
+  return rc;
+}
+
+extern "C" int hoisdf_sdf_query_bwd(const hoisdf_pyramid_grad* dpyr, const float* points, const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                                    const float* center, const float* cam_intr, float scale, int img_h, int img_w, const hoisdf_sdf_weights* w,
+                                    float clamp, float drop_p, const void* saved, long saved_bytes, const float* d_sdf,
+                                    const hoisdf_sdf_weight_grads* grads, void* workspace, long workspace_bytes, void* stream) {
+  HOISDF_REQUIRE(points && w && saved && d_sdf && grads && workspace && center && cam_intr, HOISDF_ERR_INVALID, "sdf_query_bwd: null pointer");
+  HOISDF_REQUIRE(grads->d_sdfin_w0 && grads->d_sdfin_b0 && grads->d_sdfin_w1 && grads->d_sdfin_b1 && grads->d_dec_w0 && grads->d_dec_b0 && grads->d_dec_w1 &&
+                     grads->d_dec_b1 && grads->d_dec_w2 && grads->d_dec_b2 && grads->d_dec_w3 && grads->d_dec_b3 && grads->d_dec_w4 && grads->d_dec_b4,
+                 HOISDF_ERR_INVALID, "sdf_query_bwd: every weight gradient buffer is required (zero-filled)");
+  HOISDF_REQUIRE(n_rows > 0 && n_rows < (1L << 31) && saved_bytes >= hoisdf_sdf_query_train_saved_bytes(n_rows, w->C), HOISDF_ERR_INVALID,
+                 "sdf_query_bwd: bad sizes / saved buffer");
+  Bump sv(const_cast<void*>(saved), saved_bytes), ws(workspace, workspace_bytes);
+  int rc = sdf_train_backward(dpyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w, w, clamp, drop_p, d_sdf, grads, sv, ws,
+                              false, stream);
+  if (rc == HOISDF_ERR_WORKSPACE) set_error("sdf_query_bwd: workspace (%ld bytes) too small", workspace_bytes);
+  return rc;
+}

@@ -124,6 +124,19 @@ class Model(nn.Module):
     def _sdf_rows(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None):
         """K1-K4 on a flat list of points: returns (sdf clamped (n,), sdf_raw (n,), pe (n,30), cam (n,3))."""
         c = self.cfg
+        dec = self.hand_sdf_decoder if kind == "hand" else self.obj_sdf_decoder
+        if (points.is_cuda and sample_idx is None and torch.is_grad_enabled() and ops.sdf_query_train_ok()
+                and pyr.C == self.linear_sdfin.layers[0].weight.shape[1]):
+            # one C-ABI call per direction (hoisdf_sdf_query_train_fwd / hoisdf_sdf_query_bwd)
+            lin = self.linear_sdfin.layers
+            routed = [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias]
+            for i in range(4):
+                l = getattr(dec, f"linh{i}")
+                routed += [l.effective_weight(), l.bias]
+            routed += [dec.linh4.weight, dec.linh4.bias]
+            sdf, pe, cam = ops.sdf_query_train(self._query_weights(kind), pyr, points, center, cam_intr, scale, c.ClampingDistance,
+                                               c.input_img_shape, dec.dropout_prob if dec.training else 0.0, routed)
+            return sdf, None, pe, cam
         feat, cam = ops.project_gather(pyr, points, center, cam_intr, scale, c.input_img_shape, sample_idx)
         fea = self.linear_sdfin(feat)
         pts = points.reshape(-1, 3)
@@ -131,7 +144,6 @@ class Model(nn.Module):
         # decoder input rows [feat256 | pe30 | xyz3] in a 292-wide (16-byte aligned) buffer
         n = pts.shape[0]
         x0 = torch.cat([fea, pe, pts, pts.new_zeros(n, 3)], dim=1)[:, :c.hidden_dim + c.PointFeatSize]
-        dec = self.hand_sdf_decoder if kind == "hand" else self.obj_sdf_decoder
         sdf, raw = dec.forward_clamped(x0, c.ClampingDistance)
         return sdf, raw, pe, cam
 

@@ -640,6 +640,104 @@ def sdf_query(weights: SdfQueryWeights, pyr: "PyramidNHWC", points, center, cam_
     return sdf, raw, pe, cam, (feat if feat is not None else feat_out)
 
 
+class _SdfQueryTrain(torch.autograd.Function):
+    """main/model.py:181-244 with gradients (the two SDF-loss queries of a training step) through the coarse entries
+    hoisdf_sdf_query_train_fwd / hoisdf_sdf_query_bwd (csrc/sdf_query.hip): gather -> linear_sdfin -> posenc -> decoder -> head in
+    one call, and the whole backward (down to the pyramid-gradient scatter) in another.  The values come from the cached folded
+    weight descriptor (SdfQueryWeights); the tensor arguments after the levels only route the gradients: linear_sdfin w0, b0, w1,
+    b1, then (effective weight, bias) of decoder layers 0-3 - autograd continues into the weight-norm fold -, then linh4 w, b."""
+
+    @staticmethod
+    def forward(ctx, points, center, cam_intr, scale, img_hw, clamp, drop_p, acc, wq, n_levels, *tensors):
+        from ._lib import lib
+        levels, params = tensors[:n_levels], tensors[n_levels:]
+        assert len(params) == 14
+        pyr = PyramidNHWC(levels)
+        pts = points.reshape(-1, 3).contiguous()
+        _chk(pts, center, cam_intr)
+        n = pts.shape[0]
+        rps = points.shape[-2]
+        dev = pts.device
+        w = wq.get()
+        assert w.C == pyr.C
+        seed = next_seed() if drop_p > 0 else 0
+        n_saved = lib().hoisdf_sdf_query_train_saved_bytes(n, w.C)
+        n_ws = lib().hoisdf_sdf_query_train_workspace_bytes(n, w.C, 0)
+        saved = torch.empty(n_saved, device=dev, dtype=torch.uint8)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        sdf = torch.empty(n, device=dev)
+        pe = torch.empty(n, 30, device=dev)
+        cam = torch.empty(n, 3, device=dev)
+        st = pyr.struct()
+        call("hoisdf_sdf_query_train_fwd", C.byref(st), _p(pts), None, n, rps, _p(center), _p(cam_intr), float(scale), img_hw[0], img_hw[1],
+             C.byref(w), float(clamp), float(drop_p), seed, _p(sdf), _p(pe), _p(cam), _p(saved), n_saved, _p(ws), n_ws, _st())
+        ctx.save_for_backward(pts, center, cam_intr, saved)
+        ctx.meta = (w, wq, float(scale), img_hw, float(clamp), float(drop_p), rps, [tuple(l.shape) for l in levels], pyr.B, acc,
+                    [tuple(t.shape) for t in params])
+        ctx.mark_non_differentiable(pe, cam)
+        return sdf, pe, cam
+
+    @staticmethod
+    def backward(ctx, d_sdf, _dpe, _dcam):
+        from ._lib import lib, SdfWeightGrads, _SDF_G
+        pts, center, cam_intr, saved = ctx.saved_tensors
+        w, _wq, scale, img_hw, clamp, drop_p, rps, shapes, B, acc, pshapes = ctx.meta
+        dev = pts.device
+        n, Cc = pts.shape[0], w.C
+        sizes = [512 * Cc, 512, 256 * 512, 256, 512 * 289, 512, 224 * 512, 224, 512 * 516, 512, 512 * 512, 512, 512, 1]
+        buf = _zeros(sum(sizes), dev)
+        parts, off = [], 0
+        for m in sizes:
+            parts.append(buf[off:off + m])
+            off += m
+        G = SdfWeightGrads(**{k: t.data_ptr() for k, t in zip(_SDF_G, parts)})
+        if acc is not None:
+            grads = acc.bufs
+            acc.flat.record_stream(torch.cuda.current_stream(dev))
+        else:
+            grads = [torch.zeros(sh, device=dev, dtype=torch.float32) for sh in shapes]
+        g = Pyramid()
+        g.n_levels, g.B = len(grads), B
+        for i, t in enumerate(grads):
+            g.data[i] = t.data_ptr()
+            g.C[i], g.H[i], g.W[i] = t.shape[3], t.shape[1], t.shape[2]
+        n_ws = lib().hoisdf_sdf_query_train_workspace_bytes(n, Cc, 1)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        d_sdf = d_sdf.reshape(-1).contiguous()
+        call("hoisdf_sdf_query_bwd", C.byref(g), _p(pts), None, n, rps, _p(center), _p(cam_intr), scale, img_hw[0], img_hw[1], C.byref(w),
+             clamp, drop_p, _p(saved), saved.numel(), _p(d_sdf), C.addressof(G), _p(ws), n_ws, _st())
+        dw2p = parts[8].view(512, 516)
+        pg = [parts[0].view(512, Cc), parts[1], parts[2].view(256, 512), parts[3],
+              parts[4].view(512, 289), parts[5], parts[6].view(224, 512)[:223], parts[7][:223],
+              torch.cat([dw2p[:, :223], dw2p[:, 224:513]], dim=1), parts[9], parts[10].view(512, 512), parts[11],
+              parts[12].view(1, 512), parts[13]]
+        pg = [t.reshape(sh) for t, sh in zip(pg, pshapes)]
+        if acc is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            acc.events.append(ev)
+            acc.touched = True
+            lg = [None] * len(shapes)
+        else:
+            lg = grads
+        return (None,) * 10 + tuple(lg) + tuple(pg)
+
+
+_SDF_QUERY_TRAIN_C = __import__("os").environ.get("HOISDF_SDF_QUERY_TRAIN", "c") != "ops"
+
+
+def sdf_query_train_ok() -> bool:
+    """default arithmetic only, and not while bench.py brackets the individual calls (as _coarse_layer_ok)"""
+    from . import _lib
+    return _SDF_QUERY_TRAIN_C and not _GEMM_SPLIT and _lib._timer is None
+
+
+def sdf_query_train(weights: SdfQueryWeights, pyr: "PyramidNHWC", points, center, cam_intr, scale, clamp, img_hw, drop_p, params):
+    """-> (sdf clamped (n,), pe (n,30), cam (n,3)); differentiable w.r.t. the pyramid levels and the 14 routed parameters."""
+    return _SdfQueryTrain.apply(points, center.contiguous(), cam_intr.contiguous(), scale, tuple(img_hw), clamp, drop_p, pyr.acc, weights,
+                                len(pyr.levels), *pyr.levels, *params)
+
+
 # ---------------------------------------------------------------------------------------------
 # dense lattice + selection (no grad)
 # ---------------------------------------------------------------------------------------------

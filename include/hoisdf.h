@@ -258,6 +258,30 @@ int hoisdf_select_smallest_abs(const float* sdf_raw, const int32_t* offsets, con
 /* out[r][0:width] = src[sel[r]][0:width] */
 int hoisdf_gather_rows(const float* src, int lds, const int32_t* sel, long n_sel, int width,
                        float* out, int ldo, void* stream);
+/* ---- the training-time SDF query, one call per direction (SURVEY.md section 8(b) `hoisdf_sdf_query_bwd`) ------------------
+ * reference: Model.sdf_forward with gradients (main/model.py:181-244; the two SDF-loss queries of a training step).
+ * hoisdf_sdf_query_train_fwd = the dataflow of hoisdf_sdf_query_fwd keeping, in `saved` (hoisdf_sdf_query_train_saved_bytes),
+ *   what the backward needs: gathered rows, activations, the six ReLU / dropout sign bitmaps, the tanh output.
+ * hoisdf_sdf_query_bwd: d_sdf [n_rows] (gradient of the CLAMPED sdf) -> weight gradients in the layouts of hoisdf_sdf_weights
+ *   (d_dec_w0 dense [512][289]; d_dec_w1 [224][512] and d_dec_b1 [224] with the pad row; d_dec_w2 [512][516] with the pad
+ *   columns; all zero on entry), and the pyramid gradient scatter-ADDED into dpyr (NULL: skipped).  The weight-norm fold's own
+ *   backward (hoisdf_weightnorm_bwd on the effective-weight gradients) is the caller's. */
+typedef struct hoisdf_sdf_weight_grads {
+  float *d_sdfin_w0, *d_sdfin_b0, *d_sdfin_w1, *d_sdfin_b1;
+  float *d_dec_w0, *d_dec_b0, *d_dec_w1, *d_dec_b1, *d_dec_w2, *d_dec_b2, *d_dec_w3, *d_dec_b3, *d_dec_w4, *d_dec_b4;
+} hoisdf_sdf_weight_grads;
+long hoisdf_sdf_query_train_saved_bytes(long n_rows, int C);
+long hoisdf_sdf_query_train_workspace_bytes(long n_rows, int C, int backward_pass);
+int hoisdf_sdf_query_train_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
+                               int rows_per_sample, const float* center, const float* cam_intr, float scale, int img_h, int img_w,
+                               const hoisdf_sdf_weights* w, float clamp, float drop_p, uint64_t seed, float* sdf, float* pe,
+                               float* cam_out, void* saved, long saved_bytes, void* workspace, long workspace_bytes, void* stream);
+int hoisdf_sdf_query_bwd(const hoisdf_pyramid_grad* dpyr, const float* points, const int32_t* sample_idx, long n_rows,
+                         int rows_per_sample, const float* center, const float* cam_intr, float scale, int img_h, int img_w,
+                         const hoisdf_sdf_weights* w, float clamp, float drop_p, const void* saved, long saved_bytes,
+                         const float* d_sdf, const hoisdf_sdf_weight_grads* grads, void* workspace, long workspace_bytes,
+                         void* stream);
+
 /* ---- sdf_infer in two calls (SURVEY.md section 8(b) `hoisdf_sdf_infer`) ----------------------------------------------
  * reference: Model.sdf_infer (main/model.py:246-355): dense sheared lattice inside the bbox -> SDF of every survivor ->
  * the num_points survivors of every sample with the smallest |sdf| (ascending) -> their points (scaled frame), clamped

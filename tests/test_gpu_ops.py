@@ -939,3 +939,51 @@ def test_coarse_decoder_layer_entry_equals_the_op_chain(B, S, kv, p):
     names = ["d memory", "d query_embed"] + ["d " + n for n, _ in dec.named_parameters()]
     for what, a, b in zip(names, res[True][1:], res[False][1:]):
         assert_close(a, b, rel=1e-5, what=what)
+
+
+@pytest.mark.parametrize("B,P", [(2, 300), (2, 1536)])
+def test_coarse_sdf_query_train_entries_equal_the_op_chain(B, P):
+    """hoisdf_sdf_query_train_fwd / hoisdf_sdf_query_bwd (one call per direction) against the op-by-op training-time SDF query of
+    Model._sdf_rows (gather, linear_sdfin, posenc, weight-normed decoder, head; dropout off so that both draw no seeds): clamped
+    sdf, positional encoding, camera points, every parameter gradient and the pyramid gradient."""
+    from hoisdf_amd.model import get_model
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.nets import mano as MANO
+    O = ops()
+    c = Config(); c.resnet_type = 18; c.apply_setting("dexycb"); c.num_samp_hand, c.num_samp_obj = 64, 32
+    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
+    sd = model.state_dict()
+    for k in sd:
+        if not k.startswith("mano_head"):
+            sd[k] = T.det_param(k, sd[k].shape)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    inputs, _, meta = T.synthetic_batch(B, P, 8, seed=5)
+    pts = (inputs["hand_sdf_points"] * 1.2).to(DEV)
+    root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
+    gs = rnd(B * P, seed=3).to(DEV)
+    res = {}
+    keep, keep_det = O._SDF_QUERY_TRAIN_C, O.deterministic()
+    O.set_deterministic(True)
+    try:
+        for coarse in (True, False):
+            O._SDF_QUERY_TRAIN_C = coarse
+            model.zero_grad(set_to_none=True)
+            levels = [v.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True) for v in T.synthetic_pyramid(B, seed=4).values()]
+            pyr = O.PyramidNHWC(levels)
+            sdf, raw, pe, cam = model._sdf_rows(pyr, pts, root, K, 3.1, "hand")
+            assert (raw is None) == coarse                              # the coarse path does not hand the unclamped value back
+            (sdf * gs).sum().backward()
+            named = [(n, p.grad.clone()) for n, p in model.named_parameters() if p.grad is not None]
+            res[coarse] = (sdf.detach(), pe, cam, [lv.grad.clone() for lv in levels], named)
+    finally:
+        O._SDF_QUERY_TRAIN_C = keep
+        O.set_deterministic(keep_det)
+    a, b = res[True], res[False]
+    assert_close(a[0], b[0], rel=5e-6, what="sdf")
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for i, (x, y) in enumerate(zip(a[3], b[3])):
+        assert_close(x, y, rel=2e-5, what=f"d pyramid level {i}")
+    assert [n for n, _ in a[4]] == [n for n, _ in b[4]] and len(a[4]) == 18
+    for (n, x), (_, y) in zip(a[4], b[4]):
+        assert_close(x, y, rel=2e-5, what="d " + n)
