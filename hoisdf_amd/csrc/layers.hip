@@ -1,12 +1,12 @@
 // Coarse C entries of SURVEY.md section 8(b): one transformer encoder layer (common/nets/transformer.py:286-302,
 // TransformerEncoderLayer.forward_post, plus the stack's inter_norm of the layer output, :117-131) forward and backward as ONE
-// call each.  Host-side chains of the per-op launches in this library - in-projection, attention, out-projection, residual +
+// call each; further down the same for one decoder layer (:366-395).  Host-side chains of the per-op launches in this library - in-projection, attention, out-projection, residual +
 // dropout + LayerNorm, FFN with the fused ReLU / dropout epilogue and sign bitmap, second LayerNorm, inter_norm - on the caller's
 // stream, over caller-provided buffers: `saved` holds what the backward re-reads (activations, softmax statistics, the ReLU
 // bitmap), `workspace` is scratch.  The arithmetic follows the library defaults: linear layers of >= 2048 rows as fp32 emulated
 // on the bf16 MFMA pipe (hoisdf_linear_*_emu; hoisdf_set_gemm_emu(0) / HOISDF_GEMM=f32: the exact-f32 kernels), attention as
 // the descriptor says.  The opt-in reduced-operand modes (split precision, f16 eval attention) are not offered here.
-// hoisdf_amd/ops.py's encoder_layer autograd node is a thin wrapper of these two calls.
+// hoisdf_amd/ops.py's encoder_layer / decoder_layer autograd nodes are thin wrappers of these calls.
 #include "chain.h"
 
 namespace hoisdf {
