@@ -483,6 +483,8 @@ def main():
                            "peak": peak, "unit": "TFLOP/s",
                            "frac": round(d["tflops"] / peak, 4), "traffic": None,
                            "peak_note": peak_note,
+                           # the same achieved rate against the roof the exact-f32 kernels (dtype "f32" on the f32 MFMA) are bound by
+                           "frac_of_f32_mfma_peak": round(d["tflops"] / PEAK_F32_TFLOPS, 4),
                            "avg_launch_us": round(1e3 * d["total_ms"] / d["launches"], 2),
                            "launches_per_step": d["launches"] / timed_steps,
                            "ms_per_step": round(d["total_ms"] / timed_steps, 3),
