@@ -305,6 +305,7 @@ def gemm_split() -> bool:
 _GEMM_EMU = __import__("os").environ.get("HOISDF_GEMM", "emu") != "f32"
 _GEMM_EMU_MIN_ROWS = 2048            # below this a problem is a handful of tiles: latency-bound, stays on the f32 kernel
 _GEMM_EMU_DW_MIN_ROWS = 8192         # grad-weight: the contraction runs over the rows (>= 32 slabs per slice at 256 slices)
+_GEMM_EMU_DW_MIN_WIDTH = int(__import__("os").environ.get("HOISDF_EMU_DW_MIN_WIDTH", "64"))
 _EMU_IMAGES = {}                     # (data_ptr, shape, ld, transpose) -> [image, version key, event, build stream, owner]
 
 
@@ -415,7 +416,7 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
         call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
              _p(x_scale), _p(dy_scale), _p(ws), nb, _st())
         return
-    if (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= 64 and N % 4 == 0 and K % 4 == 0
+    if (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
             and dW.data_ptr() % 16 == 0):
         from ._lib import lib

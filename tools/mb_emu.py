@@ -13,7 +13,7 @@ def timeit(fn, iters=10, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
-shapes = [(65536, 1024, 256), (65536, 256, 1024), (65536, 768, 256), (65536, 256, 256), (294912, 256, 256), (49152, 1024, 992),
+shapes = [(294912, 60, 256), (294912, 20, 256), (65536, 1024, 256), (65536, 256, 1024), (65536, 768, 256), (65536, 256, 256), (294912, 256, 256), (49152, 1024, 992),
           (49152, 512, 512), (49152, 256, 256), (16384, 256, 256), (16384, 1024, 992), (49152, 512, 256)]
 print(f"{'M':>7} {'N':>5} {'K':>5} | emulated fwd / dX / dW TF-eq (us) | exact-f32 fwd / dX / dW TF")
 for M, N, K in shapes:
