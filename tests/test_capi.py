@@ -87,3 +87,28 @@ def test_collective_library_exports_its_header():
     syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\bT (hoisdf_\w+)", syms))
     assert declared <= exported, declared - exported
+
+
+def test_coarse_entries_size_queries_and_validation_need_no_gpu(lib):
+    """the module-granularity entries: size queries are pure host arithmetic (the same carving code as the real call, dry), and
+    malformed descriptors / null buffers are refused before any launch"""
+    import ctypes as C
+    d = _lib.EncoderLayerDesc(B=32, S=2048, E=256, F=1024, H=4, n_query=1536, n_inter=1536, eps=1e-5, drop_p=0.1, attention=2,
+                              attention_bwd_emulated=1, training=1)
+    saved = lib.hoisdf_encoder_layer_saved_bytes(C.addressof(d))
+    wf, wb = lib.hoisdf_encoder_layer_workspace_bytes(C.addressof(d), 0), lib.hoisdf_encoder_layer_workspace_bytes(C.addressof(d), 1)
+    assert saved > 2048 * 32 * 256 * 4 * 3 and wf > 0 and wb > wf                 # at least the q | k | v projections are kept
+    d.E = 250                                                                    # not a multiple of the head count / of 4
+    assert lib.hoisdf_encoder_layer_saved_bytes(C.addressof(d)) == -1
+    assert lib.hoisdf_encoder_layer_fwd(None, None, C.addressof(d), None, None, None, 0, None, 0, None) == -1
+    dd = _lib.DecoderLayerDesc(B=32, Q=17, S=2048, E=256, F=1024, H=4, kv_len=1536, eps=1e-5, drop_p=0.1, training=1)
+    assert lib.hoisdf_decoder_layer_saved_bytes(C.addressof(dd)) > 0 and lib.hoisdf_decoder_layer_workspace_bytes(C.addressof(dd), 1) > 0
+    dd.Q = 65                                                                    # the masked self-attention kernel holds <= 64 queries
+    assert lib.hoisdf_decoder_layer_saved_bytes(C.addressof(dd)) == -1
+    assert lib.hoisdf_sdf_query_train_saved_bytes(49152, 992) > 49152 * 992 * 4 and lib.hoisdf_sdf_query_train_workspace_bytes(49152, 992, 1) > 0
+    assert lib.hoisdf_sdf_infer_workspace(100000, 32, 992) > 0 and lib.hoisdf_sdf_infer_workspace(-1, 32, 992) == -1
+    assert lib.hoisdf_mano_dirs_image_floats() == 145 * 2334 + 16 * 778
+    assert lib.hoisdf_mano_head_fwd(None, 96, 0, None, 10, 4, None, None, None, None, None, None, None, None, None, 0, 0, None, None, None,
+                                    None, None) == -1 and b"null" in lib.hoisdf_last_error()
+    assert lib.hoisdf_mano_head_fwd(None, 96, 0, None, 10, 0, None, None, None, None, None, None, None, None, None, 0, 0, None, None, None,
+                                    None, None) == 0                                # zero hands: nothing to do
