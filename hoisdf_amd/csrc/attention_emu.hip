@@ -320,7 +320,7 @@ __device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((c
 // backward, fused dK / dV / dQ in one pass (5 GEMM-equivalents).  Block = 128 keys, 8 waves, wave = 16 keys (lane l: key l % 16,
 // k-group g = l / 16), every contraction on v_mfma_f32_16x16x32_bf16 - 16-wide tiles keep the per-lane state (K, V fragments 48
 // registers, dK, dV accumulators 32) under 256 registers, so two waves share a SIMD (a first form with 32 keys per wave on
-// 32x32x16 tiles needed > 400 registers, ran one wave per SIMD and took 3.4 ms where this one takes 2.3 ms at B = 32, S = 2048):
+// 32x32x16 tiles needed > 400 registers, ran one wave per SIMD and took 3.4 ms where this one takes 2.2 ms at B = 32, S = 2048):
 //   S, dP      [32 q x 16 keys] = two 16 x 16 tiles, A = Q / dO rows from LDS, B = the lane's K / V fragments (registers)
 //   dV^T, dK^T [64 d x 16 keys] = four tiles each, A = dO^T / Q^T fragments, B = Pd / dS straight from the S / dP accumulator
 //              registers (a lane holds q = 16 qh + 4 g + i: k-slot 8 g + i <-> q = 4 g + i, 8 g + 4 + i <-> q = 16 + 4 g + i)

@@ -1014,7 +1014,7 @@ _ATTN_BWD_EMU = __import__("os").environ.get("HOISDF_ATTN_BWD", "emu") != "f32"
 def _emu_bwd() -> bool:
     """Emulated attention calls run their backward emulated as well (default; HOISDF_ATTN_BWD=f32 keeps the exact-f32 fused
     backward next to the emulated forward): the 8-wave form of csrc/attention_emu.hip (16 keys per wave, two waves per SIMD)
-    measures 2.47 ms against 3.07 ms for the f32 kernel at B = 32, S = 2048 (tools/mb_attn_emu.py; the first, one-wave-per-SIMD
+    measures 2.2 ms against 3.07 ms for the f32 kernel at B = 32, S = 2048 (tools/mb_attn_emu.py; the first, one-wave-per-SIMD
     form was 3.4 ms).  It is order-fixed (no atomics), so it is also what deterministic mode uses."""
     return _ATTN_BWD_EMU or deterministic()
 
