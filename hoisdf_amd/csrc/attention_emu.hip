@@ -250,21 +250,27 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    // lazy rescale: the running reference m only moves when some query of the wave sees a score more than 2^8 above it (always
+    // on the first tile, almost never afterwards) - exp2(s - m) <= 256 stays exact through the three-way split, O / l and the LSE
+    // m + log2(l) are unchanged by the choice of reference, and the 32 multiplies of the accumulator are skipped
+    if (__any(mt > m + 8.f)) {
+      const float mn = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      lsum *= alpha;
+      m = mn;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - mn);
+      const float p = __builtin_amdgcn_exp2f(s[r] - m);
       ps += p;
       s[r] = p;
     }
-    lsum = lsum * alpha + ps;
-    m = mn;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    lsum += ps;
     if (a.drop_p > 0.f) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] *= drop_scale(rowkey, (uint32_t)(kt * 32 + CR(r, h)), a.thresh, a.inv_keep);
