@@ -1,0 +1,23 @@
+import sys, os, math
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from hoisdf_amd import ops as O
+dev = "cuda"
+def timeit(fn, iters=20, warm=5):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+shapes = [(65536, 1024, 256), (65536, 256, 1024), (65536, 768, 256), (65536, 256, 256), (294912, 256, 256), (49152, 1024, 992), (49152, 512, 512), (49152, 256, 256), (49152, 512, 992)]
+out = []
+for M, N, K in shapes:
+    x = torch.randn(M, K, device=dev); dy = torch.randn(M, N, device=dev)
+    dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    bits = torch.randint(-2**31, 2**31 - 1, (M, (N + 31) // 32), device=dev, dtype=torch.int32)
+    t3 = timeit(lambda: O._gemm_bwd_weight(dy, N, None, 0.0, x, K, dW, db, M, N, K))
+    t4 = timeit(lambda: O._gemm_bwd_weight(dy, N, bits, 0.1, x, K, dW, db, M, N, K))
+    out.append(f"{t3*1e6:5.0f}/{t4*1e6:5.0f}")
+print(os.environ.get("TAG", "?").ljust(8), " ".join(out), flush=True)

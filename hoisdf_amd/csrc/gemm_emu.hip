@@ -305,6 +305,12 @@ constexpr int DW_OP_U4 = 3 * 2 * DT;                     // 16-byte units per op
 constexpr int DW_STAGE_U4 = 2 * DW_OP_U4;
 constexpr unsigned DW_LDS_BYTES = 2u * DW_STAGE_U4 * 16u;   // 98 304
 
+// a value the compiler cannot prove wave-uniform (it depends on tid < 128, which is uniform per wave) into scalar registers
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
 struct DwArgs {
   const float* dy; long lddy;
   const float* x; long ldx;
@@ -354,7 +360,16 @@ __global__ __launch_bounds__(NT, DTK == 256 ? 1 : 2) void emu_dw_kernel(DwArgs g
   const int col0 = (isA ? n0 : k0) + 4 * cg;
   const int ncol = isA ? g.N : g.K;                      // multiples of 4 (checked by the host): a patch column group is all in or out
   const bool col_ok = stager && col0 < ncol;
-  const long ld = isA ? g.lddy : g.ldx;
+  // addresses: a wave-uniform row base (scalar registers: operand pointer + slab row * leading dimension + e rows) plus ONE
+  // per-thread byte offset that never changes (chunk rows + column group) - no vector address arithmetic in the slab loop
+  const long ld = uni64(isA ? g.lddy : g.ldx);
+  // (x addressed relative to dy: pointer arithmetic on a kernel argument keeps the global address space, an integer round trip
+  // would turn the loads into flat ones)
+  const char* opbase = reinterpret_cast<const char*>(g.dy) +
+                       (long)uni64(isA ? 0ul : (uint64_t)(reinterpret_cast<const char*>(g.x) - reinterpret_cast<const char*>(g.dy)));
+  const uint32_t voff = (uint32_t)(((long)c * 8 * ld + (col_ok ? col0 : 0)) * 4);
+  const char* bitbase = reinterpret_cast<const char*>(g.bits);
+  const uint32_t boff = (uint32_t)(((long)c * 8 * g.ldbits + ((col_ok ? col0 : 0) >> 5)) * 4);
   const float* src = (isA ? g.dy : g.x) + (col_ok ? col0 : 0);
   const uint32_t* bsrc = (MASK && isA) ? g.bits + ((col_ok ? col0 : 0) >> 5) : nullptr;
   const int bsh = col0 & 31;
@@ -364,11 +379,21 @@ __global__ __launch_bounds__(NT, DTK == 256 ? 1 : 2) void emu_dw_kernel(DwArgs g
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 #define DW_LOAD(sl)                                                                                                   \
   do {                                                                                                                \
-    const int mb_ = mbeg + (sl) * KS + c * 8;                                                                         \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
-      const int m_ = min(mb_ + e, g.M - 1);                                                                           \
-      rv[e] = *reinterpret_cast<const float4*>(src + (size_t)m_ * ld);                                                \
-      if (MASK) rm[e] = isA ? bsrc[(size_t)m_ * g.ldbits] : 0xffffffffu;                                              \
+    const int ms_ = mbeg + (sl) * KS;                        /* (uniform) first row of the slab */                    \
+    if (ms_ + KS <= g.M) {                                                                                            \
+      const char* sb_ = opbase + (size_t)ms_ * ld * 4;                                                                \
+      const char* mb2_ = bitbase + (size_t)ms_ * g.ldbits * 4;                                                        \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
+        rv[e] = *reinterpret_cast<const float4*>(sb_ + (size_t)e * ld * 4 + voff);                                    \
+        if (MASK) rm[e] = isA ? *reinterpret_cast<const uint32_t*>(mb2_ + (size_t)e * g.ldbits * 4 + boff) : 0xffffffffu; \
+      }                                                                                                               \
+    } else {                                                 /* the slab that crosses the end of the operands */      \
+      const int mb_ = ms_ + c * 8;                                                                                    \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
+        const int m_ = min(mb_ + e, g.M - 1);                                                                         \
+        rv[e] = *reinterpret_cast<const float4*>(src + (size_t)m_ * ld);                                              \
+        if (MASK) rm[e] = isA ? bsrc[(size_t)m_ * g.ldbits] : 0xffffffffu;                                            \
+      }                                                                                                               \
     }                                                                                                                 \
   } while (0)
 #define DW_STORE(st, sl)                                                                                              \
@@ -383,8 +408,11 @@ __global__ __launch_bounds__(NT, DTK == 256 ? 1 : 2) void emu_dw_kernel(DwArgs g
         v_.z = (nib_ & 4u) ? v_.z * g.ascale : 0.f;                                                                   \
         v_.w = (nib_ & 8u) ? v_.w * g.ascale : 0.f;                                                                   \
       }                                                                                                               \
-      if (mb_ + e >= mend || !col_ok) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
       rv[e] = v_;                                                                                                     \
+    }                                                                                                                 \
+    if (!col_ok || mbeg + (sl) * KS + KS > mend) {           /* (rare) rows past the slice, columns past the operand */ \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                                   \
+        if (mb_ + e >= mend || !col_ok) rv[e] = make_float4(0.f, 0.f, 0.f, 0.f);                                      \
     }                                                                                                                 \
     if (do_colsum) {                                                                                                  \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
