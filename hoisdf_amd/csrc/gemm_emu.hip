@@ -636,21 +636,24 @@ extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint
 
 namespace {
 // row slices for grad-weight: one workgroup per CU (256 slots), >= 8 slabs per slice
-// k-tile width: 256 (one workgroup per CU), or 128 (two per CU) when the 256-wide tiling leaves three tiles or fewer - there the
-// narrow form packs the last wave of slices better (measured, tools/mb_emu.py: 768 x 256 107 vs 89 TF-eq, 256 x 256 103 vs 98;
-// level elsewhere).  HOISDF_EMU_DW_TILE=128 / 256 forces one form.
+// k-tile width: 256 (one workgroup per CU), or 128 (two per CU) when the 256-wide tiling leaves one or two tiles - there the
+// narrow form packs the slices better (measured, tools/mb_emu.py: 256 x 256 103 vs 98 TF-eq; three tiles, 768 x 256: 205 us wide
+// vs 216 us narrow once the slice count is a whole number per XCD, plan_dw).  HOISDF_EMU_DW_TILE=128 / 256 forces one form.
 int dw_tile(int N, int K) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("HOISDF_EMU_DW_TILE"); const int v = e ? atoi(e) : 0; forced = (v == 128 || v == 256) ? v : 0; }
   if (forced) return forced;
-  return cdiv(N, DT) * cdiv(K, 256) <= 3 ? 128 : 256;
+  return cdiv(N, DT) * cdiv(K, 256) <= 2 ? 128 : 256;
 }
 void plan_dw(long M, int N, int K, int& splitk, int& mper) {
   const int dtk = dw_tile(N, K);
   const int ntile = cdiv(N, DT) * cdiv(K, dtk);
   const int slabs = cdiv(M, KS);
   const int slots = dtk == 256 ? 256 : 512;
-  int want = ntile >= slots ? 1 : slots / ntile;
+  // slices of a tile go to the XCDs round-robin (split & 7): a whole number of slices per XCD that fits its share of the
+  // slots in ONE round (768 x 256: 6 tiles x 85 slices put 66 workgroups on XCDs 0-3 with 64 slots - a second round for 2)
+  const int per_xcd = slots / 8 / ntile;
+  int want = per_xcd >= 1 ? per_xcd * 8 : (ntile >= slots ? 1 : slots / ntile);
   if (want > slabs / 8) want = slabs / 8 > 0 ? slabs / 8 : 1;
   mper = cdiv(slabs, want) * KS;
   splitk = cdiv(M, mper);
