@@ -301,9 +301,6 @@ __global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
 // ============================================================================================================================
 namespace {
 constexpr int DT = 256;                                  // tile edge (both n and k)
-constexpr int DW_OP_U4 = 3 * 2 * DT;                     // 16-byte units per operand per stage
-constexpr int DW_STAGE_U4 = 2 * DW_OP_U4;
-constexpr unsigned DW_LDS_BYTES = 2u * DW_STAGE_U4 * 16u;   // 98 304
 
 // a value the compiler cannot prove wave-uniform (it depends on tid < 128, which is uniform per wave) into scalar registers
 __device__ __forceinline__ uint64_t uni64(uint64_t v) {
