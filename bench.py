@@ -376,6 +376,30 @@ def main():
             ms = sorted(ts)[1]
             per_bucket.append({"mbytes": round(nbytes / 2 ** 20, 1), "ms": round(ms, 3),
                                "busbw_gbps": round(2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 1) if world > 1 else None})
+        # (c) do the model's two streams still run side by side next to the process group's streams?  One single-workgroup spin
+        #     kernel (torch.cuda._sleep) on the compute stream alone, then one on each stream at once: ~1.0 = overlapped, ~2.0 = one
+        #     hardware queue (what a normal-priority second stream got before round 3: profiles/r03_second_stream_hw_queue.txt)
+        side = getattr(model, "_side_stream", None)
+        overlap_ratio = None
+        if side is not None and hasattr(torch.cuda, "_sleep"):
+            cur = torch.cuda.current_stream(dev)
+
+            def probe(both):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if both:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        torch.cuda._sleep(2000000)
+                torch.cuda._sleep(2000000)
+                if both:
+                    cur.wait_stream(side)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1)
+            probe(True)
+            overlap_ratio = round(min(probe(True) for _ in range(3)) / min(probe(False) for _ in range(3)), 2)
         t = torch.tensor([sorted(exposed)[1]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         try:
@@ -386,7 +410,9 @@ def main():
                 "gradient_mbytes": round(reducer.total_bytes() / 2 ** 20, 1), "buckets": per_bucket,
                 "exposed_ms_per_step_max_over_ranks": round(float(t), 3),
                 "all_reduce_ms_sum": round(sum(b["ms"] for b in per_bucket), 3),
-                "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}}
+                "second_stream_time_ratio_both_vs_one": overlap_ratio,
+                "env": {k: v for k, v in os.environ.items()
+                        if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "GPU_MAX_HW_QUEUES", "HOISDF_"))}}
         if rank == 0:
             print(f"[comm] {json.dumps(comm)}", file=sys.stderr)
 

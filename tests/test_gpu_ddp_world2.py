@@ -131,3 +131,58 @@ def test_world2_step_on_the_gpu_equals_the_single_process_sum():
     for n in ref_after:                                            # ... and takes the same optimizer step
         assert torch.equal(res[0][3][n], res[1][3][n]), n
         assert float((res[0][3][n] - ref_after[n]).abs().max()) <= 1e-6 + 2e-5 * float(ref_after[n].abs().max()), n
+
+
+def _rccl_overlap_worker(port, q):
+    """own process: a RCCL process group (world 1, as bench.py --force-dist), one training step of the real hot path so the
+    model has created its second stream, then single-workgroup spin kernels on one stream vs on both"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        flat = torch.ones(1 << 20, device=dev)
+        dist.all_reduce(flat)                                   # the process group's streams exist from here on
+        model, c, ops, T = _setup()
+        levels, batch, rnd = _batch(T, ops, 0)
+        _loss(model, ops, levels, batch, rnd).backward()
+        side, cur = model._side_stream, torch.cuda.current_stream(dev)
+
+        def probe(both):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if both:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    torch.cuda._sleep(2000000)
+            torch.cuda._sleep(2000000)
+            if both:
+                cur.wait_stream(side)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        probe(True)
+        q.put(("ok", min(probe(True) for _ in range(3)), min(probe(False) for _ in range(3))))
+        dist.destroy_process_group()
+    except Exception as e:                                      # noqa: BLE001
+        import traceback
+        q.put(("error", traceback.format_exc(), repr(e)))
+
+
+def test_second_stream_overlaps_the_compute_stream_next_to_a_rccl_process_group():
+    """HIP maps normal-priority streams onto 4 hardware queues round-robin; once RCCL has created its streams a normal-priority
+    second stream shared the compute stream's queue and the hand / object overlap was gone on every rank of an N > 1 job
+    (profiles/r03_second_stream_hw_queue.txt).  The model's second stream is high priority = a queue of its own: two spin
+    kernels, one per stream, must take the time of one."""
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("torch.cuda._sleep not available")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_overlap_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res[0] == "ok", res[1]
+    both, one = res[1], res[2]
+    assert both <= 1.4 * one, f"two streams: {both:.3f} ms for one spin kernel each vs {one:.3f} ms for one - they share a hardware queue"
