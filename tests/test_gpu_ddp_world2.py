@@ -140,9 +140,14 @@ def _rccl_overlap_worker(port, q):
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        flat = torch.ones(1 << 20, device=dev)
-        dist.all_reduce(flat)                                   # the process group's streams exist from here on
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            flat = torch.ones(1 << 20, device=dev)
+            dist.all_reduce(flat)                               # the process group's streams exist from here on
+            torch.cuda.synchronize()
+        except Exception as e:                                  # noqa: BLE001  (no RCCL on this box: nothing to check)
+            q.put(("skip", repr(e)))
+            return
         model, c, ops, T = _setup()
         levels, batch, rnd = _batch(T, ops, 0)
         _loss(model, ops, levels, batch, rnd).backward()
@@ -183,6 +188,8 @@ def test_second_stream_overlaps_the_compute_stream_next_to_a_rccl_process_group(
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
+    if res[0] == "skip":
+        pytest.skip("RCCL process group unavailable: " + res[1])
     assert res[0] == "ok", res[1]
     both, one = res[1], res[2]
     assert both <= 1.4 * one, f"two streams: {both:.3f} ms for one spin kernel each vs {one:.3f} ms for one - they share a hardware queue"
