@@ -148,6 +148,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_sdf_query_train_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P, _L, _P],
     "hoisdf_sdf_query_bwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _SDFW, _F, _F, _P, _L, _P, _P, _P, _L, _P],
     "hoisdf_sdf_infer_count": [_P, _P, _P, _F, _I, _I, _P, _P, _P, _P],
+    "hoisdf_sdf_infer_count_begin": [_P, _P, _P, _F, _I, _I, _P, _P, _P],
     "hoisdf_sdf_infer": [_PYR, _P, _P, _P, _F, _I, _I, _P, _P, _I, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P],
     "hoisdf_decoder_layer_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P],
     "hoisdf_decoder_layer_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _L, _P],
@@ -160,10 +161,13 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_fwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hoisdf_point_loss_fwd": [_P, _P, _L, _L, _I, _L, _I, _F, _F, _F, _P, _P, _P],
+    "hoisdf_point_loss_bwd": [_P, _P, _L, _L, _I, _L, _I, _F, _F, _F, _P, _P, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
+          "hoisdf_point_loss_blocks": ([_L], C.c_int),
           "hoisdf_sdf_infer_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_sdf_query_train_saved_bytes": ([_L, _I], C.c_long),
           "hoisdf_sdf_query_train_workspace_bytes": ([_L, _I, _I], C.c_long),

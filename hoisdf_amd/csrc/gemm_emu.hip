@@ -93,103 +93,17 @@ __global__ __launch_bounds__(256) void emu_prep_weight_kernel(const float* __res
   img[base + (2 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p2);
 }
 
-template <bool MASK>
-__global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, kh = lane >> 5;
-  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int nslab = (g.K + KS - 1) / KS;
-  const int last = nslab - 1;
-
-  f32x16 acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
+// C-tile epilogue shared by the two main-loop forms: bias, ReLU, dropout, 1-bit sign map, accumulate-into, LDS-transposed 16-byte stores
+__device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][NJ], u32x4* lds, int m0, int n0, int wm, int wn, int wave,
+                                             int lane, int l31, int kh, float post_scale) {
+  if (post_scale != 1.f) {                     // (grad-input, rotated form) 1 / keep of the forward's dropout, once per element
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // staging: thread = row of the A tile (rows past M re-read the last row: their products only reach rows that are never
-  // stored); B image pieces tid + 256 q.  All loads are unconditional (a load behind a branch makes hipcc assume the shorter
-  // queue at the merge and wait for everything): the k tail is handled by clamping the address and zeroing the value.
-  const int arow_i = min(m0 + tid, g.M - 1);
-  const float* arow = g.A + (size_t)arow_i * g.lda;
-  const uint32_t* mrow = MASK ? g.abits + (size_t)arow_i * g.ldbits : nullptr;
-  const u32x4* bsrc = g.Bimg + (size_t)tn * nslab * B_U4 + tid;
-  const int kmax4 = g.K - 4;                       // K is a multiple of 4 (checked by the host)
-  float4 ra[4];
-  u32x4 rb[NB];
-  uint32_t rm = 0xffffffffu;
-#define LOAD_SLAB(sl)                                                                                                  \
-  do {                                                                                                                 \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                      \
-        ra[q] = *reinterpret_cast<const float4*>(arow + min((sl) * KS + q * 4, kmax4));                                \
-    _Pragma("unroll") for (int q = 0; q < NB; ++q) rb[q] = bsrc[(size_t)(sl) * B_U4 + q * NT];                          \
-    if (MASK) rm = mrow[(sl) >> 1];                                                                                    \
-  } while (0)
-#define STORE_SLAB(st, sl)                                                                                             \
-  do {                                                                                                                 \
-    const int krem_ = g.K - (sl) * KS;                      /* valid k in this slab (>= 16 except in the last one) */  \
-    const uint32_t mb_ = MASK ? (rm >> (((sl) & 1) * 16)) : 0xffffu;                                                   \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
-      float4 v_ = ra[q];                                                                                               \
-      if (MASK) {                                                                                                      \
-        v_.x = ((mb_ >> (4 * q + 0)) & 1u) ? v_.x * g.ascale : 0.f;                                                    \
-        v_.y = ((mb_ >> (4 * q + 1)) & 1u) ? v_.y * g.ascale : 0.f;                                                    \
-        v_.z = ((mb_ >> (4 * q + 2)) & 1u) ? v_.z * g.ascale : 0.f;                                                    \
-        v_.w = ((mb_ >> (4 * q + 3)) & 1u) ? v_.w * g.ascale : 0.f;                                                    \
-      }                                                                                                                \
-      if (4 * q >= krem_) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
-      ra[q] = v_;                                                                                                      \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                    \
-      bf16x8 p0, p1, p2;                                                                                               \
-      split3x8(ra[2 * c], ra[2 * c + 1], p0, p1, p2);                                                                  \
-      (st)[(0 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p0);                                                    \
-      (st)[(1 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p1);                                                    \
-      (st)[(2 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p2);                                                    \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < NB; ++q) (st)[A_U4 + tid + q * NT] = rb[q];                                   \
-  } while (0)
-
-  LOAD_SLAB(0);
-  STORE_SLAB(lds, 0);
-  LOAD_SLAB(min(1, last));
-  __syncthreads();
-
-  for (int s = 0; s < nslab; ++s) {
-    const u32x4* st = lds + (s & 1) * STAGE_U4;
-    u32x4* nx = lds + ((s + 1) & 1) * STAGE_U4;
-    const u32x4* sa = st + wm * 128 + l31;
-    const u32x4* sb = st + A_U4 + wn * WN + l31;
-    bf16x8 b0[NJ], b1[NJ], b2[NJ], a[4];
-#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < NJ; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * TN + j * 32])
-#define RD_A(p) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, sa[((p) * 2 + kh) * TM + i * 32])
-#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
-    RD_B(b0, 0); RD_A(2);
-    // the next slab: registers -> the other stage (masked, converted); the slab after it -> registers (a whole slab of MFMAs
-    // to land).  Pinned here: hipcc otherwise sinks the loads to the end of the loop body.  Past the end the last slab is
-    // simply staged again into the stage nobody reads any more.
-    STORE_SLAB(nx, min(s + 1, last));
-    LOAD_SLAB(min(s + 2, last));
-    __builtin_amdgcn_sched_barrier(0);
-    MM1(b0);                                   // x2 y0            (small terms first)
-    RD_B(b1, 1); RD_A(1);
-    MM1(b1); MM1(b0);                          // x1 y1, x1 y0
-    RD_B(b2, 2); RD_A(0);
-    MM1(b2); MM1(b1); MM1(b0);                 // x0 y2, x0 y1, x0 y0
-    __syncthreads();
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= post_scale;
   }
-#undef LOAD_SLAB
-#undef STORE_SLAB
-#undef RD_A
-#undef RD_B
-#undef MM1
-
   // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); all waves are
   // past the main loop's last barrier, the staging buffer is free
   const int rbase = m0 + wm * 128 + 4 * kh;
@@ -287,6 +201,319 @@ __global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
       }
     }
   }
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nslab = (g.K + KS - 1) / KS;
+  const int last = nslab - 1;
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: thread = row of the A tile (rows past M re-read the last row: their products only reach rows that are never
+  // stored); B image pieces tid + 256 q.  All loads are unconditional (a load behind a branch makes hipcc assume the shorter
+  // queue at the merge and wait for everything): the k tail is handled by clamping the address and zeroing the value.
+  const int arow_i = min(m0 + tid, g.M - 1);
+  const float* arow = g.A + (size_t)arow_i * g.lda;
+  const uint32_t* mrow = MASK ? g.abits + (size_t)arow_i * g.ldbits : nullptr;
+  const u32x4* bsrc = g.Bimg + (size_t)tn * nslab * B_U4 + tid;
+  const int kmax4 = g.K - 4;                       // K is a multiple of 4 (checked by the host)
+  float4 ra[4];
+  u32x4 rb[NB];
+  uint32_t rm = 0xffffffffu;
+#define LOAD_SLAB(sl)                                                                                                  \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                      \
+        ra[q] = *reinterpret_cast<const float4*>(arow + min((sl) * KS + q * 4, kmax4));                                \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) rb[q] = bsrc[(size_t)(sl) * B_U4 + q * NT];                          \
+    if (MASK) rm = mrow[(sl) >> 1];                                                                                    \
+  } while (0)
+#define STORE_SLAB(st, sl)                                                                                             \
+  do {                                                                                                                 \
+    const int krem_ = g.K - (sl) * KS;                      /* valid k in this slab (>= 16 except in the last one) */  \
+    const uint32_t mb_ = MASK ? (rm >> (((sl) & 1) * 16)) : 0xffffu;                                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+      float4 v_ = ra[q];                                                                                               \
+      if (MASK) {                                                                                                      \
+        v_.x = ((mb_ >> (4 * q + 0)) & 1u) ? v_.x * g.ascale : 0.f;                                                    \
+        v_.y = ((mb_ >> (4 * q + 1)) & 1u) ? v_.y * g.ascale : 0.f;                                                    \
+        v_.z = ((mb_ >> (4 * q + 2)) & 1u) ? v_.z * g.ascale : 0.f;                                                    \
+        v_.w = ((mb_ >> (4 * q + 3)) & 1u) ? v_.w * g.ascale : 0.f;                                                    \
+      }                                                                                                                \
+      if (4 * q >= krem_) v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+      ra[q] = v_;                                                                                                      \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                    \
+      bf16x8 p0, p1, p2;                                                                                               \
+      split3x8(ra[2 * c], ra[2 * c + 1], p0, p1, p2);                                                                  \
+      (st)[(0 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p0);                                                    \
+      (st)[(1 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p1);                                                    \
+      (st)[(2 * 2 + c) * TM + tid] = __builtin_bit_cast(u32x4, p2);                                                    \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) (st)[A_U4 + tid + q * NT] = rb[q];                                   \
+  } while (0)
+
+  LOAD_SLAB(0);
+  STORE_SLAB(lds, 0);
+  LOAD_SLAB(min(1, last));
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    const u32x4* st = lds + (s & 1) * STAGE_U4;
+    u32x4* nx = lds + ((s + 1) & 1) * STAGE_U4;
+    const u32x4* sa = st + wm * 128 + l31;
+    const u32x4* sb = st + A_U4 + wn * WN + l31;
+    bf16x8 b0[NJ], b1[NJ], b2[NJ], a[4];
+#define RD_B(dst, p) _Pragma("unroll") for (int j = 0; j < NJ; ++j) dst[j] = __builtin_bit_cast(bf16x8, sb[((p) * 2 + kh) * TN + j * 32])
+#define RD_A(p) _Pragma("unroll") for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(bf16x8, sa[((p) * 2 + kh) * TM + i * 32])
+#define MM1(bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFB(a[i], bx[j], acc[i][j])
+    RD_B(b0, 0); RD_A(2);
+    // the next slab: registers -> the other stage (masked, converted); the slab after it -> registers (a whole slab of MFMAs
+    // to land).  Pinned here: hipcc otherwise sinks the loads to the end of the loop body.  Past the end the last slab is
+    // simply staged again into the stage nobody reads any more.
+    STORE_SLAB(nx, min(s + 1, last));
+    LOAD_SLAB(min(s + 2, last));
+    __builtin_amdgcn_sched_barrier(0);
+    MM1(b0);                                   // x2 y0            (small terms first)
+    RD_B(b1, 1); RD_A(1);
+    MM1(b1); MM1(b0);                          // x1 y1, x1 y0
+    RD_B(b2, 2); RD_A(0);
+    MM1(b2); MM1(b1); MM1(b0);                 // x0 y2, x0 y1, x0 y0
+    __syncthreads();
+  }
+#undef LOAD_SLAB
+#undef STORE_SLAB
+#undef RD_A
+#undef RD_B
+#undef MM1
+
+  emu_epilogue(g, acc, lds, m0, n0, wm, wn, wave, lane, l31, kh, 1.f);
+}
+
+
+// ---- main loop, second form ("rotated", hand-interleaved, line-coalesced activation loads): same tile, product order and
+// epilogue as emu_kc_kernel (forward results are bit identical), but
+//  * the six product groups of a slab are rotated by half a slab against the barrier: a phase = [x0 y2, x0 y1, x0 y0 of slab
+//    s - 1 | x2 y0, x1 y1, x1 y0 of slab s], so the 24 MFMAs right behind the barrier take fragments that were read BEFORE it and
+//    every fragment read of slab s is issued 4 ... 24 MFMAs ahead of its first use;
+//  * the staging of slab s + 1 (16 f32 per thread -> three bf16 planes -> the other stage, plus the weight image pieces) is
+//    cut into units of <= 5 VALU / one LDS or global instruction, and every unit is pinned behind ONE MFMA of the same wave:
+//    on this part a wave's VALU work hides under its OWN MFMAs only (profiles/r03_mfma_valu_overlap.txt), and left alone hipcc
+//    emits [convert + write everything | 48 MFMAs] - with one LDS array it even has to (every fragment read may alias the
+//    staging writes that precede it in program order), which is why the two stages are two distinct __shared__ objects here;
+//  * the activation tile is loaded with FOUR LANES PER ROW (lane = row l / 4 of a 16-row group, 16-byte quad l % 4 of the
+//    slab's 64 bytes; four such items per thread): a wave instruction touches 16 cache lines instead of 64.  With thread =
+//    row (the first form) every global_load_dwordx4 asks the vector memory pipe for 64 different lines, 16 bytes of each: the
+//    ablations of round 4 (profiles/r04_kc2_ablation.txt) showed the loop running at 285 - 338 TF without staging and at
+//    130 - 170 with the loads and LDS writes but WITHOUT any conversion arithmetic - the address / tag path, not the VALU,
+//    was the limiter.  A quad converts to 8 bytes per plane (ds_write_b64); rows of the second k-chunk are stored with
+//    bit 3 of the row flipped so that the half-wave's 8 rows x 2 chunks land on 32 different bank pairs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef EMU_ABL
+#define EMU_ABL 0
+#endif
+template <bool MASK, bool KTAIL>
+__global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
+  __shared__ __attribute__((aligned(16))) u32x4 st0[STAGE_U4];
+  __shared__ __attribute__((aligned(16))) u32x4 st1[STAGE_U4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nslab = (g.K + KS - 1) / KS;
+  const int last = nslab - 1;
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging roles: item i (0..3) of this thread = row i * 64 + wave * 16 + lane / 4 of the tile, quad qd = lane % 4 of the slab
+  // (k = 4 qd .. 4 qd + 3; chunk c = qd / 2, half qd % 2 of the chunk's 16 bytes).  Rows past M re-read row M - 1 (their
+  // products only reach rows that are never stored).  Byte offsets are relative to the tile's first row (< 256 rows: 32 bit).
+  const int rl = lane >> 2, qd = lane & 3, cq = qd >> 1;
+  // buffer descriptors (wave-uniform) over the tile's row panel, its sign-bitmap rows and the column tile's weight image: the
+  // loads are buffer_load (32-bit per-lane offset in ONE register + scalar slab offset) - with flat addressing hipcc keeps a
+  // 64-bit address pair per item alive across the loop and spills
+  const int rows_in = min(TM, g.M - m0);
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)((((long)rows_in - 1) * g.lda + g.K) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(MASK ? g.abits + (size_t)m0 * g.ldbits : nullptr), 0, MASK ? (int)((long)rows_in * g.ldbits * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(g.Bimg + (size_t)tn * nslab * B_U4), 0, nslab * B_U4 * 16, 0x00020000);
+  int aoff[4], moff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = min(i * 64 + wave * 16 + rl, rows_in - 1);
+    aoff[i] = (int)(((long)r * g.lda + 4 * qd) * 4);
+    moff[i] = (int)((long)r * g.ldbits * 4);
+  }
+  // 8-byte LDS slot of item 0, plane 0: unit (chunk cq, row ^ (cq << 3)), half qd & 1; item i adds 128 slots, plane p 2 * 2 * TM
+  const int wslot = 2 * (cq * TM + ((wave * 16 + rl) ^ (cq << 3))) + (qd & 1);
+  const int aread = (wm * 128 + l31) ^ (kh << 3);              // fragment rows follow the same row flip (chunk = kh)
+  const int kq = g.K - 4 * qd;                                   // quad valid in slab sl iff sl * 16 < kq
+  f32x2 rp[8], fu[8];                                            // the thread's 4 quads of the slab being staged, as pairs (+ unpacked planes)
+  uint32_t t0[8], t1[8], t2[8];                                  // their three bf16 planes (two values per register)
+  u32x4 rb[NB];
+  uint32_t rm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, mb = 0xfu;
+  bool kin = true;
+#define NOP_ ((void)0)
+// ---- staging units.  LDGA(i, sl): the quad of item i in slab sl -> rp[2 i], rp[2 i + 1] (+ its sign-bitmap word)
+#if EMU_ABL == 2 || EMU_ABL == 4
+#define LDGA(i, sl) NOP_
+#define LDGB(q, sl) NOP_
+#else
+#define LDGA(i, sl)                                                                                                    \
+  do {                                                                                                                 \
+    const int k0_ = min((sl), last) * KS;                      /* (uniform) a pad slab re-reads the last one */        \
+    const f32x4 v_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[i], k0_ * 4, 0));       \
+    rp[2 * (i)] = f32x2{v_[0], v_[1]}; rp[2 * (i) + 1] = f32x2{v_[2], v_[3]};                                          \
+    if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm, moff[i], (k0_ >> 5) * 4, 0);                           \
+  } while (0)
+#define LDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (tid + (q) * NT) * 16, min((sl), last) * (B_U4 * 16), 0)
+#endif
+// the conversion of pair p = 2 i + j (item i, half j of its quad) in four units (U1 .. U4) or two (CV1 = U1 + U2, CV2 = U3 + U4):
+//   U1  sign bitmap (bit -> all-ones / zero word -> and; the 1 / keep factor is applied once, in the epilogue) and k tail;
+//       first plane = bf16(v) (v_cvt_pk_bf16_f32), unpacked again    U2  first residual (one packed subtract)
+//   U3  second plane, unpacked                                        U4  second residual, third plane
+// UI(i, sl): per-item scalars of slab sl (the quad's four sign bits; is the quad inside K)
+#define UI(i, sl) do { if (MASK) mb = rm[i] >> ((((sl) & 1) << 4) + 4 * qd); if (KTAIL) kin = (sl) * KS < kq; } while (0)
+#if EMU_ABL == 1
+#define U1(p) do { t0[p] = __builtin_bit_cast(uint32_t, rp[p].x); t1[p] = __builtin_bit_cast(uint32_t, rp[p].y); t2[p] = t0[p]; } while (0)
+#define U2(p) NOP_
+#define U3(p) NOP_
+#define U4(p) NOP_
+#else
+#define PK_SUB(d, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+#define U1(p)                                                                                                          \
+  do {                                                                                                                 \
+    f32x2 v_ = rp[p];                                                                                                  \
+    if (MASK) {                                                                                                        \
+      const uint32_t ma_ = (uint32_t)((int32_t)(mb << (31 - 2 * ((p) & 1))) >> 31), mc_ = (uint32_t)((int32_t)(mb << (30 - 2 * ((p) & 1))) >> 31); \
+      v_.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v_.x) & ma_);                                      \
+      v_.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v_.y) & mc_);                                      \
+    }                                                                                                                  \
+    if (KTAIL) { if (!kin) v_ = f32x2{0.f, 0.f}; }             /* K is a multiple of 4: a quad is all in or all out */ \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(v_, bf16x2));                             \
+    t0[p] = h_; rp[p] = v_;                                                                                            \
+    fu[p] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                   \
+  } while (0)
+#define U2(p) PK_SUB(rp[p], rp[p], fu[p])
+#define U3(p)                                                                                                          \
+  do {                                                                                                                 \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(rp[p], bf16x2));                          \
+    t1[p] = h_;                                                                                                        \
+    fu[p] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                   \
+  } while (0)
+#define U4(p) do { f32x2 w_; PK_SUB(w_, rp[p], fu[p]); t2[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(w_, bf16x2)); } while (0)
+#endif
+// STA(st, i, tp, pl): the 8 bytes of plane pl (tp = t0 / t1 / t2) of item i -> the stage.  STB(st, q): weight image piece q.
+#if EMU_ABL == 2 || EMU_ABL == 3
+#define STA(st, i, tp, pl) asm volatile("" :: "v"(tp[2 * (i)]), "v"(tp[2 * (i) + 1]))
+#define STB(st, q) asm volatile("" :: "v"(rb[q]))
+#else
+#define STA(st, i, tp, pl) reinterpret_cast<u32x2*>(st)[wslot + (i) * 128 + (pl) * 4 * TM] = u32x2{tp[2 * (i)], tp[2 * (i) + 1]}
+#define STB(st, q) (st)[A_U4 + tid + (q) * NT] = rb[q]
+#endif
+#define LDA(st, p, i) __builtin_bit_cast(bf16x8, (st)[aread + ((p) * 2 + kh) * TM + (i) * 32])
+#define LDB(st, p, j) __builtin_bit_cast(bf16x8, (st)[A_U4 + wn * WN + l31 + ((p) * 2 + kh) * TN + (j) * 32])
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// one MFMA + the unit that hides under it
+#define M1(ax, bx, i, j, work) do { acc[i][j] = MFB(ax[i], bx[j], acc[i][j]); work; SB(); } while (0)
+#define MM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFB(ax[i], bx[j], acc[i][j])
+// phase s: on entry aX = x0 fragments of slab s - 1, b2 / b1 / bC = its weight fragments (planes 2, 1, 0), rp / rb / rm = slab
+// s + 1 as loaded; cur = the stage that holds slab s, nxt = the stage that receives slab s + 1.  On exit aY, b2, b1, bN = slab s.
+// The slot table (which unit hides under which MFMA) is generated: tools/gen/kc2_phase.py -> kc2_phase.inc.
+#include "kc2_phase.inc"
+#define SYNC() do { SB(); __syncthreads(); SB(); } while (0)
+
+  // the slab count is rounded up to an even number (a pad slab stages zeros for A: its products add exact zeros), so the phases
+  // after the head come in pairs plus one and the two register assignments never have to merge
+  const int nslab2 = (nslab + 1) & ~1;
+  bf16x8 aP[4], aQ[4], bP[NJ], bQ[NJ], b1[NJ], b2[NJ];
+  // prologue (left to the compiler): slab 0 -> st0, slab 1 -> registers; the first half of slab 0; slab 1 -> st1, slab 2 -> registers
+#define STAGE_ALL(st, sl)                                                                                              \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+      UI(i, sl);                                                                                                       \
+      U1(2 * i); U2(2 * i); U3(2 * i); U4(2 * i); U1(2 * i + 1); U2(2 * i + 1); U3(2 * i + 1); U4(2 * i + 1);          \
+      STA(st, i, t0, 0); STA(st, i, t1, 1); STA(st, i, t2, 2);                                                         \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) STB(st, q);                                                         \
+  } while (0)
+#define LOAD_ALL(sl)                                                                                                   \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) LDGA(i, sl);                                                         \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) LDGB(q, sl);                                                        \
+  } while (0)
+  LOAD_ALL(0);
+  STAGE_ALL(st0, 0);
+  LOAD_ALL(1);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { aQ[i] = LDA(st0, 2, i); aP[i] = LDA(st0, 1, i); }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { bP[j] = LDB(st0, 0, j); b1[j] = LDB(st0, 1, j); b2[j] = LDB(st0, 2, j); }
+  MM(aQ, bP);                                                  // x2 y0 of slab 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aQ[i] = LDA(st0, 0, i);
+  MM(aP, b1); MM(aP, bP);                                      // x1 y1, x1 y0
+  STAGE_ALL(st1, 1);
+  LOAD_ALL(2);
+  SYNC();                                                      // aQ = x0 fragments of slab 0, bP / b1 / b2 its weight fragments
+  for (int s = 1; s + 1 < nslab2; s += 2) {
+    PHASE(st1, st0, s, aQ, aP, bP, bQ);
+    SYNC();
+    PHASE(st0, st1, s + 1, aP, aQ, bQ, bP);
+    SYNC();
+  }
+  PHASE(st1, st0, nslab2 - 1, aQ, aP, bP, bQ);
+  SB();
+  MM(aP, b2); MM(aP, b1); MM(aP, bQ);
+  __syncthreads();
+#undef LDGA
+#undef LDGB
+#undef UI
+#undef U1
+#undef U2
+#undef U3
+#undef U4
+#undef STA
+#undef STB
+#undef LDA
+#undef LDB
+#undef SB
+#undef M1
+#undef MM
+#undef NOP_
+#undef PHASE
+#undef SYNC
+#undef STAGE_ALL
+#undef LOAD_ALL
+  emu_epilogue(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, MASK ? g.ascale : 1.f);
 }
 
 
@@ -565,7 +792,15 @@ int launch_emu(EmuArgs g, hipStream_t st) {
   g.tiles_n = cdiv(g.N, TN);
   g.vecC = al16(g.C) && (g.ldc % 4 == 0);
   const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
-  if (g.abits) hipLaunchKernelGGL((emu_kc_kernel<true>), grid, block, LDS_BYTES, st, g);
+  static int form = -1;                       // HOISDF_EMU_KC=1: the first main-loop form (A/B runs); default: the rotated form
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_KC"); form = (e && atoi(e) == 1) ? 1 : 2; }
+  if (form == 2) {
+    const bool kt = g.K % KS != 0 || (cdiv(g.K, KS) & 1);      // a pad slab (odd slab count) stages zeros through the k-tail test
+    if (g.abits && kt) hipLaunchKernelGGL((emu_kc2_kernel<true, true>), grid, block, 0, st, g);
+    else if (g.abits) hipLaunchKernelGGL((emu_kc2_kernel<true, false>), grid, block, 0, st, g);
+    else if (kt) hipLaunchKernelGGL((emu_kc2_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((emu_kc2_kernel<false, false>), grid, block, 0, st, g);
+  } else if (g.abits) hipLaunchKernelGGL((emu_kc_kernel<true>), grid, block, LDS_BYTES, st, g);
   else hipLaunchKernelGGL((emu_kc_kernel<false>), grid, block, LDS_BYTES, st, g);
   return check_launch("linear_emu");
 }

@@ -118,21 +118,31 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
 }
 
 // ---- sdf_infer (main/model.py:246-355) as two calls: count the lattice survivors (one device -> host read of B integers, which
-// sizes everything else), then lattice fill -> SDF query -> top-k by |sdf| -> gather of the selected points / values / encodings ----
+// sizes everything else; hoisdf_sdf_infer_count_begin only QUEUES it - the counts depend on the camera inputs alone, so a host
+// can request them ahead of the image encoder and wait for them when it gets here), then lattice fill -> SDF query -> top-k by |sdf| -> gather of the selected points / values / encodings ----
 namespace hoisdf {
 namespace {
 inline long up256(long b) { return (b + 255) & ~255L; }
 }  // namespace
 }  // namespace hoisdf
 
+extern "C" int hoisdf_sdf_infer_count_begin(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n, int B,
+                                            int32_t* counts_device, int32_t* counts_host, void* stream) {
+  HOISDF_REQUIRE(center && cam_intr && bbox && counts_device && counts_host && B > 0 && bins_n > 0, HOISDF_ERR_INVALID,
+                 "sdf_infer_count_begin: bad arguments");
+  if (int rc = hoisdf_lattice_count(center, cam_intr, bbox, scale, bins_n, B, counts_device, stream)) return rc;
+  if (hipMemcpyAsync(counts_host, counts_device, sizeof(int32_t) * B, hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess) {
+    set_error("sdf_infer_count_begin: queueing the read-back failed: %s", hipGetErrorString(hipGetLastError()));
+    return HOISDF_ERR_LAUNCH;
+  }
+  return HOISDF_OK;
+}
+
 extern "C" int hoisdf_sdf_infer_count(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n, int B,
                                       int32_t* counts_device, int32_t* counts_host, long* n_rows, void* stream) {
-  HOISDF_REQUIRE(center && cam_intr && bbox && counts_device && counts_host && n_rows && B > 0 && bins_n > 0, HOISDF_ERR_INVALID,
-                 "sdf_infer_count: bad arguments");
-  if (int rc = hoisdf_lattice_count(center, cam_intr, bbox, scale, bins_n, B, counts_device, stream)) return rc;
-  hipStream_t st = as_stream(stream);
-  if (hipMemcpyAsync(counts_host, counts_device, sizeof(int32_t) * B, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess) {
+  HOISDF_REQUIRE(n_rows, HOISDF_ERR_INVALID, "sdf_infer_count: bad arguments");
+  if (int rc = hoisdf_sdf_infer_count_begin(center, cam_intr, bbox, scale, bins_n, B, counts_device, counts_host, stream)) return rc;
+  if (hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
     set_error("sdf_infer_count: reading the counts back failed: %s", hipGetErrorString(hipGetLastError()));
     return HOISDF_ERR_LAUNCH;
   }
@@ -141,6 +151,26 @@ extern "C" int hoisdf_sdf_infer_count(const float* center, const float* cam_intr
   *n_rows = n;
   return HOISDF_OK;
 }
+
+namespace hoisdf {
+// offsets[b] = sum of counts[0 .. b): one wave, 64 samples per round, the carry in a register
+__global__ __launch_bounds__(64) void exclusive_scan_counts_kernel(const int32_t* __restrict__ counts, int B, int32_t* __restrict__ offsets) {
+  const int lane = threadIdx.x;
+  int carry = 0;
+  for (int base = 0; base < B; base += 64) {
+    const int b = base + lane;
+    const int c = b < B ? counts[b] : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (b < B) offsets[b] = carry + incl - c;
+    carry += __shfl(incl, 63, 64);
+  }
+}
+}  // namespace hoisdf
 
 extern "C" long hoisdf_sdf_infer_workspace(long n_rows, int B, int C) {
   if (n_rows < 0 || B <= 0 || C <= 0) return -1;
@@ -178,18 +208,9 @@ extern "C" int hoisdf_sdf_infer(const hoisdf_pyramid* pyr, const float* center, 
   const long qbytes = hoisdf_sdf_query_workspace(n, w->C, 1);
   void* qws = take(0);
   hipStream_t st = as_stream(stream);
-  // exclusive prefix of the counts: B integers, staged through a small pinned-or-pageable host array (async copy from a stack
-  // buffer would race with its lifetime: synchronous copy, B * 4 bytes)
-  {
-    int32_t* off_h = static_cast<int32_t*>(malloc(sizeof(int32_t) * B));
-    HOISDF_REQUIRE(off_h, HOISDF_ERR_LAUNCH, "sdf_infer: out of host memory");
-    int32_t acc = 0;
-    for (int b = 0; b < B; ++b) { off_h[b] = acc; acc += counts_host[b]; }
-    const hipError_t e = hipMemcpyAsync(offsets, off_h, sizeof(int32_t) * B, hipMemcpyHostToDevice, st);
-    const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(st) : e;
-    free(off_h);
-    HOISDF_REQUIRE(e2 == hipSuccess, HOISDF_ERR_LAUNCH, "sdf_infer: uploading the offsets failed: %s", hipGetErrorString(e2));
-  }
+  // exclusive prefix of the counts on the device (no host staging, no synchronisation: this call only enqueues work)
+  hipLaunchKernelGGL(exclusive_scan_counts_kernel, dim3(1), dim3(64), 0, st, counts_device, B, offsets);
+  if (int rc0 = check_launch("sdf_infer offsets")) return rc0;
   int rc = hoisdf_lattice_fill(center, cam_intr, bbox, scale, bins_n, B, offsets, pts, sidx, lidx, stream);
   if (rc) return rc;
   rc = hoisdf_sdf_query_fwd(pyr, pts, sidx, n, 1, center, cam_intr, scale, img_h, img_w, nullptr, nullptr, w, clamp, drop_p, seed, sdf, raw, pe,

@@ -193,8 +193,9 @@ class Model(nn.Module):
         return self.linear_transformerin(feat).view(B, P, -1), cam.view(B, P, 3)
 
     @torch.no_grad()
-    def sdf_infer(self, feature_pyramid, center_joint, cam_intr, bbox, sdf_scale, num_points, type="hand"):
-        """reference :246-355, batched on the device -> (points (B,K,3), sdf (B,K,1), posenc (B,K,30), None)."""
+    def sdf_infer(self, feature_pyramid, center_joint, cam_intr, bbox, sdf_scale, num_points, type="hand", counts=None):
+        """reference :246-355, batched on the device -> (points (B,K,3), sdf (B,K,1), posenc (B,K,30), None).
+        ``counts``: the lattice-survivor count queued earlier (``infer_counts_begin``), so that nothing drains here."""
         c = self.cfg
         pyr = self._pyramid(feature_pyramid)
         B = center_joint.shape[0]
@@ -202,7 +203,7 @@ class Model(nn.Module):
         try:
             pose_points, pose_sdf, pose_pe = ops.sdf_infer(self._query_weights(type), pyr, center_joint, cam_intr, bbox, sdf_scale,
                                                            c.bins_n, num_points, c.ClampingDistance, c.input_img_shape,
-                                                           dec.dropout_prob if dec.training else 0.0)
+                                                           dec.dropout_prob if dec.training else 0.0, counts)
         except ValueError as e:
             raise ValueError(str(e).replace("sdf_infer:", f"sdf_infer({type}):")) from None
         pose_sdf = pose_sdf.unsqueeze(-1)
@@ -218,9 +219,30 @@ class Model(nn.Module):
         hm = torch.exp(-(((xx[None, None] - jx) / c.sigma) ** 2) / 2 - (((yy[None, None] - jy) / c.sigma) ** 2) / 2)
         return hm.sum(1) * 255
 
+    # ---- the point-branch draw and the early survivor counts -----------------------------------
+    def draw_branch(self, mode, epoch_cnt=1e8) -> bool:
+        """reference :426-427: the ONE python-random draw of a forward; True = pre-sampled points + jitter (branch A),
+        False = query points from the dense-lattice sdf_infer (always in eval)."""
+        p = self._py_random.uniform(0, 1)
+        return (p < 0.4 or epoch_cnt < self.cfg.point_sampling_epoch) and mode == "train"
+
+    def infer_counts_begin(self, meta_info):
+        """queue the lattice-survivor counts of both fields (they depend on mano_root / obj_center_cam / cam_intr / bbox only,
+        reference :286-302).  Model.forward calls this BEFORE the image encoder; sdf_infer then waits for an event that has
+        long fired instead of draining the device twice per field (round 3: four pipeline drains per eval step)."""
+        c = self.cfg
+        K = meta_info["cam_intr"]
+        if not K.is_cuda:
+            return None
+        return {"hand": ops.sdf_infer_count_begin(meta_info["mano_root"], K, meta_info["bbox_hand"], c.hand_sdf_scale, c.bins_n),
+                "obj": ops.sdf_infer_count_begin(meta_info["obj_center_cam"], K, meta_info["bbox_obj"], c.obj_sdf_scale, c.bins_n)}
+
     # ---- the hot path ----------------------------------------------------------------------
-    def hot_path(self, pyr: ops.PyramidNHWC, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0):
-        """reference :370-402 and :424-662: everything after decoder_net except the aux image losses."""
+    def hot_path(self, pyr: ops.PyramidNHWC, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0, branch_a=None,
+                 infer_counts=None):
+        """reference :370-402 and :424-662: everything after decoder_net except the aux image losses.  ``branch_a`` /
+        ``infer_counts``: the draw and the queued survivor counts when the caller (Model.forward) made them ahead of the
+        encoder; drawn / queued here otherwise."""
         c = self.cfg
         training = mode == "train"
         if training:
@@ -253,8 +275,10 @@ class Model(nn.Module):
         on_side = (lambda: torch.cuda.stream(side)) if two else contextlib.nullcontext
         want_sdf_loss = training or c.dataset == "dexycb"                                # :370-402
 
-        p = self._py_random.uniform(0, 1)                                              # :426
-        branch_a = (p < 0.4 or epoch_cnt < c.point_sampling_epoch) and training        # :427-460
+        if branch_a is None:
+            branch_a = self.draw_branch(mode, epoch_cnt)                               # :426-427
+        if not branch_a and infer_counts is None:
+            infer_counts = self.infer_counts_begin(meta_info)      # both fields queued before anything else of this path
         log = getattr(self, "branch_log", None)
         if log is not None and training:
             log.append("A" if branch_a else "B")             # bench.py --branch-mix reports the mix it measured
@@ -263,9 +287,10 @@ class Model(nn.Module):
             jit = self._jitter or (lambda like, dd: torch.empty_like(like).uniform_(-dd, dd))
             hand_points = inputs["hand_pre_points"] + jit(inputs["hand_pre_points"], d)
             obj_points = inputs["obj_pre_points"] + jit(inputs["obj_pre_points"], d)
-        else:                                                                          # :462-481 (host reads: not overlapped)
-            hand_points, hand_sdf, hand_pe, _ = self.sdf_infer(pyr, root, K, meta_info["bbox_hand"], hs_, nh, "hand")
-            obj_points, obj_sdf, obj_pe, _ = self.sdf_infer(pyr, ocen, K, meta_info["bbox_obj"], os_, no, "obj")
+        else:                                                                          # :462-481
+            ic = infer_counts or {}
+            hand_points, hand_sdf, hand_pe, _ = self.sdf_infer(pyr, root, K, meta_info["bbox_hand"], hs_, nh, "hand", ic.get("hand"))
+            obj_points, obj_sdf, obj_pe, _ = self.sdf_infer(pyr, ocen, K, meta_info["bbox_obj"], os_, no, "obj", ic.get("obj"))
         self.hand_sigmoid_beta.data.clamp_(min=2e-3)                                   # :124
         self.obj_sigmoid_beta.data.clamp_(min=2e-3)
 
@@ -313,9 +338,8 @@ class Model(nn.Module):
                 if t is not None:
                     t.record_stream(cur)
         if want_sdf_loss:
-            cd = c.ClampingDistance
             loss["sdfhand_loss"], loss["sdfobj_loss"] = self.sdf_loss(
-                sh, so, targets["hand_sdf"].clamp(-cd, cd), targets["obj_sdf"].clamp(-cd, cd))
+                sh, so, targets["hand_sdf"], targets["obj_sdf"], clamp=c.ClampingDistance)       # :393-402, clamp fused
 
         # token streams (batch-first).  The appended cross-field tokens are detached (:540,:558) and use
         # the *other* centre for xyz ("# bug" lines :498,:508 replicated).
@@ -382,8 +406,12 @@ class Model(nn.Module):
                 else:
                     (loss["mano_mesh_loss"], loss["mano_joint_loss"], loss["pose_param_loss"],
                      loss["shape_param_loss"], _, _) = self.mano_loss(pred_m, gt_m)
-            loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))    # :656-662
-            loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
+            if obj_rot.is_cuda:                                                        # :656-662 (a15: HIP reductions)
+                loss["obj_rot"] = ops.smooth_l1_loss_broadcast(obj_rot, targets["obj_rot"], no)
+                loss["obj_trans"] = ops.smooth_l1_loss_broadcast(obj_trans, targets["rel_obj_trans"], no)
+            else:
+                loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))
+                loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
             side_made = [t for t in list(loss.values()) + list(out.values()) if torch.is_tensor(t)]
 
         # ---- hand vote heads + vote aggregation / losses (ambient stream)
@@ -405,6 +433,8 @@ class Model(nn.Module):
     def forward(self, inputs, targets, meta_info, mode, epoch_cnt=1e8, batch_ratio=0):
         """reference :357-665."""
         c = self.cfg
+        branch_a = self.draw_branch(mode, epoch_cnt)                                  # :426-427, drawn ahead of the encoder
+        infer_counts = None if branch_a else self.infer_counts_begin(meta_info)       # read back under the encoder's kernels
         img_feat, skips = self.backbone_net(inputs["img"])                            # :367-368 (PyTorch / MIOpen)
         feature_pyramid, decoder_out = self.decoder_net(img_feat, skips)
         pyr = self._pyramid(feature_pyramid)
@@ -415,7 +445,7 @@ class Model(nn.Module):
             ops.set_gemm_emu(bool(c.gemm_emu))
         if getattr(c, "attention_emu", None) is not None:
             ops.set_attention_emu(bool(c.attention_emu))
-        loss, out = self.hot_path(pyr, inputs, targets, meta_info, mode, epoch_cnt, batch_ratio)
+        loss, out = self.hot_path(pyr, inputs, targets, meta_info, mode, epoch_cnt, batch_ratio, branch_a, infer_counts)
         if mode == "train" or c.dataset == "dexycb":                                   # :404-422 aux image losses
             out["joint_heatmap_out"] = decoder_out[:, 0]
             out["hand_seg_gt_out"] = targets["hand_seg"]

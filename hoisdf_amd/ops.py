@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from ._lib import Pyramid, call
+from ._lib import Pyramid, call, lib
 
 _SEED = [0x9E3779B97F4A7C15, 0]
 _WEIGHT_GEN = [0]      # bumped by optimizers that update parameters behind autograd's back (FusedAdamW's HIP kernel does
@@ -766,35 +766,78 @@ def lattice_candidates(center, cam_intr, bbox, scale: float, bins_n: int):
     return pts, sidx, lidx, counts_h.tolist(), offsets, counts
 
 
+_PINNED_I32 = {}        # B -> free page-locked int32 buffers for the survivor counts (hipHostMalloc per call would cost more than the read)
+
+
+class SdfInferCounts:
+    """The queued lattice-survivor count of one field (hoisdf_sdf_infer_count_begin): device counts, their page-locked host
+    copy and the event behind the copy.  ``wait()`` blocks the HOST until that copy has executed - the device never drains."""
+
+    def __init__(self, center, cam_intr, bbox, scale: float, bins_n: int):
+        self.args = (center, cam_intr, bbox, float(scale), int(bins_n))      # keeps the inputs alive until the kernel has run
+        B = center.shape[0]
+        self.B = B
+        self.counts = torch.empty(B, device=center.device, dtype=torch.int32)
+        free = _PINNED_I32.setdefault(B, [])
+        self.host = free.pop() if free else torch.empty(B, dtype=torch.int32, pin_memory=True)
+        call("hoisdf_sdf_infer_count_begin", _p(center), _p(cam_intr), _p(bbox), float(scale), int(bins_n), B, _p(self.counts),
+             C.c_void_p(self.host.data_ptr()), _st())
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._list = None
+
+    def matches(self, center, cam_intr, bbox, scale, bins_n) -> bool:
+        a = self.args
+        return (a[0].data_ptr() == center.data_ptr() and a[1].data_ptr() == cam_intr.data_ptr() and a[2].data_ptr() == bbox.data_ptr()
+                and a[3] == float(scale) and a[4] == int(bins_n) and self.B == center.shape[0])
+
+    def wait(self):
+        if self._list is None:
+            self.event.synchronize()
+            self._list = self.host.tolist()
+            _PINNED_I32[self.B].append(self.host)        # the values are copied out: the buffer can serve the next request
+        return self._list
+
+
+def sdf_infer_count_begin(center, cam_intr, bbox, scale: float, bins_n: int) -> SdfInferCounts:
+    """queue the lattice-survivor count of sdf_infer (main/model.py:286-302; it depends on the camera inputs only) - call it
+    ahead of the image encoder and hand the result to ``sdf_infer(counts=...)``: the one device -> host read of the path is
+    then waited for behind work that is already queued instead of draining the pipeline."""
+    center, cam_intr, bbox = center.contiguous(), cam_intr.contiguous(), bbox.contiguous()
+    _chk(center, cam_intr, bbox)
+    return SdfInferCounts(center, cam_intr, bbox, scale, bins_n)
+
+
 @torch.no_grad()
 def sdf_infer(weights: SdfQueryWeights, pyr: "PyramidNHWC", center, cam_intr, bbox, scale: float, bins_n: int, num_points: int,
-              clamp: float, img_hw=(256, 256), drop_p: float = 0.0):
-    """hoisdf_sdf_infer_count + hoisdf_sdf_infer (main/model.py:246-355 in two C-ABI calls): -> points (B,k,3), sdf (B,k),
-    posenc (B,k,30) of the k = num_points lattice survivors with the smallest |sdf| per sample.  Raises ValueError when a
-    sample has fewer than num_points survivors (the reference fails at main/model.py:348)."""
-    from ._lib import lib, HoisdfError
+              clamp: float, img_hw=(256, 256), drop_p: float = 0.0, counts: Optional[SdfInferCounts] = None):
+    """hoisdf_sdf_infer_count_begin + hoisdf_sdf_infer (main/model.py:246-355 in two C-ABI calls): -> points (B,k,3), sdf (B,k),
+    posenc (B,k,30) of the k = num_points lattice survivors with the smallest |sdf| per sample.  ``counts``: the survivor
+    count requested earlier for the same inputs (``sdf_infer_count_begin``); without it the count is queued here and waited
+    for at once.  Raises ValueError when a sample has fewer than num_points survivors (the reference fails at
+    main/model.py:348)."""
     B = center.shape[0]
     dev = center.device
     center, cam_intr, bbox = center.contiguous(), cam_intr.contiguous(), bbox.contiguous()
     _chk(center, cam_intr, bbox)
-    counts = torch.empty(B, device=dev, dtype=torch.int32)
-    counts_h = (C.c_int32 * B)()
-    n = C.c_long(0)
-    call("hoisdf_sdf_infer_count", _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts), C.addressof(counts_h),
-         C.addressof(n), _st())
-    short = [b for b in range(B) if counts_h[b] < num_points]
+    if counts is None or not counts.matches(center, cam_intr, bbox, scale, bins_n):
+        counts = SdfInferCounts(center, cam_intr, bbox, scale, bins_n)
+    cl = counts.wait()
+    n = sum(cl)
+    short = [b for b in range(B) if cl[b] < num_points]
     if short:
-        raise ValueError(f"sdf_infer: sample {short[0]} has only {counts_h[short[0]]} lattice points inside its bbox, fewer "
+        raise ValueError(f"sdf_infer: sample {short[0]} has only {cl[short[0]]} lattice points inside its bbox, fewer "
                          f"than num_points={num_points} (the reference fails at main/model.py:348)")
+    counts_h = (C.c_int32 * B)(*cl)
     w = weights.get()
     assert w.C == pyr.C
-    nbytes = lib().hoisdf_sdf_infer_workspace(n.value, B, w.C)
+    nbytes = lib().hoisdf_sdf_infer_workspace(n, B, w.C)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     pts = torch.empty(B, num_points, 3, device=dev)
     sdf = torch.empty(B, num_points, device=dev)
     pe = torch.empty(B, num_points, 30, device=dev)
     s = pyr.struct()
-    call("hoisdf_sdf_infer", C.byref(s), _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts),
+    call("hoisdf_sdf_infer", C.byref(s), _p(center), _p(cam_intr), _p(bbox), float(scale), bins_n, B, _p(counts.counts),
          C.addressof(counts_h), num_points, img_hw[0], img_hw[1], C.byref(w), float(clamp), float(drop_p),
          next_seed() if drop_p > 0 else 0, _p(pts), _p(sdf), _p(pe), _p(ws), nbytes, _st())
     return pts, sdf, pe
@@ -1619,6 +1662,47 @@ class _VoteLoss(torch.autograd.Function):
 def vote_loss(off, cls, pts, gt_mm, radius: float):
     """K12 + the JointvoteLoss reductions: -> joints (L,B,J,3), l3d_sum (L,B), bce_sum (L,B), near_sum (B)."""
     return _VoteLoss.apply(off, cls, pts, gt_mm, radius)
+
+
+class _PointLoss(torch.autograd.Function):
+    """a15: hoisdf_point_loss_fwd / _bwd (include/hoisdf.h)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, rep, C_, Bt, kind, clamp, pred_scale):
+        pred, target = pred.contiguous(), target.contiguous()
+        _chk(pred, target)
+        n = pred.numel()
+        if target.numel() != Bt * C_ or n % (rep * C_) or (n // (rep * C_)) % Bt:
+            raise ValueError(f"point_loss: pred {tuple(pred.shape)} is not a broadcast of a ({Bt}, {C_}) target with {rep} repeats")
+        part = torch.empty(lib().hoisdf_point_loss_blocks(n), device=pred.device, dtype=torch.float32)
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        call("hoisdf_point_loss_fwd", _p(pred), _p(target), n, rep, C_, Bt, kind, float(clamp), float(pred_scale), 1.0 / n,
+             _p(part), _p(loss), _st())
+        ctx.save_for_backward(pred, target)
+        ctx.args = (n, rep, C_, Bt, kind, float(clamp), float(pred_scale))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        n, rep, C_, Bt, kind, clamp, pred_scale = ctx.args
+        d = torch.empty_like(pred)
+        call("hoisdf_point_loss_bwd", _p(pred), _p(target), n, rep, C_, Bt, kind, clamp, pred_scale, 1.0 / n, _p(g.contiguous()),
+             _p(d), _st())
+        return d, None, None, None, None, None, None, None
+
+
+def l1_loss_clamped_target(pred, target, clamp: float):
+    """mean |pred - clamp(target, +-clamp)| (SepSDFLoss on the clamped ground truth, common/nets/loss.py:64-78 with
+    main/model.py:393-400); pred and target hold the same number of elements."""
+    return _PointLoss.apply(pred, target, 1, 1, pred.numel(), 0, clamp, 1.0)
+
+
+def smooth_l1_loss_broadcast(pred, target, rep: int = 1, pred_scale: float = 1.0):
+    """torch.nn.SmoothL1Loss()(pred * pred_scale, target expanded): pred (..., Bt, rep, C) against target (Bt, C)
+    (main/model.py:656-662: rep = points; common/nets/loss.py:57-59: rep = 1, C = J * 3)."""
+    Bt = target.shape[0]
+    return _PointLoss.apply(pred, target, rep, target.numel() // Bt, Bt, 1, 0.0, pred_scale)
 
 
 # ---------------------------------------------------------------------------------------------

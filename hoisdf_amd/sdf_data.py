@@ -96,15 +96,21 @@ class SdfStore:
     def make_inputs(self, frame_ids, hand_root: torch.Tensor, obj_center: torch.Tensor, num_hand: int, num_obj: int,
                     dist: float, hand_scale: float, obj_scale: float, train: bool, seed: int,
                     do_flip: Optional[torch.Tensor] = None, rot_mat: Optional[torch.Tensor] = None,
-                    validate: bool = True) -> Dict[str, torch.Tensor]:
+                    validate: bool = True, rows: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """The point entries of one batch exactly as the reference's ``__getitem__`` hands them to the model
         (data/dexycb.py:514-549 draw, :548-549 flip ``x *= -1``, data_aug :288 in-plane rotation ``p . rot_mat^T``,
         :593-620 centre + scale), all on the device:
           inputs : hand_sdf_points (B,N_h,3), obj_sdf_points (B,N_o,3) [, hand_pre_points, obj_pre_points]
           targets: hand_sdf (B,N_h) = column 3 * hand_scale, obj_sdf (B,N_o) = column 4 * obj_scale
         ``hand_root`` / ``obj_center`` (B,3) are the centres AFTER the same flip / rotation (the dataset object computes
-        them from the augmented joints / bbox); ``do_flip`` (B,) bool, ``rot_mat`` (B,3,3)."""
-        smp = self.sample(frame_ids, num_hand, num_obj, dist, train, seed, validate)
+        them from the augmented joints / bbox); ``do_flip`` (B,) bool, ``rot_mat`` (B,3,3).
+        ``rows`` (B, n) store row ids in the reference's order [hand_sdf | obj_sdf | hand_pre | obj_pre]: hand off THESE rows
+        instead of drawing (tests/golden/g14_sampler.npz feeds numpy's own draws through the device hand-off)."""
+        if rows is None:
+            smp = self.sample(frame_ids, num_hand, num_obj, dist, train, seed, validate)
+        else:
+            rows = torch.as_tensor(rows, dtype=torch.int64, device=self.device)
+            smp = {"sdf_points": self.rows[rows.reshape(-1)].view(rows.shape[0], rows.shape[1], 6)[..., :5], "rows": rows}
         pts = smp["sdf_points"].clone()                                   # (B, n, 5): xyz, sdf_hand, sdf_obj
         B = pts.shape[0]
         if do_flip is not None:

@@ -179,6 +179,34 @@ def synthetic_batch(B: int, n_hand: int, n_obj: int, seed: int = 1234):
     return inputs, targets, meta
 
 
+def synthetic_decoder_out(B: int, seed: int = 13):
+    """a seeded stand-in for decoder_net's second output (B, 3, 128, 128): channel 0 = heat-map logits on the scale of the
+    255-peaked target, channels 1 / 2 = segmentation probabilities in (0.01, 0.99) with a few saturated pixels (BCELoss
+    clamps its logs at -100)."""
+    r = _rng("decoder_out", seed)
+    d = torch.from_numpy((0.01 + 0.98 * r.random((B, 3, 128, 128))).astype(np.float32))
+    d[:, 0] = d[:, 0] * 300.0
+    d[0, 1, 0, 0], d[0, 2, 0, 1], d[-1, 1, 5, 7], d[-1, 2, 9, 3] = 0.0, 1.0, 1.0, 0.0
+    return d
+
+
+def synthetic_sdf_frames(n_frames: int, seed: int = 14):
+    """``sdf_processed``-shaped frames ((N_h + N_o, 6) float32 rows [x y z sdf_hand sdf_obj label], tool/pre_process_sdf.py:
+    140-148) + their ``sdf_index`` rows [N_h, N_o]; about a third of the rows pass the |sdf| < 0.05 pre-filter."""
+    r = _rng("sdf_frames", seed)
+    frames, index = [], []
+    for _ in range(n_frames):
+        nh, no = int(r.integers(300, 500)), int(r.integers(200, 400))
+        a = np.zeros((nh + no, 6), np.float32)
+        a[:, :3] = (r.uniform(-0.1, 0.1, (nh + no, 3)) + np.array([0.0, 0.0, 0.7])).astype(np.float32)
+        a[:, 3] = r.uniform(-0.15, 0.15, nh + no)
+        a[:, 4] = r.uniform(-0.15, 0.15, nh + no)
+        a[:, 5] = r.integers(0, 6, nh + no)
+        frames.append(a)
+        index.append([nh, no])
+    return frames, np.asarray(index)
+
+
 def to_device(tree, device):
     if isinstance(tree, dict):
         return type(tree)((k, to_device(v, device)) for k, v in tree.items())

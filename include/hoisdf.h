@@ -286,12 +286,20 @@ int hoisdf_sdf_query_bwd(const hoisdf_pyramid_grad* dpyr, const float* points, c
  * reference: Model.sdf_infer (main/model.py:246-355): dense sheared lattice inside the bbox -> SDF of every survivor ->
  * the num_points survivors of every sample with the smallest |sdf| (ascending) -> their points (scaled frame), clamped
  * SDF values and positional encodings.
- * hoisdf_sdf_infer_count: survivors per sample into counts_device [B] and counts_host [B] (ONE device -> host read, the
- *   stream is synchronised), *n_rows = their total.  The caller sizes the workspace with
+ * hoisdf_sdf_infer_count_begin: queues the survivor count per sample into counts_device [B] and its copy into counts_host [B]
+ *   (page-locked host memory that stays alive until the stream has executed the copy) and RETURNS WITHOUT WAITING.  The counts
+ *   depend only on center / cam_intr / bbox (main/model.py:286-302), so a host can issue this ahead of the image encoder,
+ *   record an event behind it and wait for that event when it reaches sdf_infer - no pipeline drain.
+ * hoisdf_sdf_infer_count: the same followed by hipStreamSynchronize(stream) - the ONE blocking device -> host read of the
+ *   path, for hosts that do not overlap it; *n_rows = the total.  The caller sizes the workspace with
  *   hoisdf_sdf_infer_workspace(n_rows, B, C) and calls
- * hoisdf_sdf_infer: lattice fill -> hoisdf_sdf_query_fwd -> hoisdf_select_smallest_abs -> hoisdf_gather_rows; a sample
- *   with fewer than num_points survivors is refused (the reference raises at main/model.py:348).
+ * hoisdf_sdf_infer: exclusive scan of the counts (device) -> lattice fill -> hoisdf_sdf_query_fwd ->
+ *   hoisdf_select_smallest_abs -> hoisdf_gather_rows.  It only enqueues work (no host <-> device copy, no synchronisation);
+ *   counts_host is read on the host for validation and sizing.  A sample with fewer than num_points survivors is refused
+ *   (the reference raises at main/model.py:348).
  *   points_out [B][num_points][3], sdf_out [B][num_points], pe_out [B][num_points][30] (optional). */
+int hoisdf_sdf_infer_count_begin(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n,
+                                 int B, int32_t* counts_device, int32_t* counts_host, void* stream);
 int hoisdf_sdf_infer_count(const float* center, const float* cam_intr, const float* bbox, float scale, int bins_n, int B,
                            int32_t* counts_device, int32_t* counts_host, long* n_rows, void* stream);
 long hoisdf_sdf_infer_workspace(long n_rows, int B, int C);
@@ -548,6 +556,23 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
                          float radius, const float* joints, const float* stats, const float* djoints,
                          const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
                          int B, int P, int J, void* stream);
+
+/* ---- a15: the scalar point losses ------------------------------------------------
+ * reference: common/nets/loss.py:64-78 (SepSDFLoss = torch.nn.L1Loss(mean) of the clamped SDF predictions against the
+ * ground truth clamped as main/model.py:393-400 does), main/model.py:35-36,656-662 (obj_rot / obj_trans:
+ * torch.nn.SmoothL1Loss, beta 1, mean over (L, B, P, 3) against the (B, 3) target expanded over depth and points),
+ * common/nets/loss.py:57-59 (loss_all_joint_3d: SmoothL1 of joints * 1000 against the ground truth expanded over depth).
+ * Element i of pred [n] is compared with target[((i / (rep * C)) % Bt) * C + i % C] - a (Bt, C) target broadcast over
+ * leading dimensions and over `rep` repeats between Bt and C.  kind 0: |pred * pred_scale - clamp(target, +-clamp)|
+ * (clamp <= 0: the target is taken as is); kind 1: SmoothL1 with beta = 1 of the same difference.
+ * fwd: loss[0] = out_scale * sum_i (out_scale = 1 / n gives the reference's mean); order-fixed (per-block partial sums in
+ *   partials [hoisdf_point_loss_blocks(n)] added in block order): bit-reproducible.
+ * bwd: dpred[i] = g[0] * out_scale * pred_scale * dl/dd (torch's subgradients: sign(0) = 0). */
+int hoisdf_point_loss_blocks(long n);
+int hoisdf_point_loss_fwd(const float* pred, const float* target, long n, long rep, int C, long Bt, int kind,
+                          float clamp, float pred_scale, float out_scale, float* partials, float* loss, void* stream);
+int hoisdf_point_loss_bwd(const float* pred, const float* target, long n, long rep, int C, long Bt, int kind,
+                          float clamp, float pred_scale, float out_scale, const float* g, float* dpred, void* stream);
 
 /* ---- (f3) MANO head ---------------------------------------------------------------------------------------------
  * reference: common/nets/mano_head.py:12-278 (6D -> rotation -> quaternion -> axis-angle, the head), manopth/manopth/

@@ -495,6 +495,30 @@ def mano_head(pose6d: Tensor, shape: Tensor, mano_layer: Callable, hands_mean: T
 
 
 # --------------------------------------------------------------------------------------
+# f4 encoder-side auxiliary image losses                (main/model.py:128-143, :404-422)
+# --------------------------------------------------------------------------------------
+def render_gaussian_heatmap(joint_coord: Tensor, hm_hw=(128, 128), sigma: float = 2.5) -> Tensor:
+    """main/model.py:128-143: 255 * sum_j exp(-((x - jx) / sigma)^2 / 2 - ((y - jy) / sigma)^2 / 2) on the
+    cfg.output_hm_shape grid (main/config.py: output_hm_shape (64, 128, 128), sigma 2.5)."""
+    y = torch.arange(hm_hw[0], dtype=joint_coord.dtype)
+    x = torch.arange(hm_hw[1], dtype=joint_coord.dtype)
+    yy, xx = torch.meshgrid(y, x, indexing="ij")
+    jx, jy = joint_coord[:, :, 0, None, None], joint_coord[:, :, 1, None, None]
+    hm = torch.exp(-(((xx[None, None] - jx) / sigma) ** 2) / 2 - (((yy[None, None] - jy) / sigma) ** 2) / 2)
+    return hm.sum(1) * 255
+
+
+def aux_image_losses(decoder_out: Tensor, targets: Dict[str, Tensor], sigma: float = 2.5) -> Dict[str, Tensor]:
+    """main/model.py:404-422: joint_heatmap = (decoder_out[:, 0] - heatmap)^2 (common/nets/loss.py:14-20), obj_seg / hand_seg =
+    BCELoss(reduction="none") of channels 2 / 1 against the masks (main/model.py:94-95)."""
+    hm = render_gaussian_heatmap(targets["joint_coord"], decoder_out.shape[-2:], sigma)
+    return {"joint_heatmap": (decoder_out[:, 0] - hm) ** 2,
+            "obj_seg": F.binary_cross_entropy(decoder_out[:, 2], targets["obj_seg"], reduction="none"),
+            "hand_seg": F.binary_cross_entropy(decoder_out[:, 1], targets["hand_seg"], reduction="none"),
+            "heatmap": hm}
+
+
+# --------------------------------------------------------------------------------------
 # a1 the whole hot path                                  (main/model.py:370-665)
 # --------------------------------------------------------------------------------------
 def hot_path_forward(P: Params, cfg: OracleCfg, feature_pyramid: Dict[str, Tensor],

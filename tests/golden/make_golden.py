@@ -66,13 +66,14 @@ class _Backbone(torch.nn.Module):
 
 
 class _Decoder(torch.nn.Module):
-    def __init__(self, pyr):
+    def __init__(self, pyr, decoder_out=None):
         super().__init__()
         self.pyr = pyr
+        self.decoder_out = decoder_out
 
     def forward(self, a, b):
         B = next(iter(self.pyr.values())).shape[0]
-        return self.pyr, torch.full((B, 3, 128, 128), 0.5)
+        return self.pyr, (self.decoder_out if self.decoder_out is not None else torch.full((B, 3, 128, 128), 0.5))
 
 
 def build_reference(setting: str, n_hand: int, n_obj: int, bins_n: int, resnet_type=18):
@@ -188,7 +189,7 @@ def e2e_goldens():
     for setting, big in (("dexycb", False), ("ho3d", True), ("ho3d_render", False)):
         for (nh, no, bins, B) in ((48, 16, 16, 2), (384, 128, 64, 1)):
             if big and nh > 48:
-                continue
+                nh, no = 384, 128       # round 4: the big decoder (C = 3968) through the 64^3 lattice as well
             model, cfg = build_reference(setting, nh, no, bins)
             model.eval()
             pyr = T.synthetic_pyramid(B, big=big, seed=2)
@@ -206,7 +207,7 @@ def e2e_goldens():
             save(f"g7_e2e_{setting}_n{nh + no}", **keep)
 
 
-def train_goldens(sizes=((2, 48, 16, ""),), settings=("dexycb", "ho3d_render")):
+def train_goldens(sizes=((2, 48, 16, ""),), settings=("dexycb", "ho3d_render", "ho3d")):
     """g8: train-mode forward + backward with every dropout p forced to 0 (branch A)."""
     for (B, nh, no, suffix) in sizes:
         _train_goldens(B, nh, no, suffix, settings)
@@ -229,7 +230,7 @@ def _train_goldens(B, nh, no, suffix, settings, epoch_cnt=0):
                 m.dropout = 0.0
             if hasattr(m, "dropout_prob"):
                 m.dropout_prob = 0.0
-        pyr = T.synthetic_pyramid(B, big=False, seed=3)
+        pyr = T.synthetic_pyramid(B, big=setting == "ho3d", seed=3)      # "ho3d" = the big decoder: C = 3968
         pyr = {k: v.clone().requires_grad_(True) for k, v in pyr.items()}
         model.backbone_net, model.decoder_net = _Backbone(), _Decoder(pyr)
         inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=31)
@@ -282,6 +283,85 @@ def big_goldens():
                 keep[k + "_mean"] = keep.pop(k).mean(1)
         save(f"g7_e2e_{setting}_n{nh + no}", **keep)
     train_goldens(sizes=((2, 1536, 512, "_n2048"),), settings=("dexycb",))
+
+
+def aux_loss_golden():
+    """g13 (f4): the encoder-side auxiliary image losses as the reference's own forward computes them
+    (main/model.py:128-143 render_gaussian_heatmap, :404-422 MSE + 2 x BCELoss(reduction="none")) on a seeded decoder output
+    (hoisdf_amd.testing.synthetic_decoder_out), plus the gradient of the sum of their means w.r.t. the decoder output.
+    Stored: every second pixel of the maps (the test regenerates the inputs from the seeds) and the exact means."""
+    B, nh, no = 2, 48, 16
+    model, cfg = build_reference("dexycb", nh, no, 16)
+    model.train()
+    pyr = T.synthetic_pyramid(B, big=False, seed=3)
+    dec = T.synthetic_decoder_out(B, seed=13).requires_grad_(True)
+    model.backbone_net, model.decoder_net = _Backbone(), _Decoder(pyr, dec)
+    inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=31)
+    random.seed(0)
+    torch.manual_seed(1234)
+    out = model(inputs, targets, meta, "train", 0, 0.5)
+    hm = model.render_gaussian_heatmap(targets["joint_coord"])
+    tot = out["joint_heatmap"].mean() + out["obj_seg"].mean() + out["hand_seg"].mean()
+    g, = torch.autograd.grad(tot, dec)
+    sub = lambda t: t.detach()[..., ::2, ::2]
+    out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+    save("g13_aux_losses", heatmap=sub(hm), joint_heatmap=sub(out["joint_heatmap"]), obj_seg=sub(out["obj_seg"]),
+         hand_seg=sub(out["hand_seg"]), mean_joint_heatmap=out["joint_heatmap"].double().mean().numpy(),
+         mean_obj_seg=out["obj_seg"].double().mean().numpy(), mean_hand_seg=out["hand_seg"].double().mean().numpy(),
+         mean_heatmap=hm.double().mean().numpy(), grad_decoder_out=sub(g), grad_norm=g.double().norm().numpy())
+
+
+def sampler_golden():
+    """g14 (f2): the SDF sample selection and hand-off of the reference's dataset object, produced by EXECUTING the reference's
+    own source lines (data/dexycb.py:514-549 draw + flip, :288 in-plane rotation, :596-617 centre + scale) - read from
+    /root/reference at generation time, dedented and exec'ed on a synthetic ``sdf_processed`` frame set
+    (hoisdf_amd.testing.synthetic_sdf_frames) with ``np.random.seed`` fixed.  __getitem__ itself cannot run here (images,
+    annotations, cv2); the lines between the blocks (image crop / augmentation) do not touch the points except for the
+    rotation line, which is executed too.  Pinned: the eligibility sets of the |sdf| < dist pre-filter, numpy's own draws
+    for this seed (the device sampler draws from another stream - it is held to the sets and counts), and the hand-off of
+    those drawn rows."""
+    import textwrap
+    src = open(os.path.join(REF, "data", "dexycb.py")).read().split("\n")
+    block = lambda a, b: textwrap.dedent("\n".join(src[a - 1:b]))
+    draw, flip, rotate, handoff = block(514, 546), block(548, 549), block(288, 288), block(596, 617)
+    assert "np.random.choice" in draw and "sdf_points[:, 0] *= -1" in flip and "rot_mat.T" in rotate and "hand_pre_points" in handoff
+    frames, index = T.synthetic_sdf_frames(4, seed=14)
+    tmp = tempfile.mkdtemp(prefix="hoisdf_sdf_")
+    paths = []
+    for i, a in enumerate(frames):
+        paths.append(os.path.join(tmp, f"{i}.npy"))
+        np.save(paths[-1], a)
+    nh, no = 64, 48
+    out = {}
+    r = np.random.default_rng(141)
+    for mode in ("train", "test"):
+        for idx in range(len(frames)):
+            do_flip = idx % 2 == 1
+            self = types.SimpleNamespace(sdf_path_list=paths, sdf_index_list=[np.array(v) for v in index], num_samp_hand=nh,
+                                         num_samp_obj=no, mode=mode, dist=0.05, hand_sdf_scale=3.1, obj_sdf_scale=3.1)
+            ns = {"np": np, "self": self, "idx": idx, "do_flip": do_flip}
+            np.random.seed(1000 + idx)
+            exec(draw, ns)
+            exec(flip, ns)
+            th = 0.3 * (idx - 1.5)
+            ns["rot_mat"] = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+            if mode == "train":
+                exec(rotate, ns)
+            ns["hand_root"] = (np.array([0.0, 0.0, 0.7]) + 0.01 * r.standard_normal(3)).astype(np.float32)
+            ns["obj_center_cam"] = (np.array([0.03, 0.02, 0.72]) + 0.01 * r.standard_normal(3)).astype(np.float32)
+            exec(handoff, ns)
+            k = f"{mode}{idx}."
+            sd, si = frames[idx], index[idx]
+            out[k + "all_idx"] = ns["all_idx"].astype(np.int64)
+            out[k + "hand_root"], out[k + "obj_center_cam"], out[k + "rot_mat"] = ns["hand_root"], ns["obj_center_cam"], ns["rot_mat"]
+            out[k + "hand_sdf_points"], out[k + "obj_sdf_points"] = ns["hand_sdf_points"], ns["obj_sdf_points"]   # (n, 5) rows, scaled
+            out[k + "sdf_raw_label"] = ns["sdf_raw_label"]
+            if mode == "train":
+                out[k + "hand_pre_points"], out[k + "obj_pre_points"] = ns["hand_pre_points"], ns["obj_pre_points"]
+                # the eligibility sets exactly as the reference forms them (:530, :535)
+                out[k + "elig_hand"] = np.where(np.abs(sd[: si[0], 3]) < self.dist)[0].astype(np.int64)
+                out[k + "elig_obj"] = (np.where(np.abs(sd[si[0]:, 4]) < self.dist)[0] + si[0]).astype(np.int64)
+    save("g14_sampler", **out)
 
 
 def mano_golden():
@@ -422,7 +502,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik", "aux", "sampler"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -441,3 +521,7 @@ if __name__ == "__main__":
         metrics_golden()
     if "ik" in which:
         ik_golden()
+    if "aux" in which:
+        aux_loss_golden()
+    if "sampler" in which:
+        sampler_golden()

@@ -46,7 +46,7 @@ def oracle_cfg(c, **kw):
 
 
 E2E = [("dexycb", False, 48, 16, 16, 2), ("ho3d", True, 48, 16, 16, 2), ("ho3d_render", False, 48, 16, 16, 2),
-       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1),
+       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1), ("ho3d", True, 384, 128, 64, 1),
        # BASELINE.json sizes: configs[1] points, configs[3] (IK variant, 4096 points), configs[4] (8192 points)
        ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1), ("dexycb", False, 6144, 2048, 64, 1)]
 
@@ -113,7 +113,7 @@ def test_sdf_infer_selects_the_oracle_set():
         model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], tiny, 3.1, nh, "hand")
 
 
-@pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""),
+@pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
                                                   ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
 def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suffix):
     """branch A (pre-points + jitter), every dropout p = 0: losses and gradients vs g8 goldens (the _n2048 fixture is the
@@ -129,7 +129,7 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
             m.p = 0.0
         if hasattr(m, "dropout_prob"):
             m.dropout_prob = 0.0
-    pyr, levels = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=3), requires_grad=True)
+    pyr, levels = nhwc_pyramid(T.synthetic_pyramid(b, big=setting == "ho3d", seed=3), requires_grad=True)   # "ho3d": C = 3968
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=31)
     # reproduce the reference's CPU jitter stream (torch.manual_seed(1234): hand first, then obj)
     torch.manual_seed(1234)
@@ -513,3 +513,35 @@ def test_train_fwd_bwd_with_split_precision_attention_meets_the_golden_bars(nh, 
     assert n > 100
     # element-wise pyramid gradient: ill-conditioned, judged against the fp64 value as well as the reference's fp32 one
     pyramid_gradient_close(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"], suffix)
+
+
+def test_sdf_infer_with_counts_queued_ahead_equals_the_blocking_form():
+    """hoisdf_sdf_infer_count_begin (queued before other work, waited for through an event) + hoisdf_sdf_infer (device scan of
+    the offsets, no synchronisation) return what the one-shot form returns, and Model.forward's early request is consumed by
+    hot_path (main/model.py:246-355)."""
+    from hoisdf_amd import ops as O
+    nh, no, bins, b = 384, 128, 64, 3
+    model, c = build("dexycb", nh, no, bins)
+    pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, seed=8))
+    inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=81)
+    meta["bbox_hand"][1] = torch.tensor([60.0, 50, 200, 210])            # different survivor counts per sample
+    m = T.to_device(meta, DEV)
+    ref = model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand")
+    h = model.infer_counts_begin(m)
+    junk = torch.randn(2048, 2048, device=DEV) @ torch.randn(2048, 2048, device=DEV)       # work queued behind the request
+    got = model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand", h["hand"])
+    for a, r in zip(got[:3], ref[:3]):
+        assert torch.equal(a, r)
+    cl = h["hand"].wait()
+    assert len(cl) == b and cl[1] != cl[0]
+    # a handle made for other inputs is not used blindly
+    other = O.sdf_infer_count_begin(m["obj_center_cam"], m["cam_intr"], m["bbox_obj"], 3.1, bins)
+    got2 = model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand", other)
+    assert torch.equal(got2[0], ref[0])
+    # the whole eval step: early request in hot_path == no request
+    di, dt = T.to_device(inputs, DEV), T.to_device(targets, DEV)
+    with torch.no_grad():
+        _, o1 = model.hot_path(pyr, di, dt, m, "eval")
+        _, o2 = model.hot_path(pyr, di, dt, m, "eval", infer_counts=model.infer_counts_begin(m))
+    assert torch.equal(o1["hand_joints_out"], o2["hand_joints_out"])
+    del junk

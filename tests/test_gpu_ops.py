@@ -987,3 +987,78 @@ def test_coarse_sdf_query_train_entries_equal_the_op_chain(B, P):
     assert [n for n, _ in a[4]] == [n for n, _ in b[4]] and len(a[4]) == 18
     for (n, x), (_, y) in zip(a[4], b[4]):
         assert_close(x, y, rel=2e-5, what="d " + n)
+
+
+# ---------------------------------------------------------------------------------------------
+# a15: the scalar point losses (hoisdf_point_loss_fwd / _bwd) against torch in float64
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 257, 32 * 1536, 600_001])
+def test_l1_loss_with_clamped_target_matches_torch(n):
+    """SepSDFLoss on the clamped ground truth (common/nets/loss.py:64-78, main/model.py:393-400): value 1e-6 rel (an
+    order-fixed f32 sum against float64), gradient exact (+-1/n, 0 where pred == target)."""
+    O = ops()
+    g = torch.Generator().manual_seed(n)
+    pred = (torch.rand(n, 1, generator=g) - 0.5) * 0.1
+    gt = (torch.rand(n, generator=g) - 0.5) * 0.3                      # beyond the clamp on both sides
+    cd = 0.05
+    if n > 4:
+        pred[3, 0] = gt[3].clamp(-cd, cd)                              # an exact tie: torch's sign(0) = 0
+    p64 = pred.double().requires_grad_(True)
+    ref = F.l1_loss(p64, gt.double().clamp(-cd, cd).unsqueeze(-1))
+    (ref * 3.0).backward()
+    pg = pred.to(DEV).requires_grad_(True)
+    got = O.l1_loss_clamped_target(pg, gt.to(DEV), cd)
+    (got * 3.0).backward()
+    assert abs(float(got) - float(ref)) <= 1e-6 * abs(float(ref)) + 1e-12
+    assert torch.equal(pg.grad.cpu(), p64.grad.float())
+    again = O.l1_loss_clamped_target(pg.detach(), gt.to(DEV), cd)
+    assert float(again) == float(got)                                 # order-fixed: bit-reproducible
+
+
+@pytest.mark.parametrize("L,B,P,C,scale", [(6, 3, 5, 3, 1.0), (6, 32, 512, 3, 1.0), (6, 2, 1, 60, 1000.0), (1, 1, 1, 1, 1.0)])
+def test_smooth_l1_loss_broadcast_matches_torch(L, B, P, C, scale):
+    """obj_rot / obj_trans (main/model.py:656-662: (L, B, P, 3) against (B, 3)) and loss_all_joint_3d (loss.py:57-59:
+    joints * 1000 against (B, J * 3)): value 2e-6 rel, gradient 1e-6 of its max."""
+    O = ops()
+    g = torch.Generator().manual_seed(L * 1000 + P)
+    pred = torch.randn(L, B, P, C, generator=g) * (2.0 / scale)        # both SmoothL1 branches
+    tgt = torch.randn(B, C, generator=g)
+    p64 = pred.double().requires_grad_(True)
+    ref = F.smooth_l1_loss(p64 * scale, tgt.double()[None, :, None].expand(L, B, P, C))
+    ref.backward()
+    pg = pred.to(DEV).requires_grad_(True)
+    got = O.smooth_l1_loss_broadcast(pg, tgt.to(DEV), P, scale)
+    got.backward()
+    assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-12
+    assert_close(pg.grad, p64.grad, rel=1e-6, what="smooth-l1 grad")
+
+
+def test_point_loss_rejects_shapes_that_are_not_a_broadcast():
+    O = ops()
+    with pytest.raises(ValueError):
+        O.smooth_l1_loss_broadcast(torch.zeros(2, 3, 5, 3, device=DEV), torch.zeros(4, 3, device=DEV), 5)
+
+
+def test_aux_image_losses_match_the_reference_fixture():
+    """(f4) hoisdf_aux_image_losses_fwd / _bwd against tests/golden/g13_aux_losses.npz = the reference's own forward
+    (main/model.py:128-143,404-422) on the seeded decoder output: maps on every second pixel, exact means, the gradient of
+    the sum of the three means w.r.t. the decoder output."""
+    from conftest import load_golden
+    from hoisdf_amd.config import Config
+    O = ops()
+    g = load_golden("g13_aux_losses")
+    dec = T.synthetic_decoder_out(2, seed=13).to(DEV).requires_grad_(True)
+    _, targets, _ = T.synthetic_batch(2, 48, 16, seed=31)
+    l_hm, l_obj, l_hand, hm = O.aux_image_losses(dec, targets["joint_coord"].to(DEV), targets["hand_seg"].to(DEV),
+                                                 targets["obj_seg"].to(DEV), Config().sigma)
+    sub = lambda t: t.detach()[..., ::2, ::2]
+    assert_close(sub(hm), g["heatmap"], rel=3e-6, what="heatmap")
+    assert_close(sub(l_hm), g["joint_heatmap"], rel=1e-5, what="mse map")
+    assert_close(sub(l_obj), g["obj_seg"], rel=1e-5, what="bce obj map")
+    assert_close(sub(l_hand), g["hand_seg"], rel=1e-5, what="bce hand map")
+    for got, k in ((l_hm, "joint_heatmap"), (l_obj, "obj_seg"), (l_hand, "hand_seg")):
+        ref = float(g["mean_" + k])
+        assert abs(float(got.detach().double().mean()) - ref) <= 2e-6 * abs(ref), k
+    (l_hm.mean() + l_obj.mean() + l_hand.mean()).backward()
+    assert_close(sub(dec.grad), g["grad_decoder_out"], rel=1e-5, what="d decoder_out")
+    assert abs(float(dec.grad.double().norm()) - float(g["grad_norm"])) <= 1e-5 * float(g["grad_norm"])

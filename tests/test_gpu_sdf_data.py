@@ -148,3 +148,50 @@ def test_trainer_draws_its_batches_from_the_store():
         total, loss = tr.train_step(inputs, targets, meta, 0, 0.0)
         losses.append(float(total))
     assert all(np.isfinite(losses)) and "sdfhand_loss" in loss and float(loss["sdfhand_loss"]) > 0
+
+
+def test_sampler_against_the_references_own_selection_code():
+    """(f2) tests/golden/g14_sampler.npz = data/dexycb.py:514-549,:288,:596-617 executed on the synthetic frames.  The device
+    sampler draws from another random stream, so it is held to what IS comparable: the eligibility COUNTS of the |sdf| < dist
+    pre-filter (hoisdf_sdf_sample_keys' `elig`) and the sets its draws may come from; and numpy's own draws, fed through the
+    device hand-off (flip, in-plane rotation, centre, scale), must reproduce the reference's outputs (1e-6: the reference
+    rotates in float64 and rounds once)."""
+    from conftest import load_golden
+    from hoisdf_amd import testing as T
+    from hoisdf_amd.sdf_data import SdfStore
+    g = load_golden("g14_sampler")
+    frames, index = T.synthetic_sdf_frames(4, seed=14)
+    st = SdfStore(frames, index)
+    row0 = np.concatenate([[0], np.cumsum(index.sum(1))])
+    nh, no, dist, sc = 64, 48, 0.05, 3.1
+    B = len(frames)
+    for mode in ("train", "test"):
+        train = mode == "train"
+        key = lambda i, n: g[f"{mode}{i}.{n}"]
+        rows = np.stack([np.asarray(key(i, "all_idx")) + row0[i] for i in range(B)])
+        root = torch.stack([key(i, "hand_root") for i in range(B)]).float()
+        oc = torch.stack([key(i, "obj_center_cam") for i in range(B)]).float()
+        flip = torch.tensor([i % 2 == 1 for i in range(B)])
+        rot = torch.stack([key(i, "rot_mat").float() for i in range(B)]) if train else None
+        out = st.make_inputs(list(range(B)), root, oc, nh, no, dist, sc, sc, train=train, seed=0, do_flip=flip, rot_mat=rot,
+                             rows=torch.from_numpy(rows))
+        for i in range(B):
+            hp, op = key(i, "hand_sdf_points").numpy(), key(i, "obj_sdf_points").numpy()        # (n, 5) scaled rows
+            np.testing.assert_allclose(out["hand_sdf_points"][i].cpu().numpy(), hp[:, :3], atol=1e-6)
+            np.testing.assert_allclose(out["obj_sdf_points"][i].cpu().numpy(), op[:, :3], atol=1e-6)
+            np.testing.assert_allclose(out["hand_sdf"][i].cpu().numpy(), hp[:, 3], atol=1e-7)
+            np.testing.assert_allclose(out["obj_sdf"][i].cpu().numpy(), op[:, 4], atol=1e-7)
+            if train:
+                np.testing.assert_allclose(out["hand_pre_points"][i].cpu().numpy(), key(i, "hand_pre_points").numpy(), atol=1e-6)
+                np.testing.assert_allclose(out["obj_pre_points"][i].cpu().numpy(), key(i, "obj_pre_points").numpy(), atol=1e-6)
+        # the device draw: its pre points come from the reference's eligibility sets, and a k one above the set size is refused
+        # exactly where np.random.choice(replace=False) would raise
+        if train:
+            smp = st.sample(list(range(B)), nh, no, dist, True, seed=3)["rows"].cpu().numpy()
+            for i in range(B):
+                eh, eo = set(np.asarray(key(i, "elig_hand")) + row0[i]), set(np.asarray(key(i, "elig_obj")) + row0[i])
+                assert set(smp[i, nh + no:2 * nh + no]) <= eh and set(smp[i, 2 * nh + no:]) <= eo
+            n_min_h = min(len(np.asarray(key(i, "elig_hand"))) for i in range(B))
+            st.sample(list(range(B)), n_min_h, no, dist, True, seed=3)
+            with pytest.raises(ValueError):
+                st.sample(list(range(B)), n_min_h + 1, no, dist, True, seed=3)

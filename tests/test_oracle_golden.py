@@ -151,7 +151,7 @@ def test_g9_mano_and_rotations():
 
 
 E2E = [("dexycb", False, 48, 16, 16, 2), ("ho3d", True, 48, 16, 16, 2), ("ho3d_render", False, 48, 16, 16, 2),
-       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1),
+       ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1), ("ho3d", True, 384, 128, 64, 1),
        # the sizes BASELINE.json's configs[1] / configs[3] name (configs[4]'s 6144+2048 fixture is checked on the GPU only)
        ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1)]
 
@@ -189,7 +189,7 @@ def test_g7_e2e(setting, big, nh, no, bins, b):
     assert checked >= 6
 
 
-@pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""),
+@pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
                                                   ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
 def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     """_branchB: epoch >= cfg.point_sampling_epoch and the draw p = 0.844 >= 0.4 -> the query points come from the
@@ -197,13 +197,14 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     g = load_golden(f"g8_train_{setting}{suffix}")
     epoch_cnt = 10 ** 8 if suffix == "_branchB" else 0
     ik = setting == "ho3d_render"
+    big = setting == "ho3d"                              # the big decoder: C = 3968 (main/config.py:96,101-108)
     b = 2
-    Pm = T.det_params(T.hot_path_param_shapes(992, ik=ik))
+    Pm = T.det_params(T.hot_path_param_shapes(3968 if big else 992, ik=ik))
     for v in Pm.values():
         v.requires_grad_(True)
     cfg = O.OracleCfg(num_samp_hand=nh, num_samp_obj=no, bins_n=16, use_inverse_kinematics=ik,
-                      dataset="ho3d" if ik else "dexycb", dropout=0.0, sdf_dropout=0.0)
-    pyr = {k: v.requires_grad_(True) for k, v in T.synthetic_pyramid(b, big=False, seed=3).items()}
+                      dataset="ho3d" if "ho3d" in setting else "dexycb", dropout=0.0, sdf_dropout=0.0)
+    pyr = {k: v.requires_grad_(True) for k, v in T.synthetic_pyramid(b, big=big, seed=3).items()}
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=31)
     layer = MANO.ManoLayer(MANO.synthetic_assets(0))
     random.seed(0)
@@ -251,3 +252,52 @@ def test_fp64_truth_fixture_documents_the_references_own_fp32_distance():
     d = float((ref - tru).abs().max()) / mx
     assert 5e-4 < d < 1.2e-3, d
     assert abs(float(g64["total"]) - float(g["total"])) <= 1e-7 * abs(float(g["total"]))
+
+
+def test_g13_aux_image_losses():
+    """(f4) the restated auxiliary image losses against the reference's own forward (main/model.py:128-143,404-422) on the
+    seeded decoder output; every second pixel of the maps + exact means + the gradient w.r.t. the decoder output."""
+    g = load_golden("g13_aux_losses")
+    dec = T.synthetic_decoder_out(2, seed=13).requires_grad_(True)
+    _, targets, _ = T.synthetic_batch(2, 48, 16, seed=31)
+    from hoisdf_amd.config import Config
+    out = O.aux_image_losses(dec, targets, Config().sigma)
+    sub = lambda t: t[..., ::2, ::2]
+    close(sub(out["heatmap"]), g["heatmap"], atol=1e-4, rtol=1e-6)          # peaks of 255 per joint
+    close(sub(out["joint_heatmap"]), g["joint_heatmap"], atol=1e-2, rtol=1e-5)   # squared differences up to ~6e4
+    close(sub(out["obj_seg"]), g["obj_seg"], atol=1e-6, rtol=1e-6)
+    close(sub(out["hand_seg"]), g["hand_seg"], atol=1e-6, rtol=1e-6)
+    for k in ("joint_heatmap", "obj_seg", "hand_seg"):
+        assert abs(float(out[k].detach().double().mean()) - float(g["mean_" + k])) <= 1e-6 * abs(float(g["mean_" + k]))
+    (out["joint_heatmap"].mean() + out["obj_seg"].mean() + out["hand_seg"].mean()).backward()
+    close(sub(dec.grad), g["grad_decoder_out"], atol=1e-9, rtol=1e-5)
+    assert abs(float(dec.grad.double().norm()) - float(g["grad_norm"])) <= 1e-6 * float(g["grad_norm"])
+
+
+def test_g14_sampler_fixture_is_the_references_selection():
+    """(f2) tests/golden/g14_sampler.npz was produced by executing data/dexycb.py:514-549,:288,:596-617 themselves; here: its
+    row sets obey the reference's contract on the regenerated frames (regions, no repeats, the |sdf| < dist pre-filter) and
+    the hand-off it stores equals a direct numpy evaluation of the same rows - so the GPU test can trust it as the target."""
+    g = load_golden("g14_sampler")
+    frames, index = T.synthetic_sdf_frames(4, seed=14)
+    nh, no, dist, sc = 64, 48, 0.05, 3.1
+    for mode in ("train", "test"):
+        for i, (a, (n_h, n_o)) in enumerate(zip(frames, index)):
+            k = f"{mode}{i}."
+            idx = np.asarray(g[k + "all_idx"])
+            h, o = idx[:nh], idx[nh:nh + no]
+            assert len(set(h)) == nh and h.max() < n_h and len(set(o)) == no and o.min() >= n_h and o.max() < n_h + n_o
+            d = a[idx].copy()
+            if i % 2 == 1:
+                d[:, 0] *= -1
+            if mode == "train":
+                eh, eo = np.asarray(g[k + "elig_hand"]), np.asarray(g[k + "elig_obj"])
+                assert np.array_equal(eh, np.where(np.abs(a[:n_h, 3]) < dist)[0])
+                assert np.array_equal(eo, np.where(np.abs(a[n_h:, 4]) < dist)[0] + n_h)
+                assert set(idx[nh + no:2 * nh + no]) <= set(eh) and set(idx[2 * nh + no:]) <= set(eo)
+                d[:, :3] = d[:, :3].dot(g[k + "rot_mat"].double().numpy().T)
+            root, oc = g[k + "hand_root"].numpy(), g[k + "obj_center_cam"].numpy()
+            hand = d[:nh, :5].copy(); hand[:, :3] -= root; hand *= sc
+            np.testing.assert_allclose(g[k + "hand_sdf_points"].numpy(), hand, atol=1e-6)
+            if mode == "train":
+                np.testing.assert_allclose(g[k + "obj_pre_points"].numpy(), (d[2 * nh + no:, :3] - oc) * sc, atol=1e-6)
