@@ -90,6 +90,20 @@ class SdfWeightGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _SDF_G]
 
 
+MLP_MAX_LAYERS = 4
+
+
+class Mlp(C.Structure):
+    """include/hoisdf.h hoisdf_mlp"""
+    _fields_ = [("n_layers", C.c_int), ("act_last", C.c_int), ("dims", C.c_int * (MLP_MAX_LAYERS + 1)),
+                ("w", C.c_void_p * MLP_MAX_LAYERS), ("b", C.c_void_p * MLP_MAX_LAYERS)]
+
+
+class MlpGrads(C.Structure):
+    """include/hoisdf.h hoisdf_mlp_grads"""
+    _fields_ = [("dw", C.c_void_p * MLP_MAX_LAYERS), ("db", C.c_void_p * MLP_MAX_LAYERS)]
+
+
 _P, _I, _L, _F, _U64, _D = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_double
 _PYR = C.POINTER(Pyramid)
 _SDFW = C.POINTER(SdfWeights)
@@ -161,6 +175,10 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_vote_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_fwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hoisdf_vote_loss_bwd": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hoisdf_tokens_fwd": [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "hoisdf_tokens_bwd": [_P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _L, _P],
+    "hoisdf_heads_vote_fwd": [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P, _L, _P],
+    "hoisdf_heads_vote_bwd": [_P, _P, _P, _P, _P, _F, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_point_loss_fwd": [_P, _P, _L, _L, _I, _L, _I, _F, _F, _F, _P, _P, _P],
     "hoisdf_point_loss_bwd": [_P, _P, _L, _L, _I, _L, _I, _F, _F, _F, _P, _P, _P],
 }
@@ -168,6 +186,10 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
           "hoisdf_point_loss_blocks": ([_L], C.c_int),
+          "hoisdf_tokens_saved_bytes": ([_P, _L, _I], C.c_long),
+          "hoisdf_tokens_workspace_bytes": ([_P, _L, _I], C.c_long),
+          "hoisdf_heads_vote_saved_bytes": ([_P, _P, _I, _I, _I, _I], C.c_long),
+          "hoisdf_heads_vote_workspace_bytes": ([_P, _P, _I, _I, _I, _I, _I], C.c_long),
           "hoisdf_sdf_infer_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_sdf_query_train_saved_bytes": ([_L, _I], C.c_long),
           "hoisdf_sdf_query_train_workspace_bytes": ([_L, _I, _I], C.c_long),

@@ -48,13 +48,16 @@ const void* image_of(Ctx& c, const void* given, const float* W, int ldw, int N, 
   c.rc = hoisdf_linear_emu_prepare(W, ldw, N, K, transpose, img, c.stream);
   return img;
 }
+// K_pad >= K (default K): columns K .. K_pad - 1 of x are zero padding; the emulated form contracts over K_pad (they meet the zero
+// fill of the weight image, which is built from the K real columns) so that a ragged K (289) still takes the bf16 pipe
 void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const void* img, const float* b, float* y, int ldy, long M, int N,
-             int K, int act, float p, uint64_t seed, uint32_t* bits) {
+             int K, int act, float p, uint64_t seed, uint32_t* bits, int K_pad = 0) {
   if (!c.ok()) return;
-  if (emu_rows(c, M, x, ldx, K)) {
+  if (K_pad < K || (K_pad + 15) / 16 != (K + 15) / 16) K_pad = K;
+  if (emu_rows(c, M, x, ldx, K_pad)) {
     const void* im = image_of(c, img, W, ldw, N, K, 0);
     if (c.dry || !c.ok()) return;
-    c.rc = hoisdf_linear_fwd_emu(x, ldx, im, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
+    c.rc = hoisdf_linear_fwd_emu(x, ldx, im, b, y, ldy, M, N, K_pad, act, p, seed, bits, c.stream);
     return;
   }
   if (c.dry) return;
@@ -74,29 +77,32 @@ void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, floa
   c.rc = hoisdf_linear_bwd_input(dy, lddy, bits, p, W, ldw, dx, lddx, M, N, K, accumulate, c.stream);
 }
 // dW / db zero on entry (the exact-f32 kernel accumulates, the emulated one overwrites)
+// K_pad > K: dW is a dense [N][K_pad] and columns K .. K_pad - 1 of x are zero padding - both forms contract the padded width
+// (the pad columns of dW come out zero)
 void lin_bwd_weight(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* x, int ldx, float* dW, float* db, long M,
-                    int N, int K) {
+                    int N, int K, int K_pad = 0) {
   if (!c.ok()) return;
   if (!bits) p = 0.f;
-  const bool emu = c.emu && M >= EMU_DW_MIN_ROWS && (N < K ? N : K) >= 64 && N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 &&
+  if (K_pad < K) K_pad = K;
+  const bool emu = c.emu && M >= EMU_DW_MIN_ROWS && (N < K ? N : K) >= 64 && N % 4 == 0 && K_pad % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 &&
                    (c.dry || (al16(dy) && al16(x) && al16(dW)));
   if (emu) {
-    const long nws = hoisdf_linear_bwd_weight_emu_workspace(M, N, K);
+    const long nws = hoisdf_linear_bwd_weight_emu_workspace(M, N, K_pad);
     float* w = c.ws->floats(nws > 4 ? nws : 4);   // (scratch of consecutive calls is not recycled: earlier launches may still read theirs)
     if (!c.dry) {
       if (!w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-      c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K, db, M, N, K, w, nws, c.stream);
+      c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, c.stream);
     }
     return;
   }
   long nws = 0; float* w = nullptr;
   if (deterministic_mode()) {
-    nws = hoisdf_linear_bwd_weight_workspace(M, N, K);
+    nws = hoisdf_linear_bwd_weight_workspace(M, N, K_pad);
     if (nws > 0) w = c.ws->floats(nws);
     if (!c.dry && nws > 0 && !w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
   }
   if (c.dry) return;
-  c.rc = hoisdf_linear_bwd_weight(dy, lddy, bits, p, x, ldx, dW, K, db, M, N, K, w, nws, c.stream);
+  c.rc = hoisdf_linear_bwd_weight(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, c.stream);
 }
 
 

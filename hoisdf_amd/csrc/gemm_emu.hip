@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
 //    ablations of round 4 (profiles/r04_kc2_ablation.txt) showed the loop running at 285 - 338 TF without staging and at
 //    130 - 170 with the loads and LDS writes but WITHOUT any conversion arithmetic - the address / tag path, not the VALU,
 //    was the limiter.  A quad converts to 8 bytes per plane (ds_write_b64); rows of the second k-chunk are stored with
-//    bit 3 of the row flipped so that the half-wave's 8 rows x 2 chunks land on 32 different bank pairs.
+//    bit 2 of the row flipped so that a 16-lane group's 4 rows x 2 chunks x 2 halves cover all 32 banks once.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -351,29 +351,34 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging roles: item i (0..3) of this thread = row i * 64 + wave * 16 + lane / 4 of the tile, quad qd = lane % 4 of the slab
-  // (k = 4 qd .. 4 qd + 3; chunk c = qd / 2, half qd % 2 of the chunk's 16 bytes).  Rows past M re-read row M - 1 (their
-  // products only reach rows that are never stored).  Byte offsets are relative to the tile's first row (< 256 rows: 32 bit).
+  // (k = 4 qd .. 4 qd + 3; chunk c = qd / 2, half qd % 2 of the chunk's 16 bytes).  Rows past M read as zero (their products
+  // only reach rows that are never stored).
   const int rl = lane >> 2, qd = lane & 3, cq = qd >> 1;
   // buffer descriptors (wave-uniform) over the tile's row panel, its sign-bitmap rows and the column tile's weight image: the
   // loads are buffer_load (32-bit per-lane offset in ONE register + scalar slab offset) - with flat addressing hipcc keeps a
   // 64-bit address pair per item alive across the loop and spills
+  // (four descriptors each, one per item = 64-row quarter of the tile: the per-lane offset is the SAME register for all four,
+  // and rows past M read as zero through the quarter's record count - no clamping, no per-item offset registers)
   const int rows_in = min(TM, g.M - m0);
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(g.A + (size_t)m0 * g.lda), 0, (int)((((long)rows_in - 1) * g.lda + g.K) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsm = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint32_t*>(MASK ? g.abits + (size_t)m0 * g.ldbits : nullptr), 0, MASK ? (int)((long)rows_in * g.ldbits * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u32x4*>(g.Bimg + (size_t)tn * nslab * B_U4), 0, nslab * B_U4 * 16, 0x00020000);
-  int aoff[4], moff[4];
+  __amdgpu_buffer_rsrc_t rsa[4], rsm[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = min(i * 64 + wave * 16 + rl, rows_in - 1);
-    aoff[i] = (int)(((long)r * g.lda + 4 * qd) * 4);
-    moff[i] = (int)((long)r * g.ldbits * 4);
+    const int rows_q = max(min(rows_in - i * 64, 64), 0);     // valid rows of this quarter
+    rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)m0 + i * 64) * g.lda), 0,
+                                               rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+    rsm[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(MASK ? g.abits + ((size_t)m0 + i * 64) * g.ldbits : nullptr), 0,
+                                               MASK ? (int)((long)rows_q * g.ldbits * 4) : 0, 0x00020000);
   }
-  // 8-byte LDS slot of item 0, plane 0: unit (chunk cq, row ^ (cq << 3)), half qd & 1; item i adds 128 slots, plane p 2 * 2 * TM
-  const int wslot = 2 * (cq * TM + ((wave * 16 + rl) ^ (cq << 3))) + (qd & 1);
-  const int aread = (wm * 128 + l31) ^ (kh << 3);              // fragment rows follow the same row flip (chunk = kh)
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(g.Bimg + (size_t)tn * nslab * B_U4), 0, nslab * B_U4 * 16, 0x00020000);
+  const int aoff = (int)((((long)wave * 16 + rl) * g.lda + 4 * qd) * 4);
+  const int moff = (int)(((long)wave * 16 + rl) * g.ldbits * 4);
+  // 8-byte LDS slot of item 0, plane 0: unit (chunk cq, row ^ (cq << 2)), half qd & 1; item i adds 128 slots, plane p 2 * 2 * TM.
+  // ds_write_b64 is served in contiguous 16-lane groups over 32 banks (128 bytes): a group = 4 rows x 4 quads; flipping bit 2 of
+  // the row for the second chunk puts its 4 rows x 16 bytes into the other half of the bank row (PMC: SQ_LDS_BANK_CONFLICT back at
+  // the first form's level; with bit 3 flipped the two chunks collided, + 25 % LDS cycles)
+  const int wslot = 2 * (cq * TM + ((wave * 16 + rl) ^ (cq << 2))) + (qd & 1);
+  const int aread = (wm * 128 + l31) ^ (kh << 2);              // fragment rows follow the same row flip (chunk = kh)
   const int kq = g.K - 4 * qd;                                   // quad valid in slab sl iff sl * 16 < kq
   f32x2 rp[8], fu[8];                                            // the thread's 4 quads of the slab being staged, as pairs (+ unpacked planes)
   uint32_t t0[8], t1[8], t2[8];                                  // their three bf16 planes (two values per register)
@@ -389,9 +394,9 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #define LDGA(i, sl)                                                                                                    \
   do {                                                                                                                 \
     const int k0_ = min((sl), last) * KS;                      /* (uniform) a pad slab re-reads the last one */        \
-    const f32x4 v_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff[i], k0_ * 4, 0));       \
+    const f32x4 v_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa[i], aoff, k0_ * 4, 0));       \
     rp[2 * (i)] = f32x2{v_[0], v_[1]}; rp[2 * (i) + 1] = f32x2{v_[2], v_[3]};                                          \
-    if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm, moff[i], (k0_ >> 5) * 4, 0);                           \
+    if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm[i], moff, (k0_ >> 5) * 4, 0);                           \
   } while (0)
 #define LDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (tid + (q) * NT) * 16, min((sl), last) * (B_U4 * 16), 0)
 #endif
@@ -411,10 +416,11 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #define U1(p)                                                                                                          \
   do {                                                                                                                 \
     f32x2 v_ = rp[p];                                                                                                  \
-    if (MASK) {                                                                                                        \
-      const uint32_t ma_ = (uint32_t)((int32_t)(mb << (31 - 2 * ((p) & 1))) >> 31), mc_ = (uint32_t)((int32_t)(mb << (30 - 2 * ((p) & 1))) >> 31); \
-      v_.x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v_.x) & ma_);                                      \
-      v_.y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v_.y) & mc_);                                      \
+    if (MASK) {           /* bit -> all-ones / zero word (v_bfe_i32) -> v_and: written as asm, hipcc (ROCm 7.2) turns the plain   */ \
+      float xa_, xb_;     /* expression into compare + select, and MISCOMPILES the two-element form (the y lane reads x)        */ \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xa_) : "v"(__builtin_amdgcn_sbfe((int)mb, 2 * ((p) & 1), 1)), "v"(v_.x));       \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xb_) : "v"(__builtin_amdgcn_sbfe((int)mb, 2 * ((p) & 1) + 1, 1)), "v"(v_.y));   \
+      v_ = f32x2{xa_, xb_};                                                                                            \
     }                                                                                                                  \
     if (KTAIL) { if (!kin) v_ = f32x2{0.f, 0.f}; }             /* K is a multiple of 4: a quad is all in or all out */ \
     const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(v_, bf16x2));                             \
@@ -737,6 +743,243 @@ __global__ __launch_bounds__(NT, DTK == 256 ? 1 : 2) void emu_dw_kernel(DwArgs g
   }
 }
 
+// ---- grad-weight, second form ("rotated", hand-interleaved; 256 x 256 tiles): same partial-tile plan, product order and
+// epilogue as emu_dw_kernel<MASK, 256> (results are bit identical without a sign bitmap), with the main loop rebuilt the way
+// emu_kc2_kernel's was - here it matters more, because this kernel runs ONE wave per SIMD (256 accumulators) and nothing else
+// covers a wave's conversion phase:
+//  * a phase = [x1 y1, x1 y0, x2 y0 of slab s - 1 | x0 y2, x0 y1, x0 y0 of slab s] between two barriers (96 MFMAs): the 48 MFMAs
+//    behind the barrier run on fragments read before it, every fragment read is 12 ... 48 MFMAs ahead of its use;
+//  * the staging of slab s + 1 (a 4-column x 8-row patch per thread: 16 row pairs x {first plane, residual, second plane,
+//    residual + third plane}, 12 LDS writes) is pinned unit by unit behind the MFMAs of the same wave (tools/gen/dw2_phase.py);
+//    the patch sits in two half sets (columns 0-1 / 2-3 of its rows, 8-byte loads): a half is requested again for slab s + 2
+//    the moment its two columns of slab s + 1 are converted, >= 56 MFMAs ahead of its next use - no second patch set
+//    (the arch-VGPR half of the register file holds the fragments, 96, and the staging state; the accumulators fill the AGPRs);
+//  * loads are buffer loads through a per-slab descriptor [first row of the slab, end of the row slice): rows past the slice
+//    and the pad slab read as zero without a single select, columns past the operand by an out-of-range offset;
+//  * the LDS column of output index n is n ^ ((n >> 3) & 3): with the plain layout the 16-byte writes of a patch (four
+//    adjacent columns per lane = a 64-byte lane stride) hit two of the 32 store banks groups 4-way; the fragment reads
+//    (32 consecutive columns per half-wave) stay conflict-free under the swizzle;
+//  * the 1 / keep factor of the sign bitmap is applied once to the finished tile / bias-gradient partial, the bitmap itself
+//    as a bit-extended and.
+namespace {
+constexpr int DSTAGE = 3 * 2 * DT * 2;                   // 16-byte units per stage: three planes x two chunks x (256 dy + 256 x columns)
+}
+template <bool MASK, bool HASDB>
+__global__ __launch_bounds__(NT, 1) void emu_dw2_kernel(DwArgs g) {
+  constexpr int A_U4 = 3 * 2 * DT;
+  __shared__ __attribute__((aligned(16))) u32x4 s0[DSTAGE];
+  __shared__ __attribute__((aligned(16))) u32x4 s1[DSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int ntile = g.tiles_n * g.tiles_k;
+  const int bid = blockIdx.x;
+  const int split = (bid & 7) + 8 * (bid / (8 * ntile));      // every slice of one tile on the same XCD (shared L2)
+  const int t = (bid >> 3) % ntile;
+  if (split >= g.splitk) return;
+  const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
+  const int n0 = tn * DT, k0 = tk * DT;
+  const int mbeg = split * g.m_per_split;
+  const int mend = min(g.M, mbeg + g.m_per_split);
+  const int nslab = (mend - mbeg + KS - 1) / KS;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging role of the wave: waves 0 / 1 the dy patch of chunk 0 / 1 (rows 0-7 / 8-15 of the slab), waves 2 / 3 the x patch
+  const bool isA = wave < 2;
+  const int c = wave & 1, cg = lane;
+  const int col0 = (isA ? n0 : k0) + 4 * cg;
+  const bool col_ok = col0 < (isA ? g.N : g.K);             // N, K multiples of 4: a column group is all in or all out
+  const long ld = uni64(isA ? g.lddy : g.ldx);
+  const char* opbase = reinterpret_cast<const char*>(g.dy) +
+                       (long)uni64(isA ? 0ul : (uint64_t)(reinterpret_cast<const char*>(g.x) - reinterpret_cast<const char*>(g.dy)));
+  // row e of the patch: one per-lane offset register + e * (row stride), added at the load (a scalar operand of the add); a lane whose
+  // columns lie past the operand starts 1 GB out of range and reads zeros
+  const int voff0 = col_ok ? (int)(((long)c * 8 * ld + col0) * 4) : 0x40000000;
+  const int boff0 = (MASK && isA && col_ok) ? (int)(((long)c * 8 * g.ldbits + (col0 >> 5)) * 4) : 0x40000000;
+  const int ldb4 = (int)(ld * 4), ldm4 = g.ldbits * 4;
+  const uint32_t notA = isA ? 0u : 0xffffffffu;              // x patches carry no bitmap
+  const int bsh = col0 & 31;                                 // the patch's four sign bits within its bitmap word
+  constexpr bool SWZ = true;
+  const int sw = SWZ ? (cg >> 1) & 3 : 0;
+  const int wbase = (isA ? 0 : A_U4) + c * DT + 4 * cg;       // unit of the patch's first column in plane 0 (column j: + (j ^ sw))
+  const int rsw = SWZ ? (l31 >> 3) & 3 : 0;
+  const int aread = (wm * 128 + l31) ^ rsw, bread = A_U4 + ((wn * 128 + l31) ^ rsw);
+  f32x2 rvL[8], rvH[8];                                       // the patch: columns 0-1 / 2-3 of its eight rows
+  uint32_t rm[8], mpk = 0xffffffffu;                          // bitmap words of the slab in flight; the 8 x 4 sign bits of the patch being converted
+  uint32_t t0[4], t1[4], t2[4];
+  f32x2 rp_, fu_;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#define NOP_ ((void)0)
+// DLDG(hf, e, sl): half hf (columns 2 hf, 2 hf + 1) of row e of the patch of slab sl through the slab's descriptor [first row of the
+// slab, end of the slice);
+// DLDM(e, sl): its bitmap word
+#define DSLAB(sl)                                                                                                      \
+    const int ms_ = mbeg + (sl) * KS;                                                                                  \
+    const int left_ = max(mend - ms_, 0);                     /* (uniform) rows of the slice from this slab on */
+#define DLDG(hf, e, sl)                                                                                                \
+  do {                                                                                                                 \
+    DSLAB(sl)                                                                                                          \
+    const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(                                               \
+        const_cast<char*>(opbase + (size_t)ms_ * ld * 4), 0, (int)min((long)left_ * ld * 4, 0x3fffffffL), 0x00020000); \
+    const f32x2 v_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_, voff0 + (e) * ldb4 + (hf) * 8, 0, 0)); \
+    if ((hf) == 0) rvL[e] = v_; else rvH[e] = v_;                                                                      \
+  } while (0)
+#define DLDM(e, sl)                                                                                                    \
+  do {                                                                                                                 \
+    if (MASK) {                                                                                                        \
+      DSLAB(sl)                                                                                                        \
+      const __amdgpu_buffer_rsrc_t b_ = __builtin_amdgcn_make_buffer_rsrc(                                             \
+          const_cast<uint32_t*>(g.bits + (size_t)ms_ * g.ldbits), 0, (int)min((long)left_ * g.ldbits * 4, 0x3fffffffL), 0x00020000); \
+      rm[e] = __builtin_amdgcn_raw_buffer_load_b32(b_, boff0 + (e) * ldm4, 0, 0);                                      \
+    }                                                                                                                  \
+  } while (0)
+#define PK_SUB(d, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+// the conversion of rows 2 pr, 2 pr + 1 of column j of the patch: DU1 bitmap + first plane (column 0 first packs the two rows' four
+// sign bits into mpk - nibble e = row e - which frees the word registers for the next slab's words), DU2 first residual, DU3 second
+// plane, DU4 second residual + third plane
+#define DU1(j, pr)                                                                                                     \
+  do {                                                                                                                 \
+    f32x2 v_ = (j) < 2 ? f32x2{rvL[2 * (pr)][(j) & 1], rvL[2 * (pr) + 1][(j) & 1]} : f32x2{rvH[2 * (pr)][(j) & 1], rvH[2 * (pr) + 1][(j) & 1]}; \
+    if (MASK) {                                                                                                        \
+      if ((j) == 0) {                                                                                                  \
+        const uint32_t n0_ = ((rm[2 * (pr)] | notA) >> bsh) & 0xfu, n1_ = ((rm[2 * (pr) + 1] | notA) >> bsh) & 0xfu;   \
+        mpk = ((pr) == 0 ? 0u : mpk) | (n0_ << (8 * (pr))) | (n1_ << (8 * (pr) + 4));                                  \
+      }                                                                                                                \
+      float xa_, xb_;     /* (asm: see emu_kc2_kernel's U1) */                                                         \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xa_) : "v"(__builtin_amdgcn_sbfe((int)mpk, 8 * (pr) + (j), 1)), "v"(v_.x));    \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xb_) : "v"(__builtin_amdgcn_sbfe((int)mpk, 8 * (pr) + 4 + (j), 1)), "v"(v_.y)); \
+      v_ = f32x2{xa_, xb_};                                                                                            \
+    }                                                                                                                  \
+    if (HASDB) csum[j] += v_.x + v_.y;                                                                                 \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(v_, bf16x2));                             \
+    t0[pr] = h_; rp_ = v_;                                                                                             \
+    fu_ = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                     \
+  } while (0)
+#define DU2(j, pr) PK_SUB(rp_, rp_, fu_)
+#define DU3(j, pr)                                                                                                     \
+  do {                                                                                                                 \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(rp_, bf16x2));                            \
+    t1[pr] = h_;                                                                                                       \
+    fu_ = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                     \
+  } while (0)
+#define DU4(j, pr) do { f32x2 w_; PK_SUB(w_, rp_, fu_); t2[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(w_, bf16x2)); } while (0)
+#define DSTA(st, j, pl) (st)[wbase + ((j) ^ sw) + (pl) * 2 * DT] = ((pl) == 0 ? u32x4{t0[0], t0[1], t0[2], t0[3]} : (pl) == 1 ? u32x4{t1[0], t1[1], t1[2], t1[3]} : u32x4{t2[0], t2[1], t2[2], t2[3]})
+#define DLA(st, p, i) __builtin_bit_cast(bf16x8, (st)[aread + ((p) * 2 + kh) * DT + (i) * 32])
+#define DLB(st, p, j) __builtin_bit_cast(bf16x8, (st)[bread + ((p) * 2 + kh) * DT + (j) * 32])
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define M1(ax, bx, i, j, work) do { acc[i][j] = MFB(ax[i], bx[j], acc[i][j]); work; SB(); } while (0)
+#define MM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFB(ax[i], bx[j], acc[i][j])
+#define SYNC() do { SB(); __syncthreads(); SB(); } while (0)
+#include "dw2_phase.inc"
+#define DSTAGE_ALL(st)                                                                                                 \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+      _Pragma("unroll") for (int pr = 0; pr < 4; ++pr) { DU1(j, pr); DU2(j, pr); DU3(j, pr); DU4(j, pr); }             \
+      DSTA(st, j, 0); DSTA(st, j, 1); DSTA(st, j, 2);                                                                  \
+    }                                                                                                                  \
+  } while (0)
+#define DLOAD_ALL(sl) _Pragma("unroll") for (int e = 0; e < 8; ++e) { DLDG(0, e, sl); DLDG(1, e, sl); }
+#define DLOADM_ALL(sl) _Pragma("unroll") for (int e = 0; e < 8; ++e) DLDM(e, sl)
+
+  // the slab count is rounded up to an even number (a pad slab reads zeros through its empty descriptor); phases after the head
+  // come in pairs plus one.
+  const int nslab2 = (max(nslab, 1) + 1) & ~1;
+  bf16x8 aX[4], aY[4], aZ[4], bP[4], bQ[4], bR[4];
+  DLOAD_ALL(0);
+  DLOADM_ALL(0);
+  DSTAGE_ALL(s0);
+  DLOAD_ALL(1);
+  DLOADM_ALL(1);
+  __syncthreads();
+  // head (left to the compiler): the first half of slab 0, slab 1 -> s1, slab 2 requested
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { aZ[i] = DLA(s0, 0, i); aX[i] = DLA(s0, 1, i); aY[i] = DLA(s0, 2, i); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { bQ[j] = DLB(s0, 0, j); bP[j] = DLB(s0, 1, j); bR[j] = DLB(s0, 2, j); }
+  MM(aZ, bR); MM(aZ, bP); MM(aZ, bQ);                         // x0 y2, x0 y1, x0 y0 of slab 0; bP = y1, bQ = y0 stay for the next phase
+  DSTAGE_ALL(s1);
+  DLOAD_ALL(2);
+  DLOADM_ALL(2);
+  SYNC();
+  for (int s = 1; s + 1 < nslab2; s += 2) {
+    DPHASE(s1, s0, s, aX, aY, aZ, bP, bQ, bR);
+    SYNC();
+    DPHASE(s0, s1, s + 1, aX, aY, aZ, bR, bQ, bP);
+    SYNC();
+  }
+  DPHASE(s1, s0, nslab2 - 1, aX, aY, aZ, bP, bQ, bR);
+  SB();
+  MM(aX, bR); MM(aX, bQ); MM(aY, bQ);                         // x1 y1, x1 y0, x2 y0 of the last slab
+  __syncthreads();
+#undef DSLAB
+#undef DLDG
+#undef DLDM
+#undef DLOADM_ALL
+#undef PK_SUB
+#undef DU1
+#undef DU2
+#undef DU3
+#undef DU4
+#undef DSTA
+#undef DLA
+#undef DLB
+#undef SB
+#undef M1
+#undef MM
+#undef SYNC
+#undef DPHASE
+#undef DSTAGE_ALL
+#undef DLOAD_ALL
+#undef NOP_
+  const float post = MASK ? g.ascale : 1.f;
+  u32x4* lds = s0;
+  // bias gradient partial: the two chunk threads of a column group add up through LDS
+  if (HASDB && tk == 0) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (isA) *reinterpret_cast<f32x4*>(&red[c * DT + 4 * cg]) = csum * post;
+    __syncthreads();
+    if (tid < DT) {
+      const int n = n0 + tid;
+      if (n < g.N) g.colsum[(size_t)split * g.colsum_split_stride + n] = red[tid] + red[DT + tid];
+    }
+    __syncthreads();
+  }
+  // epilogue: one row of 32 x 32 blocks (32 x 128) at a time through the wave's private LDS slice
+  float* Cb = g.C + (size_t)split * g.c_split_stride;
+  const bool full = (n0 + DT <= g.N) && (k0 + DT <= g.K) && (g.K % 4 == 0);
+  constexpr int WK = DT / 2, ES = WK + 4, LPR = WK / 4, RPI = 64 / LPR;
+  float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = MASK ? acc[i][j][r] * post : acc[i][j][r];
+#pragma unroll
+    for (int p = 0; p < 32 / RPI; ++p) {
+      const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
+      const int row = n0 + wm * 128 + i * 32 + rr, col = k0 + wn * WK + cc;
+      const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
+      if (full) {
+        *reinterpret_cast<float4*>(Cb + (size_t)row * g.K + col) = v;
+      } else if (row < g.N) {
+        float* cp = Cb + (size_t)row * g.K + col;
+        if (col + 0 < g.K) cp[0] = v.x;
+        if (col + 1 < g.K) cp[1] = v.y;
+        if (col + 2 < g.K) cp[2] = v.z;
+        if (col + 3 < g.K) cp[3] = v.w;
+      }
+    }
+  }
+}
+
 // out[i] = sum_s part[s * stride + i], deterministic: a block owns 256 consecutive floats (64 lanes x float4), its 16 waves sum
 // the slices s = w, w + 16, ... in order (16 independent 1 KB streams per block keep the loads in flight) and the 16 partial sums
 // are combined in wave order through LDS.  n must be a multiple of 4 (N * K and N are).
@@ -940,7 +1183,15 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   const int ntile = g.tiles_n * g.tiles_k;
   const dim3 grid((unsigned)(ntile * 8 * cdiv(g.splitk, 8))), block(NT);
   const unsigned lb = 2u * (3 * 2 * DT + 3 * 2 * dtk) * 16u;
-  if (dtk == 256) {
+  static int form = -1;                       // HOISDF_EMU_DW=1: the first main-loop form for the 256-wide tiles (A/B runs)
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_DW"); form = (e && atoi(e) == 1) ? 1 : 2; }
+  if (dtk == 256 && form == 2) {
+    const bool hasdb = g.colsum != nullptr;
+    if (relu_bits && hasdb) hipLaunchKernelGGL((emu_dw2_kernel<true, true>), grid, block, 0, st, g);
+    else if (relu_bits) hipLaunchKernelGGL((emu_dw2_kernel<true, false>), grid, block, 0, st, g);
+    else if (hasdb) hipLaunchKernelGGL((emu_dw2_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((emu_dw2_kernel<false, false>), grid, block, 0, st, g);
+  } else if (dtk == 256) {
     if (relu_bits) hipLaunchKernelGGL((emu_dw_kernel<true, 256>), grid, block, lb, st, g);
     else hipLaunchKernelGGL((emu_dw_kernel<false, 256>), grid, block, lb, st, g);
   } else {

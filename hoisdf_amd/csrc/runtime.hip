@@ -1,4 +1,5 @@
 // Library runtime: version string and thread-local error plumbing of the C ABI.
+#include <string.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -34,7 +35,7 @@ bool gemm_emu_mode() {
   static int env = -1;
   if (env < 0) {
     const char* e = getenv("HOISDF_GEMM");
-    env = (e && e[0] == 'f') ? 0 : 1;          // "f32" -> off
+    env = (e && strcmp(e, "f32") == 0) ? 0 : 1;          // exactly "f32" -> off (hoisdf_amd/ops.py parses the same string)
     if (!env) g_gemm_emu = 0;
   }
   return g_gemm_emu != 0;

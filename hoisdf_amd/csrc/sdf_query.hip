@@ -273,7 +273,7 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, nullptr, w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf);
   if (!dry && c.ok()) c.rc = hoisdf_posenc_fwd(points, n, s.cat, CAT_LD, X0_COL + LAT, pe, stream);
   // decoder (common/nets/sdf_net.py:87-122); layer i draws dropout stream seed + i
-  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, nullptr, w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0);
+  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, nullptr, w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3);   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
   lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, nullptr, w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1);
   lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, nullptr, w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2);
   lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, nullptr, w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3);
@@ -298,11 +298,12 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD);
   lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, nullptr, dh0, HID0, n, H1 + 1, HID0, 0);
   lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0);
-  // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is dense [512][289]
+  // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is [512][292]
+  // (contracted over the padded row so that it takes the bf16 pipe like the forward; the three pad columns come out zero)
   float* dx0 = dry ? nullptr : dcat + X0_COL;
   const float* x0 = dry ? nullptr : s.cat + X0_COL;
   lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, nullptr, dx0, CAT_LD, n, HID0, X0, 1);
-  lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0);
+  lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0, X0 + 3);
   // linear_sdfin: its output sits in x0[:, 0:256] (positional encoding / xyz columns carry no gradient)
   lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, nullptr, dha, HID0, n, LAT, HID0, 0);
   lin_bwd_weight(c, dx0, CAT_LD, s.bf, 0.f, s.ha, HID0, G->d_sdfin_w1, G->d_sdfin_b1, n, LAT, HID0);

@@ -310,7 +310,9 @@ class Model(nn.Module):
             # them three times, :445/:486/:499; its detached queries run as single hoisdf_sdf_query_fwd calls)
             obj_feat, obj_cam = ops.project_gather(pyr, obj_points, ocen, K, os_, c.input_img_shape)
             obj_cam = obj_cam.view(B, no, 3)
-            obj_fea = self.linear_transformerin(obj_feat).view(B, no, -1)                               # :486-493
+            fused_tok = ops.tokens_ok(obj_feat)     # K7 + K8 as one C call per point set (hoisdf_tokens_fwd), issued once sdf / pe exist
+            if not fused_tok:
+                obj_fea = self.linear_transformerin(obj_feat).view(B, no, -1)                           # :486-493
             fd = obj_feat.detach()
             if branch_a:                # the reference tracks these calls but only ever uses them detached
                 obj_sdf, _, obj_pe, _ = self._sdf_query(pyr, obj_points, ocen, K, os_, "obj", feat=fd)
@@ -318,12 +320,21 @@ class Model(nn.Module):
             obj_h_pts = (obj_cam - root[:, None, :]) * hs_                                              # :495-518
             obj_h_sdf, _, obj_h_pe, _ = self._sdf_query(pyr, obj_h_pts, root, K, hs_, "hand", feat=fd)
             obj_h_sdf, obj_h_pe = obj_h_sdf.view(B, no, 1), obj_h_pe.view(B, no, -1)
+            S, D = nh + no, c.hidden_dim
+            tin_w = [l.weight for l in self.linear_transformerin.layers]
+            tin_b = [l.bias for l in self.linear_transformerin.layers]
+            if fused_tok:                       # the object points' own token rows (+ their MLP output for the hand stream's cross rows)
+                obj_tok = torch.empty(B, S, D, device=root.device)
+                obj_tok, obj_fea = ops.tokens(obj_tok, obj_feat, obj_cam, ocen, obj_pe, obj_sdf.detach(), self.obj_sigmoid_beta, 0,
+                                              tin_w, tin_b)
+                obj_fea = obj_fea.view(B, no, -1)
         # ---- hand points (ambient stream) ----
         if want_sdf_loss:
             sh, _, _ = self.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, hs_, "hand")
         hand_feat, hand_cam = ops.project_gather(pyr, hand_points, root, K, hs_, c.input_img_shape)
         hand_cam = hand_cam.view(B, nh, 3)
-        hand_fea = self.linear_transformerin(hand_feat).view(B, nh, -1)
+        if not fused_tok:
+            hand_fea = self.linear_transformerin(hand_feat).view(B, nh, -1)
         fd = hand_feat.detach()
         if branch_a:
             hand_sdf, _, hand_pe, _ = self._sdf_query(pyr, hand_points, root, K, hs_, "hand", feat=fd)
@@ -334,7 +345,7 @@ class Model(nn.Module):
         hand_o_sdf, hand_o_pe = hand_o_sdf.view(B, nh, 1), hand_o_pe.view(B, nh, -1)
         if two:
             cur.wait_stream(side)
-            for t in (so, obj_sdf, obj_pe, obj_fea, obj_cam, obj_h_sdf, obj_h_pe):
+            for t in (so, obj_sdf, obj_pe, obj_fea, obj_cam, obj_h_sdf, obj_h_pe):          # (obj_tok, when built there: below)
                 if t is not None:
                     t.record_stream(cur)
         if want_sdf_loss:
@@ -345,17 +356,30 @@ class Model(nn.Module):
         # the *other* centre for xyz ("# bug" lines :498,:508 replicated).
         S, D = nh + no, c.hidden_dim
         dev = root.device
-        hand_tok = torch.empty(B, S, D, device=dev)
-        obj_tok = torch.empty(B, S, D, device=dev)
-        with torch.no_grad():
-            ops.token_build(hand_tok, obj_cam.reshape(-1, 3), root, obj_h_pe, obj_fea.detach(), obj_h_sdf,
-                            self.hand_sigmoid_beta.detach(), nh)
-            ops.token_build(obj_tok, hand_cam.reshape(-1, 3), ocen, hand_o_pe, hand_fea.detach(), hand_o_sdf,
-                            self.obj_sigmoid_beta.detach(), no)
-        hand_tok = ops.token_build(hand_tok, hand_cam.reshape(-1, 3), root, hand_pe, hand_fea, hand_sdf.detach(),
-                                   self.hand_sigmoid_beta, 0)
-        obj_tok = ops.token_build(obj_tok, obj_cam.reshape(-1, 3), ocen, obj_pe, obj_fea, obj_sdf.detach(),
-                                  self.obj_sigmoid_beta, 0)
+        if fused_tok:
+            hand_tok = torch.empty(B, S, D, device=dev)
+            hand_tok, hand_fea = ops.tokens(hand_tok, hand_feat, hand_cam, root, hand_pe, hand_sdf.detach(), self.hand_sigmoid_beta, 0,
+                                            tin_w, tin_b)
+            hand_fea = hand_fea.view(B, nh, -1)
+            if two:
+                obj_tok.record_stream(cur)
+            with torch.no_grad():               # the cross rows, written into the buffers the two calls above returned
+                ops.token_build(hand_tok, obj_cam.reshape(-1, 3), root, obj_h_pe, obj_fea, obj_h_sdf,
+                                self.hand_sigmoid_beta.detach(), nh)
+                ops.token_build(obj_tok, hand_cam.reshape(-1, 3), ocen, hand_o_pe, hand_fea, hand_o_sdf,
+                                self.obj_sigmoid_beta.detach(), no)
+        else:
+            hand_tok = torch.empty(B, S, D, device=dev)
+            obj_tok = torch.empty(B, S, D, device=dev)
+            with torch.no_grad():
+                ops.token_build(hand_tok, obj_cam.reshape(-1, 3), root, obj_h_pe, obj_fea.detach(), obj_h_sdf,
+                                self.hand_sigmoid_beta.detach(), nh)
+                ops.token_build(obj_tok, hand_cam.reshape(-1, 3), ocen, hand_o_pe, hand_fea.detach(), hand_o_sdf,
+                                self.obj_sigmoid_beta.detach(), no)
+            hand_tok = ops.token_build(hand_tok, hand_cam.reshape(-1, 3), root, hand_pe, hand_fea, hand_sdf.detach(),
+                                       self.hand_sigmoid_beta, 0)
+            obj_tok = ops.token_build(obj_tok, obj_cam.reshape(-1, 3), ocen, obj_pe, obj_fea, obj_sdf.detach(),
+                                      self.obj_sigmoid_beta, 0)
 
         tgt_mask = None if c.use_inverse_kinematics else get_mano_tgt_mask(c)         # :564-569
         # Only rows < nh (hand stream) / < no (object stream) of the encoder outputs are ever read (:587-593 and
@@ -415,14 +439,18 @@ class Model(nn.Module):
             side_made = [t for t in list(loss.values()) + list(out.values()) if torch.is_tensor(t)]
 
         # ---- hand vote heads + vote aggregation / losses (ambient stream)
-        hand_off = self.linear_handvote(hand_enc)                                      # :587-593 (L,B,nh,60)
-        hand_cls = self.linear_handcls(hand_enc)
         if training or c.dataset == "dexycb":                                          # :626-638
             joints_gt = targets["joint_cam_no_trans"][:, 1:]
         else:
             joints_gt = torch.zeros(B, 20, 3, device=dev)
-        (loss["loss_joint_3d"], loss["loss_joint_cls"], loss["loss_all_joint_3d"],
-         joints) = self.joints_vote_loss(hand_rel, hand_off, hand_cls, joints_gt, batch_first=True)
+        if ops.tokens_ok(hand_enc):             # K11 + K12 as one C call per direction (hoisdf_heads_vote_fwd / _bwd)
+            (loss["loss_joint_3d"], loss["loss_joint_cls"], loss["loss_all_joint_3d"],
+             joints) = self.joints_vote_loss.forward_fused(hand_rel, hand_enc, self.linear_handvote, self.linear_handcls, joints_gt)
+        else:
+            hand_off = self.linear_handvote(hand_enc)                                  # :587-593 (L,B,nh,60)
+            hand_cls = self.linear_handcls(hand_enc)
+            (loss["loss_joint_3d"], loss["loss_joint_cls"], loss["loss_all_joint_3d"],
+             joints) = self.joints_vote_loss(hand_rel, hand_off, hand_cls, joints_gt, batch_first=True)
         out["hand_joints_out"] = joints[-1]
         if two:
             cur.wait_stream(side)

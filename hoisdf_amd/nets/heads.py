@@ -32,6 +32,18 @@ class JointvoteLoss(nn.Module):
         # below are means of those (L,B)-sized sums
         joints, l3d_sum, bce_sum, near_sum = ops.vote_loss(hand_off, hand_cls, hand_points, joint_gt,
                                                            self.hand_cls_dist)
+        return self._finish(joints, l3d_sum, bce_sum, near_sum, joint_gt, P)
+
+    def forward_fused(self, hand_points, hand_enc, vote_mlp, cls_mlp, joint_gt):
+        """the two head MLPs on all depths + the vote aggregation + the reductions as ONE C call (hoisdf_heads_vote_fwd, K11 + K12);
+        hand_enc (L,B,P,E) batch-first."""
+        joints, l3d_sum, bce_sum, near_sum = ops.heads_vote(
+            hand_enc, hand_points, joint_gt, self.hand_cls_dist, [l.weight for l in vote_mlp.layers], [l.bias for l in vote_mlp.layers],
+            [l.weight for l in cls_mlp.layers], [l.bias for l in cls_mlp.layers])
+        return self._finish(joints, l3d_sum, bce_sum, near_sum, joint_gt, hand_enc.shape[2])
+
+    def _finish(self, joints, l3d_sum, bce_sum, near_sum, joint_gt, P):
+        L, B, J = joints.shape[0], joints.shape[1], joints.shape[2]
         # the reference sums over (b, p, j), divides by near.sum() and then averages over (l, xyz)
         l3d = l3d_sum.sum(1) / near_sum.sum() / 3.0
         lcls = bce_sum.sum() / float(L * B * P * J)

@@ -306,7 +306,8 @@ _GEMM_EMU = __import__("os").environ.get("HOISDF_GEMM", "emu") != "f32"
 _GEMM_EMU_MIN_ROWS = 2048            # below this a problem is a handful of tiles: latency-bound, stays on the f32 kernel
 _GEMM_EMU_DW_MIN_ROWS = 8192         # grad-weight: the contraction runs over the rows (>= 32 slabs per slice at 256 slices)
 _GEMM_EMU_DW_MIN_WIDTH = int(__import__("os").environ.get("HOISDF_EMU_DW_MIN_WIDTH", "64"))
-_EMU_IMAGES = {}                     # (data_ptr, shape, ld, transpose) -> [image, version key, event, build stream, owner]
+_EMU_IMAGES = {}                     # (device, data_ptr, shape, ld, transpose) -> [image, version key, event, build stream, owner, reader streams]
+_EMU_PURGE_AT = [4096]
 
 
 def set_gemm_emu(on: bool) -> None:
@@ -328,13 +329,27 @@ def _emu_ok(M: int, a: torch.Tensor, lda: int, contraction: int) -> bool:
             and a.data_ptr() % 16 == 0)
 
 
+_EMU_GRAVEYARD = []                  # images of weights that no longer exist, kept for one more purge cycle (see _emu_purge)
+
+
+def _emu_purge() -> None:
+    """Drop the cache entries whose weight tensor is gone.  Never touches an entry whose owner is alive: callers (the coarse
+    encoder / decoder layer entries) hold only the raw device pointer of an image for the duration of their C call, so an
+    image must not be freed behind a live weight.  The purged images themselves are parked until the NEXT purge (thousands
+    of lookups later), far beyond any kernel that may still read them on another stream."""
+    _EMU_GRAVEYARD.clear()
+    for k in [k for k, e in _EMU_IMAGES.items() if e[4]() is None]:
+        _EMU_GRAVEYARD.append(_EMU_IMAGES.pop(k)[0])
+
+
 def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
-    """the bf16x3 slab image of a weight (hoisdf_linear_emu_prepare), cached per (storage, shape, orientation) and rebuilt in
-    place when the weight changed (torch's version counter, or the generation FusedAdamW bumps).  The build is recorded with
-    an event: a consumer on another HIP stream (the object stack runs on a second one) waits for it."""
+    """the bf16x3 slab image of a weight (hoisdf_linear_emu_prepare), cached per (device, storage, shape, orientation) and
+    rebuilt in place when the weight changed (torch's version counter, or the generation FusedAdamW bumps).  The build is
+    recorded with an event: a consumer on another HIP stream (the object stack runs on a second one) waits for it, and is
+    remembered as a reader - a rebuild waits for every stream that read the previous image before overwriting it."""
     from ._lib import lib
     N, K = W.shape
-    key = (W.data_ptr(), N, K, W.stride(0), bool(transpose))
+    key = (W.device.index, W.data_ptr(), N, K, W.stride(0), bool(transpose))
     ver = (_WEIGHT_GEN[0], W._version)
     cur = torch.cuda.current_stream(W.device)
     ent = _EMU_IMAGES.get(key)
@@ -345,19 +360,23 @@ def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
         ent[1], ent[4] = None, __import__("weakref").ref(base)
     if ent is None:
         nb = lib().hoisdf_linear_emu_image_bytes(K if transpose else N, N if transpose else K)
-        ent = [torch.empty(nb, device=W.device, dtype=torch.uint8), None, None, None, __import__("weakref").ref(base)]
-        if len(_EMU_IMAGES) > 4096:          # weights that came and went (tests): do not grow without bound
-            _EMU_IMAGES.clear()
+        ent = [torch.empty(nb, device=W.device, dtype=torch.uint8), None, None, None, __import__("weakref").ref(base), set()]
+        if len(_EMU_IMAGES) >= _EMU_PURGE_AT[0]:     # weights that came and went (tests): do not grow without bound
+            _emu_purge()
+            _EMU_PURGE_AT[0] = max(4096, 2 * len(_EMU_IMAGES))
         _EMU_IMAGES[key] = ent
     if ent[1] != ver:
-        if ent[3] is not None and ent[3] != cur:
-            cur.wait_stream(ent[3])          # the previous image's last readers on the other stream
+        for s_ in ent[5]:
+            if s_ != cur:
+                cur.wait_stream(s_)          # every stream that read the previous image (the builder included)
+        ent[5].clear()
         call("hoisdf_linear_emu_prepare", _p(W), W.stride(0), N, K, int(transpose), _p(ent[0]), _st())
         ev = torch.cuda.Event()
         ev.record(cur)
         ent[1], ent[2], ent[3] = ver, ev, cur
     elif ent[3] != cur:
         cur.wait_event(ent[2])
+    ent[5].add(cur)
     return ent[0]
 
 
@@ -685,7 +704,7 @@ class _SdfQueryTrain(torch.autograd.Function):
         w, _wq, scale, img_hw, clamp, drop_p, rps, shapes, B, acc, pshapes = ctx.meta
         dev = pts.device
         n, Cc = pts.shape[0], w.C
-        sizes = [512 * Cc, 512, 256 * 512, 256, 512 * 289, 512, 224 * 512, 224, 512 * 516, 512, 512 * 512, 512, 512, 1]
+        sizes = [512 * Cc, 512, 256 * 512, 256, 512 * 292, 512, 224 * 512, 224, 512 * 516, 512, 512 * 512, 512, 512, 1]
         buf = _zeros(sum(sizes), dev)
         parts, off = [], 0
         for m in sizes:
@@ -709,7 +728,7 @@ class _SdfQueryTrain(torch.autograd.Function):
              clamp, drop_p, _p(saved), saved.numel(), _p(d_sdf), C.addressof(G), _p(ws), n_ws, _st())
         dw2p = parts[8].view(512, 516)
         pg = [parts[0].view(512, Cc), parts[1], parts[2].view(256, 512), parts[3],
-              parts[4].view(512, 289), parts[5], parts[6].view(224, 512)[:223], parts[7][:223],
+              parts[4].view(512, 292)[:, :289], parts[5], parts[6].view(224, 512)[:223], parts[7][:223],
               torch.cat([dw2p[:, :223], dw2p[:, 224:513]], dim=1), parts[9], parts[10].view(512, 512), parts[11],
               parts[12].view(1, 512), parts[13]]
         pg = [t.reshape(sh) for t, sh in zip(pg, pshapes)]
@@ -725,6 +744,7 @@ class _SdfQueryTrain(torch.autograd.Function):
 
 
 _SDF_QUERY_TRAIN_C = __import__("os").environ.get("HOISDF_SDF_QUERY_TRAIN", "c") != "ops"
+_TOKENS_C = __import__("os").environ.get("HOISDF_TOKENS", "c") != "ops"           # coarse K7 + K8 / K11 + K12 entries
 
 
 def sdf_query_train_ok() -> bool:
@@ -1503,8 +1523,10 @@ def _coarse_layer_ok(p, x, *weights) -> bool:
     """the C entry covers the default arithmetic; the opt-in split / f16 modes and bench.py's per-call event timing (which
     brackets the individual C-ABI calls from Python) take the op-by-op node"""
     from . import _lib
+    # (without kept planes the C entry's backward would fall back to the f32 kernel with dQ atomics: in deterministic mode the
+    # op-by-op node, whose emulated backward converts on its own, keeps the step order-fixed)
     return (_ENCODER_LAYER_C and not _GEMM_SPLIT and not _ATTENTION_SPLIT and _lib._timer is None
-            and not _use_f16(p, x, *weights))
+            and not _use_f16(p, x, *weights) and not (deterministic() and not _SPLIT_KEEP))
 
 
 def encoder_layer(x, n_query, p, H, w_in, b_in, w_out, b_out, g1, be1, w1, b1, w2, b2, g2, be2, g3, be3, eps=1e-5,
@@ -1662,6 +1684,153 @@ class _VoteLoss(torch.autograd.Function):
 def vote_loss(off, cls, pts, gt_mm, radius: float):
     """K12 + the JointvoteLoss reductions: -> joints (L,B,J,3), l3d_sum (L,B), bce_sum (L,B), near_sum (B)."""
     return _VoteLoss.apply(off, cls, pts, gt_mm, radius)
+
+
+# ---------------------------------------------------------------------------------------------
+# K1 + K7 + K8 and K11 + K12 as single C calls (include/hoisdf.h hoisdf_tokens_*, hoisdf_heads_vote_*)
+# ---------------------------------------------------------------------------------------------
+def _mlp_struct(weights, biases, act_last: bool):
+    from ._lib import Mlp, MLP_MAX_LAYERS
+    n = len(weights)
+    if not 1 <= n <= MLP_MAX_LAYERS:
+        raise ValueError(f"an MLP of {n} layers does not fit hoisdf_mlp ({MLP_MAX_LAYERS})")
+    m = Mlp()
+    m.n_layers, m.act_last = n, int(act_last)
+    m.dims[0] = weights[0].shape[1]
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        if not w.is_contiguous() or w.shape[1] != m.dims[i]:
+            raise ValueError("hoisdf_mlp needs dense weights chained dims[i] -> dims[i + 1]")
+        m.dims[i + 1] = w.shape[0]
+        m.w[i], m.b[i] = w.data_ptr(), b.data_ptr()
+    return m
+
+
+def _mlp_grads(weights, biases, device):
+    """-> (hoisdf_mlp_grads, [dw..., db...] views of ONE zero-filled buffer from the step's arena)"""
+    from ._lib import MlpGrads
+    sizes = [w.numel() for w in weights] + [b.numel() for b in biases]
+    buf = _zeros(sum(sizes), device)
+    parts, off = [], 0
+    for n in sizes:
+        parts.append(buf[off:off + n])
+        off += n
+    G = MlpGrads()
+    k = len(weights)
+    for i in range(k):
+        G.dw[i], G.db[i] = parts[i].data_ptr(), parts[k + i].data_ptr()
+    return G, [parts[i].view_as(weights[i]) for i in range(k)], [parts[k + i] for i in range(k)]
+
+
+class _Tokens(torch.autograd.Function):
+    """hoisdf_tokens_fwd / _bwd on gathered rows: (tok with rows [row0, row0 + P) written, fea)."""
+
+    @staticmethod
+    def forward(ctx, tok, feat, cam, center, pe, sdf, beta, row0, n_layers, *wb):
+        ws_, bs_ = wb[:n_layers], wb[n_layers:]
+        B, S, D = tok.shape
+        feat2, cam = _rows(feat), cam.reshape(-1, 3).contiguous()
+        P = feat2.shape[0] // B
+        pe, sdf = pe.reshape(-1, 30).contiguous(), sdf.reshape(-1).contiguous()
+        _chk(tok, feat2, cam, center, pe, sdf, beta, *ws_, *bs_)
+        if feat2.stride(0) != feat2.shape[1]:
+            feat2 = feat2.contiguous()
+        m = _mlp_struct(ws_, bs_, True)
+        M = B * P
+        n_saved = lib().hoisdf_tokens_saved_bytes(C.addressof(m), M, 0)
+        n_ws = lib().hoisdf_tokens_workspace_bytes(C.addressof(m), M, 0)
+        saved = torch.empty(n_saved, device=tok.device, dtype=torch.uint8)
+        ws = torch.empty(n_ws, device=tok.device, dtype=torch.uint8)
+        fea = torch.empty(M, D - 33, device=tok.device)
+        call("hoisdf_tokens_fwd", None, None, _p(center), None, 1.0, 0, 0, _p(feat2), _p(cam), C.addressof(m), _p(pe), _p(sdf), _p(beta),
+             _p(tok), _p(fea), None, B, P, S, row0, D, _p(saved), n_saved, _p(ws), n_ws, _st())
+        ctx.save_for_backward(feat2, sdf, beta, saved, *ws_, *bs_)
+        ctx.meta = (B, P, S, row0, D, n_layers, feat.shape)
+        ctx.mark_dirty(tok)
+        ctx.mark_non_differentiable(fea)
+        return tok, fea
+
+    @staticmethod
+    def backward(ctx, dtok, _dfea):
+        feat2, sdf, beta, saved = ctx.saved_tensors[:4]
+        B, P, S, row0, D, n, fshape = ctx.meta
+        ws_, bs_ = ctx.saved_tensors[4:4 + n], ctx.saved_tensors[4 + n:]
+        dev = dtok.device
+        dtok = dtok.contiguous()
+        m = _mlp_struct(ws_, bs_, True)
+        G, dws, dbs = _mlp_grads(ws_, bs_, dev)
+        M = B * P
+        dfeat = torch.empty_like(feat2)
+        dbeta = _zeros(1, dev)
+        n_ws = lib().hoisdf_tokens_workspace_bytes(C.addressof(m), M, 1)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        call("hoisdf_tokens_bwd", None, None, None, None, 1.0, 0, 0, _p(feat2), C.addressof(m), _p(sdf), _p(beta), _p(dtok), _p(saved),
+             saved.numel(), C.addressof(G), _p(dfeat), 0, _p(dbeta), B, P, S, row0, D, _p(ws), n_ws, _st())
+        dtok_in = dtok.clone()
+        dtok_in[:, row0:row0 + P] = 0            # the rows this op wrote do not depend on the incoming buffer contents
+        return (dtok_in, dfeat.view(fshape), None, None, None, None, dbeta, None, None, *dws, *dbs)
+
+
+def tokens_ok(*tensors) -> bool:
+    """the C entry covers the default arithmetic; bench.py's per-call event timing and the split mode take the op chain"""
+    from . import _lib
+    return _TOKENS_C and not _GEMM_SPLIT and _lib._timer is None and all(t.is_cuda for t in tensors)
+
+
+def tokens(tok, feat, cam, center, pe, sdf, beta, row0: int, weights, biases):
+    """K7 + K8 in one C call: rows [row0, row0 + P) of tok (B,S,D) = [cam - center | pe | MLP(feat) * sigma(sdf, beta)];
+    -> (tok, fea = MLP(feat) (B P, D - 33), detached: for the cross-field tokens of the other stream)."""
+    return _Tokens.apply(tok, feat, cam, center.contiguous(), pe, sdf, beta, row0, len(weights), *weights, *biases)
+
+
+class _HeadsVote(torch.autograd.Function):
+    """hoisdf_heads_vote_fwd / _bwd: enc (L,B,P,E) -> joints (L,B,J,3), l3d_sum (L,B), bce_sum (L,B), near_sum (B)."""
+
+    @staticmethod
+    def forward(ctx, enc, pts, gt_mm, radius, nv, nc, *wb):
+        vw, vb, cw, cb = wb[:nv], wb[nv:2 * nv], wb[2 * nv:2 * nv + nc], wb[2 * nv + nc:]
+        enc, pts, gt_mm = enc.contiguous(), pts.contiguous(), gt_mm.contiguous()
+        _chk(enc, pts, gt_mm, *wb)
+        L, B, P, E = enc.shape
+        J = cw[-1].shape[0]
+        dev = enc.device
+        mv, mc = _mlp_struct(vw, vb, False), _mlp_struct(cw, cb, False)
+        n_saved = lib().hoisdf_heads_vote_saved_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J)
+        n_ws = lib().hoisdf_heads_vote_workspace_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J, 0)
+        saved = torch.empty(n_saved, device=dev, dtype=torch.uint8)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        joints = torch.empty(L, B, J, 3, device=dev)
+        l3d, bce, near = torch.empty(L, B, device=dev), torch.empty(L, B, device=dev), torch.empty(B, device=dev)
+        call("hoisdf_heads_vote_fwd", _p(enc), C.addressof(mv), C.addressof(mc), _p(pts), _p(gt_mm), float(radius), _p(joints), _p(l3d),
+             _p(bce), _p(near), L, B, P, J, _p(saved), n_saved, _p(ws), n_ws, _st())
+        ctx.save_for_backward(enc, pts, gt_mm, joints, saved, *wb)
+        ctx.meta = (float(radius), nv, nc, J)
+        ctx.mark_non_differentiable(near)
+        return joints, l3d, bce, near
+
+    @staticmethod
+    def backward(ctx, dj, dl3d, dbce, _dnear):
+        enc, pts, gt_mm, joints, saved = ctx.saved_tensors[:5]
+        wb = ctx.saved_tensors[5:]
+        radius, nv, nc, J = ctx.meta
+        vw, vb, cw, cb = wb[:nv], wb[nv:2 * nv], wb[2 * nv:2 * nv + nc], wb[2 * nv + nc:]
+        L, B, P, E = enc.shape
+        dev = enc.device
+        mv, mc = _mlp_struct(vw, vb, False), _mlp_struct(cw, cb, False)
+        Gv, dvw, dvb = _mlp_grads(vw, vb, dev)
+        Gc, dcw, dcb = _mlp_grads(cw, cb, dev)
+        n_ws = lib().hoisdf_heads_vote_workspace_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J, 1)
+        ws = torch.empty(n_ws, device=dev, dtype=torch.uint8)
+        denc = torch.empty_like(enc)
+        c = lambda t: None if t is None else t.contiguous()
+        dj, dl3d, dbce = c(dj), c(dl3d), c(dbce)
+        call("hoisdf_heads_vote_bwd", _p(enc), C.addressof(mv), C.addressof(mc), _p(pts), _p(gt_mm), radius, _p(joints), _p(saved),
+             saved.numel(), _p(dj), _p(dl3d), _p(dbce), C.addressof(Gv), C.addressof(Gc), _p(denc), L, B, P, J, _p(ws), n_ws, _st())
+        return (denc, None, None, None, None, None, *dvw, *dvb, *dcw, *dcb)
+
+
+def heads_vote(enc, pts, gt_mm, radius: float, vote_w, vote_b, cls_w, cls_b):
+    """K11 + K12 in one C call (linear_handvote + linear_handcls on all depths + vote aggregation + JointvoteLoss sums)."""
+    return _HeadsVote.apply(enc, pts, gt_mm, radius, len(vote_w), len(cls_w), *vote_w, *vote_b, *cls_w, *cls_b)
 
 
 class _PointLoss(torch.autograd.Function):

@@ -263,7 +263,7 @@ int hoisdf_gather_rows(const float* src, int lds, const int32_t* sel, long n_sel
  * hoisdf_sdf_query_train_fwd = the dataflow of hoisdf_sdf_query_fwd keeping, in `saved` (hoisdf_sdf_query_train_saved_bytes),
  *   what the backward needs: gathered rows, activations, the six ReLU / dropout sign bitmaps, the tanh output.
  * hoisdf_sdf_query_bwd: d_sdf [n_rows] (gradient of the CLAMPED sdf) -> weight gradients in the layouts of hoisdf_sdf_weights
- *   (d_dec_w0 dense [512][289]; d_dec_w1 [224][512] and d_dec_b1 [224] with the pad row; d_dec_w2 [512][516] with the pad
+ *   (d_dec_w0 [512][292]: the 289 real columns + the three zero pad columns of the decoder-input row; d_dec_w1 [224][512] and d_dec_b1 [224] with the pad row; d_dec_w2 [512][516] with the pad
  *   columns; all zero on entry), and the pyramid gradient scatter-ADDED into dpyr (NULL: skipped).  The weight-norm fold's own
  *   backward (hoisdf_weightnorm_bwd on the effective-weight gradients) is the caller's. */
 typedef struct hoisdf_sdf_weight_grads {
@@ -556,6 +556,58 @@ int hoisdf_vote_loss_bwd(const float* off, const float* cls, const float* pts, c
                          float radius, const float* joints, const float* stats, const float* djoints,
                          const float* dl3d_sum, const float* dbce_sum, float* doff, float* dcls, int L,
                          int B, int P, int J, void* stream);
+
+/* ---- K1 + K7 + K8 and K11 + K12 as single calls (SURVEY.md section 8(b) `hoisdf_token_build_*`, `hoisdf_heads_vote_*`) ----------
+ * An MLP = Linear (+ ReLU) chain as common/nets/layer.py:168-201 builds it: layer i maps dims[i] -> dims[i + 1] with weight
+ * w[i] [dims[i + 1]][dims[i]] (dense) and bias b[i]; ReLU after every layer but the last, and after the last one too when
+ * act_last (linear_transformerin, main/model.py:58-62).  Gradient buffers are zero on entry and hold the gradient on return.
+ *
+ * hoisdf_tokens_fwd: the token rows of one point set (reference: Model.get_input_transformer, main/model.py:145-179, + the
+ *   sigma gate and concatenation, :123-126,520-562): feat [B P][C] = the gathered pyramid rows (feat_in with their camera points
+ *   cam_in [B P][3]; or feat_in = NULL: projected + gathered here from pyr / points [B][P][3] / cam_intr, cam_out [B P][3]
+ *   receives the camera points) -> MLP -> fea [B P][D - 33] -> tok[b][row0 + p][:] = [cam - center | pe | fea * sigmoid(sdf /
+ *   beta) / beta] (hoisdf_token_build_fwd).  fea_out (optional) receives the MLP output for other consumers (the detached
+ *   cross-field tokens, :540,:558).  hoisdf_tokens_bwd: dtok [B][S][D] -> the MLP's weight gradients, *dbeta += ..., and the
+ *   gradient of the gathered rows into dfeat [B P][C] (overwritten or, accumulate_dfeat = 1, added to) - or, when the rows were
+ *   gathered inside and dpyr is given, scatter-added into the pyramid gradient.
+ * hoisdf_heads_vote_fwd: enc [L][B][P][E] = the intermediate hand rows of all L encoder depths (main/model.py:587-593) ->
+ *   linear_handvote / linear_handcls -> hoisdf_vote_loss_fwd: joints [L][B][J][3] and the three reductions of
+ *   JointvoteLoss (see hoisdf_vote_loss_fwd).  hoisdf_heads_vote_bwd: gradients of joints / l3d_sum / bce_sum (any may be NULL)
+ *   -> both MLPs' weight gradients and denc [L B P][E] (overwritten). */
+#define HOISDF_MLP_MAX_LAYERS 4
+typedef struct hoisdf_mlp {
+  int n_layers, act_last;
+  int dims[HOISDF_MLP_MAX_LAYERS + 1];
+  const float* w[HOISDF_MLP_MAX_LAYERS];
+  const float* b[HOISDF_MLP_MAX_LAYERS];
+} hoisdf_mlp;
+typedef struct hoisdf_mlp_grads {
+  float* dw[HOISDF_MLP_MAX_LAYERS];
+  float* db[HOISDF_MLP_MAX_LAYERS];
+} hoisdf_mlp_grads;
+long hoisdf_tokens_saved_bytes(const hoisdf_mlp* mlp, long n_rows, int gather_inside);
+long hoisdf_tokens_workspace_bytes(const hoisdf_mlp* mlp, long n_rows, int backward_pass);
+int hoisdf_tokens_fwd(const hoisdf_pyramid* pyr, const float* points, const float* center, const float* cam_intr, float scale,
+                      int img_h, int img_w, const float* feat_in, const float* cam_in, const hoisdf_mlp* mlp, const float* pe,
+                      const float* sdf, const float* beta_ptr, float* tok, float* fea_out, float* cam_out, int B, int P, int S,
+                      int row0, int D, void* saved, long saved_bytes, void* workspace, long workspace_bytes, void* stream);
+int hoisdf_tokens_bwd(const hoisdf_pyramid_grad* dpyr, const float* points, const float* center, const float* cam_intr,
+                      float scale, int img_h, int img_w, const float* feat_in, const hoisdf_mlp* mlp, const float* sdf,
+                      const float* beta_ptr, const float* dtok, const void* saved, long saved_bytes,
+                      const hoisdf_mlp_grads* grads, float* dfeat, int accumulate_dfeat, float* dbeta, int B, int P, int S,
+                      int row0, int D, void* workspace, long workspace_bytes, void* stream);
+long hoisdf_heads_vote_saved_bytes(const hoisdf_mlp* vote, const hoisdf_mlp* cls, int L, int B, int P, int J);
+long hoisdf_heads_vote_workspace_bytes(const hoisdf_mlp* vote, const hoisdf_mlp* cls, int L, int B, int P, int J,
+                                       int backward_pass);
+int hoisdf_heads_vote_fwd(const float* enc, const hoisdf_mlp* vote, const hoisdf_mlp* cls, const float* pts,
+                          const float* joint_gt_mm, float radius, float* joints, float* l3d_sum, float* bce_sum,
+                          float* near_sum, int L, int B, int P, int J, void* saved, long saved_bytes, void* workspace,
+                          long workspace_bytes, void* stream);
+int hoisdf_heads_vote_bwd(const float* enc, const hoisdf_mlp* vote, const hoisdf_mlp* cls, const float* pts,
+                          const float* joint_gt_mm, float radius, const float* joints, const void* saved, long saved_bytes,
+                          const float* djoints, const float* dl3d_sum, const float* dbce_sum,
+                          const hoisdf_mlp_grads* vote_grads, const hoisdf_mlp_grads* cls_grads, float* denc, int L, int B,
+                          int P, int J, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- a15: the scalar point losses ------------------------------------------------
  * reference: common/nets/loss.py:64-78 (SepSDFLoss = torch.nn.L1Loss(mean) of the clamped SDF predictions against the

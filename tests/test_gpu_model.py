@@ -543,5 +543,6 @@ def test_sdf_infer_with_counts_queued_ahead_equals_the_blocking_form():
     with torch.no_grad():
         _, o1 = model.hot_path(pyr, di, dt, m, "eval")
         _, o2 = model.hot_path(pyr, di, dt, m, "eval", infer_counts=model.infer_counts_begin(m))
-    assert torch.equal(o1["hand_joints_out"], o2["hand_joints_out"])
+    # (not bit-wise: the few-tile decoder GEMMs of the forward use split-K float atomics)
+    assert float((o1["hand_joints_out"] - o2["hand_joints_out"]).abs().max()) <= 1e-6 * float(o1["hand_joints_out"].abs().max())
     del junk

@@ -36,12 +36,34 @@ def child():
         h2 = hashlib.sha1(dx.cpu().numpy().tobytes()).hexdigest()[:12]
         t3 = timeit(lambda: O._gemm_bwd_input(dy, N, None, 0.0, W, dx, K, M, N, K, 0))
         h3 = hashlib.sha1(dx.cpu().numpy().tobytes()).hexdigest()[:12]
+        # grad-weight (+ bias gradient): plain and with the sign bitmap
+        dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+        if N % 4 == 0 and K % 4 == 0 and M >= 8192:
+            t4 = timeit(lambda: O._gemm_bwd_weight(dy, N, None, 0.0, x, K, dW, db, M, N, K))
+            h4 = hashlib.sha1(dW.cpu().numpy().tobytes()).hexdigest()[:12] + hashlib.sha1(db.cpu().numpy().tobytes()).hexdigest()[:6]
+            t5 = timeit(lambda: O._gemm_bwd_weight(dy, N, bits, 0.1, x, K, dW, db, M, N, K))
+            keep = ((bits[:, torch.arange(N, device=dev) // 32] >> (torch.arange(N, device=dev) % 32)) & 1).double()
+            ge = dy.double() * keep / 0.9
+            edw = ((dW.double() - ge.t() @ x.double()).abs().max() / (ge.t() @ x.double()).abs().max()).item()
+            edb = ((db.double() - ge.sum(0)).abs().max() / ge.sum(0).abs().max()).item()
+        else:
+            t4 = t5 = float("inf"); h4 = ""; edw = edb = 0.0
+        # masked grad-input vs fp64
+        O._gemm_bwd_input(dy, N, bits, 0.1, W, dx, K, M, N, K, 0)
+        if M <= 70000:
+            keep2 = ((bits[:, torch.arange(N, device=dev) // 32] >> (torch.arange(N, device=dev) % 32)) & 1).double()
+            rdx = (dy.double() * keep2 / 0.9) @ W.double()
+            edx = ((dx.double() - rdx).abs().max() / rdx.abs().max()).item()
+            del keep2, rdx
+        else:
+            edx = 0.0
         # vs fp64 on a row sample
         idx = torch.arange(0, M, max(1, M // 64), device=dev)[:64]
         ref = (x[idx].double() @ W.double().t())
         O._gemm_fwd(x, K, W, None, y, N, M, N, K, 0, 0.0, 0, None)
         err = ((y[idx].double() - ref).abs().max() / ref.abs().max()).item()
-        out.append(dict(shape=[M, N, K], tf=[fl / t / 1e12 for t in (t0, t1, t3, t2)], us=[t * 1e6 for t in (t0, t1, t3, t2)], h=[h0, h1, h3, h2], err=err))
+        out.append(dict(shape=[M, N, K], tf=[fl / t / 1e12 for t in (t0, t1, t3, t2, t4, t5)], us=[t * 1e6 for t in (t0, t1, t3, t2, t4, t5)],
+                        h=[h0, h1, h3, h2, h4], err=err, edx=edx, edw=edw, edb=edb))
     print("RESULT " + json.dumps(out))
 
 
@@ -65,10 +87,11 @@ if __name__ == "__main__":
                 print(label, p.stdout[-3000:], p.stderr[-3000:]); sys.exit(1)
             res.setdefault(label, []).append(json.loads(line[0][7:]))
     labels = list(res)
-    print("TF-eq (best of 2 runs): fwd / fwd+bias+relu+dropout / dx / dx+mask; '=' all four outputs bit-equal to the first configuration; err = max |err| / max |ref| vs fp64 (plain fwd)")
+    print("TF-eq (best of 2 runs): fwd / fwd+bias+relu+dropout / dx / dx+mask / dW+db / dW+db+mask; '=' outputs bit-equal to the first configuration (fwd, fwd+act, dx, dx+mask, dW+db); err vs fp64: plain fwd, masked dx, masked dW, masked db")
     for i, (M, N, K) in enumerate(SHAPES):
         print(f"{M:7d} {N:5d} {K:5d}")
         for l in labels:
-            b = [max(r[i]["tf"][j] for r in res[l]) for j in range(4)]
-            eq = "".join("=" if res[l][0][i]["h"][j] == res[labels[0]][0][i]["h"][j] else "x" for j in range(4))
-            print(f"      {l:>10}: " + " ".join(f"{v:6.1f}" for v in b) + f"  {eq}  err {res[l][0][i]['err']:.2e}")
+            b = [max(r[i]["tf"][j] for r in res[l]) for j in range(6)]
+            eq = "".join("=" if res[l][0][i]["h"][j] == res[labels[0]][0][i]["h"][j] else "x" for j in range(5))
+            r0 = res[l][0][i]
+            print(f"      {l:>10}: " + " ".join(f"{v:6.1f}" for v in b) + f"  {eq}  err {r0['err']:.1e} dx {r0['edx']:.1e} dW {r0['edw']:.1e} db {r0['edb']:.1e}")
