@@ -35,7 +35,8 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (
 # the arithmetic type of the headline line: every contraction is fp32 - either the exact-f32 MFMA or (default for the large
 # linear layers and the attention forward) fp32 emulated with EXACT 3-way bf16 operand splits, 6 products, f32 accumulation:
 # error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
-DTYPE_F32 = "f32"
+DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--gemm f32 --attention f32)
+DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # the default: 3-way exact bf16 split, 6 products, f32 accumulation
 PMC_FILE = "r03_pmc.json"
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
@@ -62,20 +63,11 @@ class KernelTimer:
         "hoisdf_attention_fwd_emu": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_emu": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
-        "hoisdf_attention_fwd_split": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
-        "hoisdf_attention_bwd_split": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
-        "hoisdf_attention_fwd_split_keep": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
-        "hoisdf_attention_bwd_split_kept": lambda a: 10.0 * a[16] * a[17] * a[18] * a[20] * 64,
-        # split-precision linear layers: same argument positions as the f32 entries (+ workspace); algorithmic FLOPs
-        # (the 3 split products are not counted), operand conversion passes inside the timed call
         # fp32 emulated on the bf16 pipe: (x, ldx, image, bias, y, ldy, M, N, K, ...) / (dy, lddy, bits, p, image, dx, lddx, M, N, K, ...);
         # algorithmic FLOPs (the six bf16 products per product are not counted)
         "hoisdf_linear_fwd_emu": lambda a: 2.0 * a[6] * a[7] * a[8],
         "hoisdf_linear_bwd_input_emu": lambda a: 2.0 * a[7] * a[8] * a[9],
         "hoisdf_linear_bwd_weight_emu": lambda a: 2.0 * a[9] * a[10] * a[11],
-        "hoisdf_linear_fwd_split": lambda a: 2.0 * a[7] * a[8] * a[9],
-        "hoisdf_linear_bwd_input_split": lambda a: 2.0 * a[8] * a[9] * a[10],
-        "hoisdf_linear_bwd_weight_split": lambda a: 2.0 * a[9] * a[10] * a[11],
         # the gradient-free SDF query (K1-K4 behind one C-ABI call): its six GEMMs, 2 (C*512 + 512*256) +
         # 2 (289*512 + 512*223 + 512*512 + 512*512 + 512) FLOP per point; the gather / posenc time inside the call is
         # charged to the GEMM family as well
@@ -91,11 +83,8 @@ class KernelTimer:
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
-             "hoisdf_attention_fwd_split": (9, 11, 13), "hoisdf_attention_bwd_split": (16, 18, 20),
-             "hoisdf_attention_fwd_split_keep": (9, 11, 13), "hoisdf_attention_bwd_split_kept": (16, 18, 20),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
-             "hoisdf_linear_fwd_split": (7, 8, 9), "hoisdf_linear_bwd_input_split": (8, 9, 10),
-             "hoisdf_linear_bwd_weight_split": (9, 10, 11)}
+             }
 
     def begin(self, name, args):
         s = torch.cuda.Event(enable_timing=True)
@@ -155,20 +144,20 @@ def main():
     ap.add_argument("--aten-report", action="store_true",
                     help="after the warm-up, run one extra step under torch.profiler and print the ATen ops by name and input "
                          "shape (stderr): where the glue launches come from")
-    ap.add_argument("--gemm", choices=("emu", "f32", "split"), default="emu",
+    ap.add_argument("--gemm", choices=("emu", "f32"), default="emu",
                     help="linear layers: emu = fp32 emulated on the bf16 MFMA pipe (exact 3-way bf16 operand splits, 6 products, f32 "
-                         "accumulation: fp32-equivalent, the default); f32 = the exact-f32 MFMA GEMM; split = f16 hi+lo operands, "
-                         "3 products (22-bit operands: a separately labelled second line)")
-    ap.add_argument("--attention", choices=("emu", "f32", "split"), default="emu",
+                         "accumulation: fp32-equivalent, the default); f32 = the exact-f32 MFMA GEMM")
+    ap.add_argument("--attention", choices=("emu", "f32"), default="emu",
                     help="attention: emu = forward and backward emulated like --gemm emu (HOISDF_ATTN_BWD=f32 keeps the exact-f32 fused "
-                         "backward); f32 = exact-f32 MFMA kernels; split = f16 hi+lo operands (second line)")
+                         "backward); f32 = exact-f32 MFMA kernels")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 32, [3]: 16, [4]: 8 / max(2, gpus))")
     ap.add_argument("--n-hand", type=int, default=None)
     ap.add_argument("--n-obj", type=int, default=None)
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-f32", type=int, default=1, help="also time 10 steps of the exact-f32 path (outside the timed region) into `exact_f32`")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--time-every", type=int, default=20, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
+    ap.add_argument("--time-every", type=int, default=7, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce even with one rank (single-GPU check of the N>1 path)")
     ap.add_argument("--shape-report", action="store_true", help="per-shape kernel table on stderr")
@@ -223,9 +212,6 @@ def main():
     cfg.apply_setting({1: "dexycb", 3: "ho3d_render", 4: "dexycb"}[args.config])
     cfg.num_samp_hand, cfg.num_samp_obj, cfg.bins_n = args.n_hand, args.n_obj, 64
     cfg.attention_f16_eval = args.config == 4
-    cfg.attention_split = train and args.attention == "split"
-    cfg.gemm_split = train and args.gemm == "split"
-    cfg.gemm_split_eval = (not train) and args.gemm == "split"
     cfg.gemm_emu = args.gemm == "emu"
     cfg.attention_emu = args.attention == "emu"
     ops.set_gemm_emu(cfg.gemm_emu)
@@ -416,6 +402,32 @@ def main():
         if rank == 0:
             print(f"[comm] {json.dumps(comm)}", file=sys.stderr)
 
+    # ---- the same step with every contraction on the exact-f32 MFMA kernels (round 2's headline path), OUTSIDE the timed region:
+    # the driver-run record then carries both numbers (2 warm-up + 10 steps; every rank takes part, max over ranks)
+    exact = None
+    if train and args.exact_f32 and (args.gemm == "emu" or args.attention == "emu") and not args.branch_mix:
+        cfg.gemm_emu = cfg.attention_emu = False
+        ops.set_gemm_emu(False)
+        ops.set_attention_emu(False)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dt1], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt1 = float(t)
+        exact = {"what": "the same train step with --gemm f32 --attention f32 (exact-f32 MFMA linear layers and attention forward; backward "
+                         "as HOISDF_ATTN_BWD says), 10 steps outside the timed region", "dtype": DTYPE_F32,
+                 "value": round(world * args.batch * 10 / dt1, 3), "unit": "samples/s", "ms_per_step": round(1e3 * dt1 / 10, 3)}
+        cfg.gemm_emu, cfg.attention_emu = args.gemm == "emu", args.attention == "emu"
+        ops.set_gemm_emu(cfg.gemm_emu)
+        ops.set_attention_emu(cfg.attention_emu)
+
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -425,11 +437,6 @@ def main():
     value = world * args.batch * args.steps / dt
     enc = f"ResNet-{args.resnet} encoder (PyTorch/MIOpen; the reference has no HRNet)"
     if args.config == 1:
-        if args.attention == "split" or args.gemm == "split":
-            what = " and ".join(w for w, on in (("attention fwd+bwd (cfg.attention_split)", args.attention == "split"),
-                                                ("the large linear layers' three contractions (cfg.gemm_split)",
-                                                 args.gemm == "split")) if on)
-            enc += f"; SECOND LINE: training {what} in split precision, not the f32 headline"
         mix = (f"epoch >= {cfg.point_sampling_epoch} point-branch mix: {branches['A']} steps pre-points (A) / "
                f"{branches['B']} steps dense-lattice sdf_infer (B)") if args.branch_mix else "point branch A (pre-points)"
         workload = (f"BASELINE configs[1]: DexYCB-shape synthetic batch {args.batch}/GPU, {args.n_hand}+{args.n_obj} SDF "
@@ -447,11 +454,9 @@ def main():
                   f"samples/sec, inference (BASELINE configs[{args.config}])",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": DTYPE_F32 if (args.config != 4 and args.attention != "split" and args.gemm != "split") else
-                 ("f32 (attention" + (" and linear-layer" if args.gemm == "split" else "") +
-                  " contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax)"
-                  if (args.config == 4 or args.attention == "split") else
-                  "f32 (linear-layer contractions: f16 hi+lo split operands x3 products, f32 accumulate)"),
+        "dtype": (DTYPE_EMU if (args.gemm == "emu" or args.attention == "emu") else DTYPE_F32) if args.config != 4 else
+                 "f32 (attention contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax; linear layers " +
+                 ("bf16x3-emulated fp32)" if args.gemm == "emu" else "exact f32)"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config,
                    "global_batch": world * args.batch, "points": args.n_hand + args.n_obj,
@@ -459,12 +464,12 @@ def main():
     }
     res["config"]["arithmetic"] = {
         "linear_layers": {"emu": "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate",
-                          "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[args.gemm],
+                          "f32": "exact-f32 MFMA"}[args.gemm],
         "attention": {"emu": "forward and backward emulated fp32 (as the linear layers; the 17-query decoder attention exact-f32)"
                              if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
                              "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
-                      "f32": "exact-f32 MFMA", "split": "f16 hi+lo operands, 3 products (22-bit)"}[
-                          "split" if args.attention == "split" else ("f32" if (args.attention == "f32" or args.config == 4) else "emu")],
+                      "f32": "exact-f32 MFMA", "f16": "f16-MFMA eval kernel (BASELINE configs[4]): f16 hi+lo operands, 3 products"}[
+                          "f16" if args.config == 4 else ("f32" if args.attention == "f32" else "emu")],
         "accuracy_evidence": "tests/test_gpu_emu.py, tools/emu_accuracy.py: error vs fp64 <= the exact-f32 kernels' and hipBLASLt fp32's"}
     if timer is not None:
         ks = timer.summary()
@@ -474,23 +479,19 @@ def main():
         # the MFMA roof of the arithmetic it runs:
         #   f32    exact-f32 MFMA kernels: 157.3 TFLOP/s
         #   emu    fp32 emulated with 3-way bf16 splits: six bf16 products per product -> 2500 / 6 TFLOP/s of fp32-equivalent work
-        #   split  f16 hi + lo pairs (opt-in second line): three f16 products per product -> 2500 / 3
-        sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's emulation / split switch
-        sq_emu = args.gemm != "split" and bool(_lib.lib().hoisdf_get_gemm_emu())
+        #   split  f16 hi + lo pairs (the configs[4] eval attention): three f16 products per product -> 2500 / 3
+        sq = ["hoisdf_sdf_query_fwd"]           # its six GEMMs follow the library's emulation switch
+        sq_emu = bool(_lib.lib().hoisdf_get_gemm_emu())
         FAMS = [
             ("attn_delta + attn_bwd_fused (dK, dV, dQ in one pass)", ["hoisdf_attention_bwd"], "f32"),
             ("attn_fwd_kernel", ["hoisdf_attention_fwd"], "f32"),
             ("gemm_f32_kernel (linear fwd + grad-input + grad-weight)",
-             ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if (args.gemm == "split" or sq_emu) else sq), "f32"),
-            ("emu_kc_kernel (linear fwd + grad-input)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
-            ("emu_dw_kernel (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
+             ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if sq_emu else sq), "f32"),
+            ("emu_kc2_kernel (linear fwd + grad-input; emu_kc_kernel with HOISDF_EMU_KC=1)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
+            ("emu_dw2_kernel / emu_dw_kernel<128> (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
             ("emu_attn_fwd_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
             ("emu_attn_bwd_stag_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
             ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
-            ("gemm_split_kernel (linear fwd + grad-input + grad-weight, + conversion passes)",
-             ["hoisdf_linear_fwd_split", "hoisdf_linear_bwd_input_split", "hoisdf_linear_bwd_weight_split"] + (sq if args.gemm == "split" else []), "split"),
-            ("split_fwd_kernel (+ conversion passes)", ["hoisdf_attention_fwd_split", "hoisdf_attention_fwd_split_keep"], "split"),
-            ("split_bwd_dkv + split_bwd_dq (+ conversion passes)", ["hoisdf_attention_bwd_split", "hoisdf_attention_bwd_split_kept"], "split"),
         ]
         PEAK = {"f32": (PEAK_F32_TFLOPS, "f32 MFMA peak (= f32 vector peak), MI355X_MICROARCH.md:41"),
                 "emu": (round(PEAK_F16_TFLOPS / 6.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product (MI355X_MICROARCH.md:42)"),
@@ -558,6 +559,8 @@ def main():
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),
                               "launches_per_step": v["launches"] / timed_steps, "avg_us": round(v["avg_us"], 2)}
                           for n, v in ks.items()}
+    if exact is not None:
+        res["exact_f32"] = exact
     if comm is not None:
         res["comm"] = comm
     if world == 1 and not args.no_cpu_baseline:

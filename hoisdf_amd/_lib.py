@@ -119,9 +119,6 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight_emu": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
-    "hoisdf_linear_fwd_split": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _L, _P],
-    "hoisdf_linear_bwd_input_split": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P, _L, _P],
-    "hoisdf_linear_bwd_weight_split": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _P, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "hoisdf_sdf_query_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _P, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _P, _L, _P],
@@ -139,6 +136,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_aux_image_losses_bwd": [_P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "hoisdf_token_build_bwd_ordered": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_attention_fwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                              _I, _F, _U64, _P],
@@ -146,12 +144,6 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_fwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P],
     "hoisdf_attention_bwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
                                  _L, _P],
-    "hoisdf_attention_fwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _P],
-    "hoisdf_attention_bwd_split": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
-                                   _U64, _P, _L, _P],
-    "hoisdf_attention_fwd_split_keep": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _P],
-    "hoisdf_attention_bwd_split_kept": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
-                                        _U64, _P, _P, _L, _P],
     "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                    _U64, _P],
@@ -183,9 +175,10 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_point_loss_bwd": [_P, _P, _L, _L, _I, _L, _I, _F, _F, _F, _P, _P, _P],
 }
 _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
-_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_gemm_split": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
+_OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
           "hoisdf_point_loss_blocks": ([_L], C.c_int),
+          "hoisdf_token_build_bwd_partials": ([], C.c_int),
           "hoisdf_tokens_saved_bytes": ([_P, _L, _I], C.c_long),
           "hoisdf_tokens_workspace_bytes": ([_P, _L, _I], C.c_long),
           "hoisdf_heads_vote_saved_bytes": ([_P, _P, _I, _I, _I, _I], C.c_long),
@@ -199,12 +192,10 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_split": ([_
           "hoisdf_encoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
-          "hoisdf_linear_split_workspace": ([_L, _I, _I, _I], C.c_long),
           "hoisdf_linear_emu_image_bytes": ([_I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
-          "hoisdf_attention_split_workspace": ([_I, _I, _I, _I, _I], C.c_long),
           "hoisdf_attention_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long),
           "hoisdf_attention_bwd_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
 

@@ -38,11 +38,8 @@ class Config:
     # not in the reference: BASELINE.json configs[4] ("fp16 MFMA attention"): f16-operand attention kernel for
     # gradient-free forward passes (mode != "train"); off = exact f32 everywhere (the parity configuration)
     attention_f16_eval = False
-    gemm_split_eval = False      # the same for inference (the dense-lattice SDF query of sdf_infer is GEMM-bound); off: exact f32
-    gemm_split = False           # training linear layers (fwd, grad-input, grad-weight) on the 16-bit MFMA pipe, f16 hi+lo split operands (csrc/gemm_split.hip)
     gemm_emu = None              # None: follow the library default (on; HOISDF_GEMM=f32 turns it off).  True / False: linear layers as fp32 emulated on the bf16 MFMA pipe (exact 3-way bf16 splits, 6 products; csrc/gemm_emu.hip) / the exact-f32 MFMA GEMM
     attention_emu = None         # the same for the attention forward (csrc/attention_emu.hip); HOISDF_ATTENTION=f32 turns the default off
-    attention_split = False      # training attention on the 16-bit MFMA pipe with f16 hi+lo split operands (csrc/attention_split.hip)
     # not in the reference: run the object transformer stack on a second HIP stream next to the hand stack
     overlap_streams = True
     resnet_type = 50

@@ -307,6 +307,282 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 }
 
 
+// ============================================================================================================================
+// forward, second form (round 4): the same tiles, fragments, product order and online softmax as emu_attn_fwd_kernel (with
+// dropout off the outputs are bit identical), software-pipelined over the key tiles and hand-interleaved:
+//     S phase : the 24 MFMAs of S(t + 1) = K(t + 1) . Q^T   with the softmax / dropout / three-way split of tile t behind them
+//     PV phase: the 24 MFMAs of O^T += V(t)^T . P(t)^T      with the running maximum of tile t + 1, its dropout decisions (one hash
+//               per two keys), the staging writes of K(t + 2) / V(t + 1) and the loads of K(t + 3) / V(t + 2) behind them
+// In the first form a wave runs [24 MFMAs | ~250 VALU | 24 MFMAs] per key tile and the MFMA pipe is 40 % busy (PMC, round 4): the
+// VALU work of a tile is about as long as its MFMAs, and on this part it only hides under the SAME wave's MFMAs.  Here every unit
+// of it is pinned behind one MFMA of the other tile (tools/gen/attn_fwd2_phase.py).  K rows and V^T tiles are double-buffered
+// separately (K(t + 1) and V(t) are read while K(t + 2) and V(t + 1) are written): four __shared__ objects of 13.5 KB, one barrier
+// per tile.
+// ============================================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
+  __shared__ __attribute__((aligned(16))) __bf16 Kb0[3 * ROWS_T];
+  __shared__ __attribute__((aligned(16))) __bf16 Kb1[3 * ROWS_T];
+  __shared__ __attribute__((aligned(16))) __bf16 Vb0[3 * TRN_T];
+  __shared__ __attribute__((aligned(16))) __bf16 Vb1[3 * TRN_T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, c = lane & 31;
+  int qtile, bh;
+  if (!emu_block((a.Lq + 127) / 128, a.B * a.H, qtile, bh)) return;
+  const int b = bh / a.H, head = bh - b * a.H;
+  const int qrow = qtile * 128 + wave * 32 + c;
+  const __bf16* kp[3] = {a.k[0] + (size_t)bh * a.Lkp * D, a.k[1] + (size_t)bh * a.Lkp * D, a.k[2] + (size_t)bh * a.Lkp * D};
+  const __bf16* vp[3] = {a.vt[0] + (size_t)bh * D * a.Lkp, a.vt[1] + (size_t)bh * D * a.Lkp, a.vt[2] + (size_t)bh * D * a.Lkp};
+
+  bf16x8 qf[4][3];                        // Q^T fragments: k-step j <-> d = 16 j + 8 h .. + 7 of the lane's query
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const __bf16* sq = a.q[p] + ((size_t)bh * a.Lqp + qrow) * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j][p] = *reinterpret_cast<const bf16x8*>(sq + 16 * j + 8 * h);
+  }
+  const uint32_t rowkey = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + qrow));
+  const uint32_t dthr = a.thresh & 0xffff0000u;
+  float m = -INFINITY, lsum = 0.f, ps = 0.f;
+  f32x16 o[2], s_cur, s_nxt;
+  float dsc[16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dsc[r] = 1.f;
+  const int ntiles = (a.kv_len + 31) / 32;
+  const int lastt = ntiles - 1;
+  u32x4 rk[3], rv[3];
+  bf16x8 kf[2][3], vf[2][3], pw[2][3];
+  uint32_t w0[8], w1[8], w2[8], hx[8];     // the three planes of P(t) (two scores per word), the dropout hashes of tile t + 1
+  f32x2 e_[8], f_[8];
+  float mt = -INFINITY;
+#define KFRAG(KB, p, j) (*reinterpret_cast<const bf16x8*>(&(KB)[(p) * ROWS_T + c * RP + 16 * (j) + 8 * h]))
+#define VFRAG(VB, p, dt, jj) frag_trn((VB) + (p) * TRN_T, (dt) * 32 + c, jj, h)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define PK_SUB(d, x, y) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y))
+// ---- units of the S phase: scores 2 pr, 2 pr + 1 of tile t -> probabilities -> (dropout) -> three bf16 planes
+#define PE1(pr) do { e_[pr] = f32x2{__builtin_amdgcn_exp2f(s_cur[2 * (pr)] - m), __builtin_amdgcn_exp2f(s_cur[2 * (pr) + 1] - m)}; } while (0)
+#define PE2(pr)                                                                                                        \
+  do {                                                                                                                 \
+    ps += e_[pr].x + e_[pr].y;                                                                                         \
+    if (DROP) e_[pr] = f32x2{e_[pr].x * dsc[2 * (pr)], e_[pr].y * dsc[2 * (pr) + 1]};                                   \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(e_[pr], bf16x2));                         \
+    w0[pr] = h_;                                                                                                       \
+    f_[pr] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                  \
+  } while (0)
+#define PE3(pr)                                                                                                        \
+  do {                                                                                                                 \
+    PK_SUB(e_[pr], e_[pr], f_[pr]);                                                                                    \
+    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(e_[pr], bf16x2));                         \
+    w1[pr] = h_;                                                                                                       \
+    f_[pr] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                  \
+  } while (0)
+#define PE4(pr)                                                                                                        \
+  do {                                                                                                                 \
+    f32x2 r_; PK_SUB(r_, e_[pr], f_[pr]);                                                                              \
+    w2[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r_, bf16x2));                                        \
+    if (((pr) & 3) == 3) {                      /* a key half-tile is complete: its three B fragments */                \
+      pw[(pr) >> 2][0] = __builtin_bit_cast(bf16x8, u32x4{w0[(pr) - 3], w0[(pr) - 2], w0[(pr) - 1], w0[pr]});          \
+      pw[(pr) >> 2][1] = __builtin_bit_cast(bf16x8, u32x4{w1[(pr) - 3], w1[(pr) - 2], w1[(pr) - 1], w1[pr]});          \
+      pw[(pr) >> 2][2] = __builtin_bit_cast(bf16x8, u32x4{w2[(pr) - 3], w2[(pr) - 2], w2[(pr) - 1], w2[pr]});          \
+    }                                                                                                                  \
+  } while (0)
+// ---- units of the PV phase: running maximum of tile t + 1 (four scores each), dropout decisions of tile t + 1 (pair pr = keys
+// CR(2 pr, h), CR(2 pr, h) + 1: one hash, the low half decides the even key), staging
+// (the empty asm statements pin a unit's result HERE: without them the optimiser sinks the maximum into the rarely taken statistics
+// branch and the hashes into the next iteration, i.e. out from under the MFMAs)
+// (v_max3_f32 through asm: fmaxf() costs three instructions per score here - hipcc canonicalises both operands of every v_max_f32 -
+// 62 per tile against 8; the scores are never NaN.  hipcc does not pad hazards for asm operands: the units sit >= 4 MFMAs = 128
+// cycles behind the last MFMA that wrote s_nxt, far beyond the 11 wait states an 8-pass result needs)
+#define PM(i)                                                                                                          \
+  do {                                                                                                                 \
+    float t_;                                                                                                          \
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(t_) : "v"(s_nxt[4 * (i)]), "v"(s_nxt[4 * (i) + 1]), "v"(s_nxt[4 * (i) + 2])); \
+    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mt) : "v"(t_), "v"(s_nxt[4 * (i) + 3]));                           \
+  } while (0)
+#define PH1(pr) do { if (DROP) { uint32_t x_ = hbase + (uint32_t)(CR(2 * (pr), 0) >> 1) * 0x9E3779B9U; x_ ^= x_ >> 15; hx[pr] = x_ * 0x2C1B3C6DU; asm volatile("" : "+v"(hx[pr])); } } while (0)
+#define PH2(pr) do { if (DROP) { hx[pr] ^= hx[pr] >> 12; asm volatile("" : "+v"(hx[pr])); } } while (0)
+#define PH3(pr) do { if (DROP) { dsc[2 * (pr)] = (hx[pr] << 16) >= dthr ? a.inv_keep : 0.f; dsc[2 * (pr) + 1] = hx[pr] >= dthr ? a.inv_keep : 0.f; asm volatile("" : "+v"(dsc[2 * (pr)]), "+v"(dsc[2 * (pr) + 1])); } } while (0)
+#define STK(p) st_rows(kw + (p) * ROWS_T, rk[p], tid)
+#define STV(p) st_trn(vw + (p) * TRN_T, rv[p], tid)
+#define LDK(p) rk[p] = ld_rows(kp[p], (size_t)ktn * 32, tid)
+#define LDV(p) rv[p] = ld_trn(vp[p], a.Lkp, (size_t)vtn * 32, tid)
+#ifndef FWD2_ABL
+#define FWD2_ABL 0
+#endif
+#if FWD2_ABL & 1            /* ablation (timing only, wrong results): no softmax / split / hash arithmetic */
+#undef PE1
+#undef PE2
+#undef PE3
+#undef PE4
+#undef PM
+#undef PH1
+#undef PH2
+#undef PH3
+#define PE1(pr) ((void)0)
+#define PE2(pr) ((void)0)
+#define PE3(pr) ((void)0)
+#define PE4(pr) ((void)0)
+#define PM(i) ((void)0)
+#define PH1(pr) ((void)0)
+#define PH2(pr) ((void)0)
+#define PH3(pr) ((void)0)
+#endif
+#if FWD2_ABL & 8            /* no exp / subtract */
+#undef PE1
+#define PE1(pr) do { e_[pr] = f32x2{s_cur[2 * (pr)], s_cur[2 * (pr) + 1]}; } while (0)
+#endif
+#if FWD2_ABL & 16           /* no split arithmetic (planes = raw bits) */
+#undef PE2
+#undef PE3
+#undef PE4
+#define PE2(pr) do { ps += e_[pr].x + e_[pr].y; w0[pr] = __builtin_bit_cast(uint32_t, e_[pr].x); } while (0)
+#define PE3(pr) do { w1[pr] = __builtin_bit_cast(uint32_t, e_[pr].y); } while (0)
+#define PE4(pr)                                                                                                        \
+  do {                                                                                                                 \
+    w2[pr] = w0[pr] ^ w1[pr];                                                                                          \
+    if (((pr) & 3) == 3) {                                                                                             \
+      pw[(pr) >> 2][0] = __builtin_bit_cast(bf16x8, u32x4{w0[(pr) - 3], w0[(pr) - 2], w0[(pr) - 1], w0[pr]});          \
+      pw[(pr) >> 2][1] = __builtin_bit_cast(bf16x8, u32x4{w1[(pr) - 3], w1[(pr) - 2], w1[(pr) - 1], w1[pr]});          \
+      pw[(pr) >> 2][2] = __builtin_bit_cast(bf16x8, u32x4{w2[(pr) - 3], w2[(pr) - 2], w2[(pr) - 1], w2[pr]});          \
+    }                                                                                                                  \
+  } while (0)
+#endif
+#if FWD2_ABL & 32           /* no running maximum */
+#undef PM
+#define PM(i) ((void)0)
+#endif
+#if FWD2_ABL & 2            /* no staging: the tiles of the prologue are re-read */
+#undef STK
+#undef STV
+#undef LDK
+#undef LDV
+#define STK(p) ((void)0)
+#define STV(p) ((void)0)
+#define LDK(p) ((void)0)
+#define LDV(p) ((void)0)
+#endif
+#if FWD2_ABL & 4            /* no barrier */
+#define FWD2_SYNC() ((void)0)
+#else
+#define FWD2_SYNC() __syncthreads()
+#endif
+#include "attn_fwd2_phase.inc"
+
+  // ---- prologue: K(0), V(0), K(1) staged; K(2), V(1) in registers; S(0) and its statistics
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { rk[p] = ld_rows(kp[p], 0, tid); rv[p] = ld_trn(vp[p], a.Lkp, 0, tid); }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { st_rows(Kb0 + p * ROWS_T, rk[p], tid); st_trn(Vb0 + p * TRN_T, rv[p], tid); }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) rk[p] = ld_rows(kp[p], (size_t)min(1, lastt) * 32, tid);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) st_rows(Kb1 + p * ROWS_T, rk[p], tid);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { rk[p] = ld_rows(kp[p], (size_t)min(2, lastt) * 32, tid); rv[p] = ld_trn(vp[p], a.Lkp, (size_t)min(1, lastt) * 32, tid); }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x8 k0 = KFRAG(Kb0, 0, j), k1 = KFRAG(Kb0, 1, j), k2 = KFRAG(Kb0, 2, j);
+    MB6(s_nxt, k0, k1, k2, qf[j][0], qf[j][1], qf[j][2]);
+  }
+  uint32_t hbase = rowkey + (uint32_t)(2 * h) * 0x9E3779B9U;      // + (kt * 16) * G per tile: the hash input of the lane's key pair 0 (keys 4 h, 4 h + 1)
+  // the statistics step every tile goes through once its scores exist (s_nxt = scores of tile `KT`): mask the keys past kv_len,
+  // running maximum with the lazy rescale of the first form, dropout decisions (prologue only: the loop does them in units)
+#define FWD2_TILE_STATS(KT, DO_HASH)                                                                                   \
+  do {                                                                                                                 \
+    if ((KT) == lastt) {                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) if ((KT) * 32 + CR(r, h) >= a.kv_len) s_nxt[r] = -INFINITY;       \
+      mt = -INFINITY;                                                                                                  \
+      PM(0); PM(1); PM(2); PM(3);                                                                                      \
+    }                                                                                                                  \
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));                                                                            \
+    if (__any(mt > m + 8.f)) {                                                                                         \
+      const float mn = fmaxf(m, mt);                                                                                   \
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);                                                              \
+      lsum *= alpha;                                                                                                   \
+      m = mn;                                                                                                          \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[t_][r] *= alpha; \
+    }                                                                                                                  \
+    if (DO_HASH) { _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) { PH1(pr); PH2(pr); PH3(pr); } }                    \
+  } while (0)
+  // (plain C++ here, not PM: the maximum follows the MFMAs of S(0) directly, and only compiler-visible instructions get the wait
+  // states an MFMA result needs before a VALU read - an asm v_max3 here read s_nxt before the last product had landed: a slightly
+  // wrong running maximum, i.e. run-to-run last-bit differences and, rarely, an overflowing exponent)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_nxt[r]);
+  FWD2_TILE_STATS(0, true);
+  s_cur = s_nxt;
+  __syncthreads();                          // every wave is through with Kb0 (K(0)): the first PV phase overwrites it
+  // one key tile: S(t + 1) from KR with the softmax of tile t, PV(t) from VR with the statistics of tile t + 1; K(t + 2) -> KW,
+  // V(t + 1) -> VW, K(t + 3) / V(t + 2) requested.  (Past the end the last tile is re-read and its scores are dropped.)
+#define FWD2_ITER(t, KR, KW, VR, VW)                                                                                   \
+  do {                                                                                                                 \
+    __bf16* kw = (KW); __bf16* vw = (VW);                                                                              \
+    const int ktn = min((t) + 3, lastt), vtn = min((t) + 2, lastt);                                                    \
+    kf[0][0] = KFRAG(KR, 0, 0); kf[0][1] = KFRAG(KR, 1, 0); kf[0][2] = KFRAG(KR, 2, 0);                                \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;                                                     \
+    ps = 0.f;                                                                                                          \
+    SB();                                                                                                              \
+    FWD2_S(KR);                                                                                                        \
+    lsum += ps;                                                                                                        \
+    vf[0][0] = VFRAG(VR, 0, 0, 0); vf[0][1] = VFRAG(VR, 1, 0, 0); vf[0][2] = VFRAG(VR, 2, 0, 0);                       \
+    mt = -INFINITY;                                                                                                    \
+    hbase += 16u * 0x9E3779B9U;                                                                                        \
+    SB();                                                                                                              \
+    FWD2_PV(VR);                                                                                                       \
+    if ((t) + 1 <= lastt) FWD2_TILE_STATS((t) + 1, false);      /* (the re-read tile past the end is dropped) */          \
+    s_cur = s_nxt;                                                                                                     \
+    FWD2_SYNC();                                                                                                       \
+  } while (0)
+  int t = 0;
+  for (; t + 1 < ntiles; t += 2) {
+    FWD2_ITER(t, Kb1, Kb0, Vb0, Vb1);
+    FWD2_ITER(t + 1, Kb0, Kb1, Vb1, Vb0);
+  }
+  if (t < ntiles) FWD2_ITER(t, Kb1, Kb0, Vb0, Vb1);
+#undef KFRAG
+#undef VFRAG
+#undef SB
+#undef PK_SUB
+#undef PE1
+#undef PE2
+#undef PE3
+#undef PE4
+#undef PM
+#undef PH1
+#undef PH2
+#undef PH3
+#undef STK
+#undef STV
+#undef LDK
+#undef LDV
+#undef FWD2_S
+#undef FWD2_PV
+#undef FWD2_TILE_STATS
+#undef FWD2_ITER
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  if (qrow < a.Lq) {
+    const float inv = 1.f / ltot;
+    float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * h) =
+            make_float4(o[tt][4 * g + 0] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
+  }
+}
+
+
 namespace {
 // element offset (bf16) of the 16-byte chunk `ch` of row `r` of a [rows][128] tile (256-byte rows, 16 chunks)
 __device__ __forceinline__ int b2_wide_off(int r, int ch) { return r * 128 + ((ch ^ (r & 15)) << 3); }
@@ -704,7 +980,12 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   a.out = o; a.lse = lse; a.ldo = ldo;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  hipLaunchKernelGGL(emu_attn_fwd_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, st, a);
+  static int form = -1;                       // HOISDF_EMU_ATTN_FWD=1: the first (unpipelined) form (A/B runs)
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_FWD"); form = (e && atoi(e) == 1) ? 1 : 2; }
+  const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
+  if (form == 1) hipLaunchKernelGGL(emu_attn_fwd_kernel, fgrid, dim3(256), 0, st, a);
+  else if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_fwd2_kernel<true>, fgrid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(emu_attn_fwd2_kernel<false>, fgrid, dim3(256), 0, st, a);
   return check_launch("attention_fwd_emu");
 }
 

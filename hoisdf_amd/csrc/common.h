@@ -41,10 +41,19 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 __device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint32_t row) {
   return mix32((uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0xC2B2AE3DU)) + row * 0x85EBCA77U;
 }
-__device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {
-  uint32_t x = rowkey + col * 0x9E3779B9U;
+// Round 4: ONE hash serves the two columns 2 c, 2 c + 1 of a row - its high 16 bits decide the odd column, its low 16 bits the even
+// one (threshold at 16-bit granularity: p = 0.1 drops 6553 / 65536 = 0.09999).  The emulated attention forward, where the
+// hash was the largest single VALU item of a key tile (16 scores per lane = 8 column pairs), computes 8 hashes instead of 16;
+// everywhere else the function is evaluated per element as before (one extra shift).  Every kernel goes through these two
+// helpers, so forward and backward masks stay the same function of (seed, row, col).
+__device__ __forceinline__ uint32_t drop_hash(uint32_t rowkey, uint32_t colpair) {
+  uint32_t x = rowkey + colpair * 0x9E3779B9U;
   x ^= x >> 15; x *= 0x2C1B3C6DU; x ^= x >> 12;
-  return x >= thresh;
+  return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, uint32_t thresh) {
+  const uint32_t h = drop_hash(rowkey, col >> 1);
+  return ((col & 1u) ? h : (h << 16)) >= (thresh & 0xffff0000u);
 }
 // multiplier applied to a kept element; 0 for a dropped one.
 __device__ __forceinline__ float drop_scale(uint32_t rowkey, uint32_t col, uint32_t thresh, float inv_keep) {
@@ -63,7 +72,6 @@ static inline uint32_t drop_threshold(float p) {
 //   LayerNorm / SDF head / sigma-gate backward -> parked per block and summed in block order by the last block
 //   to arrive (block_column_sum below, library-owned scratch: deterministic mode is single-stream).
 bool deterministic_mode();
-bool gemm_split_mode();           // hoisdf_set_gemm_split: the contractions INSIDE composite entries (sdf_query) in split precision
 bool gemm_emu_mode();             // hoisdf_set_gemm_emu: ... as fp32 emulated on the bf16 MFMA pipe (default on)
 struct DetScratch {
   float* part;          // [gridDim.x][ncols] partials

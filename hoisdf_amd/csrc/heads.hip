@@ -93,9 +93,10 @@ static int tokens_backward(const hoisdf_mlp* mlp, const hoisdf_mlp_grads* G, con
   Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
   const int F = mlp->dims[mlp->n_layers];
   float* dfea = ws.floats(M * F);
+  float* part = ws.floats(hoisdf_token_build_bwd_partials());
   if (!dry) {
-    if (!dfea) { set_error("tokens_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
-    c.rc = hoisdf_token_build_bwd(dtok, s.fea, F, sdf, beta, dfea, F, dbeta, B, P, S, row0, D, stream);
+    if (!dfea || !part) { set_error("tokens_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
+    c.rc = hoisdf_token_build_bwd_ordered(dtok, s.fea, F, sdf, beta, dfea, F, dbeta, part, B, P, S, row0, D, stream);
   }
   mlp_backward(c, mlp, G, feat, mlp->dims[0], M, s.mlp, dfea, F, dfeat, mlp->dims[0], accumulate_dfeat);
   if (c.ok() && !dry && ws.overflow) { set_error("tokens_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }

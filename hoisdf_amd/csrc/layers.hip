@@ -5,7 +5,7 @@
 // stream, over caller-provided buffers: `saved` holds what the backward re-reads (activations, softmax statistics, the ReLU
 // bitmap), `workspace` is scratch.  The arithmetic follows the library defaults: linear layers of >= 2048 rows as fp32 emulated
 // on the bf16 MFMA pipe (hoisdf_linear_*_emu; hoisdf_set_gemm_emu(0) / HOISDF_GEMM=f32: the exact-f32 kernels), attention as
-// the descriptor says.  The opt-in reduced-operand modes (split precision, f16 eval attention) are not offered here.
+// the descriptor says.  The opt-in reduced-operand mode (f16 eval attention) is not offered here.
 // hoisdf_amd/ops.py's encoder_layer / decoder_layer autograd nodes are thin wrappers of these calls.
 #include "chain.h"
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __res
                                                               const float* __restrict__ beta_ptr,
                                                               float* __restrict__ dfeat, int lddfeat,
                                                               float* __restrict__ dbeta, int B, int P, int S,
-                                                              int row0, int D, DetScratch ds) {
+                                                              int row0, int D, DetScratch ds, float* __restrict__ partials) {
   const int lane = threadIdx.x & 63;
   const float braw = beta_ptr[0];
   const float beta = fmaxf(braw, 2e-3f);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __res
     }
   }
   acc = wave_sum(acc);
-  if (!ds.on) {
+  if (!ds.on && !partials) {
     if (lane == 0 && dbeta) atomicAdd(dbeta, acc);
     return;
   }
@@ -213,8 +213,21 @@ __global__ __launch_bounds__(256) void token_build_bwd_kernel(const float* __res
   __syncthreads();
   if (threadIdx.x == 0) wsum[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   __syncthreads();
+  if (partials) {                               // (ordered form) the block's sum; token_beta_finish_kernel adds them in block order
+    if (threadIdx.x == 0) partials[blockIdx.x] = wsum[0];
+    return;
+  }
   __shared__ unsigned s_last;
   if (dbeta) block_column_sum(dbeta, 1, dbeta, 0, wsum, &s_last, ds);
+}
+
+// dbeta[0] += sum of the per-block partials, in block order (one wave: lane l adds blocks l, l + 64, ... in order, then the
+// 64 lane sums are combined by the fixed shuffle tree)
+__global__ __launch_bounds__(64) void token_beta_finish_kernel(const float* __restrict__ partials, int n, float* __restrict__ dbeta) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) a += partials[i];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) dbeta[0] += a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -502,8 +515,26 @@ extern "C" int hoisdf_token_build_bwd(const float* dtok, const float* feat, int 
   int blocks = row_grid((long)B * P);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(token_build_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dtok, feat, ldfeat,
-                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D, det_scratch((size_t)blocks));
+                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D, det_scratch((size_t)blocks), (float*)nullptr);
   return check_launch("token_build_bwd");
+}
+
+extern "C" int hoisdf_token_build_bwd_partials(void) { return 1024; }
+
+extern "C" int hoisdf_token_build_bwd_ordered(const float* dtok, const float* feat, int ldfeat, const float* sdf,
+                                              const float* beta_ptr, float* dfeat, int lddfeat, float* dbeta, float* partials,
+                                              int B, int P, int S, int row0, int D, void* stream) {
+  HOISDF_REQUIRE(dtok && feat && sdf && beta_ptr && dfeat && dbeta && partials, HOISDF_ERR_INVALID, "token_build_bwd_ordered: null pointer");
+  HOISDF_REQUIRE(B > 0 && P >= 0 && row0 >= 0 && row0 + P <= S && D > 33 && ldfeat >= D - 33 && lddfeat >= D - 33,
+                 HOISDF_ERR_INVALID, "token_build_bwd_ordered: bad sizes");
+  if (P == 0) return HOISDF_OK;
+  int blocks = row_grid((long)B * P);
+  if (blocks > 1024) blocks = 1024;
+  DetScratch off{};
+  hipLaunchKernelGGL(token_build_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dtok, feat, ldfeat,
+                     sdf, beta_ptr, dfeat, lddfeat, dbeta, B, P, S, row0, D, off, partials);
+  hipLaunchKernelGGL(token_beta_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), partials, blocks, dbeta);
+  return check_launch("token_build_bwd_ordered");
 }
 
 extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,

@@ -27,10 +27,8 @@ int check_launch(const char* what) {
 }
 
 static int g_det = -1;          // -1: not decided yet (environment), 0 / 1
-static int g_gemm_split = 0;    // library-internal contractions (hoisdf_sdf_query_fwd) in split precision
 static int g_gemm_emu = 1;      // ... as fp32 emulated on the bf16 pipe (gemm_emu.hip); default on, HOISDF_GEMM=f32 / the setter turn it off
 
-bool gemm_split_mode() { return g_gemm_split != 0; }
 bool gemm_emu_mode() {
   static int env = -1;
   if (env < 0) {
@@ -71,8 +69,6 @@ DetScratch det_scratch(size_t floats) {
 
 }  // namespace hoisdf
 
-extern "C" void hoisdf_set_gemm_split(int on) { hoisdf::g_gemm_split = on ? 1 : 0; }
-extern "C" int hoisdf_get_gemm_split(void) { return hoisdf::g_gemm_split; }
 extern "C" void hoisdf_set_gemm_emu(int on) { (void)hoisdf::gemm_emu_mode(); hoisdf::g_gemm_emu = on ? 1 : 0; }
 extern "C" int hoisdf_get_gemm_emu(void) { return hoisdf::gemm_emu_mode() ? 1 : 0; }
 extern "C" void hoisdf_set_deterministic(int on) { hoisdf::g_det = on ? 1 : 0; }

@@ -10,8 +10,7 @@
 //     [h1 | x0] of common/nets/sdf_net.py:104-106 is the row itself - layer 2 contracts all 516 columns with a
 //     column-padded weight matrix (zeros under the pad columns);
 //   * the weight-norm fold of the four decoder layers is done once by the caller (cached across calls in eval mode).
-// The contractions run on the fp32-emulating bf16x3 kernel (gemm_emu.hip; default), on gemm_f32_kernel (hoisdf_set_gemm_emu(0))
-// or, under hoisdf_set_gemm_split, on the split-precision GEMM: at ~1.7 kFLOP per byte of activations these layers are
+// The contractions run on the fp32-emulating bf16x3 kernel (gemm_emu.hip; default) or on gemm_f32_kernel (hoisdf_set_gemm_emu(0)): at ~1.7 kFLOP per byte of activations these layers are
 // MFMA-bound, and a monolithic kernel that keeps a point tile's 512-wide activations on-chip is limited to 64-row
 // tiles by the 160 KB LDS (64 x 512 x 4 B = 128 KB + weight slab), i.e. 30 FLOP per streamed weight byte and two waves
 // per SIMD - measured/estimated below the 105-120 TF the tiled GEMM reaches on these shapes.
@@ -22,13 +21,7 @@ using namespace hoisdf;
 namespace {
 constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, CAT_LD = 516, X0_COL = 224;
 inline long align64(long v) { return (v + 63) / 64 * 64; }
-// scratch of the split-precision form of the six layers (hoisdf_set_gemm_split): the largest of their workspaces
-inline long split_scratch_bytes(long n_rows, int C) {
-  long m = hoisdf_linear_split_workspace(n_rows, HID0, C, 0);
-  const long o = hoisdf_linear_split_workspace(n_rows, HID0, CAT_LD, 0);
-  return m > o ? m : o;
-}
-constexpr long SPLIT_MIN_ROWS = 2048;
+constexpr long EMU_MIN_ROWS_Q = 2048;
 
 // scratch of the emulated form (hoisdf_set_gemm_emu): the bf16x3 slab image of the layer's weight, built right before the layer
 inline long emu_scratch_bytes(int C) {
@@ -36,13 +29,10 @@ inline long emu_scratch_bytes(int C) {
   return ((a > b ? a : b) + 255) / 256 * 256;
 }
 
-// one layer: fp32 emulated on the bf16 MFMA pipe (default, large point sets), the exact-f32 MFMA GEMM, or (library switch) the
-// split-precision GEMM.  K_pad >= K: columns K .. K_pad - 1 of x are zero padding (they meet zero weights in the image).
+// one layer: fp32 emulated on the bf16 MFMA pipe (default, large point sets) or the exact-f32 MFMA GEMM.  K_pad >= K: columns K .. K_pad - 1 of x are zero padding (they meet zero weights in the image).
 int layer(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, long M, int N, int K,
-          int K_pad, float drop_p, uint64_t seed, void* scratch, long scratch_bytes, void* emu_img, void* stream) {
-  if (scratch && M >= SPLIT_MIN_ROWS)
-    return hoisdf_linear_fwd_split(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, scratch, scratch_bytes, stream);
-  if (emu_img && M >= SPLIT_MIN_ROWS && hoisdf_linear_emu_supported(x, ldx, K_pad) && (K_pad + 15) / 16 == (K + 15) / 16) {
+          int K_pad, float drop_p, uint64_t seed, void* emu_img, void* stream) {
+  if (emu_img && M >= EMU_MIN_ROWS_Q && hoisdf_linear_emu_supported(x, ldx, K_pad) && (K_pad + 15) / 16 == (K + 15) / 16) {
     if (int rc = hoisdf_linear_emu_prepare(W, ldw, N, K, 0, emu_img, stream)) return rc;
     return hoisdf_linear_fwd_emu(x, ldx, emu_img, b, y, ldy, M, N, K_pad, 1, drop_p, seed, nullptr, stream);
   }
@@ -54,7 +44,7 @@ extern "C" long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat) {
   if (n_rows <= 0 || C <= 0) return 0;
   long fl = align64(n_rows * HID0) * 2 + align64(n_rows * CAT_LD);
   if (need_feat) fl += align64(n_rows * (long)C);
-  return fl * (long)sizeof(float) + emu_scratch_bytes(C) + split_scratch_bytes(n_rows, C);
+  return fl * (long)sizeof(float) + emu_scratch_bytes(C);
 }
 
 extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
@@ -79,9 +69,7 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   float* hb = ha + align64(n_rows * HID0);
   float* cat = hb + align64(n_rows * HID0);
   float* feat_ws = cat + align64(n_rows * CAT_LD);
-  const long sbytes = split_scratch_bytes(n_rows, C);
-  void* scratch = gemm_split_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - sbytes)) : nullptr;
-  void* img = (gemm_emu_mode() && !gemm_split_mode()) ? static_cast<void*>(static_cast<char*>(workspace) + (need - sbytes - emu_scratch_bytes(C)))
+  void* img = gemm_emu_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - emu_scratch_bytes(C)))
                                                       : nullptr;
   int rc;
   // K1 (unless the caller shares its gathered rows)
@@ -97,22 +85,22 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   }
   float* x0 = cat + X0_COL;
   // K2: linear_sdfin (main/model.py:63-69): C -> 512 -> 256, ReLU after both; the second layer lands in x0[:, 0:256]
-  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, scratch, sbytes, img, stream);
+  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, img, stream);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, scratch, sbytes, img, stream);
+  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, img, stream);
   if (rc) return rc;
   // K3: posenc + xyz into x0[:, 256:289], pad columns 289..291 zeroed (common/utils/sdf_utils.py:96-141)
   rc = hoisdf_posenc_fwd(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, stream);
   if (rc) return rc;
   // K4: decoder (common/nets/sdf_net.py:87-122); dropout(p) after every hidden ReLU when the module is in train() mode
   // (the reference's detached training-time queries run with it on), stream ids seed + layer
-  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, scratch, sbytes, img, stream);   // the three pad columns of x0 are zero
+  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, img, stream);   // the three pad columns of x0 are zero
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, scratch, sbytes, img, stream);
+  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, stream);
   if (rc) return rc;
-  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, scratch, sbytes, img, stream);
+  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, stream);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, scratch, sbytes, img, stream);
+  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, stream);
   if (rc) return rc;
   return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
 }

@@ -467,8 +467,6 @@ class Model(nn.Module):
         feature_pyramid, decoder_out = self.decoder_net(img_feat, skips)
         pyr = self._pyramid(feature_pyramid)
         ops.set_attention_f16_eval(bool(getattr(c, "attention_f16_eval", False)) and mode != "train")
-        ops.set_attention_split(bool(getattr(c, "attention_split", False)) and mode == "train")
-        ops.set_gemm_split(bool(getattr(c, "gemm_split", False)) if mode == "train" else bool(getattr(c, "gemm_split_eval", False)))
         if getattr(c, "gemm_emu", None) is not None:
             ops.set_gemm_emu(bool(c.gemm_emu))
         if getattr(c, "attention_emu", None) is not None:

@@ -92,7 +92,7 @@ def zero_arena_begin_step(device) -> None:
     """Call at the start of every training step (before forward) to serve the backward's zero-initialised scratch from one
     buffer that is cleared with a single memset.  See _ZeroArena for the validity contract."""
     _ARENA.begin_step(torch.device(device))
-    _SPLIT_PLANES.clear()          # kept attention planes of graphs that never ran their backward
+    _EMU_PLANES.clear()            # kept attention planes of graphs that never ran their backward
     _EMU_PLANES.clear()
 
 
@@ -282,25 +282,6 @@ def project_gather(pyr: PyramidNHWC, points, center, cam_intr, scale, img_hw=(25
 # ---------------------------------------------------------------------------------------------
 # linear
 # ---------------------------------------------------------------------------------------------
-_GEMM_SPLIT = False
-_GEMM_SPLIT_MIN_ROWS = 2048          # below this the problem is a few tiles: latency-bound, stays on the f32 kernel
-_GEMM_SPLIT_DW_MIN = 512             # grad-weight: narrower outputs stay on the f32 kernel (see _gemm_bwd_weight)
-
-
-def set_gemm_split(on: bool) -> None:
-    """cfg.gemm_split: run the large linear-layer contractions (forward, grad-input, grad-weight) on the 16-bit MFMA pipe
-    with f16 hi + lo split operands (3 products, f32 accumulation; csrc/gemm_split.hip).  Off by default: the headline
-    path is exact fp32."""
-    global _GEMM_SPLIT
-    _GEMM_SPLIT = bool(on)
-    from ._lib import lib
-    lib().hoisdf_set_gemm_split(int(_GEMM_SPLIT))          # the layers inside hoisdf_sdf_query_fwd follow
-
-
-def gemm_split() -> bool:
-    return _GEMM_SPLIT
-
-
 # ---- fp32 emulated on the bf16 MFMA pipe (csrc/gemm_emu.hip): forward / grad-input of the large linear layers ------------
 _GEMM_EMU = __import__("os").environ.get("HOISDF_GEMM", "emu") != "f32"
 _GEMM_EMU_MIN_ROWS = 2048            # below this a problem is a handful of tiles: latency-bound, stays on the f32 kernel
@@ -325,7 +306,7 @@ def gemm_emu() -> bool:
 
 
 def _emu_ok(M: int, a: torch.Tensor, lda: int, contraction: int) -> bool:
-    return (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_MIN_ROWS and contraction % 4 == 0 and lda % 4 == 0
+    return (_GEMM_EMU and M >= _GEMM_EMU_MIN_ROWS and contraction % 4 == 0 and lda % 4 == 0
             and a.data_ptr() % 16 == 0)
 
 
@@ -380,23 +361,7 @@ def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
     return ent[0]
 
 
-def _split_ok(M: int, N: int, K: int) -> bool:
-    return _GEMM_SPLIT and M >= _GEMM_SPLIT_MIN_ROWS and N >= 64 and K >= 64
-
-
-def _split_ws(M, N, K, which, device):
-    from ._lib import lib
-    nbytes = lib().hoisdf_linear_split_workspace(M, N, K, which)
-    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
-
-
 def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
-    """-> the per-row scales of x the split call left in its workspace (a hint for the split grad-weight), or None"""
-    if _split_ok(M, N, K):
-        ws, nb = _split_ws(M, N, K, 0, y.device)
-        call("hoisdf_linear_fwd_split", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act),
-             float(drop_p), seed, _p(bits), _p(ws), nb, _st())
-        return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
     if _emu_ok(M, x2, ldx, K):
         call("hoisdf_linear_fwd_emu", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _st())
@@ -407,12 +372,6 @@ def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
 
 
 def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
-    """-> the per-row scales of dy the split call left in its workspace (hint for the split grad-weight), or None"""
-    if _split_ok(M, N, K):
-        ws, nb = _split_ws(M, N, K, 1, dx.device)
-        call("hoisdf_linear_bwd_input_split", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
-             int(accumulate), _p(ws), nb, _st())
-        return ws[:4 * M].view(torch.float32) if min(N, K) >= _GEMM_SPLIT_DW_MIN else None
     if _emu_ok(M, dy2, lddy, N):
         call("hoisdf_linear_bwd_input_emu", _p(dy2), lddy, _p(bits), float(p), _p(_emu_image(W, True)), _p(dx), lddx, M, N, K,
              int(accumulate), _st())
@@ -423,19 +382,8 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
 
 
 def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None):
-    """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the split form overwrites."""
-    # the split grad-weight kernel converts both (transposed) operands once per output tile: it only beats the f32 kernel
-    # when the output is wide enough to amortise that (tools/mb_gsplit.py: 65536x512x992 599 vs 657 us, 16384x512x3968
-    # 894 vs 1095 us, but 65536x768x256 373 vs 293 us)
-    # the split grad-weight has to write both operands as transposed planes first: it only beats the f32 kernel when the
-    # output is wide enough to amortise that (tools/mb_gsplit.py: 65536x512x992 537 vs 649 us, 16384x512x3968 608 vs 1082 us,
-    # but 65536x768x256 379 vs 285 us) - the 256-wide transformer shapes stay on the f32 kernel
-    if _split_ok(M, N, K) and min(N, K) >= _GEMM_SPLIT_DW_MIN and dW.stride(0) == K:
-        ws, nb = _split_ws(M, N, K, 2, dW.device)
-        call("hoisdf_linear_bwd_weight_split", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
-             _p(x_scale), _p(dy_scale), _p(ws), nb, _st())
-        return
-    if (_GEMM_EMU and not _GEMM_SPLIT and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
+    """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the emulated form overwrites."""
+    if (_GEMM_EMU and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
             and dW.data_ptr() % 16 == 0):
         from ._lib import lib
@@ -750,7 +698,7 @@ _TOKENS_C = __import__("os").environ.get("HOISDF_TOKENS", "c") != "ops"         
 def sdf_query_train_ok() -> bool:
     """default arithmetic only, and not while bench.py brackets the individual calls (as _coarse_layer_ok)"""
     from . import _lib
-    return _SDF_QUERY_TRAIN_C and not _GEMM_SPLIT and _lib._timer is None
+    return _SDF_QUERY_TRAIN_C and _lib._timer is None
 
 
 def sdf_query_train(weights: SdfQueryWeights, pyr: "PyramidNHWC", points, center, cam_intr, scale, clamp, img_hw, drop_p, params):
@@ -906,8 +854,9 @@ class _TokenBuild(torch.autograd.Function):
         dtok = dtok.contiguous()
         dfeat = torch.empty(B * P, D - 33, device=dtok.device, dtype=torch.float32)
         dbeta = _zeros(1, dtok.device)
-        call("hoisdf_token_build_bwd", _p(dtok), _p(feat2), feat2.stride(0), _p(sdf), _p(beta), _p(dfeat), D - 33,
-             _p(dbeta), B, P, S, row0, D, _st())
+        part = torch.empty(lib().hoisdf_token_build_bwd_partials(), device=dtok.device, dtype=torch.float32)
+        call("hoisdf_token_build_bwd_ordered", _p(dtok), _p(feat2), feat2.stride(0), _p(sdf), _p(beta), _p(dfeat), D - 33,
+             _p(dbeta), _p(part), B, P, S, row0, D, _st())       # beta gradient summed in block order: no float atomics
         # the rows this op wrote do not depend on the incoming buffer contents
         dtok_in = dtok.clone()
         dtok_in[:, row0:row0 + P] = 0
@@ -943,17 +892,6 @@ def _attn_bwd(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
          _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, drop_p, seed, _st())
 
 
-_ATTENTION_SPLIT = False
-
-
-def set_attention_split(on: bool) -> None:
-    """cfg.attention_split: run the TRAINING attention (forward with dropout + backward) on the 16-bit MFMA pipe with f16
-    hi + lo split operands (3 products per contraction, f32 accumulation / softmax; csrc/attention_split.hip).  Off by
-    default: the exact-f32 kernels are the parity configuration and what bench.py's headline line measures."""
-    global _ATTENTION_SPLIT
-    _ATTENTION_SPLIT = bool(on)
-
-
 _ATTENTION_EMU = __import__("os").environ.get("HOISDF_ATTENTION", "emu") != "f32"
 
 
@@ -971,65 +909,23 @@ def attention_emu() -> bool:
 
 
 def _use_split(Lq: int) -> int:
-    """attention kernel family for a call with Lq queries: 0 = exact-f32 MFMA, 1 = f16 hi + lo split (opt-in), 2 = bf16x3
-    emulated fp32 (default).  The 17-query decoder attention keeps its own f32 kernels."""
+    """attention kernel family for a call with Lq queries: 0 = exact-f32 MFMA, 2 = bf16x3 emulated fp32 (default; family 1, the
+    f16 hi + lo split-precision training kernels of round 2, was retired in round 4: the emulated fp32 kernels are faster and
+    exact).  The 17-query decoder attention keeps its own f32 kernels."""
     if Lq < 32:
         return 0
-    return 1 if _ATTENTION_SPLIT else (2 if _ATTENTION_EMU else 0)
+    return 2 if _ATTENTION_EMU else 0
 
 
-# forward workspaces whose Q / K / V planes the matching backward reuses (hoisdf_attention_fwd_split_keep /
-# _bwd_split_kept): keyed by the operands' addresses - the autograd node keeps q, k, v alive until its backward, so a key
-# cannot be taken over by another live call; leftovers of graphs that never ran backward go at the next step / at 64 entries
-_SPLIT_PLANES = {}
-_SPLIT_KEEP = __import__("os").environ.get("HOISDF_SPLIT_KEEP", "1") != "0"
+# forward workspaces whose Q / K / V planes the matching backward reuses (hoisdf_attention_fwd_emu(keep = 1) ->
+# hoisdf_attention_bwd_emu(fwd_workspace)): keyed by the operands' addresses - the autograd node keeps q, k, v alive until its
+# backward, so a key cannot be taken over by another live call; leftovers of graphs that never ran backward go at the next step /
+# at 64 entries.  HOISDF_PLANES_KEEP=0 (or the older name HOISDF_SPLIT_KEEP=0): every backward converts on its own.
+_SPLIT_KEEP = __import__("os").environ.get("HOISDF_PLANES_KEEP", __import__("os").environ.get("HOISDF_SPLIT_KEEP", "1")) != "0"
 
 
 def _planes_key(q, k, v, H, kv_len):
     return (q.data_ptr(), k.data_ptr(), v.data_ptr(), tuple(q.shape), k.shape[1], H, kv_len)
-
-
-def _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed, keep=False):
-    """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it"""
-    from ._lib import lib
-    B, Lq, E = q.shape
-    Lk = k.shape[1]
-    for t, L in ((q, Lq), (k, Lk), (v, Lk)):
-        assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
-    keep = keep and _SPLIT_KEEP
-    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 2 if keep else 0)
-    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
-    o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
-    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    call("hoisdf_attention_fwd_split_keep" if keep else "hoisdf_attention_fwd_split", _p(q), q.stride(1), _p(k), k.stride(1),
-         _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
-    if keep:
-        if len(_SPLIT_PLANES) >= 64:
-            _SPLIT_PLANES.clear()
-        _SPLIT_PLANES[_planes_key(q, k, v, H, kv_len)] = ws
-    return o, lse
-
-
-def _attn_bwd_split(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
-    from ._lib import lib
-    B, Lq, E = q.shape
-    Lk = k.shape[1]
-    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
-    kept = _SPLIT_PLANES.pop(_planes_key(q, k, v, H, kv_len), None)
-    nbytes = lib().hoisdf_attention_split_workspace(B, H, Lq, Lk, 3 if kept is not None else 1)
-    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
-    delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    # power of two that brings max|dO| into [2, 4): computed on the device, read by the kernels through a pointer
-    mx = do.abs().max().clamp_min(1e-30)
-    sd = torch.exp2(torch.floor(torch.log2(4.0 / mx))).reshape(1).contiguous()
-    if kept is not None:
-        kept.record_stream(torch.cuda.current_stream(q.device))
-        call("hoisdf_attention_bwd_split_kept", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do),
-             E, _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept),
-             _p(ws), nbytes, _st())
-        return
-    call("hoisdf_attention_bwd_split", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E,
-         _p(sd), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(ws), nbytes, _st())
 
 
 _EMU_PLANES = {}
@@ -1085,13 +981,11 @@ def _emu_bwd() -> bool:
 def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False):
     if mode == 2:
         return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=keep and _emu_bwd())
-    if mode == 1:
-        return _attn_fwd_split(q, k, v, H, kv_len, drop_p, seed, keep=keep)
     return _attn_fwd(q, k, v, H, kv_len, drop_p, seed)
 
 
 def _attn_bwd_mode(mode, *a):
-    return (_attn_bwd_emu if (mode == 2 and _emu_bwd()) else (_attn_bwd_split if mode == 1 else _attn_bwd))(*a)
+    return (_attn_bwd_emu if (mode == 2 and _emu_bwd()) else _attn_bwd)(*a)
 
 
 class _AttentionSelf(torch.autograd.Function):
@@ -1525,7 +1419,7 @@ def _coarse_layer_ok(p, x, *weights) -> bool:
     from . import _lib
     # (without kept planes the C entry's backward would fall back to the f32 kernel with dQ atomics: in deterministic mode the
     # op-by-op node, whose emulated backward converts on its own, keeps the step order-fixed)
-    return (_ENCODER_LAYER_C and not _GEMM_SPLIT and not _ATTENTION_SPLIT and _lib._timer is None
+    return (_ENCODER_LAYER_C and _lib._timer is None
             and not _use_f16(p, x, *weights) and not (deterministic() and not _SPLIT_KEEP))
 
 
@@ -1607,7 +1501,7 @@ _DECODER_LAYER_C = __import__("os").environ.get("HOISDF_DECODER_LAYER", "c") != 
 def decoder_layer_ok(p, *tensors) -> bool:
     """as _coarse_layer_ok: default arithmetic only, and not while bench.py brackets the individual calls"""
     from . import _lib
-    return (_DECODER_LAYER_C and not _GEMM_SPLIT and not _ATTENTION_SPLIT and _lib._timer is None and not _use_f16(p, *tensors))
+    return (_DECODER_LAYER_C and _lib._timer is None and not _use_f16(p, *tensors))
 
 
 def decoder_layer(tgt, memory, query_pos, mask_u8, kv_len, p, H, eps, *params):
@@ -1773,7 +1667,7 @@ class _Tokens(torch.autograd.Function):
 def tokens_ok(*tensors) -> bool:
     """the C entry covers the default arithmetic; bench.py's per-call event timing and the split mode take the op chain"""
     from . import _lib
-    return _TOKENS_C and not _GEMM_SPLIT and _lib._timer is None and all(t.is_cuda for t in tensors)
+    return _TOKENS_C and _lib._timer is None and all(t.is_cuda for t in tensors)
 
 
 def tokens(tok, feat, cam, center, pe, sdf, beta, row0: int, weights, biases):

@@ -66,11 +66,6 @@ const char* hoisdf_last_error(void);
  * results.  Contract: one stream at a time (the ordered block reductions share a library-owned scratch); grad-weight is
  * order-fixed only when the caller passes the workspace (hoisdf_linear_bwd_weight_workspace). */
 void hoisdf_set_deterministic(int on);
-/* Split-precision switch for the contractions INSIDE composite entries (today: the six layers of hoisdf_sdf_query_fwd run
- * hoisdf_linear_fwd_split instead of hoisdf_linear_fwd for >= 2048 points).  Off by default; the host mirror turns it on
- * together with cfg.gemm_split.  The per-layer entries are chosen by the caller and are not affected. */
-void hoisdf_set_gemm_split(int on);
-int hoisdf_get_gemm_split(void);
 /* the contractions inside composite entries as fp32 emulated on the bf16 MFMA pipe (hoisdf_linear_fwd_emu); default ON
  * (environment HOISDF_GEMM=f32 or hoisdf_set_gemm_emu(0): the exact-f32 MFMA kernel) */
 void hoisdf_set_gemm_emu(int on);
@@ -152,30 +147,6 @@ long hoisdf_linear_bwd_weight_emu_workspace(long M, int N, int K);
 int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx,
                                  float* dW, int lddw, float* db, long M, int N, int K, float* workspace, long workspace_floats,
                                  void* stream);
-/* ---- split-precision linear layers (opt-in; cfg.gemm_split) -----------------------------------
- * reference: the same call sites as hoisdf_linear_* (common/nets/layer.py:168-201, common/nets/transformer.py:286-302,
- * main/model.py:181-244).  Same contracts and argument meaning as hoisdf_linear_fwd / _bwd_input / _bwd_weight, but the
- * contraction runs on the 16-bit MFMA pipe with both operands split into f16 hi + lo parts (3 products, f32 accumulation,
- * power-of-two operand scaling: ~21-22 significant bits per operand instead of 24) - NOT bit-compatible with the f32
- * entries, within 1e-6 relative of them on the model's shapes.  Each call converts its operands into `workspace`
- * (hoisdf_linear_split_workspace(M, N, K, which) BYTES; which = 0 forward, 1 grad-input, 2 grad-weight) and runs one GEMM
- * kernel.  Forward / grad-input read the f32 activations directly (a one-read pre-pass finds the per-row power-of-two scales,
- * left in workspace[0..M) as floats; the rows are split into hi / lo on their way into LDS).  Grad-weight writes both
- * operands once as transposed hi / lo planes; it needs the row scales of x and dy and recomputes them unless the caller
- * hands over the ones the forward / grad-input calls left behind.  dW (dense, lddw == K) and db are fully OVERWRITTEN,
- * order-fixed (no atomics). */
-long hoisdf_linear_split_workspace(long M, int N, int K, int which);
-int hoisdf_linear_fwd_split(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy,
-                            long M, int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits,
-                            void* workspace, long workspace_bytes, void* stream);
-int hoisdf_linear_bwd_input_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* W,
-                                  int ldw, float* dx, int lddx, long M, int N, int K, int accumulate, void* workspace,
-                                  long workspace_bytes, void* stream);
-int hoisdf_linear_bwd_weight_split(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
-                                   int ldx, float* dW, int lddw, float* db, long M, int N, int K,
-                                   const float* x_row_scale /* optional: workspace[0..M) floats of the forward call on x */,
-                                   const float* dy_row_scale /* optional: workspace[0..M) floats of the grad-input call on dy */,
-                                   void* workspace, long workspace_bytes, void* stream);
 /* dpre = dy * (y > 0) * 1/(1-p): backward of relu followed by dropout, given the
  * post-dropout output y (an element is kept-and-positive iff y > 0).  In place allowed. */
 int hoisdf_relu_dropout_bwd(const float* y, int ldy, const float* dy, int lddy, float* dpre,
@@ -334,6 +305,14 @@ int hoisdf_token_build_bwd(const float* dtok, const float* feat, int ldfeat, con
                            const float* beta_ptr, float* dfeat, int lddfeat, float* dbeta, int B,
                            int P, int S, int row0, int D, void* stream);
 
+/* The same with the beta gradient ORDER-FIXED: every block parks its partial sum in partials [hoisdf_token_build_bwd_partials()]
+ * and a one-wave launch adds them to *dbeta in block order - run-to-run identical, and without the cross-block float atomics whose
+ * order noise reached 1e-2 of this heavily cancelling scalar (hoisdf_amd/ops.py and hoisdf_tokens_bwd use this form). */
+int hoisdf_token_build_bwd_partials(void);
+int hoisdf_token_build_bwd_ordered(const float* dtok, const float* feat, int ldfeat, const float* sdf, const float* beta_ptr,
+                                   float* dfeat, int lddfeat, float* dbeta, float* partials, int B, int P, int S, int row0,
+                                   int D, void* stream);
+
 /* ---- K9/K10: attention -------------------------------------------------------------------
  * reference: nn.MultiheadAttention as used by common/nets/transformer.py:286-302,366-395.
  * q rows [B][Lq][.. ldq], k/v rows [B][Lk][.. ldk/ldv], head h occupies columns
@@ -383,36 +362,6 @@ int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, c
                              const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                              int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
                              void* workspace, long workspace_bytes, void* stream);
-/* ---- split-precision attention for training (opt-in: cfg.attention_split) -----------------------------------------
- * Same contract as hoisdf_attention_fwd / _bwd (streaming softmax, keys >= kv_len masked, dropout mask = the same
- * function of (seed, query, key), LSE in the log2 domain), but every contraction runs on the 16-bit MFMA pipe with f16
- * hi + lo operands and three products (f32 accumulation; ~21-22 significant bits instead of 24): forward S = QK^T,
- * O = PV; backward S, dP = dO V^T, dV = Pd^T dO, dK = dS^T Q, dQ = dS K as two order-fixed kernels (no atomics).
- * workspace: hoisdf_attention_split_workspace(B, H, Lq, Lk, mode) bytes, 16-byte aligned (f16 hi / lo copies of the
- * operands, row-major and transposed; mode 0 forward, 1 backward, 2 / 3 the plane-sharing pair below).  delta [B][H][Lq] is scratch of the backward.  dout_scale (device pointer, may be
- * NULL = 1): a power of two sd that brings max|dout| * sd into [2, 4) - f16 hi + lo pairs keep 22 bits only above 2^-3,
- * so gradients are moved up before the split and the factor is taken out of the f32 results. */
-long hoisdf_attention_split_workspace(int B, int H, int Lq, int Lk, int mode);
-int hoisdf_attention_fwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                               int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
-                               uint64_t seed, void* workspace, long workspace_bytes, void* stream);
-int hoisdf_attention_bwd_split(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                               const float* o, int ldo, const float* dout, int lddo, const float* dout_scale,
-                               const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq,
-                               int Lk, int kv_len,
-                               float drop_p, uint64_t seed, void* workspace, long workspace_bytes, void* stream);
-/* The same pair with the operand planes shared: the forward converts Q, K, V once into ALL the planes the backward needs
- * (workspace mode 2: rows + transposed of the three operands) and the backward, given that workspace, converts only dO
- * (its own workspace: mode 3).  Saves three conversion passes per attention call of a training step; the caller keeps the
- * forward workspace alive and untouched until the backward of the same q, k, v. */
-int hoisdf_attention_fwd_split_keep(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                                    int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
-                                    uint64_t seed, void* workspace, long workspace_bytes, void* stream);
-int hoisdf_attention_bwd_split_kept(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                                    const float* o, int ldo, const float* dout, int lddo, const float* dout_scale,
-                                    const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H, int Lq,
-                                    int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
-                                    void* workspace, long workspace_bytes, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
 int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,

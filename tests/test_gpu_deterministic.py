@@ -60,23 +60,15 @@ def _hot_step(model, levels, batch):
             [l.grad for l in lv])
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_two_identical_hot_path_steps_are_bit_identical(det_mode, split):
+def test_two_identical_hot_path_steps_are_bit_identical(det_mode):
     """B = 4, 384 + 128 points, dropout on: forward value, all 260+ hot-path parameter gradients and the five pyramid-level
-    gradients of two identical steps agree bit for bit.  split=True: with cfg.attention_split + cfg.gemm_split (those
-    kernels have no atomics at all; the 2048-row GEMMs of this size take the split path)."""
+    gradients of two identical steps agree bit for bit."""
     from hoisdf_amd import ops
     model, c = _model(384, 128, with_encoder=False)
     levels = [v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in T.synthetic_pyramid(4, seed=3).values()]
     batch = tuple(T.to_device(x, DEV) for x in T.synthetic_batch(4, 384, 128, seed=5))
-    ops.set_attention_split(split)
-    ops.set_gemm_split(split)
-    try:
-        l1, g1, p1 = _hot_step(model, levels, batch)
-        l2, g2, p2 = _hot_step(model, levels, batch)
-    finally:
-        ops.set_attention_split(False)
-        ops.set_gemm_split(False)
+    l1, g1, p1 = _hot_step(model, levels, batch)
+    l2, g2, p2 = _hot_step(model, levels, batch)
     assert l1 == l2
     assert set(g1) == set(g2) and len(g1) > 250
     bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]

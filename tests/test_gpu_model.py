@@ -153,9 +153,9 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
             assert p.grad is not None, name
             gn = p.grad.double().norm().item()
             # branch B: the scalar beta gradients are heavily cancelling sums over near-surface points (two fp32 summation
-            # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py); on the device the cross-block
-            # float atomics of token_build_bwd add an order-dependent part: 39 of 40 runs within 3e-3, one at 7.6e-3
-            rt = 1e-2 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
+            # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py); since round 4 the device sums
+            # them in a fixed block order (hoisdf_token_build_bwd_ordered) - the bar is the CPU's own order noise, 3e-3
+            rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
             assert abs(gn - float(g[key])) <= rt * float(g[key]) + 1e-6, (name, gn, float(g[key]))
             n += 1
         elif not name.startswith(("backbone", "decoder_net")):
@@ -166,7 +166,7 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
         err = (a.float().cpu() - ref).abs().max().item()
         assert err <= rel * float(ref.abs().max()) + 1e-9, err
 
-    brel = 1e-2 if suffix == "_branchB" else 1e-3
+    brel = 3e-3 if suffix == "_branchB" else 1e-3
     gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"], brel)
     gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
     gclose(model.linear_handcls.layers[2].weight.grad, g["grad.linear_handcls.layers.2.weight"])
@@ -256,12 +256,11 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     assert abs(res["value"] - 8 / (res["ms_per_step"] * 1e-3)) <= 1e-2 * res["value"]     # whole-job samples / max-rank time
 
 
-@pytest.mark.parametrize("gemm,nh,no", [(False, 384, 128), (True, 384, 128), (False, 6144, 2048), (True, 6144, 2048)])
-def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm, nh, no):
+@pytest.mark.parametrize("nh,no", [(384, 128), (6144, 2048)])
+def test_eval_with_f16_mfma_attention_meets_the_joint_bar(nh, no):
     """BASELINE configs[4] ("fp16 MFMA attention"): with the f16-operand attention kernel switched on, the eval
     forward still matches the REFERENCE golden joints / vertices within the north-star 1e-4 m - at 512 points and at
-    configs[4]'s own 6144 + 2048 = 8192 points (g7_e2e_dexycb_n8192, the reference's forward at that size).  gemm=True: the
-    linear layers (the dense-lattice SDF query included) in split precision as well (cfg.gemm_split_eval)."""
+    configs[4]'s own 6144 + 2048 = 8192 points (g7_e2e_dexycb_n8192, the reference's forward at that size)."""
     from hoisdf_amd import ops
     setting, bins, b = "dexycb", 64, 1
     g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
@@ -269,13 +268,11 @@ def test_eval_with_f16_mfma_attention_meets_the_joint_bar(gemm, nh, no):
     pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=2))
     inputs, targets, meta = (T.to_device(x, DEV) for x in T.synthetic_batch(b, nh, no, seed=21))
     ops.set_attention_f16_eval(True)
-    ops.set_gemm_split(gemm)
     try:
         with torch.no_grad():
             loss, out = model.hot_path(pyr, inputs, targets, meta, "eval")
     finally:
         ops.set_attention_f16_eval(False)
-        ops.set_gemm_split(False)
     for k in ("hand_joints_out", "mano_joints_out", "mano_mesh_out"):
         err = (out[k].float().cpu() - g[k]).abs().max().item()
         assert err <= 1e-4, f"{k}: {err:.3e}"
@@ -463,56 +460,6 @@ def test_two_stream_step_with_reducer_matches_single_stream_autograd():
         num = sum(float((got[n] - ref[n]).double().pow(2).sum()) for n in ref)
         den = sum(float(ref[n].double().pow(2).sum()) for n in ref)
         assert set(got) == set(ref) and (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
-
-
-@pytest.mark.parametrize("gemm", [False, True])
-@pytest.mark.parametrize("nh,no,suffix", [(48, 16, ""), (1536, 512, "_n2048")])
-def test_train_fwd_bwd_with_split_precision_attention_meets_the_golden_bars(nh, no, suffix, gemm):
-    """cfg.attention_split (training attention on the 16-bit MFMA pipe, f16 hi+lo operands x3): the train-mode forward +
-    backward still matches the REFERENCE fixtures within the same bars as the exact-f32 path - losses 1e-4 relative,
-    per-parameter gradient norms 1e-3 relative (g8_train_dexycb, and the N = 2048 fixture).  gemm=True adds cfg.gemm_split
-    (the large linear layers' three contractions in the same split precision, csrc/gemm_split.hip)."""
-    from hoisdf_amd import ops
-    g = load_golden(f"g8_train_dexycb{suffix}")
-    b = 2
-    model, c = build("dexycb", nh, no, 16, train=True)
-    c.dropout = 0.0
-    for m in model.modules():
-        if hasattr(m, "p"):
-            m.p = 0.0
-        if hasattr(m, "dropout_prob"):
-            m.dropout_prob = 0.0
-    pyr, levels = nhwc_pyramid(T.synthetic_pyramid(b, big=False, seed=3), requires_grad=True)
-    inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=31)
-    torch.manual_seed(1234)
-    jit = [torch.empty_like(inputs["hand_pre_points"]).uniform_(-0.05, 0.05),
-           torch.empty_like(inputs["obj_pre_points"]).uniform_(-0.05, 0.05)]
-    model._jitter = lambda like, d: jit.pop(0).to(DEV)
-    model._py_random = random.Random(0)
-    inputs, targets, meta = (T.to_device(x, DEV) for x in (inputs, targets, meta))
-    ops.set_attention_split(True)
-    ops.set_gemm_split(gemm)
-    try:
-        loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
-        losses = {k: v.mean() for k, v in loss.items()}
-        total = sum(losses.values())
-        total.backward()
-    finally:
-        ops.set_attention_split(False)
-        ops.set_gemm_split(False)
-    for k, v in losses.items():
-        ref = g["loss." + k]
-        assert abs(float(v) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref))), (k, float(v), float(ref))
-    n = 0
-    for name, p in model.named_parameters():
-        key = "gradnorm." + name
-        if key in g:
-            gn = p.grad.double().norm().item()
-            assert abs(gn - float(g[key])) <= 1e-3 * float(g[key]) + 1e-6, (name, gn, float(g[key]))
-            n += 1
-    assert n > 100
-    # element-wise pyramid gradient: ill-conditioned, judged against the fp64 value as well as the reference's fp32 one
-    pyramid_gradient_close(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"], suffix)
 
 
 def test_sdf_infer_with_counts_queued_ahead_equals_the_blocking_form():

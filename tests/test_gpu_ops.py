@@ -59,93 +59,6 @@ def test_linear_fwd_bwd(M, N, K, act):
     assert_close(bg.grad, b.grad, what="db")
 
 
-@pytest.mark.parametrize("M,N,K,act,p", [(4096, 512, 992, True, 0.0), (2500, 223, 292, True, 0.2), (2176, 128, 223, False, 0.0),
-                                         (3000, 96, 516, True, 0.0), (2048, 768, 256, False, 0.0)])
-def test_linear_split_precision_matches_fp64(M, N, K, act, p):
-    """csrc/gemm_split.hip (cfg.gemm_split: f16 hi + lo operands, 3 products, power-of-two operand scaling): forward,
-    grad-input (also accumulating), grad-weight and bias gradient against fp64 at 2e-6 of the tensor's max - the exact-f32
-    kernel's own distance on these shapes is ~1e-6.  Rows of x and dy span 8 decades (exercises the per-row / per-tensor
-    scaling), ragged M / N / K (padding, the scalar conversion path for K % 4 != 0), ReLU + dropout through the sign bitmap."""
-    O = ops()
-    O.manual_seed(77)
-    g = torch.Generator().manual_seed(M + N + K)
-    decades = lambda n: torch.pow(10.0, -8.0 * torch.rand(n, 1, generator=g))
-    x = (torch.randn(M, K, generator=g) * decades(M)).to(DEV).requires_grad_(True)
-    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV).requires_grad_(True)
-    b = (torch.randn(N, generator=g) * 1e-3).to(DEV).requires_grad_(True)
-    gy = (torch.randn(M, N, generator=g) * 1e-5 * decades(M)).to(DEV)
-    gy[::7] = 0.0                                              # all-zero gradient rows (masked samples) ...
-    with torch.no_grad():
-        x[5::11] = 0.0                                         # ... and all-zero activation rows must not cost the others bits
-    O.set_gemm_split(True)
-    keep_min = O._GEMM_SPLIT_DW_MIN
-    O._GEMM_SPLIT_DW_MIN = 64                          # also the ragged / narrow shapes through the split grad-weight
-    try:
-        y = O.linear(x, W, b, act=act, drop_p=p)
-        y.backward(gy)
-        # accumulate-into form of grad-input (the fused encoder-layer node uses it)
-        dx_acc = torch.full((M, K), 0.25, device=DEV)
-        O._lin_bwd_input(gy, None, 0.0, W.detach(), dx_acc, True)
-    finally:
-        O.set_gemm_split(False)
-        O._GEMM_SPLIT_DW_MIN = keep_min
-    pre = x.detach().double() @ W.detach().double().t() + b.detach().double()
-    if act:
-        kept = y.detach() > 0                                  # the kernel's own ReLU / dropout decisions
-        pos = pre > 0
-        flips = (kept & ~pos).sum().item()
-        assert flips <= 2, flips                               # a kept element must be positive in fp64 too (up to rounding at 0)
-        if p > 0:
-            frac = (kept & pos).sum().item() / max(pos.sum().item(), 1)
-            assert abs(frac - (1 - p)) < 0.01, frac
-        else:
-            assert (pos & ~kept).sum().item() <= 2
-        scale = kept.double() / (1 - p)
-    else:
-        scale = torch.ones_like(pre)
-    assert_close(y, pre * scale, rel=2e-6, what="y")
-    dye = gy.double() * scale
-    assert_close(x.grad, dye @ W.detach().double(), rel=2e-6, what="dx")
-    assert_close(W.grad, dye.t() @ x.detach().double(), rel=2e-6, what="dW")
-    assert_close(b.grad, dye.sum(0), rel=2e-6, what="db")
-    assert_close(dx_acc, gy.double() @ W.detach().double() + 0.25, rel=2e-6, what="dx accumulate")
-
-
-def test_linear_split_grad_weight_accepts_the_row_scales_of_the_other_calls():
-    """hoisdf_linear_bwd_weight_split's optional hints: the per-row scales the forward call left in its workspace (x) and the
-    grad-input call in its own (dy) replace the two pre-passes; the result stays within 2e-6 of fp64 and of the hint-free call."""
-    O = ops()
-    from hoisdf_amd._lib import lib
-    M, N, K = 4096, 512, 640
-    g = torch.Generator().manual_seed(5)
-    x = (torch.randn(M, K, generator=g) * torch.pow(10.0, -4.0 * torch.rand(M, 1, generator=g))).to(DEV)
-    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
-    dy = (torch.randn(M, N, generator=g) * 1e-4 * torch.pow(10.0, -4.0 * torch.rand(M, 1, generator=g))).to(DEV)
-    st = O._st()
-    ws = [torch.empty(lib().hoisdf_linear_split_workspace(M, N, K, w), device=DEV, dtype=torch.uint8) for w in (0, 1, 2)]
-    y = torch.empty(M, N, device=DEV)
-    dx = torch.empty(M, K, device=DEV)
-    O.call("hoisdf_linear_fwd_split", O._p(x), K, O._p(W), K, None, O._p(y), N, M, N, K, 0, 0.0, 0, None, O._p(ws[0]),
-           ws[0].numel(), st)
-    O.call("hoisdf_linear_bwd_input_split", O._p(dy), N, None, 0.0, O._p(W), K, O._p(dx), K, M, N, K, 0, O._p(ws[1]),
-           ws[1].numel(), st)
-    xs, ds = ws[0][:4 * M].view(torch.float32), ws[1][:4 * M].view(torch.float32)
-    assert float(xs.min()) > 0 and float(ds.min()) > 0                      # powers of two left by the two calls
-    assert torch.equal(torch.exp2(torch.log2(xs).round()), xs)
-    outs = []
-    for hints in (False, True):
-        dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
-        O.call("hoisdf_linear_bwd_weight_split", O._p(dy), N, None, 0.0, O._p(x), K, O._p(dW), K, O._p(db), M, N, K,
-               O._p(xs) if hints else None, O._p(ds) if hints else None, O._p(ws[2]), ws[2].numel(), st)
-        outs.append((dW, db))
-    ref = dy.double().t() @ x.double()
-    for dW, db in outs:
-        assert_close(dW, ref, rel=2e-6, what="dW")
-        assert_close(db, dy.double().sum(0), rel=2e-6, what="db")
-    assert_close(y, x.double() @ W.double().t(), rel=2e-6, what="y")
-    assert_close(dx, dy.double() @ W.double(), rel=2e-6, what="dx")
-
-
 def test_layernorm_on_the_first_rows_of_every_group():
     """hoisdf_layernorm_rows_fwd / _bwd (the encoder stack's inter_norm on the rows the caller reads): compact output and
     statistics, full-size dx with the untouched rows passing dx_add through, vs torch in fp64."""
@@ -688,48 +601,6 @@ def test_attention_few_queries_kernel_incl_dropout():
     assert abs(float(od.mean()) - 1.0) < 0.03
 
 
-def test_sdf_query_split_precision_layers():
-    """hoisdf_set_gemm_split: the six layers inside hoisdf_sdf_query_fwd in split precision (>= 2048 points) against the
-    exact-f32 call on the same inputs - 5e-6 of the field's range, ragged K = 289 / N = 224 / ld = 516 layers included."""
-    from hoisdf_amd.model import get_model
-    from hoisdf_amd.config import Config
-    from hoisdf_amd.nets import mano as MANO
-    O = ops()
-    c = Config(); c.resnet_type = 18; c.apply_setting("dexycb"); c.num_samp_hand, c.num_samp_obj = 1200, 100
-    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
-    sd = model.state_dict()
-    for k in sd:
-        if not k.startswith("mano_head"):
-            sd[k] = T.det_param(k, sd[k].shape)
-    model.load_state_dict(sd)
-    model = model.to(DEV).eval()
-    B, P = 2, 1200                                               # 2400 rows: above the 2048-row threshold, not a tile multiple
-    pyr = O.PyramidNHWC([v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in T.synthetic_pyramid(B, seed=4).values()])
-    inputs, _, meta = T.synthetic_batch(B, P, 8, seed=5)
-    pts = (inputs["hand_sdf_points"] * 1.2).to(DEV)
-    root, K = meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV)
-    keep_emu = O.gemm_emu()
-    with torch.no_grad():
-        O.set_gemm_emu(False)
-        try:
-            ref_sdf, ref_raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")       # exact-f32 MFMA layers
-            O.set_gemm_split(True)
-            try:
-                sdf, raw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
-            finally:
-                O.set_gemm_split(False)
-            O.set_gemm_emu(True)                                   # the default: the six layers as bf16x3-emulated fp32
-            esdf, eraw, _, _ = model._sdf_query(pyr, pts, root, K, 3.1, "hand")
-        finally:
-            O.set_gemm_emu(keep_emu)
-    assert not torch.equal(raw, ref_raw)                          # the split path really ran
-    assert_close(raw, ref_raw, rel=5e-6, what="raw"); assert_close(sdf, ref_sdf, rel=5e-6, what="sdf")
-    assert not torch.equal(eraw, ref_raw)                         # ... and so did the emulated one
-    # (two fp32-class implementations through six chained layers: their roundings differ - measured 2.3e-6 of the raw range and,
-    # run to run with the exact path's split-k atomics, 4e-6 .. 7e-6 of the clamped field's 0.15)
-    assert_close(eraw, ref_raw, rel=5e-6, what="emulated raw"); assert_close(esdf, ref_sdf, rel=1e-5, what="emulated sdf")
-
-
 def test_sdf_query_one_call_matches_the_op_chain():
     """hoisdf_sdf_query_fwd (K1-K4 in one C-ABI call, in-place concatenations, optional shared gather) against the
     differentiable op chain the model uses where gradients are needed, and against the oracle."""
@@ -778,79 +649,6 @@ def test_sdf_query_one_call_matches_the_op_chain():
     with torch.no_grad():
         raw5 = model._sdf_query(pyr, pts, root, K, 3.1, "hand")[1]
     assert bool(torch.isfinite(raw5).all()) and float((raw5 - raw4).abs().mean()) > 1e-3
-
-
-@pytest.mark.parametrize("B,L,kv,p", [(2, 200, None, 0.0), (3, 333, 250, 0.0), (2, 1024, None, 0.1), (1, 96, None, 0.3)])
-def test_attention_split_precision_training_kernels(B, L, kv, p):
-    """csrc/attention_split.hip (f16 hi+lo operands, 3 products, f32 accumulate): forward + backward against the fp64
-    reference (p = 0) and against the exact-f32 kernels with the SAME dropout mask (p > 0)."""
-    O = ops()
-    import hoisdf_amd.ops as OO
-    E, H = 256, 4
-    qkv = rnd(B, L, 3 * E, seed=40)
-    go = rnd(B, L, E, seed=41)
-    OO.set_attention_split(True)
-    try:
-        OO.manual_seed(99)
-        x = qkv.to(DEV).requires_grad_(True)
-        o = O.attention_self(x, H, kv, p)
-        o.backward(go.to(DEV))
-    finally:
-        OO.set_attention_split(False)
-    if p == 0.0:
-        q64 = qkv.double().requires_grad_(True)
-        ref = _ref_attention(q64[..., :E], q64[..., E:2 * E], q64[..., 2 * E:], H, kv)
-        ref.backward(go.double())
-        ro, rg = ref, q64.grad
-    else:
-        OO.manual_seed(99)                     # same seed stream -> same mask in the f32 kernels
-        y = qkv.to(DEV).requires_grad_(True)
-        ro = O.attention_self(y, H, kv, p)
-        ro.backward(go.to(DEV))
-        rg = y.grad
-    assert_close(o, ro, rel=2e-5, what="split attn out")
-    assert_close(x.grad, rg, rel=5e-5, what="split attn dqkv")
-    if kv is not None:
-        assert float(x.grad[:, kv:, E:].abs().max()) == 0.0
-    # the plane-sharing pair (forward keeps the Q / K / V planes for the backward: hoisdf_attention_fwd_split_keep /
-    # _bwd_split_kept, the default above) against the self-contained pair: same planes, bit-identical results
-    keep = OO._SPLIT_KEEP
-    OO._SPLIT_KEEP = False
-    OO.set_attention_split(True)
-    try:
-        OO.manual_seed(99)
-        z = qkv.to(DEV).requires_grad_(True)
-        oz = O.attention_self(z, H, kv, p)
-        oz.backward(go.to(DEV))
-    finally:
-        OO.set_attention_split(False)
-        OO._SPLIT_KEEP = keep
-    assert keep and not OO._SPLIT_PLANES                                  # every kept workspace was consumed by its backward
-    assert torch.equal(oz, o) and torch.equal(z.grad, x.grad)
-
-
-def test_attention_split_cross_shapes():
-    O = ops()
-    import hoisdf_amd.ops as OO
-    B, Lq, Lk, E, H, kv = 2, 150, 700, 256, 4, 600
-    q = rnd(B, Lq, E, seed=42).double().requires_grad_(True)
-    kvt = rnd(B, Lk, 2 * E, seed=43).double().requires_grad_(True)
-    ref = _ref_attention(q, kvt[..., :E], kvt[..., E:], H, kv)
-    go = rnd(B, Lq, E, seed=44)
-    ref.backward(go.double())
-    OO.set_attention_split(True)
-    try:
-        qg = q.detach().float().to(DEV).requires_grad_(True)
-        kg = kvt.detach().float().to(DEV).requires_grad_(True)
-        o = O.attention_cross(qg, kg, H, kv)
-        o.backward(go.to(DEV))
-    finally:
-        OO.set_attention_split(False)
-    assert_close(o, ref, rel=2e-5, what="split cross out")
-    assert_close(qg.grad, q.grad, rel=5e-5, what="split cross dq")
-    assert_close(kg.grad, kvt.grad, rel=5e-5, what="split cross dkv")
-
-
 
 
 @pytest.mark.parametrize("B,S,nq,ni,p,det", [(2, 64, None, None, 0.0, True), (4, 1024, None, 768, 0.1, False), (4, 1024, 768, 768, 0.1, False),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """diagnostic: the stride-32 pyramid gradient of the N=2048 training fixture in the three GEMM modes (exact f32 MFMA, bf16x3
-emulation, f16 split) against the reference golden and against each other"""
+emulation) against the reference golden and against each other"""
 import sys, os, random
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -31,15 +31,14 @@ def run(mode, rep=1):
     model._jitter = lambda like, d: jit.pop(0).to(DEV)
     model._py_random = random.Random(0)
     inputs, targets, meta = ({k: v.to(DEV) for k, v in d.items()} for d in (inputs, targets, meta))
-    ops.set_gemm_emu(mode == "emu"); ops.set_gemm_split(mode == "split")
+    ops.set_gemm_emu(mode == "emu")
     loss, out = model.hot_path(pyr, inputs, targets, meta, "train", 0, 0.5)
     total = sum(v.mean() for v in loss.values()); total.backward()
-    ops.set_gemm_split(False)
     return levels[4].grad.permute(0, 3, 1, 2)[:, ::16].detach().cpu().double(), {k: float(v.mean()) for k, v in loss.items()}
 ref = torch.from_numpy(g["grad.pyr.stride32"]).double()
-res = {m: run(m) for m in ("f32", "emu", "split", "f32", "emu")}
+res = {m: run(m) for m in ("f32", "emu", "f32", "emu")}
 res2 = {}
-for i, m in enumerate(("f32", "emu", "split")):
+for i, m in enumerate(("f32", "emu")):
     res2[m] = res[m]
 mx = float(ref.abs().max())
 print("max |ref| =", mx)
@@ -47,6 +46,6 @@ for m, (gr, ls) in res2.items():
     d = (gr - ref).abs()
     idx = np.unravel_index(int(d.argmax()), d.shape)
     print(f"{m:6s} vs golden: max {float(d.max()) / mx:.3e} of max at {idx}: got {float(gr[idx]):+.6e} ref {float(ref[idx]):+.6e}   rms {float((d**2).mean().sqrt()) / mx:.3e}")
-for a, b in (("f32", "emu"), ("f32", "split"), ("emu", "split")):
+for a, b in (("f32", "emu"),):
     d = (res2[a][0] - res2[b][0]).abs()
     print(f"{a} vs {b}: max {float(d.max()) / mx:.3e} of max, rms {float((d**2).mean().sqrt()) / mx:.3e}")

@@ -62,10 +62,6 @@ def attn():
                 t3 = timeit(lambda: ops._attn_fwd_f16(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, S), iters=5)
             print(f"attn B={B} S={S} f16-MFMA fwd (incl. K/V conversion): {fl/t3/1e12:6.1f} TF ({t3*1e3:.2f} ms)")
         print(f"attn B={B} S={S} p={p}: fwd {fl/t1/1e12:6.1f} TF ({t1*1e3:.2f} ms)  bwd {2.5*fl/t2/1e12:6.1f} TF algorithmic ({t2*1e3:.2f} ms)")
-        os_, ls_ = ops._attn_fwd_split(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, S, p, 1234)
-        t4 = timeit(lambda: ops._attn_fwd_split(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], H, S, p, 1234), iters=5)
-        t5 = timeit(lambda: ops._attn_bwd_split(qkv[:, :, :E], qkv[:, :, E:2 * E], qkv[:, :, 2 * E:], os_, ls_, do, d[:, :, :E], d[:, :, E:2 * E], d[:, :, 2 * E:], H, S, p, 1234), iters=5)
-        print(f"     split (f16 hi+lo x3, incl. conversion passes): fwd {fl/t4/1e12:6.1f} TF ({t4*1e3:.2f} ms)  bwd {2.5*fl/t5/1e12:6.1f} TF algorithmic ({t5*1e3:.2f} ms)")
 
 
 if __name__ == "__main__":

@@ -16,14 +16,14 @@ PMCG=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU")
 for cfg in "form1:HOISDF_EMU_KC=1" "$@"; do
   label=${cfg%%:*}; envs=${cfg#*:}
-  for case in linear_fwd_emu_65536x1024x256 linear_fwd_emu_65536x256x1024; do
+  for case in ${PMC_CASES:-linear_fwd_emu_65536x1024x256 linear_fwd_emu_65536x256x1024}; do
     i=0
     for grp in "${PMCG[@]}"; do
       i=$((i+1))
       rm -rf /tmp/pmc_run
       env $envs timeout 300 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc_run -- python $R/tools/pmc_case.py $case > /tmp/pmc_log.txt 2>&1
       C=$(find /tmp/pmc_run -name "*counter_collection.csv" | head -1)
-      if [ -n "$C" ]; then grep -E "Counter_Name|emu_kc" $C > $O/${label}.${case}.g$i.csv; else echo "no csv for $label $case group $i: $(tail -2 /tmp/pmc_log.txt)"; fi
+      if [ -n "$C" ]; then grep -E "Counter_Name|${PMC_KERNEL:-emu_kc}" $C > $O/${label}.${case}.g$i.csv; else echo "no csv for $label $case group $i: $(tail -2 /tmp/pmc_log.txt)"; fi
     done
   done
 done

@@ -9,7 +9,7 @@ for f in sorted(os.listdir(d)):
     rows = list(csv.DictReader(open(os.path.join(d, f))))
     acc = collections.defaultdict(list)
     for r in rows:
-        if "emu_kc" in r.get("Kernel_Name", ""):
+        if os.environ.get("PMC_KERNEL", "emu_kc") in r.get("Kernel_Name", ""):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         tab[(case, k)][label] = sum(v) / len(v)
