@@ -99,6 +99,12 @@ class Mlp(C.Structure):
                 ("w", C.c_void_p * MLP_MAX_LAYERS), ("b", C.c_void_p * MLP_MAX_LAYERS)]
 
 
+class EmuPrepItem(C.Structure):
+    """include/hoisdf.h hoisdf_emu_prep_item"""
+    _fields_ = [("W", C.c_void_p), ("image", C.c_void_p), ("first_block", C.c_long), ("ldw", C.c_int), ("N", C.c_int),
+                ("K", C.c_int), ("transpose", C.c_int)]
+
+
 class MlpGrads(C.Structure):
     """include/hoisdf.h hoisdf_mlp_grads"""
     _fields_ = [("dw", C.c_void_p * MLP_MAX_LAYERS), ("db", C.c_void_p * MLP_MAX_LAYERS)]
@@ -116,6 +122,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_bwd_input": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_linear_emu_prepare": [_P, _I, _I, _I, _I, _P, _P],
+    "hoisdf_linear_emu_prepare_batch": [_P, _I, _L, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight_emu": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
@@ -193,6 +200,7 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_image_bytes": ([_I, _I], C.c_long),
+          "hoisdf_linear_emu_prepare_blocks": ([_I, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),

@@ -67,10 +67,8 @@ struct EmuArgs {
 
 // ---- weight -> slab image.  transpose = 0: image row n, contraction k = W[n][k] (forward);  1: image row k, contraction
 // n = W[n][k] (grad-input: dx = dy . W).  One thread per (tile, slab, chunk, row): 8 source values -> 3 x 16 bytes.
-__global__ __launch_bounds__(256) void emu_prep_weight_kernel(const float* __restrict__ W, int ldw, int R, int Kc, int transpose,
-                                                              int nslab, long total, u32x4* __restrict__ img) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void emu_prep_weight_unit(const float* __restrict__ W, int ldw, int R, int Kc, int transpose, int nslab,
+                                                     long idx, u32x4* __restrict__ img) {
   const int r = (int)(idx % TN);
   const int c = (int)((idx / TN) % 2);
   const int s = (int)((idx / (2 * TN)) % nslab);
@@ -91,6 +89,28 @@ __global__ __launch_bounds__(256) void emu_prep_weight_kernel(const float* __res
   img[base + (0 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p0);
   img[base + (1 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p1);
   img[base + (2 * 2 + c) * TN + r] = __builtin_bit_cast(u32x4, p2);
+}
+
+__global__ __launch_bounds__(256) void emu_prep_weight_kernel(const float* __restrict__ W, int ldw, int R, int Kc, int transpose,
+                                                              int nslab, long total, u32x4* __restrict__ img) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) emu_prep_weight_unit(W, ldw, R, Kc, transpose, nslab, idx, img);
+}
+
+// many images in one launch (all weights of a model after an optimizer step): the block finds its item in the table by its
+// first-block offsets (ascending)
+__global__ __launch_bounds__(256) void emu_prep_weight_batch_kernel(const hoisdf_emu_prep_item* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hoisdf_emu_prep_item it = items[lo];
+  const int R = it.transpose ? it.K : it.N, Kc = it.transpose ? it.N : it.K;
+  const int nslab = ((Kc + KS - 1) / KS);
+  const long total = (long)((R + TN - 1) / TN) * nslab * 2 * TN;
+  const long idx = ((long)blockIdx.x - it.first_block) * 256 + threadIdx.x;
+  if (idx < total) emu_prep_weight_unit(it.W, it.ldw, R, Kc, it.transpose, nslab, idx, static_cast<u32x4*>(it.image));
 }
 
 // C-tile epilogue shared by the two main-loop forms: bias, ReLU, dropout, 1-bit sign map, accumulate-into, LDS-transposed 16-byte stores
@@ -390,6 +410,18 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #if EMU_ABL == 2 || EMU_ABL == 4
 #define LDGA(i, sl) NOP_
 #define LDGB(q, sl) NOP_
+#elif EMU_ABL == 5 || EMU_ABL == 7          /* no weight-image loads (7: nor their stage writes) */
+#define LDGA(i, sl)                                                                                                    \
+  do {                                                                                                                 \
+    const int k0_ = min((sl), last) * KS;                                                                              \
+    const f32x4 v_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa[i], aoff, k0_ * 4, 0));       \
+    rp[2 * (i)] = f32x2{v_[0], v_[1]}; rp[2 * (i) + 1] = f32x2{v_[2], v_[3]};                                          \
+    if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm[i], moff, (k0_ >> 5) * 4, 0);                           \
+  } while (0)
+#define LDGB(q, sl) NOP_
+#elif EMU_ABL == 6                          /* no activation loads */
+#define LDGA(i, sl) NOP_
+#define LDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (tid + (q) * NT) * 16, min((sl), last) * (B_U4 * 16), 0)
 #else
 #define LDGA(i, sl)                                                                                                    \
   do {                                                                                                                 \
@@ -440,6 +472,9 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #if EMU_ABL == 2 || EMU_ABL == 3
 #define STA(st, i, tp, pl) asm volatile("" :: "v"(tp[2 * (i)]), "v"(tp[2 * (i) + 1]))
 #define STB(st, q) asm volatile("" :: "v"(rb[q]))
+#elif EMU_ABL == 7
+#define STA(st, i, tp, pl) reinterpret_cast<u32x2*>(st)[wslot + (i) * 128 + (pl) * 4 * TM] = u32x2{tp[2 * (i)], tp[2 * (i) + 1]}
+#define STB(st, q) asm volatile("" :: "v"(rb[q]))
 #else
 #define STA(st, i, tp, pl) reinterpret_cast<u32x2*>(st)[wslot + (i) * 128 + (pl) * 4 * TM] = u32x2{tp[2 * (i)], tp[2 * (i) + 1]}
 #define STB(st, q) (st)[A_U4 + tid + (q) * NT] = rb[q]
@@ -472,8 +507,11 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
   } while (0)
 #define LOAD_ALL(sl)                                                                                                   \
   do {                                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) LDGA(i, sl);                                                         \
-    _Pragma("unroll") for (int q = 0; q < NB; ++q) LDGB(q, sl);                                                        \
+    /* issue order pinned to a phase's: the vmcnt waits inside the loop are counted against BOTH histories that reach   */ \
+    /* the loop head (left free, hipcc put item 0 second to last here and the odd phases waited vmcnt(1) at slot 2)    */ \
+    SB(); LDGA(0, sl); SB();                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < NB; ++q) { LDGB(q, sl); SB(); }                                              \
+    _Pragma("unroll") for (int i = 1; i < 4; ++i) { LDGA(i, sl); SB(); }                                               \
   } while (0)
   LOAD_ALL(0);
   STAGE_ALL(st0, 0);
@@ -1067,6 +1105,20 @@ extern "C" int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, 
   hipLaunchKernelGGL(emu_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldw, R, Kc,
                      transpose, nslab, total, static_cast<u32x4*>(image));
   return check_launch("linear_emu_prepare");
+}
+
+extern "C" long hoisdf_linear_emu_prepare_blocks(int N, int K, int transpose) {
+  if (N <= 0 || K <= 0) return 0;
+  const int R = transpose ? K : N, Kc = transpose ? N : K;
+  return ((long)cdiv(R, TN) * cdiv(Kc, KS) * 2 * TN + 255) / 256;
+}
+
+extern "C" int hoisdf_linear_emu_prepare_batch(const hoisdf_emu_prep_item* d_items, int n, long total_blocks, void* stream) {
+  HOISDF_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < (1L << 31), HOISDF_ERR_INVALID, "linear_emu_prepare_batch: bad sizes");
+  if (n == 0 || total_blocks == 0) return HOISDF_OK;
+  HOISDF_REQUIRE(d_items, HOISDF_ERR_INVALID, "linear_emu_prepare_batch: null table");
+  hipLaunchKernelGGL(emu_prep_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), d_items, n);
+  return check_launch("linear_emu_prepare_batch");
 }
 
 extern "C" int hoisdf_linear_emu_supported(const float* a, long lda, int Kc) {

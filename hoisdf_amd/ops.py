@@ -33,6 +33,7 @@ def set_deterministic(on: bool) -> None:
 
 def bump_weight_generation() -> None:
     _WEIGHT_GEN[0] += 1
+    _emu_refresh_images()
 
 
 def manual_seed(seed: int) -> None:
@@ -321,6 +322,57 @@ def _emu_purge() -> None:
     _EMU_GRAVEYARD.clear()
     for k in [k for k, e in _EMU_IMAGES.items() if e[4]() is None]:
         _EMU_GRAVEYARD.append(_EMU_IMAGES.pop(k)[0])
+    _EMU_EPOCH[0] += 1
+
+
+_EMU_EPOCH = [0]                     # bumped whenever an entry joins or leaves _EMU_IMAGES: the batch table is rebuilt
+_EMU_TABLE = {}                      # device index -> (epoch, keys, device table, n, total_blocks)
+_EMU_BATCH = __import__("os").environ.get("HOISDF_EMU_BATCH_PREP", "1") != "0"
+
+
+def _emu_refresh_images() -> None:
+    """After an optimizer step (bump_weight_generation): rebuild EVERY cached weight image whose parameter is alive in one launch
+    per device (hoisdf_linear_emu_prepare_batch) on the current stream, instead of ~170 few-microsecond launches strewn over the
+    next step's critical path.  An entry keeps its device pointer (data_ptr is in the key), so the device-side table is built
+    once per cache composition.  HOISDF_EMU_BATCH_PREP=0: images are rebuilt one by one at their first use (the round-3 flow)."""
+    if not _EMU_BATCH or not _EMU_IMAGES:
+        return
+    from ._lib import EmuPrepItem, lib
+    import ctypes as C
+    by_dev = {}
+    for k, e in _EMU_IMAGES.items():
+        if e[4]() is not None:
+            by_dev.setdefault(k[0], []).append((k, e))
+    for dev, ents in by_dev.items():
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            tab = _EMU_TABLE.get(dev)
+            if tab is None or tab[0] != _EMU_EPOCH[0] or tab[1] != [k for k, _ in ents]:     # (a weight died: never read freed memory)
+                arr = (EmuPrepItem * len(ents))()
+                blk = 0
+                for i, (k, e) in enumerate(ents):
+                    _, ptr, N, K, ldw, tr = k
+                    arr[i].W, arr[i].image, arr[i].first_block = ptr, e[0].data_ptr(), blk
+                    arr[i].ldw, arr[i].N, arr[i].K, arr[i].transpose = ldw, N, K, int(tr)
+                    blk += lib().hoisdf_linear_emu_prepare_blocks(N, K, int(tr))
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                tab = (_EMU_EPOCH[0], [k for k, _ in ents], host.to(f"cuda:{dev}"), len(ents), blk)
+                _EMU_TABLE[dev] = tab
+            readers = set()
+            for _, e in ents:
+                readers |= e[5]
+            for s_ in readers:
+                if s_ != cur:
+                    cur.wait_stream(s_)      # every stream that read a previous image
+            call("hoisdf_linear_emu_prepare_batch", _p(tab[2]), tab[3], tab[4], _st())
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for _, e in ents:
+                base = e[4]()
+                if base is None:
+                    continue
+                e[5].clear()
+                e[1], e[2], e[3] = (_WEIGHT_GEN[0], base._version), ev, cur
 
 
 def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
@@ -346,6 +398,7 @@ def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
             _emu_purge()
             _EMU_PURGE_AT[0] = max(4096, 2 * len(_EMU_IMAGES))
         _EMU_IMAGES[key] = ent
+        _EMU_EPOCH[0] += 1
     if ent[1] != ver:
         for s_ in ent[5]:
             if s_ != cur:

@@ -133,6 +133,17 @@ int hoisdf_linear_bwd_weight(const float* dy, int lddy, const uint32_t* relu_bit
  * entries. */
 long hoisdf_linear_emu_image_bytes(int rows, int K);
 int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, int transpose, void* image, void* stream);
+/* All images of a model in ONE launch (after an optimizer step: ~170 weights x two orientations in the reference's hot path,
+ * a few microseconds each when built one by one).  `d_items` is a DEVICE table of n items, first_block ascending from 0
+ * (item i occupies hoisdf_linear_emu_prepare_blocks(N, K, transpose) blocks), total_blocks = the sum. */
+typedef struct hoisdf_emu_prep_item {
+  const float* W;          /* [N][ldw] */
+  void* image;             /* hoisdf_linear_emu_image_bytes(transpose ? K : N, transpose ? N : K) bytes, 16-byte aligned */
+  long first_block;
+  int ldw, N, K, transpose;
+} hoisdf_emu_prep_item;
+long hoisdf_linear_emu_prepare_blocks(int N, int K, int transpose);
+int hoisdf_linear_emu_prepare_batch(const hoisdf_emu_prep_item* d_items, int n, long total_blocks, void* stream);
 int hoisdf_linear_emu_supported(const float* a, long lda, int contraction);
 int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
                           int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);

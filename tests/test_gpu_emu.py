@@ -203,6 +203,43 @@ def test_emulated_image_cache_follows_weight_updates_and_owners():
     assert n_diff <= 4, n_diff                                        # only elements within rounding of zero may differ
 
 
+def test_batched_image_refresh_equals_the_single_builds():
+    """ops.bump_weight_generation() (what FusedAdamW calls after its HIP update) rebuilds every cached image in one
+    hoisdf_linear_emu_prepare_batch launch: images bit-identical to hoisdf_linear_emu_prepare's, both orientations, ragged
+    shapes and a row slice of a weight (the attention in-projection's q / kv parts); a weight that died is skipped."""
+    O = ops()
+    from hoisdf_amd._lib import call, lib
+    g = torch.Generator().manual_seed(7)
+    shapes = [(256, 256), (1024, 256), (256, 1024), (768, 256), (60, 256), (200, 60), (512, 292), (3, 1000)]
+    Ws = [(torch.randn(n, k, generator=g) / 8).to(DEV) for n, k in shapes]
+    x = torch.randn(2048, 256, generator=g).to(DEV)
+    imgs = []
+    for W in Ws:
+        for tr in (False, True):
+            imgs.append((W, tr, O._emu_image(W, tr)))
+    sl = Ws[3][256:]                                             # a view: rows 256 .. 767
+    imgs.append((sl, False, O._emu_image(sl, False)))
+    dead = (torch.randn(128, 64, generator=g)).to(DEV)
+    O._emu_image(dead, False)
+    del dead
+    with torch.no_grad():
+        for W in Ws:
+            W.mul_(1.5).add_(0.01)                                # (also bumps torch's version counters)
+    O.bump_weight_generation()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for W, tr, img in imgs:
+        N, K = W.shape
+        ref = torch.empty_like(img)
+        call("hoisdf_linear_emu_prepare", p(W), W.stride(0), N, K, int(tr), p(ref), st)
+        assert torch.equal(img, ref), (tuple(W.shape), tr)
+        assert O._emu_image(W, tr) is img                        # and the entry is current: no rebuild at the next use
+    n_before = len([k for k in O._EMU_IMAGES])
+    y = O.linear(x, Ws[0])
+    assert_close(y, x.double() @ Ws[0].double().t(), rel=2e-6, what="linear after the batched refresh")
+    assert len(O._EMU_IMAGES) == n_before
+
+
 def _ref_attn64(q, k, v, H, kv=None):
     B, Lq, E = q.shape
     qh, kh, vh = (t.view(t.shape[0], t.shape[1], H, 64).transpose(1, 2) for t in (q, k, v))
