@@ -37,7 +37,7 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (
 # error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
 DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--gemm f32 --attention f32)
 DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # the default: 3-way exact bf16 split, 6 products, f32 accumulation
-PMC_FILE = "r03_pmc.json"
+PMC_FILE = "r04_pmc.json"
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
 

@@ -1021,11 +1021,17 @@ __global__ __launch_bounds__(NT, 1) void emu_dw2_kernel(DwArgs g) {
 // out[i] = sum_s part[s * stride + i], deterministic: a block owns 256 consecutive floats (64 lanes x float4), its 16 waves sum
 // the slices s = w, w + 16, ... in order (16 independent 1 KB streams per block keep the loads in flight) and the 16 partial sums
 // are combined in wave order through LDS.  n must be a multiple of 4 (N * K and N are).
+// Two reductions in one launch (dW and db of a grad-weight call): blocks [0, blocks0) serve (part, stride, out, n), the rest
+// (part1, stride1, out1, n1).
 __global__ __launch_bounds__(1024) void emu_reduce_partials_kernel(const float* __restrict__ part, long stride, int splits,
-                                                                   float* __restrict__ out, long n) {
+                                                                   float* __restrict__ out, long n, int blocks0,
+                                                                   const float* __restrict__ part1, long stride1,
+                                                                   float* __restrict__ out1, long n1) {
   __shared__ float4 red[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x * 64 + lane) * 4;
+  int blk = blockIdx.x;
+  if (blk >= blocks0) { blk -= blocks0; part = part1; stride = stride1; out = out1; n = n1; }
+  const long i = ((long)blk * 64 + lane) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
     const float* p = part + i;
@@ -1253,10 +1259,9 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   if (int rc = check_launch("linear_bwd_weight_emu")) return rc;
   if (g.splitk > 1) {
     const long n = (long)N * K;
-    hipLaunchKernelGGL(emu_reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(1024), 0, st, workspace, n, g.splitk, dW, n);
-    if (db)
-      hipLaunchKernelGGL(emu_reduce_partials_kernel, dim3((unsigned)((N + 255) / 256)), dim3(1024), 0, st,
-                         workspace + (size_t)g.splitk * N * K, (long)N, g.splitk, db, (long)N);
+    const int b0 = (int)((n + 255) / 256), b1 = db ? (N + 255) / 256 : 0;
+    hipLaunchKernelGGL(emu_reduce_partials_kernel, dim3((unsigned)(b0 + b1)), dim3(1024), 0, st, workspace, n, g.splitk, dW, n, b0,
+                       workspace + (size_t)g.splitk * N * K, (long)N, db, (long)N);
     return check_launch("linear_bwd_weight_emu reduce");
   }
   return HOISDF_OK;

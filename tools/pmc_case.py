@@ -6,12 +6,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 CASES = {
     # name: (C entry, kernel substring, shape)
     "attn_bwd_f32_32x2048x2048": ("hoisdf_attention_bwd", "attn_bwd_fused_kernel", (32, 2048, 2048)),
-    "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd_kernel", (32, 2048, 2048)),
+    "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd2_kernel", (32, 2048, 2048)),
     "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd_stag_kernel", (32, 2048, 2048)),
-    "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu", "emu_kc_kernel<false>", (65536, 1024, 256)),
-    "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu", "emu_kc_kernel<false>", (65536, 256, 1024)),
-    "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu", "emu_kc_kernel<true>", (65536, 1024, 256)),
-    "linear_bwd_weight_emu_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw_kernel<true, 256>", (65536, 1024, 256)),
+    "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 1024, 256)),
+    "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 256, 1024)),
+    "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu", "emu_kc2_kernel<true, false>", (65536, 1024, 256)),
+    "linear_bwd_weight_emu_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw2_kernel<true, true>", (65536, 1024, 256)),
     "linear_fwd_f32_65536x1024x256": ("hoisdf_linear_fwd", "gemm_f32_kernel<true, true, false, false>", (65536, 1024, 256)),
 }
 if __name__ == "__main__":
