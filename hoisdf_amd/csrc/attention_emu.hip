@@ -956,25 +956,17 @@ extern "C" long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int
   return (long)(planes * sizeof(__bf16));
 }
 
-extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-                                        int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
-                                        uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
-  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
-  HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
-                 HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
-  const long need = hoisdf_attention_emu_workspace(B, H, Lq, Lk, keep ? 2 : 0);
-  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_fwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
+namespace {
+// the forward over planes that are in the workspace already (layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only
+// form: [Q rows | K rows | V^T])
+int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
+                    void* workspace, int keep, hipStream_t st) {
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
-  hipStream_t st = as_stream(stream);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
-  // layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only form: [Q rows | K rows | V^T]
   const Planes pq = carve(w, nq, true, false);
   const Planes pk = carve(w, nk, true, false);
   const Planes pv = carve(w, nk, keep != 0, true);
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
   EmuAttn a{};
   for (int i = 0; i < 3; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
   a.out = o; a.lse = lse; a.ldo = ldo;
@@ -987,6 +979,55 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   else if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_fwd2_kernel<true>, fgrid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(emu_attn_fwd2_kernel<false>, fgrid, dim3(256), 0, st, a);
   return check_launch("attention_fwd_emu");
+}
+}  // namespace
+
+extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                        int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
+                                        uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
+  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
+  HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
+                 HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
+  const long need = hoisdf_attention_emu_workspace(B, H, Lq, Lk, keep ? 2 : 0);
+  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_fwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
+  const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
+  hipStream_t st = as_stream(stream);
+  __bf16* w = reinterpret_cast<__bf16*>(workspace);
+  const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
+  const Planes pq = carve(w, nq, true, false);
+  const Planes pk = carve(w, nk, true, false);
+  const Planes pv = carve(w, nk, keep != 0, true);
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st);
+}
+
+// (internal, common.h) the plane addresses of a forward workspace as targets of linear_fwd_emu_qkv: q_part for a GEMM over the
+// B Lq query rows, kv_part for one over the B Lk memory rows (the same struct twice when Lq == Lk and one GEMM makes all three parts)
+void hoisdf::attention_emu_plane_targets(void* workspace, int B, int H, int Lq, int Lk, int keep, QkvPlanes& qp, QkvPlanes& kvp) {
+  const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
+  __bf16* w = reinterpret_cast<__bf16*>(workspace);
+  const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
+  const Planes pq = carve(w, nq, true, false);
+  const Planes pk = carve(w, nk, true, false);
+  const Planes pv = carve(w, nk, keep != 0, true);
+  qp = QkvPlanes{}; kvp = QkvPlanes{};
+  qp.on = kvp.on = 1; qp.H = kvp.H = H; qp.E = kvp.E = H * 64; qp.qscale = kvp.qscale = QS2;
+  qp.L = Lq; qp.Lp = Lqp; kvp.L = Lk; kvp.Lp = Lkp;
+  for (int i = 0; i < 3; ++i) {
+    qp.r[0][i] = pq.r[i];
+    kvp.r[1][i] = pk.r[i]; kvp.r[2][i] = pv.r[i]; kvp.vt[i] = pv.t[i];
+    if (Lq == Lk) { kvp.r[0][i] = pq.r[i]; qp.r[1][i] = pk.r[i]; qp.r[2][i] = pv.r[i]; qp.vt[i] = pv.t[i]; }
+  }
+}
+
+int hoisdf::attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
+                                     uint64_t seed, void* workspace, int keep, void* stream) {
+  HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0 && B > 0 &&
+                     H > 0 && Lq > 0 && Lk > 0 && kv_len > 0 && kv_len <= Lk && drop_p >= 0.f && drop_p < 1.f,
+                 HOISDF_ERR_INVALID, "attention_fwd_emu_planes: bad arguments");
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, as_stream(stream));
 }
 
 // backward workspace: dO rows (3 planes) + the dQ partials [ceil(Lk / 128)][B H][Lq][64] f32
@@ -1003,7 +1044,10 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
                                         int ldo, const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk,
                                         float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
                                         const void* fwd_workspace, void* workspace, long workspace_bytes, void* stream) {
-  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_bwd_emu")) return rc;
+  // with the forward's planes (fwd_workspace) q, k, v themselves are not read: they may be null; ldq / ldk / ldv still give the
+  // layouts of dq / dk / dv
+  if (int rc = check_emu(fwd_workspace && !q ? o : q, fwd_workspace && !k ? o : k, fwd_workspace && !v ? o : v, ldq, ldk, ldv, B, H, Lq,
+                         Lk, kv_len, drop_p, "attention_bwd_emu")) return rc;
   HOISDF_REQUIRE(o && dout && lse && delta && dq && dk && dv && workspace, HOISDF_ERR_INVALID, "attention_bwd_emu: null pointer");
   HOISDF_REQUIRE(ldo >= H * 64 && lddo >= H * 64 && ((ldo | lddo) & 3) == 0 &&
                      (((uintptr_t)o | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)workspace |

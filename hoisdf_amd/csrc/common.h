@@ -71,6 +71,25 @@ static inline uint32_t drop_threshold(float p) {
 //   gather backward -> pixel-tile owners walking the points in order (gather.hip); per-block column sums of
 //   LayerNorm / SDF head / sigma-gate backward -> parked per block and summed in block order by the last block
 //   to arrive (block_column_sum below, library-owned scratch: deterministic mode is single-stream).
+// ---- in-projection -> attention planes (round 4): the emulated forward GEMM of an attention in-projection can write its output
+// tile straight into the bf16x3 planes the emulated attention kernels read (attention_emu.hip) instead of an f32 [M][N] matrix
+// that a conversion pass would re-read: row planes [b H + head][Lp][64] and, for the value part, the transposed planes
+// [b H + head][64][Lp].  The GEMM's columns are columns col0 .. col0 + N - 1 of the [q | k | v] projection (each part E wide,
+// heads of 64), its rows are (b, s) = (row / L, row % L).  Requires L % 128 == 0 and N % 64 == 0 (whole wave tiles).
+struct QkvPlanes {
+  void* r[3][3];     // [part q / k / v][piece] row planes, null: that part's rows are not wanted
+  void* vt[3];       // transposed value planes, null: not wanted
+  int on, L, Lp, H, E, col0;
+  float qscale;      // the query part is scaled before the split (softmax scale in the log2 domain)
+};
+int linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, const float* bias, long M, int N, int K, const QkvPlanes& pl,
+                       void* stream);
+// attention_emu.hip: where the planes of a forward workspace live (hoisdf_attention_emu_workspace(.., keep ? 2 : 0) bytes), and the
+// forward / backward over planes that are already there
+void attention_emu_plane_targets(void* workspace, int B, int H, int Lq, int Lk, int keep, QkvPlanes& q_part, QkvPlanes& kv_part);
+int attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
+                             void* workspace, int keep, void* stream);
+
 bool deterministic_mode();
 bool gemm_emu_mode();             // hoisdf_set_gemm_emu: ... as fp32 emulated on the bf16 MFMA pipe (default on)
 struct DetScratch {

@@ -62,6 +62,7 @@ struct EmuArgs {
   int M, N, K;                              // output rows, output columns, contraction length
   int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
   int tiles_m, tiles_n, vecC, beta;
+  QkvPlanes qkv;                            // .on: the output tile goes into attention planes instead of C (common.h)
 };
 }  // namespace
 
@@ -151,6 +152,63 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j][r] *= drop_scale(rk, (uint32_t)(cbase + j * 32), g.thresh, g.inv_keep);
       }
+  }
+  if (g.qkv.on) {
+    // attention-plane output (common.h QkvPlanes): the wave's 128 x 64 sub-tile is 128 consecutive tokens of one sample x one head
+    // of one part; per 32-row block through the wave-private LDS slice: row planes as 8 lanes x 16 bytes per token and piece,
+    // transposed value planes as one d per lane, 8 consecutive tokens (16 bytes) per store
+    constexpr int ES = WN + 4;
+    float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+    const int row0 = m0 + wm * 128, cw = n0 + wn * WN;
+    if (row0 + 128 > g.M || cw + WN > g.N) return;           // (never: the launcher takes whole wave tiles only)
+    const int colg = g.qkv.col0 + cw;
+    const int part = colg / g.qkv.E, head = (colg - part * g.qkv.E) >> 6;
+    const int b = row0 / g.qkv.L, s0 = row0 - b * g.qkv.L;
+    const size_t bh = (size_t)b * g.qkv.H + head;
+    const float sc = part == 0 ? g.qkv.qscale : 1.f;
+    __bf16* const r0 = static_cast<__bf16*>(g.qkv.r[part][0]);
+    __bf16* const r1 = static_cast<__bf16*>(g.qkv.r[part][1]);
+    __bf16* const r2 = static_cast<__bf16*>(g.qkv.r[part][2]);
+    const bool trn = part == 2 && g.qkv.vt[0] != nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r] * sc;
+      if (r0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 8;
+          const float4 u = *reinterpret_cast<const float4*>(w + rr * ES + cc);
+          const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc + 4);
+          bf16x8 p0, p1, p2;
+          split3x8(u, v, p0, p1, p2);
+          const size_t o = ((size_t)bh * g.qkv.Lp + s0 + i * 32 + rr) * 64 + cc;
+          *reinterpret_cast<bf16x8*>(r0 + o) = p0;
+          *reinterpret_cast<bf16x8*>(r1 + o) = p1;
+          *reinterpret_cast<bf16x8*>(r2 + o) = p2;
+        }
+      }
+      if (trn) {
+        __bf16* const t0 = static_cast<__bf16*>(g.qkv.vt[0]);
+        __bf16* const t1 = static_cast<__bf16*>(g.qkv.vt[1]);
+        __bf16* const t2 = static_cast<__bf16*>(g.qkv.vt[2]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* c0 = w + (8 * q) * ES + lane;
+          const float4 u = make_float4(c0[0], c0[ES], c0[2 * ES], c0[3 * ES]);
+          const float4 v = make_float4(c0[4 * ES], c0[5 * ES], c0[6 * ES], c0[7 * ES]);
+          bf16x8 p0, p1, p2;
+          split3x8(u, v, p0, p1, p2);
+          const size_t o = ((size_t)bh * 64 + lane) * g.qkv.Lp + s0 + i * 32 + 8 * q;
+          *reinterpret_cast<bf16x8*>(t0 + o) = p0;
+          *reinterpret_cast<bf16x8*>(t1 + o) = p1;
+          *reinterpret_cast<bf16x8*>(t2 + o) = p2;
+        }
+      }
+    }
+    return;
   }
   const bool full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
   if (full && g.vecC) {
@@ -1145,6 +1203,21 @@ extern "C" int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_imag
   g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
+  return launch_emu(g, as_stream(stream));
+}
+
+// hoisdf_linear_fwd_emu whose output goes into attention planes (common.h QkvPlanes; internal: the coarse layer entries use it)
+int hoisdf::linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, const float* bias, long M, int N, int K,
+                               const QkvPlanes& pl, void* stream) {
+  HOISDF_REQUIRE(x && w_image && M > 0 && N > 0 && K > 0 && ldx >= K && M < (1L << 31), HOISDF_ERR_INVALID, "linear_fwd_emu_qkv: bad arguments");
+  HOISDF_REQUIRE(hoisdf_linear_emu_supported(x, ldx, K), HOISDF_ERR_INVALID, "linear_fwd_emu_qkv: x alignment / K");
+  HOISDF_REQUIRE(pl.on && pl.L > 0 && pl.L % 128 == 0 && M % pl.L == 0 && N % 64 == 0 && pl.E % 64 == 0 && pl.Lp >= pl.L &&
+                     pl.col0 % 64 == 0 && pl.col0 + N <= 3 * pl.E,
+                 HOISDF_ERR_INVALID, "linear_fwd_emu_qkv: plane geometry (L=%d Lp=%d N=%d E=%d col0=%d)", pl.L, pl.Lp, N, pl.E, pl.col0);
+  EmuArgs g{};
+  g.A = x; g.lda = ldx; g.Bimg = static_cast<const u32x4*>(w_image);
+  g.C = nullptr; g.ldc = N; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
+  g.inv_keep = 1.f; g.qkv = pl;
   return launch_emu(g, as_stream(stream));
 }
 

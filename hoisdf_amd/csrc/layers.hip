@@ -7,6 +7,8 @@
 // on the bf16 MFMA pipe (hoisdf_linear_*_emu; hoisdf_set_gemm_emu(0) / HOISDF_GEMM=f32: the exact-f32 kernels), attention as
 // the descriptor says.  The opt-in reduced-operand mode (f16 eval attention) is not offered here.
 // hoisdf_amd/ops.py's encoder_layer / decoder_layer autograd nodes are thin wrappers of these calls.
+#include <stdlib.h>
+
 #include "chain.h"
 
 namespace hoisdf {
@@ -33,7 +35,14 @@ int rows_copy_add(float* dst, long dst_gs, const float* src, long src_gs, int gr
 
 struct Geo {
   int B, S, E, F, H, nq, ni; bool full; long M, Ms; float eps, p; int att, att_bwd_emu;
+  bool fused_qkv;      // the in-projection writes the attention planes directly (linear_fwd_emu_qkv): no f32 q / k / v, no conversion pass
 };
+// HOISDF_QKV_PLANES=0: the in-projection writes f32 q / k / v and the attention entry converts them (the round-3 flow; A/B runs)
+bool qkv_planes_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HOISDF_QKV_PLANES"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on == 1;
+}
 int geometry(const hoisdf_encoder_layer_desc* d, Geo& g) {
   HOISDF_REQUIRE(d, HOISDF_ERR_INVALID, "encoder_layer: null descriptor");
   HOISDF_REQUIRE(d->B > 0 && d->S > 0 && d->E > 0 && d->F > 0 && d->H > 0 && d->E % d->H == 0 && d->E % 4 == 0 && d->F % 4 == 0,
@@ -48,6 +57,10 @@ int geometry(const hoisdf_encoder_layer_desc* d, Geo& g) {
   g.eps = d->eps; g.p = d->drop_p;
   g.att = g.nq < 32 ? 0 : d->attention;                     // (the emulated kernels tile 32 queries)
   g.att_bwd_emu = g.att == 2 && d->attention_bwd_emulated && d->training;
+  // emulated attention forward (and, in training, the emulated backward over the kept planes: nothing else reads q / k / v),
+  // heads of 64, whole 128-token wave tiles per sample, the in-projection on the emulated GEMM
+  g.fused_qkv = qkv_planes_enabled() && g.att == 2 && (g.att_bwd_emu || !d->training) && g.E == g.H * 64 && g.S % 128 == 0 &&
+                g.nq % 128 == 0 && gemm_emu_mode() && g.M >= EMU_MIN_ROWS;
   return HOISDF_OK;
 }
 
@@ -59,8 +72,11 @@ struct Saved {
 void carve_saved(const Geo& g, Bump& b, Saved& s) {
   const int E = g.E;
   s.qkv = s.qbuf = s.kvbuf = s.xq = nullptr;
-  if (g.full) s.qkv = b.floats(g.Ms * 3 * E);
-  else { s.qbuf = b.floats(g.M * E); s.kvbuf = b.floats(g.Ms * 2 * E); s.xq = b.floats(g.M * E); }
+  if (g.full) { if (!g.fused_qkv) s.qkv = b.floats(g.Ms * 3 * E); }
+  else {
+    if (!g.fused_qkv) { s.qbuf = b.floats(g.M * E); s.kvbuf = b.floats(g.Ms * 2 * E); }
+    s.xq = b.floats(g.M * E);
+  }
   s.o = b.floats(g.M * E); s.lse = b.floats((long)g.B * g.H * g.nq); s.a = b.floats(g.M * E); s.x1 = b.floats(g.M * E);
   s.h = b.floats(g.M * g.F); s.bits = static_cast<uint32_t*>(b.take(g.M * ((g.F + 31) / 32) * 4)); s.f = b.floats(g.M * E);
   s.st = b.floats(6 * g.M);
@@ -74,9 +90,34 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
   Saved s;
   carve_saved(g, d->training ? saved : ws, s);
   const int E = g.E, F = g.F;
-  const float *q, *k, *v; int ldq, ldkv;
+  const float *q = nullptr, *k = nullptr, *v = nullptr; int ldq = 0, ldkv = 0;
   const float* xq2 = x;
-  if (g.full) {
+  void* aw = s.planes; long ab = s.planes_bytes;
+  if (g.att == 2 && !aw) { ab = hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 0); aw = ws.take(ab); }
+  if (g.fused_qkv) {
+    // in-projection straight into the attention planes (same values as the f32 matrix + conversion pass: bit-identical planes)
+    QkvPlanes pq{}, pkv{};
+    const void* im = nullptr; const void* im_q = nullptr; const void* im_kv = nullptr;
+    if (g.full) im = image_of(c, w->img_in, w->w_in, E, 3 * E, E, 0);
+    else {
+      if (!dry && c.ok()) c.rc = rows_copy_add(s.xq, (long)g.nq * E, x, (long)g.S * E, g.B, g.nq, E, 0, c.st);
+      xq2 = s.xq;
+      im_q = image_of(c, w->img_in_q, w->w_in, E, E, E, 0);
+      im_kv = image_of(c, w->img_in_kv, w->w_in + (size_t)E * E, E, 2 * E, E, 0);
+    }
+    if (!dry && c.ok()) {
+      if (!aw) c.rc = HOISDF_ERR_WORKSPACE;
+      else {
+        attention_emu_plane_targets(aw, g.B, g.H, g.nq, g.S, s.planes ? 1 : 0, pq, pkv);
+        if (g.full) c.rc = linear_fwd_emu_qkv(x, E, im, w->b_in, g.Ms, 3 * E, E, pq, stream);
+        else {
+          c.rc = linear_fwd_emu_qkv(s.xq, E, im_q, w->b_in, g.M, E, E, pq, stream);
+          pkv.col0 = E;
+          if (c.ok()) c.rc = linear_fwd_emu_qkv(x, E, im_kv, w->b_in ? w->b_in + E : nullptr, g.Ms, 2 * E, E, pkv, stream);
+        }
+      }
+    }
+  } else if (g.full) {
     lin_fwd(c, x, E, w->w_in, E, w->img_in, w->b_in, s.qkv, 3 * E, g.Ms, 3 * E, E, 0, 0.f, 0, nullptr);
     q = s.qkv; k = s.qkv + E; v = s.qkv + 2 * E; ldq = ldkv = 3 * E;
   } else {
@@ -86,9 +127,10 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
     lin_fwd(c, x, E, w->w_in + (size_t)E * E, E, w->img_in_kv, w->b_in ? w->b_in + E : nullptr, s.kvbuf, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr);
     q = s.qbuf; k = s.kvbuf; v = s.kvbuf + E; ldq = E; ldkv = 2 * E;
   }
-  if (g.att == 2) {
-    void* aw = s.planes; long ab = s.planes_bytes;
-    if (!aw) { ab = hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 0); aw = ws.take(ab); }
+  if (g.fused_qkv) {
+    if (!dry && c.ok())
+      c.rc = attention_fwd_emu_planes(s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], aw, s.planes ? 1 : 0, stream);
+  } else if (g.att == 2) {
     if (!dry && c.ok()) {
       if (!aw) c.rc = HOISDF_ERR_WORKSPACE;
       else c.rc = hoisdf_attention_fwd_emu(q, ldq, k, ldkv, v, ldkv, s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], aw, ab,
@@ -161,13 +203,15 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   if (g.full) {
     float* dqkv = ws.floats(Ms * 3 * E);
     if (!dry && !dqkv) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
-    attn_bwd(s.qkv, 3 * E, s.qkv + E, s.qkv + 2 * E, 3 * E, dqkv, dqkv + E, dqkv + 2 * E);
+    if (g.fused_qkv) attn_bwd(nullptr, 3 * E, nullptr, nullptr, 3 * E, dqkv, dqkv + E, dqkv + 2 * E);       // (the kept planes are the operands)
+    else attn_bwd(s.qkv, 3 * E, s.qkv + E, s.qkv + 2 * E, 3 * E, dqkv, dqkv + E, dqkv + 2 * E);
     lin_bwd_input(c, dqkv, 3 * E, nullptr, 0.f, w->w_in, E, w->img_t_in, dxq, E, Ms, 3 * E, E, 1);   // += : attention branch joins the residual
     lin_bwd_weight(c, dqkv, 3 * E, nullptr, 0.f, x, E, G->dw_in, G->db_in, Ms, 3 * E, E);
   } else {
     float* dq = ws.floats(M * E); float* dkv = ws.floats(Ms * 2 * E);
     if (!dry && (!dq || !dkv)) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
-    attn_bwd(s.qbuf, E, s.kvbuf, s.kvbuf + E, 2 * E, dq, dkv, dkv + E);
+    if (g.fused_qkv) attn_bwd(nullptr, E, nullptr, nullptr, 2 * E, dq, dkv, dkv + E);
+    else attn_bwd(s.qbuf, E, s.kvbuf, s.kvbuf + E, 2 * E, dq, dkv, dkv + E);
     lin_bwd_input(c, dq, E, nullptr, 0.f, w->w_in, E, w->img_t_in_q, dxq, E, M, E, E, 1);
     lin_bwd_weight(c, dq, E, nullptr, 0.f, s.xq, E, G->dw_in, G->db_in, M, E, E);
     lin_bwd_input(c, dkv, 2 * E, nullptr, 0.f, w->w_in + (size_t)E * E, E, w->img_t_in_kv, dx, E, Ms, 2 * E, E, 0);
