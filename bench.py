@@ -68,6 +68,10 @@ class KernelTimer:
         "hoisdf_linear_fwd_emu": lambda a: 2.0 * a[6] * a[7] * a[8],
         "hoisdf_linear_bwd_input_emu": lambda a: 2.0 * a[7] * a[8] * a[9],
         "hoisdf_linear_bwd_weight_emu": lambda a: 2.0 * a[9] * a[10] * a[11],
+        # the one-wave-per-tile emulated form for < 2048 rows: the argument lists of the exact-f32 entries (no workspace)
+        "hoisdf_linear_fwd_emu_small": lambda a: 2.0 * a[7] * a[8] * a[9],
+        "hoisdf_linear_bwd_input_emu_small": lambda a: 2.0 * a[8] * a[9] * a[10],
+        "hoisdf_linear_bwd_weight_emu_small": lambda a: 2.0 * a[9] * a[10] * a[11],
         # the gradient-free SDF query (K1-K4 behind one C-ABI call): its six GEMMs, 2 (C*512 + 512*256) +
         # 2 (289*512 + 512*223 + 512*512 + 512*512 + 512) FLOP per point; the gather / posenc time inside the call is
         # charged to the GEMM family as well
@@ -84,6 +88,8 @@ class KernelTimer:
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
+             "hoisdf_linear_fwd_emu_small": (7, 8, 9), "hoisdf_linear_bwd_input_emu_small": (8, 9, 10),
+             "hoisdf_linear_bwd_weight_emu_small": (9, 10, 11),
              }
 
     def begin(self, name, args):
@@ -489,7 +495,9 @@ def main():
              ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if sq_emu else sq), "f32"),
             ("emu_kc2_kernel (linear fwd + grad-input; emu_kc_kernel with HOISDF_EMU_KC=1)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
             ("emu_dw2_kernel / emu_dw_kernel<128> (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
-            ("emu_attn_fwd_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
+            ("emu_small_kernel / emu_small_dw_kernel (linear layers of < 2048 rows: decoder stack, heads; latency-bound)",
+             ["hoisdf_linear_fwd_emu_small", "hoisdf_linear_bwd_input_emu_small", "hoisdf_linear_bwd_weight_emu_small"], "emu"),
+            ("emu_attn_fwd2_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
             ("emu_attn_bwd_stag_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
             ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
         ]

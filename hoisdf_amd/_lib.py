@@ -125,6 +125,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_emu_prepare_batch": [_P, _I, _L, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
+    "hoisdf_linear_fwd_emu_small": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
+    "hoisdf_linear_bwd_input_emu_small": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P],
+    "hoisdf_linear_bwd_weight_emu_small": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P],
     "hoisdf_linear_bwd_weight_emu": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
@@ -203,6 +206,8 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_linear_emu_prepare_blocks": ([_I, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
+          "hoisdf_linear_emu_small_max_rows": ([], C.c_int),
+          "hoisdf_linear_emu_small_supported": ([_P, _L, _P, _L, _L, _I, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
           "hoisdf_attention_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long),
           "hoisdf_attention_bwd_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long)}

@@ -2,6 +2,8 @@
 // (with a null base it only measures - the size queries run the same carving code as the real calls) and the linear-layer
 // dispatch of the library defaults (fp32 emulated on the bf16 pipe from 2048 rows up, otherwise the exact-f32 kernels).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -36,6 +38,17 @@ struct Ctx {
   bool ok() const { return rc == HOISDF_OK; }
 };
 
+// HOISDF_EMU_SMALL=0: small-M linear layers stay on the exact-f32 tiled kernel (the round-3 flow; A/B runs)
+inline bool emu_small_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HOISDF_EMU_SMALL"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  return on == 1;
+}
+// small row counts (decoder stack, heads): the one-wave-per-tile emulated form (gemm_emu_small.hip)
+inline bool emu_small(const Ctx& c, long M, const float* a, long lda, const float* W, long ldw, int N, int K) {
+  if (!c.emu || !emu_small_enabled() || M > hoisdf_linear_emu_small_max_rows() || N % 4 || K % 4 || lda % 4 || ldw % 4) return false;
+  return c.dry || hoisdf_linear_emu_small_supported(a, lda, W, ldw, M, N, K);
+}
 bool emu_rows(const Ctx& c, long M, const float* a, long lda, int contraction) {
   // (dry pass: pointers are null - assume aligned, which the real pass then checks again; the workspace is an upper bound)
   return c.emu && M >= EMU_MIN_ROWS && contraction % 4 == 0 && lda % 4 == 0 && (c.dry || al16(a));
@@ -61,6 +74,7 @@ void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const voi
     return;
   }
   if (c.dry) return;
+  if (emu_small(c, M, x, ldx, W, ldw, N, K)) { c.rc = hoisdf_linear_fwd_emu_small(x, ldx, W, ldw, b, y, ldy, M, N, K, act, p, seed, bits, c.stream); return; }
   c.rc = hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
 }
 void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* W, int ldw, const void* img_t, float* dx,
@@ -74,6 +88,7 @@ void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, floa
     return;
   }
   if (c.dry) return;
+  if (emu_small(c, M, dy, lddy, W, ldw, N, K)) { c.rc = hoisdf_linear_bwd_input_emu_small(dy, lddy, bits, p, W, ldw, dx, lddx, M, N, K, accumulate, c.stream); return; }
   c.rc = hoisdf_linear_bwd_input(dy, lddy, bits, p, W, ldw, dx, lddx, M, N, K, accumulate, c.stream);
 }
 // dW / db zero on entry (the exact-f32 kernel accumulates, the emulated one overwrites)
@@ -93,6 +108,10 @@ void lin_bwd_weight(Ctx& c, const float* dy, int lddy, const uint32_t* bits, flo
       if (!w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
       c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, c.stream);
     }
+    return;
+  }
+  if (c.emu && emu_small_enabled() && M <= hoisdf_linear_emu_small_max_rows()) {       // (no alignment demands: scalar loads)
+    if (!c.dry) c.rc = hoisdf_linear_bwd_weight_emu_small(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, c.stream);
     return;
   }
   long nws = 0; float* w = nullptr;

@@ -306,6 +306,21 @@ def gemm_emu() -> bool:
     return _GEMM_EMU
 
 
+_EMU_SMALL = __import__("os").environ.get("HOISDF_EMU_SMALL", "1") != "0"
+_EMU_SMALL_MAX = [None]
+
+
+def _emu_small_ok(M: int, a: torch.Tensor, lda: int, W: torch.Tensor, N: int, K: int) -> bool:
+    """small row counts (the 17-query decoder stack, the heads): the one-wave-per-tile emulated kernels (hoisdf_linear_*_emu_small)"""
+    if not (_GEMM_EMU and _EMU_SMALL):
+        return False
+    if _EMU_SMALL_MAX[0] is None:
+        from ._lib import lib
+        _EMU_SMALL_MAX[0] = lib().hoisdf_linear_emu_small_max_rows()
+    return (1 <= M <= _EMU_SMALL_MAX[0] and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and W.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)
+
+
 def _emu_ok(M: int, a: torch.Tensor, lda: int, contraction: int) -> bool:
     return (_GEMM_EMU and M >= _GEMM_EMU_MIN_ROWS and contraction % 4 == 0 and lda % 4 == 0
             and a.data_ptr() % 16 == 0)
@@ -419,8 +434,8 @@ def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
         call("hoisdf_linear_fwd_emu", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _st())
         return None
-    call("hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0), _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p),
-         seed, _p(bits), _st())
+    call("hoisdf_linear_fwd_emu_small" if _emu_small_ok(M, x2, ldx, W, N, K) else "hoisdf_linear_fwd", _p(x2), ldx, _p(W), W.stride(0),
+         _p(b), _p(y), ldy, M, N, K, int(act), float(drop_p), seed, _p(bits), _st())
     return None
 
 
@@ -429,8 +444,8 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
         call("hoisdf_linear_bwd_input_emu", _p(dy2), lddy, _p(bits), float(p), _p(_emu_image(W, True)), _p(dx), lddx, M, N, K,
              int(accumulate), _st())
         return None
-    call("hoisdf_linear_bwd_input", _p(dy2), lddy, _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K,
-         int(accumulate), _st())
+    call("hoisdf_linear_bwd_input_emu_small" if _emu_small_ok(M, dy2, lddy, W, N, K) else "hoisdf_linear_bwd_input", _p(dy2), lddy,
+         _p(bits), float(p), _p(W), W.stride(0), _p(dx), lddx, M, N, K, int(accumulate), _st())
     return None
 
 
@@ -444,6 +459,10 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
         ws = torch.empty(max(nws, 4), device=dW.device, dtype=torch.float32)
         call("hoisdf_linear_bwd_weight_emu", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
              _p(ws), nws, _st())
+        return
+    if _GEMM_EMU and _EMU_SMALL and M <= (_EMU_SMALL_MAX[0] or 2047):
+        call("hoisdf_linear_bwd_weight_emu_small", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), dW.stride(0), _p(db), M, N, K,
+             _st())
         return
     ws, nws = None, 0
     if deterministic():             # partial tiles + ordered reduce instead of split-k atomics

@@ -149,6 +149,20 @@ int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const fl
                           int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);
 int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image,
                                 float* dx, int lddx, long M, int N, int K, int accumulate, void* stream);
+/* The same three contractions for SMALL row counts (M <= hoisdf_linear_emu_small_max_rows() = 2047: the 17-query decoder stack,
+ * common/nets/transformer.py:366-395, and the regression heads - ~100 calls of 544 x 256 x 256 per training step that the tiled
+ * kernels cut into a handful of tiles): one wave per 32 x 32 output tile, operands read from the f32 matrices themselves (no
+ * weight image, no workspace), same arithmetic (exact three-way bf16 split, six products, f32 accumulation), same epilogues and
+ * sign-map convention as the entries above.  Operands 16-byte aligned, leading dims / N / K multiples of 4
+ * (hoisdf_linear_emu_small_supported).  The grad-weight form OVERWRITES dW (any lddw >= K) and db, order-fixed (no atomics). */
+int hoisdf_linear_emu_small_max_rows(void);
+int hoisdf_linear_emu_small_supported(const float* a, long lda, const float* W, long ldw, long M, int N, int K);
+int hoisdf_linear_fwd_emu_small(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy, long M,
+                                int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);
+int hoisdf_linear_bwd_input_emu_small(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* W, int ldw,
+                                      float* dx, int lddx, long M, int N, int K, int accumulate, void* stream);
+int hoisdf_linear_bwd_weight_emu_small(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx,
+                                       float* dW, int lddw, float* db, long M, int N, int K, void* stream);
 /* dW[N][K] = dy_eff[M][N]^T . x[M][K], db[N] = column sums of dy_eff (db may be NULL), same emulation: both activation operands
  * are split into bf16 triples inside the kernel (a register transpose per 4-column x 8-row patch, no transposed copy through
  * HBM).  dW (dense: lddw == K) and db are fully OVERWRITTEN; the rows are split over the workgroups into partial tiles in

@@ -119,6 +119,53 @@ def test_emulated_grad_weight_matches_fp64(M, N, K, act, p):
     assert_close(dW1, dW3, rel=2e-6, what="emulated vs exact-f32 dW")
 
 
+@pytest.mark.parametrize("M,N,K,act,p", [(544, 256, 256, False, 0.0), (544, 1024, 256, True, 0.1), (544, 256, 1024, False, 0.0),
+                                         (17, 256, 256, True, 0.0), (1, 64, 32, False, 0.0), (100, 60, 20, True, 0.2),
+                                         (2047, 224, 292, True, 0.0), (33, 36, 516, False, 0.0), (700, 4, 256, True, 0.0)])
+def test_small_row_emulated_linear_matches_fp64_and_the_exact_kernels_masks(M, N, K, act, p):
+    """hoisdf_linear_fwd_emu_small / _bwd_input_emu_small / _bwd_weight_emu_small (one wave per 32 x 32 tile; the decoder stack's and
+    the heads' row counts) through ops.linear: y, dx (plain and accumulating), dW, db against fp64 at the exact kernel's 2e-6; ragged
+    M / N / K (partial tiles, k tails), ReLU + dropout through the sign bitmap; the dropout mask and the sign map are the exact-f32
+    kernel's (same hash, same convention) wherever the pre-activation is not at rounding level; two runs are bit-identical."""
+    O = ops()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    decades = lambda n: torch.pow(10.0, -6.0 * torch.rand(n, 1, generator=g))
+    x0 = (torch.randn(M, K, generator=g) * decades(M)).to(DEV)
+    W0 = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b0 = (torch.randn(N, generator=g) * 1e-3).to(DEV)
+    gy = (torch.randn(M, N, generator=g) * decades(M)).to(DEV)
+    gy[::7] = 0.0
+    assert O._emu_small_ok(M, x0, K, W0, N, K)
+    res = {}
+    for mode in ("small", "small", "f32"):
+        O.set_gemm_emu(mode == "small")
+        O.manual_seed(77)
+        x, W, b = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = O.linear(x, W, b, act=act, drop_p=p)
+        y.backward(gy)
+        res.setdefault(mode, []).append((y.detach(), x.grad, W.grad, b.grad))
+    O.set_gemm_emu(True)
+    (y, dx, dW, db), again, (yf, _, _, _) = res["small"][0], res["small"][1], res["f32"][0]
+    for a_, b_ in zip((y, dx, dW, db), again):
+        assert torch.equal(a_, b_)
+    pre = x0.double() @ W0.double().t() + b0.double()
+    if act:
+        kept = y > 0
+        # the exact-f32 kernel keeps / drops the same elements, up to pre-activations within rounding of zero
+        assert ((kept != (yf > 0)) & (pre.abs() > 1e-6 * pre.abs().max())).sum().item() == 0
+        scale = kept.double() / (1 - p)
+    else:
+        scale = torch.ones_like(pre)
+    assert_close(y, pre * scale, rel=2e-6, what="y")
+    dye = gy.double() * scale
+    assert_close(dx, dye @ W0.double(), rel=2e-6, what="dx")
+    assert_close(dW, dye.t() @ x0.double(), rel=2e-6, what="dW")
+    assert_close(db, dye.sum(0), rel=2e-6, what="db")
+    dx_acc = torch.full((M, K), 0.25, device=DEV)
+    O._lin_bwd_input(gy, None, 0.0, W0, dx_acc, True)
+    assert_close(dx_acc, gy.double() @ W0.double() + 0.25, rel=2e-6, what="dx accumulate")
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 256), (4096, 256, 1024), (4096, 512, 992)])
 def test_emulated_linear_is_no_less_accurate_than_the_exact_f32_kernel(M, N, K):
     """element-wise |err vs fp64| / sum_k |a_k||b_k| of the emulated kernels next to the exact-f32 MFMA kernels AND the vendor's
