@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--attention", choices=("emu", "f32"), default="emu",
                     help="attention: emu = forward and backward emulated like --gemm emu (HOISDF_ATTN_BWD=f32 keeps the exact-f32 fused "
                          "backward); f32 = exact-f32 MFMA kernels")
+    ap.add_argument("--f16-attention", type=int, default=-1, choices=(-1, 0, 1),
+                    help="configs[4] words its attention as reduced precision: 1 (its default) = the f16-MFMA eval kernel (f16 hi+lo operands, "
+                         "3 products), 0 = the emulated fp32 attention of the other configs (6 bf16 products, fp32-equivalent)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 32, [3]: 16, [4]: 8 / max(2, gpus))")
     ap.add_argument("--n-hand", type=int, default=None)
     ap.add_argument("--n-obj", type=int, default=None)
@@ -217,7 +220,7 @@ def main():
     cfg.resnet_type = args.resnet
     cfg.apply_setting({1: "dexycb", 3: "ho3d_render", 4: "dexycb"}[args.config])
     cfg.num_samp_hand, cfg.num_samp_obj, cfg.bins_n = args.n_hand, args.n_obj, 64
-    cfg.attention_f16_eval = args.config == 4
+    cfg.attention_f16_eval = (args.config == 4) if args.f16_attention < 0 else bool(args.f16_attention)
     cfg.gemm_emu = args.gemm == "emu"
     cfg.attention_emu = args.attention == "emu"
     ops.set_gemm_emu(cfg.gemm_emu)
@@ -475,7 +478,7 @@ def main():
                              if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
                              "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
                       "f32": "exact-f32 MFMA", "f16": "f16-MFMA eval kernel (BASELINE configs[4]): f16 hi+lo operands, 3 products"}[
-                          "f16" if args.config == 4 else ("f32" if args.attention == "f32" else "emu")],
+                          "f16" if cfg.attention_f16_eval else ("f32" if args.attention == "f32" else "emu")],
         "accuracy_evidence": "tests/test_gpu_emu.py, tools/emu_accuracy.py: error vs fp64 <= the exact-f32 kernels' and hipBLASLt fp32's"}
     if timer is not None:
         ks = timer.summary()
