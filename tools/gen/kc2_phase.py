@@ -29,13 +29,13 @@ def variant(v):
     of the thread's four rows): UI + 8 conversion units (two pairs x U1..U4), three 8-byte LDS writes, the reload."""
     t = reads()
     for q, sl in ((0, 6), (1, 7), (2, 10)): add(t, sl, f"STB(nxt, {q})")
-    for q in range(3): add(t, 11 + q, f"LDGB({q}, (s) + 2)")
-    if v == 1:      # spread: one conversion unit per MFMA from slot 2; an item's writes and reload right behind its last unit
+    for q in range(3): add(t, (14 + 8 * q) if v == 3 else (11 + q), f"LDGB({q}, (s) + 2)")   # 3: the image loads spread between the activation loads
+    if v == 1 or v == 3:      # spread: one conversion unit per MFMA from slot 2; an item's writes and reload right behind its last unit
         start, step = 2, 8
     elif v == 2:    # late: the conversion starts at slot 12 (loads have had 10 more MFMAs to land)
         start, step = 12, 8
     else:
-        raise SystemExit("variant 1..2")
+        raise SystemExit("variant 1..3")
     for i in range(4):
         s0 = start + step * i
         units = [f"UI({i}, (s) + 1); U1({2 * i})", f"U2({2 * i})", f"U3({2 * i})", f"U4({2 * i})",
