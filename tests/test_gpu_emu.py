@@ -166,6 +166,37 @@ def test_small_row_emulated_linear_matches_fp64_and_the_exact_kernels_masks(M, N
     assert_close(dx_acc, gy.double() @ W0.double() + 0.25, rel=2e-6, what="dx accumulate")
 
 
+def test_small_row_and_batch_entries_edge_cases():
+    """empty problems are accepted and touch nothing; operands the one-wave-per-tile form cannot take (K or a leading dimension that is
+    not a multiple of 4, a misaligned pointer, too many rows) are refused by the entry with HOISDF_ERR_INVALID and routed to the
+    exact-f32 kernel by ops.linear; an empty image batch is a no-op."""
+    O = ops()
+    from hoisdf_amd._lib import lib
+    L = lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(64, 32, device=DEV); W = torch.randn(16, 32, device=DEV); y = torch.full((64, 16), 7.0, device=DEV)
+    assert L.hoisdf_linear_fwd_emu_small(p(x), 32, p(W), 32, None, p(y), 16, 0, 16, 32, 0, 0.0, 0, None, st) == 0
+    assert L.hoisdf_linear_bwd_input_emu_small(p(y), 16, None, 0.0, p(W), 32, p(x), 32, 0, 16, 32, 0, st) == 0
+    torch.cuda.synchronize()
+    assert bool((y == 7.0).all())
+    assert L.hoisdf_linear_emu_prepare_batch(None, 0, 0, st) == 0
+    mx = L.hoisdf_linear_emu_small_max_rows()
+    assert L.hoisdf_linear_emu_small_supported(p(x), 32, p(W), 32, 64, 16, 32) == 1
+    assert L.hoisdf_linear_emu_small_supported(p(x), 32, p(W), 32, mx + 1, 16, 32) == 0
+    assert L.hoisdf_linear_emu_small_supported(p(x), 30, p(W), 32, 64, 16, 32) == 0            # leading dimension
+    assert L.hoisdf_linear_emu_small_supported(C.c_void_p(x.data_ptr() + 4), 32, p(W), 32, 63, 16, 32) == 0   # alignment
+    assert L.hoisdf_linear_fwd_emu_small(p(x), 32, p(W), 32, None, p(y), 16, mx + 1, 16, 32, 0, 0.0, 0, None, st) < 0
+    assert b"linear_fwd_emu_small" in L.hoisdf_last_error()
+    # ragged K (not a multiple of 4): ops.linear takes the exact-f32 kernel and stays correct
+    x2 = torch.randn(100, 17, device=DEV, requires_grad=True); W2 = torch.randn(12, 17, device=DEV, requires_grad=True)
+    assert not O._emu_small_ok(100, x2, 17, W2, 12, 17)
+    y2 = O.linear(x2, W2)
+    y2.sum().backward()
+    assert_close(y2, x2.detach().double() @ W2.detach().double().t(), rel=2e-6, what="ragged K forward")
+    assert_close(W2.grad, torch.ones(100, 12, device=DEV).double().t() @ x2.detach().double(), rel=2e-6, what="ragged K dW")
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 256), (4096, 256, 1024), (4096, 512, 992)])
 def test_emulated_linear_is_no_less_accurate_than_the_exact_f32_kernel(M, N, K):
     """element-wise |err vs fp64| / sum_k |a_k||b_k| of the emulated kernels next to the exact-f32 MFMA kernels AND the vendor's
