@@ -1242,14 +1242,21 @@ extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint
 
 namespace {
 // row slices for grad-weight: one workgroup per CU (256 slots), >= 8 slabs per slice
-// k-tile width: 256 (one workgroup per CU), or 128 (two per CU) when the 256-wide tiling leaves one or two tiles - there the
-// narrow form packs the slices better (measured, tools/mb_emu.py: 256 x 256 103 vs 98 TF-eq; three tiles, 768 x 256: 205 us wide
-// vs 216 us narrow once the slice count is a whole number per XCD, plan_dw).  HOISDF_EMU_DW_TILE=128 / 256 forces one form.
+// k-tile width: 256 (one workgroup per CU, the rotated emu_dw2_kernel) unless K <= 128 (half of a 256-wide tile would be padding).
+// With the round-3 main loop (HOISDF_EMU_DW=1) the 128-wide form (two workgroups per CU) was the faster one for one or two output
+// tiles; the rotated loop reversed that (round 4, tools/mb_kc2.py: 65536 x 256 x 256 109 -> 118 TF, masked 92 -> 109;
+// 294912 x 256 x 256 123 -> 141 / 127 -> 150; 49152 x 512 x 256 124 -> 139).  HOISDF_EMU_DW_TILE=128 / 256 forces one form.
+bool dw_old_form() {
+  static int form = -1;
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_DW"); form = (e && atoi(e) == 1) ? 1 : 2; }
+  return form == 1;
+}
 int dw_tile(int N, int K) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("HOISDF_EMU_DW_TILE"); const int v = e ? atoi(e) : 0; forced = (v == 128 || v == 256) ? v : 0; }
   if (forced) return forced;
-  return cdiv(N, DT) * cdiv(K, 256) <= 2 ? 128 : 256;
+  if (dw_old_form()) return cdiv(N, DT) * cdiv(K, 256) <= 2 ? 128 : 256;
+  return K <= 128 ? 128 : 256;
 }
 void plan_dw(long M, int N, int K, int& splitk, int& mper) {
   const int dtk = dw_tile(N, K);
@@ -1314,8 +1321,7 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   const int ntile = g.tiles_n * g.tiles_k;
   const dim3 grid((unsigned)(ntile * 8 * cdiv(g.splitk, 8))), block(NT);
   const unsigned lb = 2u * (3 * 2 * DT + 3 * 2 * dtk) * 16u;
-  static int form = -1;                       // HOISDF_EMU_DW=1: the first main-loop form for the 256-wide tiles (A/B runs)
-  if (form < 0) { const char* e = getenv("HOISDF_EMU_DW"); form = (e && atoi(e) == 1) ? 1 : 2; }
+  const int form = dw_old_form() ? 1 : 2;     // HOISDF_EMU_DW=1: the first main-loop form for the 256-wide tiles (A/B runs)
   if (dtk == 256 && form == 2) {
     const bool hasdb = g.colsum != nullptr;
     if (relu_bits && hasdb) hipLaunchKernelGGL((emu_dw2_kernel<true, true>), grid, block, 0, st, g);

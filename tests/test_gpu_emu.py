@@ -85,7 +85,9 @@ def test_emulated_linear_matches_fp64_at_the_exact_kernels_bar(M, N, K, act, p):
 @pytest.mark.parametrize("M,N,K,act,p", [(8192, 256, 256, False, 0.0), (16384, 1024, 256, True, 0.1), (9000, 224, 516, True, 0.0),
                                          (8192, 768, 256, False, 0.0), (70000, 256, 1024, True, 0.0), (8200, 64, 992, False, 0.0),
                                          # one or two 256-tiles of output: the 128-wide k-tile form (two workgroups per CU), ragged too
-                                         (9000, 224, 256, True, 0.1), (8200, 512, 252, True, 0.0), (65536, 256, 256, False, 0.0)])
+                                         (9000, 224, 256, True, 0.1), (8200, 512, 252, True, 0.0), (65536, 256, 256, False, 0.0),
+                                         # K <= 128: the 128-wide k-tile form (two workgroups per CU) is still the one that runs
+                                         (8300, 256, 128, True, 0.1), (9000, 320, 96, False, 0.0)])
 def test_emulated_grad_weight_matches_fp64(M, N, K, act, p):
     """hoisdf_linear_bwd_weight_emu (in-kernel transposing split of both activation operands, partial tiles + ordered reduce)
     through ops.linear's backward: dW, db against fp64 at the exact kernel's 2e-6; ragged M (row tail inside a slab and a short
