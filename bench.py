@@ -497,7 +497,7 @@ def main():
             ("gemm_f32_kernel (linear fwd + grad-input + grad-weight)",
              ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if sq_emu else sq), "f32"),
             ("emu_kc2_kernel (linear fwd + grad-input; emu_kc_kernel with HOISDF_EMU_KC=1)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
-            ("emu_dw2_kernel / emu_dw_kernel<128> (linear grad-weight, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
+            ("emu_dw2_kernel (linear grad-weight, + ordered reduce; emu_dw_kernel<128> for K <= 128)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
             ("emu_small_kernel / emu_small_dw_kernel (linear layers of < 2048 rows: decoder stack, heads; latency-bound)",
              ["hoisdf_linear_fwd_emu_small", "hoisdf_linear_bwd_input_emu_small", "hoisdf_linear_bwd_weight_emu_small"], "emu"),
             ("emu_attn_fwd2_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
