@@ -1,0 +1,36 @@
+// Shared declarations of the fp32-emulating attention kernels (attention_emu.hip: conversion pre-pass, forward, the round-3 backward;
+// attention_emu_bwd4.hip: the round-5 backward).
+#pragma once
+#include "common.h"
+
+namespace hoisdf {
+namespace emu_attn {
+
+struct EmuAttn {
+  // planes (any may be null when a kernel does not use it): [p] = piece 0, 1, 2
+  const __bf16 *q[3];              // Q rows (pre-scaled)
+  const __bf16 *k[3];              // K rows
+  const __bf16 *v[3], *vt[3];      // V rows (backward), V^T (forward)
+  const __bf16 *d[3];              // dO rows
+  const float* lse_in; const float* delta;
+  float* out; float* lse; float* dq_part; float* dk; float* dv;
+  int ldo, ldk, ldv;
+  int B, H, Lq, Lk, Lqp, Lkp, kv_len;
+  float drop_p, inv_keep;
+  uint32_t thresh;
+  uint64_t seed;
+};
+
+__device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
+  const int L = blockIdx.x, slot = L >> 3;        // every tile of a (b, head) on one XCD, as in attention.hip
+  bh = (slot / nx) * 8 + (L & 7);
+  tile = slot % nx;
+  return bh < nbh;
+}
+
+}  // namespace emu_attn
+
+// attention_emu_bwd4.hip: launches emu_attn_bwd4_kernel over planes that are already converted (the argument block of
+// hoisdf_attention_bwd_emu); returns a HOISDF status
+int attention_bwd4_emu_launch(const emu_attn::EmuAttn& a, hipStream_t st);
+}  // namespace hoisdf

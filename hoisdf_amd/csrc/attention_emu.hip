@@ -19,9 +19,11 @@
 // The dropout mask is the same function of (seed, query, key) as in the f32 kernels.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attention_emu.h"
 
 namespace hoisdf {
+using emu_attn::EmuAttn;
+using emu_attn::emu_block;
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,28 +61,6 @@ constexpr float LN2 = 0.6931471805599453f;
     const float r2_ = r1_ - (float)b_;           \
     p0[i] = a_; p1[i] = b_; p2[i] = (__bf16)r2_; \
   } while (0)
-
-struct EmuAttn {
-  // planes (any may be null when a kernel does not use it): [p] = piece 0, 1, 2
-  const __bf16 *q[3];              // Q rows (pre-scaled)
-  const __bf16 *k[3];              // K rows
-  const __bf16 *v[3], *vt[3];      // V rows (backward), V^T (forward)
-  const __bf16 *d[3];              // dO rows
-  const float* lse_in; const float* delta;
-  float* out; float* lse; float* dq_part; float* dk; float* dv;
-  int ldo, ldk, ldv;
-  int B, H, Lq, Lk, Lqp, Lkp, kv_len;
-  float drop_p, inv_keep;
-  uint32_t thresh;
-  uint64_t seed;
-};
-
-__device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
-  const int L = blockIdx.x, slot = L >> 3;        // every tile of a (b, head) on one XCD, as in attention.hip
-  bh = (slot / nx) * 8 + (L & 7);
-  tile = slot % nx;
-  return bh < nbh;
-}
 
 // tile copies global -> registers -> LDS.  Row-major plane tile: 32 rows x 64 bf16, thread -> (row t >> 3, 8 values at
 // (t & 7) * 8).  Transposed plane tile: 64 rows (d) x 32 bf16, thread -> (row t >> 2, 8 values at (t & 3) * 8), stored as two
@@ -1094,10 +1074,16 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  const dim3 grid(cdiv(Lk, 128) * 8 * cdiv(B * H, 8));
-  if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<true>, grid, dim3(512), B3_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<false>, grid, dim3(512), B3_LDS_BYTES, st, a);
-  if (int rc = check_launch("attention_bwd_emu")) return rc;
+  static int form = -1;                       // HOISDF_EMU_ATTN_BWD=3: the round-3 form (8 waves x 16 keys, half-step barriers; A/B runs)
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_BWD"); form = (e && atoi(e) == 3) ? 3 : 4; }
+  if (form == 4) {
+    if (int rc = attention_bwd4_emu_launch(a, st)) return rc;
+  } else {
+    const dim3 grid(cdiv(Lk, 128) * 8 * cdiv(B * H, 8));
+    if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<true>, grid, dim3(512), B3_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<false>, grid, dim3(512), B3_LDS_BYTES, st, a);
+    if (int rc = check_launch("attention_bwd_emu")) return rc;
+  }
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
                      B, H, Lq);
