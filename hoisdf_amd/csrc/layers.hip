@@ -9,6 +9,9 @@
 // hoisdf_amd/ops.py's encoder_layer / decoder_layer autograd nodes are thin wrappers of these calls.
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "chain.h"
 
 namespace hoisdf {
@@ -43,6 +46,23 @@ bool qkv_planes_enabled() {
   if (on < 0) { const char* e = getenv("HOISDF_QKV_PLANES"); on = (e && atoi(e) == 0) ? 0 : 1; }
   return on == 1;
 }
+// The layout of `saved` depends on g.fused_qkv, which reads process-wide switches (hoisdf_set_gemm_emu, HOISDF_QKV_PLANES): the
+// forward records its decision per saved buffer and the backward of that buffer takes it from here, so a switch flipped between a
+// layer's forward and its backward (bench.py and the cfg.gemm_emu setter do flip it at run time) cannot make the two carve differently.
+struct SavedForms {
+  std::mutex mu;
+  std::unordered_map<const void*, int> form;
+  void put(const void* saved, bool fused) { std::lock_guard<std::mutex> l(mu); if (form.size() > 4096) form.clear(); form[saved] = fused ? 1 : 0; }
+  int take(const void* saved) {
+    std::lock_guard<std::mutex> l(mu);
+    auto it = form.find(saved);
+    if (it == form.end()) return -1;
+    const int f = it->second; form.erase(it);
+    return f;
+  }
+};
+SavedForms& saved_forms() { static SavedForms s; return s; }
+
 int geometry(const hoisdf_encoder_layer_desc* d, Geo& g) {
   HOISDF_REQUIRE(d, HOISDF_ERR_INVALID, "encoder_layer: null descriptor");
   HOISDF_REQUIRE(d->B > 0 && d->S > 0 && d->E > 0 && d->F > 0 && d->H > 0 && d->E % d->H == 0 && d->E % 4 == 0 && d->F % 4 == 0,
@@ -263,6 +283,7 @@ extern "C" int hoisdf_encoder_layer_fwd(const float* x, const hoisdf_encoder_lay
   static char none;                                  // (a real pass never measures: a null buffer is an empty one)
   if (!sv.base) { sv.base = &none; sv.cap = 0; }
   if (!ws.base) { ws.base = &none; ws.cap = 0; }
+  if (d->training) saved_forms().put(saved, g.fused_qkv);
   const int rc = forward(x, w, d, g, x_out, y_out, sv, ws, false, stream);
   if (rc == HOISDF_ERR_WORKSPACE) set_error("encoder_layer_fwd: workspace (%ld bytes) or saved buffer (%ld bytes) too small", workspace_bytes, saved_bytes);
   return rc;
@@ -279,6 +300,8 @@ extern "C" int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, cons
                  HOISDF_ERR_INVALID, "encoder_layer_bwd: every parameter gradient buffer is required (zero-filled)");
   HOISDF_REQUIRE(d->training, HOISDF_ERR_INVALID, "encoder_layer_bwd: the forward call must have run with training = 1");
   HOISDF_REQUIRE(al16(x) && al16(dx) && al16(saved) && al16(workspace), HOISDF_ERR_INVALID, "encoder_layer_bwd: buffers must be 16-byte aligned");
+  const int recorded = saved_forms().take(saved);              // what the forward of THIS saved buffer decided (-1: unknown host, recompute)
+  if (recorded >= 0) g.fused_qkv = recorded != 0;
   Bump sv(const_cast<void*>(saved), saved_bytes), ws(workspace, workspace_bytes);
   const int rc = backward(x, x_out, w, d, g, sv, g_x_out, g_y, dx, grads, ws, false, stream);
   if (rc == HOISDF_OK && sv.overflow) { set_error("encoder_layer_bwd: saved buffer too small"); return HOISDF_ERR_WORKSPACE; }

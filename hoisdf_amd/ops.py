@@ -94,7 +94,6 @@ def zero_arena_begin_step(device) -> None:
     buffer that is cleared with a single memset.  See _ZeroArena for the validity contract."""
     _ARENA.begin_step(torch.device(device))
     _EMU_PLANES.clear()            # kept attention planes of graphs that never ran their backward
-    _EMU_PLANES.clear()
 
 
 def zero_arena_end_step() -> None:
@@ -310,14 +309,18 @@ _EMU_SMALL = __import__("os").environ.get("HOISDF_EMU_SMALL", "1") != "0"
 _EMU_SMALL_MAX = [None]
 
 
+def _emu_small_max_rows() -> int:
+    if _EMU_SMALL_MAX[0] is None:
+        from ._lib import lib
+        _EMU_SMALL_MAX[0] = lib().hoisdf_linear_emu_small_max_rows()
+    return _EMU_SMALL_MAX[0]
+
+
 def _emu_small_ok(M: int, a: torch.Tensor, lda: int, W: torch.Tensor, N: int, K: int) -> bool:
     """small row counts (the 17-query decoder stack, the heads): the one-wave-per-tile emulated kernels (hoisdf_linear_*_emu_small)"""
     if not (_GEMM_EMU and _EMU_SMALL):
         return False
-    if _EMU_SMALL_MAX[0] is None:
-        from ._lib import lib
-        _EMU_SMALL_MAX[0] = lib().hoisdf_linear_emu_small_max_rows()
-    return (1 <= M <= _EMU_SMALL_MAX[0] and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and W.stride(0) % 4 == 0
+    return (1 <= M <= _emu_small_max_rows() and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and W.stride(0) % 4 == 0
             and a.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)
 
 
@@ -355,9 +358,23 @@ def _emu_refresh_images() -> None:
     from ._lib import EmuPrepItem, lib
     import ctypes as C
     by_dev = {}
-    for k, e in _EMU_IMAGES.items():
-        if e[4]() is not None:
-            by_dev.setdefault(k[0], []).append((k, e))
+    for k, e in list(_EMU_IMAGES.items()):
+        base = e[4]()
+        if base is None:
+            continue
+        # the owner must still COVER the cached address: param.data = ..., module.to() / .float(), load_state_dict(assign=True) keep the
+        # Parameter object alive but free its old storage - the batch kernel must never read that
+        try:
+            st = base.untyped_storage()
+            lo = st.data_ptr()
+            ok = base.is_cuda and base.device.index == k[0] and lo <= k[1] and k[1] + 4 * ((k[2] - 1) * k[4] + k[3]) <= lo + st.nbytes()
+        except RuntimeError:
+            ok = False
+        if not ok:
+            _EMU_GRAVEYARD.append(_EMU_IMAGES.pop(k)[0])
+            _EMU_EPOCH[0] += 1
+            continue
+        by_dev.setdefault(k[0], []).append((k, e))
     for dev, ents in by_dev.items():
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
@@ -387,6 +404,7 @@ def _emu_refresh_images() -> None:
                 if base is None:
                     continue
                 e[5].clear()
+                e[5].add(cur)                # the building stream: a rebuild from another stream has to wait for this build too
                 e[1], e[2], e[3] = (_WEIGHT_GEN[0], base._version), ev, cur
 
 
@@ -460,7 +478,9 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
         call("hoisdf_linear_bwd_weight_emu", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
              _p(ws), nws, _st())
         return
-    if _GEMM_EMU and _EMU_SMALL and M <= (_EMU_SMALL_MAX[0] or 2047):
+    if M == 0:
+        return                      # an empty row set: dW / db stay zero (what the f32 entry does)
+    if _GEMM_EMU and _EMU_SMALL and M <= _emu_small_max_rows():
         call("hoisdf_linear_bwd_weight_emu_small", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), dW.stride(0), _p(db), M, N, K,
              _st())
         return
