@@ -232,8 +232,6 @@ class Model(nn.Module):
         long fired instead of draining the device twice per field (round 3: four pipeline drains per eval step)."""
         c = self.cfg
         K = meta_info["cam_intr"]
-        if not K.is_cuda:
-            return None
         return {"hand": ops.sdf_infer_count_begin(meta_info["mano_root"], K, meta_info["bbox_hand"], c.hand_sdf_scale, c.bins_n),
                 "obj": ops.sdf_infer_count_begin(meta_info["obj_center_cam"], K, meta_info["bbox_obj"], c.obj_sdf_scale, c.bins_n)}
 
@@ -295,11 +293,10 @@ class Model(nn.Module):
         self.obj_sigmoid_beta.data.clamp_(min=2e-3)
 
         so = None
-        if root.is_cuda:
-            # both streams read the cached SDF-query weight descriptors: (re)build them HERE, on the ambient stream and
-            # ahead of side.wait_stream, so neither stream can launch a query before the folded weights are written
-            self._query_weights("hand").get()
-            self._query_weights("obj").get()
+        # both streams read the cached SDF-query weight descriptors: (re)build them HERE, on the ambient stream and
+        # ahead of side.wait_stream, so neither stream can launch a query before the folded weights are written
+        self._query_weights("hand").get()
+        self._query_weights("obj").get()
         if two:
             side.wait_stream(cur)                       # the points, the pyramid, the inputs and the query weights are ready
         with on_side():                                 # ---- object points ----
@@ -430,12 +427,8 @@ class Model(nn.Module):
                 else:
                     (loss["mano_mesh_loss"], loss["mano_joint_loss"], loss["pose_param_loss"],
                      loss["shape_param_loss"], _, _) = self.mano_loss(pred_m, gt_m)
-            if obj_rot.is_cuda:                                                        # :656-662 (a15: HIP reductions)
-                loss["obj_rot"] = ops.smooth_l1_loss_broadcast(obj_rot, targets["obj_rot"], no)
-                loss["obj_trans"] = ops.smooth_l1_loss_broadcast(obj_trans, targets["rel_obj_trans"], no)
-            else:
-                loss["obj_rot"] = F.smooth_l1_loss(obj_rot, targets["obj_rot"][None, :, None].expand_as(obj_rot))
-                loss["obj_trans"] = F.smooth_l1_loss(obj_trans, targets["rel_obj_trans"][None, :, None].expand_as(obj_trans))
+            loss["obj_rot"] = ops.smooth_l1_loss_broadcast(obj_rot, targets["obj_rot"], no)            # :656-662 (a15: HIP reductions)
+            loss["obj_trans"] = ops.smooth_l1_loss_broadcast(obj_trans, targets["rel_obj_trans"], no)
             side_made = [t for t in list(loss.values()) + list(out.values()) if torch.is_tensor(t)]
 
         # ---- hand vote heads + vote aggregation / losses (ambient stream)
@@ -478,13 +471,9 @@ class Model(nn.Module):
             out["hand_seg_pred_out"] = decoder_out[:, 1]
             out["obj_seg_gt_out"] = targets["obj_seg"]
             out["obj_seg_pred_out"] = decoder_out[:, 2]
-            if decoder_out.is_cuda:          # (f4) one HIP pass: Gaussian heat-map target + MSE + the two BCE maps
-                loss["joint_heatmap"], loss["obj_seg"], loss["hand_seg"], _ = ops.aux_image_losses(
-                    decoder_out, targets["joint_coord"], targets["hand_seg"], targets["obj_seg"], c.sigma)
-            else:                            # CPU: the encoder-only plumbing path (no HIP hot path runs there anyway)
-                loss["joint_heatmap"] = (decoder_out[:, 0] - self.render_gaussian_heatmap(targets["joint_coord"])) ** 2
-                loss["obj_seg"] = F.binary_cross_entropy(decoder_out[:, 2], targets["obj_seg"], reduction="none")
-                loss["hand_seg"] = F.binary_cross_entropy(decoder_out[:, 1], targets["hand_seg"], reduction="none")
+            # (f4) one HIP pass: Gaussian heat-map target + MSE + the two BCE maps
+            loss["joint_heatmap"], loss["obj_seg"], loss["hand_seg"], _ = ops.aux_image_losses(
+                decoder_out, targets["joint_coord"], targets["hand_seg"], targets["obj_seg"], c.sigma)
         return {**loss, **out}
 
 

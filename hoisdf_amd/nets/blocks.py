@@ -164,7 +164,7 @@ class TransformerEncoder(nn.Module):
         inter = []
         n = self.inter_norm
         last = len(self.layers) - 1
-        if FUSED_LAYER_NODES and x.is_cuda:
+        if FUSED_LAYER_NODES:
             # one autograd node per layer (+ its inter_norm): multi-consumer gradients are summed inside the kernels
             for i, l in enumerate(self.layers):
                 a = l.self_attn

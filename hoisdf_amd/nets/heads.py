@@ -47,10 +47,8 @@ class JointvoteLoss(nn.Module):
         # the reference sums over (b, p, j), divides by near.sum() and then averages over (l, xyz)
         l3d = l3d_sum.sum(1) / near_sum.sum() / 3.0
         lcls = bce_sum.sum() / float(L * B * P * J)
-        if joints.is_cuda:          # a15: HIP reduction (hoisdf_point_loss_fwd), the (B, J, 3) target broadcast over depth
-            lall = ops.smooth_l1_loss_broadcast(joints, joint_gt.reshape(B, J * 3), 1, 1000.0)
-        else:
-            lall = F.smooth_l1_loss(joints * 1000, joint_gt[None].expand(L, B, J, 3))
+        # a15: HIP reduction (hoisdf_point_loss_fwd), the (B, J, 3) target broadcast over depth (no eager form: a CPU tensor raises in ops)
+        lall = ops.smooth_l1_loss_broadcast(joints, joint_gt.reshape(B, J * 3), 1, 1000.0)
         return l3d.mean(), lcls, lall, joints
 
 
@@ -59,12 +57,8 @@ class SepSDFLoss(nn.Module):
     main/model.py:393-400 does before calling the loss); None = the targets are taken as they are."""
 
     def forward(self, hand_sdf, obj_sdf, hand_sdf_gt, obj_sdf_gt, clamp=None):
-        if hand_sdf.is_cuda:        # a15: hoisdf_point_loss_fwd / _bwd
-            c = 0.0 if clamp is None else float(clamp)
-            return (ops.l1_loss_clamped_target(hand_sdf, hand_sdf_gt, c), ops.l1_loss_clamped_target(obj_sdf, obj_sdf_gt, c))
-        if clamp is not None:
-            hand_sdf_gt, obj_sdf_gt = hand_sdf_gt.clamp(-clamp, clamp), obj_sdf_gt.clamp(-clamp, clamp)
-        return (F.l1_loss(hand_sdf, hand_sdf_gt.unsqueeze(-1)), F.l1_loss(obj_sdf, obj_sdf_gt.unsqueeze(-1)))
+        c = 0.0 if clamp is None else float(clamp)              # a15: hoisdf_point_loss_fwd / _bwd (no eager form)
+        return (ops.l1_loss_clamped_target(hand_sdf, hand_sdf_gt, c), ops.l1_loss_clamped_target(obj_sdf, obj_sdf_gt, c))
 
 
 class ManoLoss(nn.Module):
