@@ -159,6 +159,7 @@ SIGNATURES: Dict[str, List] = {
                                    _U64, _P],
     "hoisdf_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _U64, _P],
     "hoisdf_add_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _U64, _P],
+    "hoisdf_residual_dropout": [_P, _P, _P, _L, _I, _F, _U64, _P],
     "hoisdf_layernorm_rows_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _P],
     "hoisdf_layernorm_rows_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "hoisdf_sdf_query_train_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _L, _P, _L, _P],

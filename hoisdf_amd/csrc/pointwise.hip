@@ -424,6 +424,30 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
   block_column_sum(dgamma, D, dbeta, D, flat, &s_last, ds);
 }
 
+// ------------------------------------------------------------------------------------------
+// y = x + dropout(r)  (x == nullptr: y = dropout(r), the backward's dr = dy * mask / keep): the residual of a PRE-norm layer
+// (common/nets/transformer.py:304-331,397-437; the post-norm layers fuse this into add_ln_*).  Same (seed, row, column) mask
+// function as add_ln_fwd_kernel.  One float4 per thread.
+__global__ __launch_bounds__(256) void residual_dropout_kernel(const float* __restrict__ x, const float* __restrict__ r, float* __restrict__ y,
+                                                               long n4, int D4, float drop_p, float inv_keep, uint64_t seed, uint32_t thresh) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 b = reinterpret_cast<const float4*>(r)[i];
+  if (drop_p > 0.f) {
+    const long row = i / D4;
+    const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)((i - row * D4) * 4);
+    b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
+    b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
+    b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
+    b.w *= drop_scale(rk, e + 3, thresh, inv_keep);
+  }
+  if (x) {
+    const float4 a = reinterpret_cast<const float4*>(x)[i];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+  }
+  reinterpret_cast<float4*>(y)[i] = b;
+}
+
 }  // namespace hoisdf
 
 using namespace hoisdf;
@@ -547,6 +571,18 @@ extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const fl
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
                      mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0);
   return check_launch("add_layernorm_fwd");
+}
+
+extern "C" int hoisdf_residual_dropout(const float* x, const float* r, float* y, long M, int D, float drop_p, uint64_t seed, void* stream) {
+  HOISDF_REQUIRE(r && y && M >= 0, HOISDF_ERR_INVALID, "residual_dropout: null pointer");
+  HOISDF_REQUIRE(D > 0 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID, "residual_dropout: D=%d must be a multiple of 4, drop_p=%f", D, drop_p);
+  HOISDF_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, HOISDF_ERR_INVALID,
+                 "residual_dropout: buffers must be 16-byte aligned");
+  const long n4 = M * (D / 4);
+  if (n4 == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(residual_dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), x, r, y, n4, D / 4, drop_p,
+                     1.f / (1.f - drop_p), seed, drop_threshold(drop_p));
+  return check_launch("residual_dropout");
 }
 
 extern "C" int hoisdf_layernorm_rows_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,

@@ -121,11 +121,13 @@ class Model(nn.Module):
         beta.data.clamp_(min=2e-3)
         return torch.sigmoid(input / beta) / beta
 
-    def _sdf_rows(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None):
-        """K1-K4 on a flat list of points: returns (sdf clamped (n,), sdf_raw (n,), pe (n,30), cam (n,3))."""
+    def _sdf_rows(self, pyr, points, center, cam_intr, scale, kind, sample_idx=None, want_class=False):
+        """K1-K4 on a flat list of points: returns (sdf clamped (n,), sdf_raw (n,), pe (n,30), cam (n,3)) and, with ``want_class``
+        (cfg.ClassifierBranch: the public sdf_forward / sdf_infer hand the decoder's class logits back, main/model.py:236-240 -
+        nothing in Model.forward reads them, so the hot path never asks), the logits (n,6) as a fifth element."""
         c = self.cfg
         dec = self.hand_sdf_decoder if kind == "hand" else self.obj_sdf_decoder
-        if (points.is_cuda and sample_idx is None and torch.is_grad_enabled() and ops.sdf_query_train_ok()
+        if (not want_class and sample_idx is None and torch.is_grad_enabled() and ops.sdf_query_train_ok()
                 and pyr.C == self.linear_sdfin.layers[0].weight.shape[1]):
             # one C-ABI call per direction (hoisdf_sdf_query_train_fwd / hoisdf_sdf_query_bwd)
             lin = self.linear_sdfin.layers
@@ -144,6 +146,9 @@ class Model(nn.Module):
         # decoder input rows [feat256 | pe30 | xyz3] in a 292-wide (16-byte aligned) buffer
         n = pts.shape[0]
         x0 = torch.cat([fea, pe, pts, pts.new_zeros(n, 3)], dim=1)[:, :c.hidden_dim + c.PointFeatSize]
+        if want_class:
+            sdf, raw, cls = dec.forward_clamped(x0, c.ClampingDistance, want_class=True)
+            return sdf, raw, pe, cam, cls
         sdf, raw = dec.forward_clamped(x0, c.ClampingDistance)
         return sdf, raw, pe, cam
 
@@ -179,8 +184,12 @@ class Model(nn.Module):
         return sdf, raw, pe, f
 
     def sdf_forward(self, feature_pyramid, sdf_points, center_joint, cam_intr, sdf_scale, type="hand"):
-        """reference :181-244 -> (pred_sdf (B,P,1), None, pos_enc3d (B,P,30))."""
+        """reference :181-244 -> (pred_sdf (B,P,1), pred_class (B,P,6) with cfg.ClassifierBranch else None, pos_enc3d (B,P,30))."""
         B, P, _ = sdf_points.shape
+        if self.cfg.ClassifierBranch:
+            sdf, _, pe, _, cls = self._sdf_rows(self._pyramid(feature_pyramid), sdf_points, center_joint, cam_intr, sdf_scale, type,
+                                                want_class=True)
+            return sdf.view(B, P, 1), cls.view(B, P, -1), pe.view(B, P, -1)
         sdf, _, pe, _ = self._sdf_rows(self._pyramid(feature_pyramid), sdf_points, center_joint, cam_intr,
                                        sdf_scale, type)
         return sdf.view(B, P, 1), None, pe.view(B, P, -1)
@@ -194,7 +203,7 @@ class Model(nn.Module):
 
     @torch.no_grad()
     def sdf_infer(self, feature_pyramid, center_joint, cam_intr, bbox, sdf_scale, num_points, type="hand", counts=None):
-        """reference :246-355, batched on the device -> (points (B,K,3), sdf (B,K,1), posenc (B,K,30), None).
+        """reference :246-355, batched on the device -> (points (B,K,3), sdf (B,K,1), posenc (B,K,30), class logits (B,K,6) | None).
         ``counts``: the lattice-survivor count queued earlier (``infer_counts_begin``), so that nothing drains here."""
         c = self.cfg
         pyr = self._pyramid(feature_pyramid)
@@ -207,7 +216,10 @@ class Model(nn.Module):
         except ValueError as e:
             raise ValueError(str(e).replace("sdf_infer:", f"sdf_infer({type}):")) from None
         pose_sdf = pose_sdf.unsqueeze(-1)
-        return pose_points, pose_sdf, pose_pe, None
+        pose_class = None
+        if c.ClassifierBranch:          # :351-352: the logits of the selected points (the decoder re-evaluated on them)
+            pose_class = self.sdf_forward(pyr, pose_points, center_joint, cam_intr, sdf_scale, type)[1]
+        return pose_points, pose_sdf, pose_pe, pose_class
 
     def render_gaussian_heatmap(self, joint_coord):
         """reference :128-143 (encoder-side auxiliary target; plain torch)."""

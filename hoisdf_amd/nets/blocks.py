@@ -63,15 +63,17 @@ class SDFDecoder(nn.Module):
     Layers 0-3 weight-normed, ReLU + dropout(0.2) in training; skip-concat before layer 2."""
 
     def __init__(self, latent_size, point_feat_size, dims=(512, 512, 512, 512), dropout_prob=0.2,
-                 use_classifier=False):
+                 use_classifier=False, num_class=6):
         super().__init__()
-        assert not use_classifier, "ClassifierBranch=False in every released configuration"
         d0 = latent_size + point_feat_size
         self.in_dim = d0
         self.linh0 = _WNLinear(d0, dims[0])
         self.linh1 = _WNLinear(dims[0], dims[1] - d0)
         self.linh2 = _WNLinear(dims[1], dims[2])
         self.linh3 = _WNLinear(dims[2], dims[3])
+        self.use_classifier = bool(use_classifier)
+        if self.use_classifier:              # cfg.ClassifierBranch (common/nets/sdf_net.py:73-75): 6 class logits from the last hidden layer
+            self.classifier_head = nn.Linear(dims[3], num_class)
         self.linh4 = nn.Linear(dims[3], 1)
         self.dropout_prob = dropout_prob
 
@@ -85,15 +87,20 @@ class SDFDecoder(nn.Module):
         return ops.linear(h2, self.linh3.effective_weight(), self.linh3.bias, act=True, drop_p=p)
 
     def forward(self, input):
-        """(P, 289) -> (tanh sdf (P,1), None): the reference's call signature
-        (it returns a dummy tensor as second element when the classifier is off)."""
+        """(P, 289) -> (tanh sdf (P,1), class logits (P,6) | None): the reference's call signature
+        (it returns a dummy tensor as second element when the classifier is off, common/nets/sdf_net.py:119-122)."""
         h3 = self.hidden(input)
         _, raw = ops.sdf_head(h3, self.linh4.weight, self.linh4.bias, 1e30)
-        return raw.unsqueeze(1), None
+        return raw.unsqueeze(1), self.classify(h3)
 
-    def forward_clamped(self, x0, clamp):
+    def classify(self, h3):
+        """common/nets/sdf_net.py:93-94: the logits are read off the INPUT of the last layer"""
+        return ops.linear(h3, self.classifier_head.weight, self.classifier_head.bias) if self.use_classifier else None
+
+    def forward_clamped(self, x0, clamp, want_class=False):
         h3 = self.hidden(x0)
-        return ops.sdf_head(h3, self.linh4.weight, self.linh4.bias, clamp)
+        out = ops.sdf_head(h3, self.linh4.weight, self.linh4.bias, clamp)
+        return (*out, self.classify(h3)) if want_class else out
 
 
 # -------------------------------------------------------------------------------------------------
@@ -116,8 +123,9 @@ class _MHA(nn.Module):
 
 
 class TransformerEncoderLayer(nn.Module):
-    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False):
         super().__init__()
+        self.normalize_before = bool(normalize_before)
         self.self_attn = _MHA(d_model, nhead)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
@@ -133,6 +141,8 @@ class TransformerEncoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         a = self.self_attn
         E = x.shape[-1]
+        if self.normalize_before:
+            return self.forward_pre(x, p)
         if n_query is None or n_query >= x.shape[1]:
             qkv = ops.linear(x, a.in_proj_weight, a.in_proj_bias)
             o = ops.attention_self(qkv, a.num_heads, drop_p=p)
@@ -148,14 +158,27 @@ class TransformerEncoderLayer(nn.Module):
         h = ops.linear(h, self.linear2.weight, self.linear2.bias)
         return ops.add_layernorm(x, h, self.norm2.weight, self.norm2.bias, self.norm2.eps, p)
 
+    def forward_pre(self, x, p):
+        """cfg.pre_norm (common/nets/transformer.py:304-321): x += drop(attn(LN1 x)); x += drop(FFN(LN2 x)) - every row is produced
+        (the residual stream of all rows feeds the next layer), op by op on the same kernels"""
+        a = self.self_attn
+        x2 = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        o = ops.attention_self(ops.linear(x2, a.in_proj_weight, a.in_proj_bias), a.num_heads, drop_p=p)
+        x = ops.residual_dropout(x, ops.linear(o, a.out_proj.weight, a.out_proj.bias), p)
+        x2 = ops.add_layernorm(x, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.linear(x2, self.linear1.weight, self.linear1.bias, act=True, drop_p=p)
+        return ops.residual_dropout(x, ops.linear(h, self.linear2.weight, self.linear2.bias), p)
+
 
 class TransformerEncoder(nn.Module):
-    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout):
+    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout, normalize_before=False):
         super().__init__()
-        self.layers = nn.ModuleList(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout)
+        self.layers = nn.ModuleList(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before)
                                     for _ in range(num_layers))
         self.inter_norm = nn.LayerNorm(d_model)
-        self.norm = None
+        # common/nets/transformer.py:86: the stack's closing norm exists only with normalize_before
+        self.norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.normalize_before = bool(normalize_before)
         self.num_layers = num_layers
 
     def forward(self, x, n_keep=None):
@@ -164,6 +187,15 @@ class TransformerEncoder(nn.Module):
         inter = []
         n = self.inter_norm
         last = len(self.layers) - 1
+        if self.normalize_before:
+            # pre-norm stack (cfg.pre_norm): op by op, all rows through every layer, encoder.norm on the output (:199-200)
+            for layer in self.layers:
+                x = layer(x)
+                inter.append(ops.add_layernorm(x, None, n.weight, n.bias, n.eps))
+            x = ops.add_layernorm(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+            if n_keep is not None and n_keep < x.shape[1]:
+                x, inter = x[:, :n_keep].contiguous(), [y[:, :n_keep] for y in inter]
+            return x, torch.stack(inter)
         if FUSED_LAYER_NODES:
             # one autograd node per layer (+ its inter_norm): multi-consumer gradients are summed inside the kernels
             for i, l in enumerate(self.layers):
@@ -183,8 +215,9 @@ class TransformerEncoder(nn.Module):
 
 
 class TransformerDecoderLayer(nn.Module):
-    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False):
         super().__init__()
+        self.normalize_before = bool(normalize_before)
         self.self_attn = _MHA(d_model, nhead)
         self.multihead_attn = _MHA(d_model, nhead)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
@@ -198,6 +231,21 @@ class TransformerDecoderLayer(nn.Module):
         p = self.p if self.training else 0.0
         E = tgt.shape[-1]
         sa, ca = self.self_attn, self.multihead_attn
+        if self.normalize_before:
+            # cfg.pre_norm (common/nets/transformer.py:397-424)
+            t2 = ops.add_layernorm(tgt, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            qk = ops.linear(t2 + query_pos, sa.in_proj_weight[:2 * E], sa.in_proj_bias[:2 * E])
+            v = ops.linear(t2, sa.in_proj_weight[2 * E:], sa.in_proj_bias[2 * E:])
+            o = ops.attention_small(qk[..., :E], qk[..., E:], v, tgt_mask_u8, sa.num_heads, p)
+            tgt = ops.residual_dropout(tgt, ops.linear(o, sa.out_proj.weight, sa.out_proj.bias), p)
+            t2 = ops.add_layernorm(tgt, None, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            q = ops.linear(t2 + query_pos, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
+            kv = ops.linear(memory, ca.in_proj_weight[E:], ca.in_proj_bias[E:])
+            o = ops.attention_cross(q, kv, ca.num_heads, kv_len, p)
+            tgt = ops.residual_dropout(tgt, ops.linear(o, ca.out_proj.weight, ca.out_proj.bias), p)
+            t2 = ops.add_layernorm(tgt, None, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+            h = ops.linear(t2, self.linear1.weight, self.linear1.bias, act=True, drop_p=p)
+            return ops.residual_dropout(tgt, ops.linear(h, self.linear2.weight, self.linear2.bias), p)
         # masked self-attention over the queries: q = k = tgt + query_pos, v = tgt
         qk = ops.linear(tgt + query_pos, sa.in_proj_weight[:2 * E], sa.in_proj_bias[:2 * E])
         v = ops.linear(tgt, sa.in_proj_weight[2 * E:], sa.in_proj_bias[2 * E:])
@@ -216,17 +264,18 @@ class TransformerDecoderLayer(nn.Module):
 
 
 class TransformerDecoder(nn.Module):
-    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout):
+    def __init__(self, d_model, nhead, num_layers, dim_feedforward, dropout, normalize_before=False):
         super().__init__()
-        self.layers = nn.ModuleList(TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout)
+        self.layers = nn.ModuleList(TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before)
                                     for _ in range(num_layers))
         self.norm = nn.LayerNorm(d_model)
+        self.normalize_before = bool(normalize_before)
 
     def forward(self, memory, query_embed, tgt_mask_u8, kv_len):
         B = memory.shape[0]
         n = self.norm
         l0 = self.layers[0]
-        if FUSED_LAYER_NODES and memory.is_cuda and ops.decoder_layer_ok(l0.p if l0.training else 0.0, memory, query_embed, l0.linear1.weight):
+        if FUSED_LAYER_NODES and not self.normalize_before and ops.decoder_layer_ok(l0.p if l0.training else 0.0, memory, query_embed, l0.linear1.weight):
             # one C-ABI call per layer and direction (csrc/layers.hip hoisdf_decoder_layer_fwd / _bwd)
             x = torch.zeros(B, query_embed.shape[0], query_embed.shape[1], device=memory.device)
             outs = []
@@ -287,9 +336,9 @@ class Transformer(nn.Module):
                  dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False,
                  return_intermediate_dec=False):
         super().__init__()
-        assert activation == "relu" and not normalize_before, "reference config: post-norm, relu"
-        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout)
-        self.decoder = TransformerDecoder(d_model, nhead, num_decoder_layers, dim_feedforward, dropout)
+        assert activation == "relu", "the reference builds relu layers (main/model.py:704-720)"
+        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout, normalize_before)
+        self.decoder = TransformerDecoder(d_model, nhead, num_decoder_layers, dim_feedforward, dropout, normalize_before)
         self.d_model, self.nhead = d_model, nhead
         for p in self.parameters():
             if p.dim() > 1:
@@ -315,8 +364,8 @@ class VoteTransformer(nn.Module):
     def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, dim_feedforward=2048, dropout=0.1,
                  activation="relu", normalize_before=False, return_intermediate_dec=False):
         super().__init__()
-        assert activation == "relu" and not normalize_before
-        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout)
+        assert activation == "relu"
+        self.encoder = TransformerEncoder(d_model, nhead, num_encoder_layers, dim_feedforward, dropout, normalize_before)
         self.d_model, self.nhead = d_model, nhead
         for p in self.parameters():
             if p.dim() > 1:

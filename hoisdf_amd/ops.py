@@ -1256,6 +1256,34 @@ def add_layernorm(x, r, gamma, beta, eps: float = 1e-5, drop_p: float = 0.0):
     return _AddLayerNorm.apply(x, r, gamma, beta, eps, drop_p if r is not None else 0.0, seed)
 
 
+class _ResidualDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, drop_p, seed):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        r2 = r.reshape(-1, x.shape[-1]).contiguous()
+        _chk(x2, r2)
+        M, D = x2.shape
+        y = torch.empty_like(x2)
+        call("hoisdf_residual_dropout", _p(x2), _p(r2), _p(y), M, D, float(drop_p), seed, _st())
+        ctx.meta = (float(drop_p), seed, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        drop_p, seed, shape = ctx.meta
+        if drop_p == 0.0:
+            return dy, dy, None, None
+        dy2 = dy.reshape(-1, shape[-1]).contiguous()
+        dr = torch.empty_like(dy2)
+        call("hoisdf_residual_dropout", None, _p(dy2), _p(dr), dy2.shape[0], dy2.shape[1], drop_p, seed, _st())
+        return dy, dr.view(shape), None, None
+
+
+def residual_dropout(x, r, drop_p: float = 0.0):
+    """x + dropout(r): the residual of a pre-norm layer (cfg.pre_norm; the post-norm layers use add_layernorm)."""
+    return _ResidualDropout.apply(x, r, drop_p, next_seed() if drop_p > 0 else 0)
+
+
 # ---------------------------------------------------------------------------------------------
 # one transformer encoder layer as ONE autograd node
 # ---------------------------------------------------------------------------------------------

@@ -23,7 +23,8 @@ PYRAMID_BIG = OrderedDict(stride2=(128, 128), stride4=(256, 64), stride8=(512, 3
 
 def hot_path_param_shapes(C: int = 992, ik: bool = False, hidden: int = 256,
                           enc_layers: int = 6, dec_layers: int = 4,
-                          ffn: int = 1024) -> "OrderedDict[str, Tuple[int, ...]]":
+                          ffn: int = 1024, pre_norm: bool = False,
+                          classifier: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
     """State-dict schema of the hot path (reference
     main/model.py:49-90, common/nets/sdf_net.py:50-62, common/nets/transformer.py)."""
     S: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
@@ -46,6 +47,9 @@ def hot_path_param_shapes(C: int = 992, ik: bool = False, hidden: int = 256,
             S[f"{kind}_sdf_decoder.linh{i}.bias"] = (o,)
             S[f"{kind}_sdf_decoder.linh{i}.weight_g"] = (o, 1)
             S[f"{kind}_sdf_decoder.linh{i}.weight_v"] = (o, n)
+        if classifier:                      # common/nets/sdf_net.py:73-75 (cfg.ClassifierBranch)
+            S[f"{kind}_sdf_decoder.classifier_head.weight"] = (6, 512)
+            S[f"{kind}_sdf_decoder.classifier_head.bias"] = (6,)
         S[f"{kind}_sdf_decoder.linh4.weight"] = (1, 512)
         S[f"{kind}_sdf_decoder.linh4.bias"] = (1,)
 
@@ -69,6 +73,8 @@ def hot_path_param_shapes(C: int = 992, ik: bool = False, hidden: int = 256,
             S[p + ".linear2.bias"] = (D,)
             ln(p + ".norm1")
             ln(p + ".norm2")
+        if pre_norm:                        # common/nets/transformer.py:33,87: encoder.norm only with normalize_before
+            ln(prefix + ".norm")
         ln(prefix + ".inter_norm")
 
     enc("hand_transformer.encoder", enc_layers)

@@ -410,6 +410,12 @@ int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const float* r, co
                              float* dx, float* dr, float* dgamma, float* dbeta, long M, int D, float drop_p,
                              uint64_t seed, void* stream);
 
+/* y = x + dropout(r) over rows of width D (multiple of 4) - the residual of a PRE-norm layer (reference
+ * common/nets/transformer.py:304-331 TransformerEncoderLayer.forward_pre, :397-437 TransformerDecoderLayer.forward_pre; main/config.py:122
+ * cfg.pre_norm).  x == NULL: y = dropout(r), which is also the backward (dr = dropout-mask(dy) with the SAME seed; dx = dy).
+ * The mask is the (seed, row, column) function of hoisdf_add_layernorm_fwd.  Buffers 16-byte aligned; y may alias r. */
+int hoisdf_residual_dropout(const float* x, const float* r, float* y, long M, int D, float drop_p, uint64_t seed, void* stream);
+
 /* Plain LayerNorm of the FIRST `take` rows of every group of `rows_per_group` input rows (the encoder stack's inter_norm:
  * main/model.py:587-593 only ever reads the hand / object rows of each layer's normalised output).  x [groups *
  * rows_per_group][D]; y, mean, rstd compact [groups * take].  Backward: dy compact; dx covers ALL input rows - rows that

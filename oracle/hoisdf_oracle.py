@@ -63,6 +63,8 @@ class OracleCfg:
     random_ratio: Tuple[float, float] = (0.3, 0.7)            # config.py:68
     random_move_dist: Tuple[float, float, float] = (0.03, 0.05, 0.07)  # config.py:69
     sdf_dropout: float = 0.2            # common/nets/sdf_net.py:20
+    pre_norm: bool = False              # config.py:122 (no released configuration turns it on)
+    ClassifierBranch: bool = False      # config.py:91  (dito)
     lambda_verts3d: float = 1e4         # config.py:150-154
     lambda_joints3d: float = 1e4
     lambda_manopose: float = 10
@@ -155,11 +157,16 @@ def weightnorm_weight(P: Params, prefix: str) -> Tensor:
 
 
 def sdf_decoder(x0: Tensor, P: Params, prefix: str, training: bool = False,
-                p_drop: float = 0.2) -> Tensor:
+                p_drop: float = 0.2, classifier: bool = False):
     """x0 (P,289) -> tanh output (P,1).  common/nets/sdf_net.py:87-122.
-    Layers 0..3 weight-normed + ReLU + dropout; input re-concatenated before layer 2."""
+    Layers 0..3 weight-normed + ReLU + dropout; input re-concatenated before layer 2.
+    ``classifier`` (use_classifier, :73-75,93-94,119-122): also the 6 class logits of ``classifier_head`` applied to the input of
+    the last layer -> (sdf, logits)."""
     h = x0
+    logits = None
     for layer in range(5):
+        if classifier and layer == 4:
+            logits = F.linear(h, P[f"{prefix}.classifier_head.weight"], P[f"{prefix}.classifier_head.bias"])
         if layer == 2:
             h = torch.cat([h, x0], dim=1)
         if layer < 4:
@@ -170,7 +177,8 @@ def sdf_decoder(x0: Tensor, P: Params, prefix: str, training: bool = False,
         if layer < 4:
             h = F.relu(h)
             h = F.dropout(h, p=p_drop, training=training)
-    return torch.tanh(h)[:, 0:1]
+    out = torch.tanh(h)[:, 0:1]
+    return (out, logits) if classifier else out
 
 
 def sdf_decoder_input(points_fea: Tensor, pts: Tensor) -> Tuple[Tensor, Tensor]:
@@ -188,7 +196,11 @@ def sdf_forward(P: Params, cfg: OracleCfg, pyramid, points: Tensor, center: Tens
     feats = sample_pyramid(pyramid, grid, cfg.mutliscale_layers)
     points_fea = mlp(feats, P, "linear_sdfin", 2, True)
     x0, pe = sdf_decoder_input(points_fea, points)
-    sdf = sdf_decoder(x0, P, f"{kind}_sdf_decoder", training, cfg.sdf_dropout)
+    sdf = sdf_decoder(x0, P, f"{kind}_sdf_decoder", training, cfg.sdf_dropout, cfg.ClassifierBranch)
+    if cfg.ClassifierBranch:            # main/model.py:236-240: the logits ride along (nothing downstream reads them)
+        sdf, logits = sdf
+        sdf = sdf.reshape(B, Np, 1).clamp(-cfg.ClampingDistance, cfg.ClampingDistance)
+        return sdf, pe.reshape(B, Np, -1), logits.reshape(B, Np, 6)
     sdf = sdf.reshape(B, Np, 1).clamp(-cfg.ClampingDistance, cfg.ClampingDistance)
     return sdf, pe.reshape(B, Np, -1)
 
@@ -313,8 +325,15 @@ def _ln(x: Tensor, P: Params, prefix: str) -> Tensor:
 
 
 def encoder_layer(x: Tensor, P: Params, prefix: str, cfg: OracleCfg, training: bool) -> Tensor:
-    """Post-norm encoder layer (pos == 0).  common/nets/transformer.py:286-302."""
+    """Post-norm encoder layer (pos == 0), common/nets/transformer.py:286-302; with cfg.pre_norm forward_pre, :304-321."""
     p = cfg.dropout
+    if cfg.pre_norm:
+        x2 = _ln(x, P, prefix + ".norm1")
+        x = x + F.dropout(mha(x2, x2, x2, P, prefix + ".self_attn", cfg.nheads, None, p, training), p, training)
+        x2 = _ln(x, P, prefix + ".norm2")
+        h = F.relu(F.linear(x2, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
+        h = F.linear(F.dropout(h, p, training), P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"])
+        return x + F.dropout(h, p, training)
     a = mha(x, x, x, P, prefix + ".self_attn", cfg.nheads, None, p, training)
     x = _ln(x + F.dropout(a, p, training), P, prefix + ".norm1")
     h = F.relu(F.linear(x, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
@@ -332,13 +351,26 @@ def encoder(src: Tensor, P: Params, prefix: str, n_layers: int, cfg: OracleCfg,
     for l in range(n_layers):
         x = encoder_layer(x, P, f"{prefix}.layers.{l}", cfg, training)
         inter.append(_ln(x, P, prefix + ".inter_norm"))
+    if cfg.pre_norm:                    # encoder.norm exists only with normalize_before (:82-84) and closes the stack (:199-200)
+        x = _ln(x, P, prefix + ".norm")
     return x, torch.stack(inter)
 
 
 def decoder_layer(tgt, memory, query_pos, P, prefix, cfg: OracleCfg, tgt_mask, memory_mask,
                   training: bool) -> Tensor:
-    """Post-norm decoder layer.  common/nets/transformer.py:366-395 (pos == 0)."""
+    """Post-norm decoder layer, common/nets/transformer.py:366-395 (pos == 0); with cfg.pre_norm forward_pre, :397-424."""
     p = cfg.dropout
+    if cfg.pre_norm:
+        t2 = _ln(tgt, P, prefix + ".norm1")
+        qk = t2 + query_pos
+        tgt = tgt + F.dropout(mha(qk, qk, t2, P, prefix + ".self_attn", cfg.nheads, tgt_mask, p, training), p, training)
+        t2 = _ln(tgt, P, prefix + ".norm2")
+        tgt = tgt + F.dropout(mha(t2 + query_pos, memory, memory, P, prefix + ".multihead_attn", cfg.nheads, memory_mask, p, training),
+                              p, training)
+        t2 = _ln(tgt, P, prefix + ".norm3")
+        h = F.relu(F.linear(t2, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"]))
+        h = F.linear(F.dropout(h, p, training), P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"])
+        return tgt + F.dropout(h, p, training)
     qk = tgt + query_pos
     a = mha(qk, qk, tgt, P, prefix + ".self_attn", cfg.nheads, tgt_mask, p, training)
     tgt = _ln(tgt + F.dropout(a, p, training), P, prefix + ".norm1")
@@ -533,6 +565,10 @@ def hot_path_forward(P: Params, cfg: OracleCfg, feature_pyramid: Dict[str, Tenso
     training = mode == "train"
     loss: Dict[str, Tensor] = {}
     out: Dict[str, Tensor] = {}
+    _sdf_forward = globals()["sdf_forward"]
+
+    def sdf_forward(*a, **k):            # Model.forward drops the class logits of cfg.ClassifierBranch (main/model.py:376,445,499)
+        return _sdf_forward(*a, **k)[:2]
     mano_root = meta_info["mano_root"]
     obj_center = meta_info["obj_center_cam"]
     K = meta_info["cam_intr"]

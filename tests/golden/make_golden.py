@@ -364,6 +364,55 @@ def sampler_golden():
     save("g14_sampler", **out)
 
 
+def option_goldens():
+    """The two reference switches no released configuration turns on (round-4 verdict item 6):
+      g5p  cfg.pre_norm = True          common/nets/transformer.py:304-331 (encoder forward_pre), :397-437 (decoder forward_pre),
+                                        encoder.norm on the stack output (:82-84, :199-200); main/config.py:122
+      g2c  cfg.ClassifierBranch = True  common/nets/sdf_net.py:73-75,93-94,119-122 (classifier_head on the last hidden layer),
+                                        main/model.py:236-240 (sdf_forward reshapes the logits); main/config.py:91
+    Same inputs as g5 / g2 / g1; the state-dict keys of both variants are stored for the schema test."""
+    from main.config import cfg
+    B, nh, no = 2, 48, 16
+    pyr = T.synthetic_pyramid(B, big=False, seed=1)
+    inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=11)
+    root, K = meta["mano_root"], meta["cam_intr"]
+    try:
+        cfg.pre_norm = True
+        model, _ = build_reference("dexycb", nh, no, 16)
+        model.eval()
+        keys_pre = sorted(k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net")))
+        with torch.no_grad():
+            r = np.random.default_rng(7)
+            S = nh + no
+            src = torch.from_numpy(r.standard_normal((S, B, 256)).astype(np.float32))
+            from common.utils.misc import get_mano_tgt_mask, get_mano_memory_mask
+            l0 = model.hand_transformer.encoder.layers[0](src)
+            hs, mem, inter, _ = model.hand_transformer(
+                src=src, mask=None, pos_embed=torch.zeros_like(src), src_mask=None,
+                query_embed=model.mano_query_embed.weight, tgt_mask=get_mano_tgt_mask(),
+                memory_mask=get_mano_memory_mask())
+            omem, ointer = model.obj_transformer(src=src, mask=None, pos_embed=torch.zeros_like(src), src_mask=None)
+            save("g5p_transformer_prenorm", src=src, enc_layer0=l0, hs=hs, memory=mem, inter=inter, obj_memory=omem, obj_inter=ointer)
+    finally:
+        cfg.pre_norm = False
+    try:
+        cfg.ClassifierBranch = True
+        model, _ = build_reference("dexycb", nh, no, 16)
+        model.eval()
+        keys_cls = sorted(k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net")))
+        with torch.no_grad():
+            x = torch.from_numpy(np.random.default_rng(5).standard_normal((96, 289)).astype(np.float32))
+            y, c = model.hand_sdf_decoder(x)
+            sh, ch, peh = model.sdf_forward(pyr, inputs["hand_sdf_points"], root, K, cfg.hand_sdf_scale, "hand")
+            save("g2c_sdf_decoder_cls", x=x, y=y, cls=c, sdf_hand=sh, cls_hand=ch, pe_hand=peh)
+    finally:
+        cfg.ClassifierBranch = False
+    import json
+    with open(os.path.join(OUT, "g10_state_dict_options.json"), "w") as f:
+        json.dump({"pre_norm": keys_pre, "classifier": keys_cls}, f, indent=0)
+    print("  wrote g10_state_dict_options.json")
+
+
 def mano_golden():
     """g9: hoisdf_amd.nets.mano.ManoLayer vs manopth's own ManoLayer.forward
     (manopth/manopth/manolayer.py:111-276) on the same synthetic asset."""
@@ -502,7 +551,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik", "aux", "sampler"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik", "aux", "sampler", "options"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -525,3 +574,5 @@ if __name__ == "__main__":
         aux_loss_golden()
     if "sampler" in which:
         sampler_golden()
+    if "options" in which:
+        option_goldens()

@@ -192,6 +192,151 @@ def test_transformer_seq_first_surface_matches_golden():
         assert err <= 1e-4, (k, err)
 
 
+def build_opts(nh, no, bins, train=False, **opts):
+    """build() with reference config switches set (cfg.pre_norm / cfg.ClassifierBranch, main/config.py:122,91)"""
+    from hoisdf_amd.model import get_model
+    from hoisdf_amd.nets import mano as MANO
+    c = Config()
+    c.resnet_type = 18
+    c.apply_setting("dexycb")
+    c.num_samp_hand, c.num_samp_obj, c.bins_n = nh, no, bins
+    for k, v in opts.items():
+        assert hasattr(c, k), k
+        setattr(c, k, v)
+    model = get_model("test", cfg=c, mano_layer=MANO.ManoLayer(MANO.synthetic_assets(0)), with_encoder=False)
+    sd = model.state_dict()
+    for k in sd:
+        if not k.startswith("mano_head"):
+            sd[k] = T.det_param(k, sd[k].shape)
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).train(train), c
+
+
+def test_pre_norm_transformers_match_the_reference_fixture():
+    """cfg.pre_norm = True (common/nets/transformer.py:304-331,397-437 + encoder.norm): the reference's own outputs (g5p), and
+    the state dict carries encoder.norm like the reference's"""
+    from hoisdf_amd.model import get_mano_memory_mask, get_mano_tgt_mask
+    import json, os
+    g = load_golden("g5p_transformer_prenorm")
+    model, c = build_opts(48, 16, 16, pre_norm=True)
+    ref_keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g10_state_dict_options.json")))["pre_norm"]
+    ours = {k for k in model.state_dict() if not k.startswith(("mano_head", "backbone_net", "decoder_net"))}
+    assert ours == {k for k in ref_keys if not k.startswith("mano_head")}, sorted(ours ^ set(ref_keys))[:6]
+    src = g["src"].to(DEV)
+    with torch.no_grad():
+        hs, mem, inter, _ = model.hand_transformer(src=src, mask=None, pos_embed=torch.zeros_like(src), src_mask=None,
+                                                   query_embed=model.mano_query_embed.weight,
+                                                   tgt_mask=get_mano_tgt_mask(c), memory_mask=get_mano_memory_mask(c))
+        omem, ointer = model.obj_transformer(src=src, mask=None, pos_embed=torch.zeros_like(src), src_mask=None)
+    for a, k in ((hs, "hs"), (mem, "memory"), (inter, "inter"), (omem, "obj_memory"), (ointer, "obj_inter")):
+        err = (a.cpu() - g[k]).abs().max().item()
+        assert err <= 2e-4, (k, err)
+
+
+def test_pre_norm_backward_matches_the_oracle():
+    """gradients of a pre-norm encoder stack + decoder (dropout off) against autograd of the CPU oracle on the same weights"""
+    from oracle import hoisdf_oracle as R
+    from hoisdf_amd.model import get_mano_memory_mask, get_mano_tgt_mask
+    g = load_golden("g5p_transformer_prenorm")
+    model, c = build_opts(48, 16, 16, train=True, pre_norm=True)
+    for m in model.modules():
+        if hasattr(m, "p"):
+            m.p = 0.0
+    src = g["src"].to(DEV).requires_grad_(True)
+    hs, mem, inter, _ = model.hand_transformer(src=src, mask=None, pos_embed=torch.zeros_like(src), src_mask=None,
+                                               query_embed=model.mano_query_embed.weight,
+                                               tgt_mask=get_mano_tgt_mask(c), memory_mask=get_mano_memory_mask(c))
+    w = torch.linspace(-1, 1, hs.numel(), device=DEV).view_as(hs)
+    ((hs * w).sum() + inter.pow(2).mean()).backward()
+    P = {k: v.clone().requires_grad_(True) for k, v in T.det_params(T.hot_path_param_shapes(992, pre_norm=True)).items()}
+    ocfg = R.OracleCfg(num_samp_hand=48, num_samp_obj=16, pre_norm=True)
+    s2 = g["src"].clone().requires_grad_(True)
+    m2, i2 = R.encoder(s2, P, "hand_transformer.encoder", 6, ocfg, False)
+    h2 = R.decoder(m2, P["mano_query_embed.weight"], P, "hand_transformer.decoder", 4, ocfg, R.mano_tgt_mask(), R.memory_mask(17, 48, 16), False)
+    ((h2 * w.cpu()).sum() + i2.pow(2).mean()).backward()
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+    assert rel(src.grad, s2.grad) <= 2e-4
+    sd = dict(model.named_parameters())
+    for k in ("hand_transformer.encoder.norm.weight", "hand_transformer.encoder.layers.0.self_attn.in_proj_weight",
+              "hand_transformer.encoder.layers.5.linear2.weight", "hand_transformer.decoder.layers.0.norm1.weight",
+              "hand_transformer.decoder.layers.3.multihead_attn.in_proj_weight", "hand_transformer.encoder.inter_norm.bias"):
+        assert rel(sd[k].grad, P[k].grad) <= 5e-4, (k, rel(sd[k].grad, P[k].grad))
+
+
+def test_classifier_branch_matches_the_reference_fixture():
+    """cfg.ClassifierBranch = True (common/nets/sdf_net.py:73-75,93-94,119-122; main/model.py:236-240,351-352): the decoder's
+    class logits against the reference's own, the SDF unchanged, sdf_infer hands the logits of its selected points back"""
+    import json, os
+    g = load_golden("g2c_sdf_decoder_cls")
+    model, c = build_opts(48, 16, 16, ClassifierBranch=True)
+    ref_keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g10_state_dict_options.json")))["classifier"]
+    ours = {k for k in model.state_dict() if not k.startswith(("mano_head", "backbone_net", "decoder_net"))}
+    assert ours == {k for k in ref_keys if not k.startswith("mano_head")}
+    with torch.no_grad():
+        y, cls = model.hand_sdf_decoder(g["x"].to(DEV))
+    assert float((y.cpu() - g["y"]).abs().max()) <= 2e-5 and float((cls.cpu() - g["cls"]).abs().max()) <= 1e-4
+    pyr = T.synthetic_pyramid(2, big=False, seed=1)
+    inputs, targets, meta = T.synthetic_batch(2, 48, 16, seed=11)
+    P, _ = nhwc_pyramid(pyr)
+    di, dm = T.to_device(inputs, DEV), T.to_device(meta, DEV)
+    with torch.no_grad():
+        sh, ch, peh = model.sdf_forward(P, di["hand_sdf_points"], dm["mano_root"], dm["cam_intr"], c.hand_sdf_scale, "hand")
+    assert float((sh.cpu() - g["sdf_hand"]).abs().max()) <= 2e-5
+    assert float((ch.cpu() - g["cls_hand"]).abs().max()) <= 1e-4 and ch.shape == (2, 48, 6)
+    dm["bbox_hand"] = torch.tensor([20.0, 20, 236, 236], device=DEV).repeat(2, 1)
+    pts, sdf, pe, pcls = model.sdf_infer(P, dm["mano_root"], dm["cam_intr"], dm["bbox_hand"], c.hand_sdf_scale, 24, "hand")
+    assert pcls.shape == (2, 24, 6)
+    with torch.no_grad():
+        _, again, _ = model.sdf_forward(P, pts, dm["mano_root"], dm["cam_intr"], c.hand_sdf_scale, "hand")
+    assert float((pcls - again).abs().max()) <= 1e-5          # (few-tile GEMMs: summation order is not fixed)
+
+
+@pytest.mark.parametrize("opts", [dict(pre_norm=True), dict(ClassifierBranch=True)])
+def test_training_step_with_the_option_switches_matches_the_oracle(opts):
+    """a whole hot-path train step (dropout off) with either switch on: losses and a few gradients against the CPU oracle"""
+    from oracle import hoisdf_oracle as R
+    nh, no, b = 48, 16, 2
+    model, c = build_opts(nh, no, 16, train=True, **opts)
+    for m in model.modules():
+        if hasattr(m, "p"):
+            m.p = 0.0
+        if hasattr(m, "dropout_prob"):
+            m.dropout_prob = 0.0
+    pyr = T.synthetic_pyramid(b, big=False, seed=1)
+    inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=11)
+    P_, _ = nhwc_pyramid(pyr)
+    di, dt, dm = (T.to_device(x, DEV) for x in (inputs, targets, meta))
+    # the oracle's CPU jitter stream (torch.manual_seed(1234): hand first, then obj), handed to the model through its test hook
+    torch.manual_seed(1234)
+    jit = [torch.empty_like(inputs["hand_pre_points"]).uniform_(-0.05, 0.05), torch.empty_like(inputs["obj_pre_points"]).uniform_(-0.05, 0.05)]
+    model._jitter = lambda like, d: jit.pop(0).to(DEV)
+    model._py_random = random.Random(0)
+    loss, out = model.hot_path(P_, di, dt, dm, "train", 0, 0.5)
+    total = sum(v.mean() for v in loss.values())
+    total.backward()
+    Pm = {k: v.clone().requires_grad_(True)
+          for k, v in T.det_params(T.hot_path_param_shapes(992, pre_norm=bool(opts.get("pre_norm")), classifier=bool(opts.get("ClassifierBranch")))).items()}
+    ocfg = oracle_cfg(c, dropout=0.0, sdf_dropout=0.0, pre_norm=bool(opts.get("pre_norm")), ClassifierBranch=bool(opts.get("ClassifierBranch")))
+    from hoisdf_amd.nets import mano as MANO
+    layer_cpu = MANO.ManoLayer(MANO.synthetic_assets(0))
+    torch.manual_seed(1234)
+    ref = R.hot_path_forward(Pm, ocfg, pyr, inputs, targets, meta, "train", mano_layer=layer_cpu, hands_mean=layer_cpu.th_hands_mean,
+                             epoch_cnt=0, batch_ratio=0.5, rng=random.Random(0))
+    rl = {k: v for k, v in ref.items() if not k.endswith("_out")}
+    for k, v in loss.items():
+        a, r_ = float(v.mean()), float(rl[k].mean())
+        assert abs(a - r_) <= 2e-4 * max(1.0, abs(r_)), (k, a, r_)
+    sum(v.mean() for v in rl.values()).backward()
+    sd = dict(model.named_parameters())
+    for k in ("linear_transformerin.layers.0.weight", "hand_transformer.encoder.layers.0.linear1.weight", "obj_transformer.encoder.layers.2.norm2.weight",
+              "hand_sdf_decoder.linh4.weight"):
+        ga, gr = sd[k].grad.cpu(), Pm[k].grad
+        assert float((ga - gr).norm()) <= 2e-3 * float(gr.norm()) + 1e-9, (k, float((ga - gr).norm()), float(gr.norm()))
+    if opts.get("ClassifierBranch"):
+        assert sd["hand_sdf_decoder.classifier_head.weight"].grad is None          # nothing reads the logits (as in the reference)
+
+
 def test_full_model_with_encoder_runs_and_is_finite():
     """ResNet-18 encoder (PyTorch/MIOpen) + HIP hot path, one train step with dropout ON."""
     from hoisdf_amd.model import get_model

@@ -125,6 +125,48 @@ def test_g5_transformer(P):
     close(omem, g["obj_memory"], atol=5e-5); close(ointer, g["obj_inter"], atol=5e-5)
 
 
+def test_g5p_transformer_prenorm():
+    """cfg.pre_norm = True (main/config.py:122): forward_pre of both layer types + encoder.norm, against the reference's own output"""
+    g = load_golden("g5p_transformer_prenorm")
+    P = T.det_params(T.hot_path_param_shapes(992, pre_norm=True))
+    cfg = O.OracleCfg(num_samp_hand=NH, num_samp_obj=NO, pre_norm=True)
+    src = g["src"]
+    close(O.encoder_layer(src, P, "hand_transformer.encoder.layers.0", cfg, False), g["enc_layer0"], atol=5e-5)
+    mem, inter = O.encoder(src, P, "hand_transformer.encoder", 6, cfg, False)
+    close(mem, g["memory"], atol=1e-4); close(inter, g["inter"], atol=1e-4)
+    tm, mm = O.mano_tgt_mask(), O.memory_mask(17, NH, NO)
+    hs = O.decoder(mem, P["mano_query_embed.weight"], P, "hand_transformer.decoder", 4, cfg, tm, mm, False)
+    close(hs, g["hs"], atol=1e-4)
+    omem, ointer = O.encoder(src, P, "obj_transformer.encoder", 3, cfg, False)
+    close(omem, g["obj_memory"], atol=1e-4); close(ointer, g["obj_inter"], atol=1e-4)
+    # the switch changes the result (the fixture is not the post-norm one)
+    assert float((g["memory"] - load_golden("g5_transformer")["memory"]).abs().max()) > 1e-2
+
+
+def test_g2c_sdf_decoder_with_the_classifier_branch(stage_inputs):
+    """cfg.ClassifierBranch = True (main/config.py:91): class logits from the last hidden layer, against the reference's own output"""
+    g = load_golden("g2c_sdf_decoder_cls")
+    P = T.det_params(T.hot_path_param_shapes(992, classifier=True))
+    y, c = O.sdf_decoder(g["x"], P, "hand_sdf_decoder", classifier=True)
+    close(y, g["y"]); close(c, g["cls"], atol=5e-5)
+    pyr, inputs, _, meta = stage_inputs
+    cfg = O.OracleCfg(num_samp_hand=NH, num_samp_obj=NO, ClassifierBranch=True)
+    sh, peh, ch = O.sdf_forward(P, cfg, pyr, inputs["hand_sdf_points"], meta["mano_root"], meta["cam_intr"], 3.1, "hand")
+    close(sh, g["sdf_hand"]); close(peh, g["pe_hand"]); close(ch, g["cls_hand"], atol=5e-5)
+    # the SDF itself does not depend on the switch
+    close(sh, load_golden("g1_sdf_forward")["sdf_hand"])
+
+
+def test_option_state_dict_schemas_match_the_reference():
+    import json, os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g10_state_dict_options.json")))
+    skip = ("mano_head.", "mano_layer.")
+    for key, kw in (("pre_norm", dict(pre_norm=True)), ("classifier", dict(classifier=True))):
+        ours = set(T.hot_path_param_shapes(992, **kw))
+        theirs = {k for k in ref[key] if not k.startswith(skip)}
+        assert ours == theirs, (key, sorted(ours ^ theirs)[:8])
+
+
 def test_g6_vote(P):
     g = load_golden("g6_vote")
     inter = load_golden("g5_transformer")["inter"]
