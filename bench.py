@@ -59,6 +59,7 @@ class KernelTimer:
         "hoisdf_attention_bwd": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,B,H,Lq,Lk,kv_len,ws,nws): algorithmic QK^T + PV (the 3x split products are not counted)
         "hoisdf_attention_fwd_f16": lambda a: 4.0 * a[8] * a[9] * a[10] * a[12] * 64,
+        "hoisdf_attention_fwd_bf16x2": lambda a: 4.0 * a[8] * a[9] * a[10] * a[12] * 64,      # same argument list
         # emulated fp32 attention: (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         "hoisdf_attention_fwd_emu": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_emu": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
@@ -85,7 +86,7 @@ class KernelTimer:
 
     SHAPE = {"hoisdf_linear_fwd": (7, 8, 9), "hoisdf_linear_bwd_input": (8, 9, 10), "hoisdf_linear_bwd_weight": (9, 10, 11),
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
-             "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
+             "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_attention_fwd_bf16x2": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
              "hoisdf_linear_fwd_emu_small": (7, 8, 9), "hoisdf_linear_bwd_input_emu_small": (8, 9, 10),
@@ -501,12 +502,14 @@ def main():
             ("emu_small_kernel / emu_small_dw_kernel (linear layers of < 2048 rows: decoder stack, heads; latency-bound)",
              ["hoisdf_linear_fwd_emu_small", "hoisdf_linear_bwd_input_emu_small", "hoisdf_linear_bwd_weight_emu_small"], "emu"),
             ("emu_attn_fwd2_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
-            ("emu_attn_bwd_stag_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes)", ["hoisdf_attention_bwd_emu"], "emu"),
-            ("attn_fwd_f16_kernel (+ operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
+            ("emu_attn_bwd4_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes; emu_attn_bwd_stag_kernel with HOISDF_EMU_ATTN_BWD=3)",
+             ["hoisdf_attention_bwd_emu"], "emu"),
+            ("emu_attn_fwd2_kernel<NPL = 2> (bf16 hi + lo operands, three products; + conversion passes)", ["hoisdf_attention_fwd_bf16x2"], "split"),
+            ("attn_fwd_f16_kernel (round 2, HOISDF_ATTN16=f16; + operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
         ]
         PEAK = {"f32": (PEAK_F32_TFLOPS, "f32 MFMA peak (= f32 vector peak), MI355X_MICROARCH.md:41"),
                 "emu": (round(PEAK_F16_TFLOPS / 6.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product (MI355X_MICROARCH.md:42)"),
-                "split": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense f16 MFMA peak 2500 TFLOP/s / 3 products per product")}
+                "split": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per product (hi + lo operand pairs)")}
         agg = {}
         for fam, members, cls in FAMS:
             ms = sum(ks[m]["total_ms"] for m in members if m in ks)

@@ -151,6 +151,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_bwd": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                              _I, _F, _U64, _P],
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "hoisdf_attention_fwd_bf16x2": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P],
     "hoisdf_attention_bwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
                                  _L, _P],
@@ -210,6 +211,7 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_linear_emu_small_max_rows": ([], C.c_int),
           "hoisdf_linear_emu_small_supported": ([_P, _L, _P, _L, _L, _I, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
+          "hoisdf_attention_bf16x2_workspace": ([_I, _I, _I, _I], C.c_long),
           "hoisdf_attention_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long),
           "hoisdf_attention_bwd_emu_workspace": ([_I, _I, _I, _I, _I], C.c_long)}
 

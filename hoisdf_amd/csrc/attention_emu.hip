@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<bf16x8*>(r0 + o + 8 * i) = pa[i][0];
       *reinterpret_cast<bf16x8*>(r1 + o + 8 * i) = pa[i][1];
-      *reinterpret_cast<bf16x8*>(r2 + o + 8 * i) = pa[i][2];
+      if (r2) *reinterpret_cast<bf16x8*>(r2 + o + 8 * i) = pa[i][2];          // (two-plane callers pass null third planes)
     }
   }
   if (t0) {                                                // block-uniform
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<u32x4*>(t0 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[0][d * TP + rc + 8 * i]);
       *reinterpret_cast<u32x4*>(t1 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[1][d * TP + rc + 8 * i]);
-      *reinterpret_cast<u32x4*>(t2 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[2][d * TP + rc + 8 * i]);
+      if (t2) *reinterpret_cast<u32x4*>(t2 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[2][d * TP + rc + 8 * i]);
     }
   }
 }
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 // ============================================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-template <bool DROP>
+// NPL = planes per operand: 3 = fp32-equivalent (six products per product); 2 = bf16 hi + lo operands, three products - the 16-bit-operand
+// evaluation kernel of BASELINE configs[4] (hoisdf_attention_fwd_bf16x2; ~2^-17 relative operand error, f32 softmax and accumulation)
+template <bool DROP, int NPL>
 __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   __shared__ __attribute__((aligned(16))) __bf16 Kb0[3 * ROWS_T];
   __shared__ __attribute__((aligned(16))) __bf16 Kb1[3 * ROWS_T];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 
   bf16x8 qf[4][3];                        // Q^T fragments: k-step j <-> d = 16 j + 8 h .. + 7 of the lane's query
 #pragma unroll
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < NPL; ++p) {
     const __bf16* sq = a.q[p] + ((size_t)bh * a.Lqp + qrow) * D;
 #pragma unroll
     for (int j = 0; j < 4; ++j) qf[j][p] = *reinterpret_cast<const bf16x8*>(sq + 16 * j + 8 * h);
@@ -372,6 +374,16 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
       pw[(pr) >> 2][2] = __builtin_bit_cast(bf16x8, u32x4{w2[(pr) - 3], w2[(pr) - 2], w2[(pr) - 1], w2[pr]});          \
     }                                                                                                                  \
   } while (0)
+// (two planes: the second piece closes the split)
+#define PE3B(pr)                                                                                                       \
+  do {                                                                                                                 \
+    f32x2 r_; PK_SUB(r_, e_[pr], f_[pr]);                                                                              \
+    w1[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r_, bf16x2));                                        \
+    if (((pr) & 3) == 3) {                                                                                             \
+      pw[(pr) >> 2][0] = __builtin_bit_cast(bf16x8, u32x4{w0[(pr) - 3], w0[(pr) - 2], w0[(pr) - 1], w0[pr]});          \
+      pw[(pr) >> 2][1] = __builtin_bit_cast(bf16x8, u32x4{w1[(pr) - 3], w1[(pr) - 2], w1[(pr) - 1], w1[pr]});          \
+    }                                                                                                                  \
+  } while (0)
 // ---- units of the PV phase: running maximum of tile t + 1 (four scores each), dropout decisions of tile t + 1 (pair pr = keys
 // CR(2 pr, h), CR(2 pr, h) + 1: one hash, the low half decides the even key), staging
 // (the empty asm statements pin a unit's result HERE: without them the optimiser sinks the maximum into the rarely taken statistics
@@ -400,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #undef PE2
 #undef PE3
 #undef PE4
+#undef PE3B
 #undef PM
 #undef PH1
 #undef PH2
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #define PE2(pr) ((void)0)
 #define PE3(pr) ((void)0)
 #define PE4(pr) ((void)0)
+#define PE3B(pr) ((void)0)
 #define PM(i) ((void)0)
 #define PH1(pr) ((void)0)
 #define PH2(pr) ((void)0)
@@ -456,22 +470,27 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 
   // ---- prologue: K(0), V(0), K(1) staged; K(2), V(1) in registers; S(0) and its statistics
 #pragma unroll
-  for (int p = 0; p < 3; ++p) { rk[p] = ld_rows(kp[p], 0, tid); rv[p] = ld_trn(vp[p], a.Lkp, 0, tid); }
+  for (int p = 0; p < NPL; ++p) { rk[p] = ld_rows(kp[p], 0, tid); rv[p] = ld_trn(vp[p], a.Lkp, 0, tid); }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) { st_rows(Kb0 + p * ROWS_T, rk[p], tid); st_trn(Vb0 + p * TRN_T, rv[p], tid); }
+  for (int p = 0; p < NPL; ++p) { st_rows(Kb0 + p * ROWS_T, rk[p], tid); st_trn(Vb0 + p * TRN_T, rv[p], tid); }
 #pragma unroll
-  for (int p = 0; p < 3; ++p) rk[p] = ld_rows(kp[p], (size_t)min(1, lastt) * 32, tid);
+  for (int p = 0; p < NPL; ++p) rk[p] = ld_rows(kp[p], (size_t)min(1, lastt) * 32, tid);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) st_rows(Kb1 + p * ROWS_T, rk[p], tid);
+  for (int p = 0; p < NPL; ++p) st_rows(Kb1 + p * ROWS_T, rk[p], tid);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) { rk[p] = ld_rows(kp[p], (size_t)min(2, lastt) * 32, tid); rv[p] = ld_trn(vp[p], a.Lkp, (size_t)min(1, lastt) * 32, tid); }
+  for (int p = 0; p < NPL; ++p) { rk[p] = ld_rows(kp[p], (size_t)min(2, lastt) * 32, tid); rv[p] = ld_trn(vp[p], a.Lkp, (size_t)min(1, lastt) * 32, tid); }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const bf16x8 k0 = KFRAG(Kb0, 0, j), k1 = KFRAG(Kb0, 1, j), k2 = KFRAG(Kb0, 2, j);
-    MB6(s_nxt, k0, k1, k2, qf[j][0], qf[j][1], qf[j][2]);
+    const bf16x8 k0 = KFRAG(Kb0, 0, j), k1 = KFRAG(Kb0, 1, j);
+    if constexpr (NPL == 3) {
+      const bf16x8 k2 = KFRAG(Kb0, 2, j);
+      MB6(s_nxt, k0, k1, k2, qf[j][0], qf[j][1], qf[j][2]);
+    } else {
+      s_nxt = MB(k1, qf[j][0], s_nxt); s_nxt = MB(k0, qf[j][1], s_nxt); s_nxt = MB(k0, qf[j][0], s_nxt);
+    }
   }
   uint32_t hbase = rowkey + (uint32_t)(2 * h) * 0x9E3779B9U;      // + (kt * 16) * G per tile: the hash input of the lane's key pair 0 (keys 4 h, 4 h + 1)
   // the statistics step every tile goes through once its scores exist (s_nxt = scores of tile `KT`): mask the keys past kv_len,
@@ -507,17 +526,17 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   do {                                                                                                                 \
     __bf16* kw = (KW); __bf16* vw = (VW);                                                                              \
     const int ktn = min((t) + 3, lastt), vtn = min((t) + 2, lastt);                                                    \
-    kf[0][0] = KFRAG(KR, 0, 0); kf[0][1] = KFRAG(KR, 1, 0); kf[0][2] = KFRAG(KR, 2, 0);                                \
+    kf[0][0] = KFRAG(KR, 0, 0); kf[0][1] = KFRAG(KR, 1, 0); if constexpr (NPL == 3) kf[0][2] = KFRAG(KR, 2, 0);        \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) s_nxt[r] = 0.f;                                                     \
     ps = 0.f;                                                                                                          \
     SB();                                                                                                              \
-    FWD2_S(KR);                                                                                                        \
+    if constexpr (NPL == 3) FWD2_S(KR); else FWD2_S2(KR);                                                              \
     lsum += ps;                                                                                                        \
-    vf[0][0] = VFRAG(VR, 0, 0, 0); vf[0][1] = VFRAG(VR, 1, 0, 0); vf[0][2] = VFRAG(VR, 2, 0, 0);                       \
+    vf[0][0] = VFRAG(VR, 0, 0, 0); vf[0][1] = VFRAG(VR, 1, 0, 0); if constexpr (NPL == 3) vf[0][2] = VFRAG(VR, 2, 0, 0); \
     mt = -INFINITY;                                                                                                    \
     hbase += 16u * 0x9E3779B9U;                                                                                        \
     SB();                                                                                                              \
-    FWD2_PV(VR);                                                                                                       \
+    if constexpr (NPL == 3) FWD2_PV(VR); else FWD2_PV2(VR);                                                            \
     if ((t) + 1 <= lastt) FWD2_TILE_STATS((t) + 1, false);      /* (the re-read tile past the end is dropped) */          \
     s_cur = s_nxt;                                                                                                     \
     FWD2_SYNC();                                                                                                       \
@@ -546,6 +565,9 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #undef LDV
 #undef FWD2_S
 #undef FWD2_PV
+#undef FWD2_S2
+#undef FWD2_PV2
+#undef PE3B
 #undef FWD2_TILE_STATS
 #undef FWD2_ITER
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
@@ -956,8 +978,8 @@ int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
   if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_FWD"); form = (e && atoi(e) == 1) ? 1 : 2; }
   const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
   if (form == 1) hipLaunchKernelGGL(emu_attn_fwd_kernel, fgrid, dim3(256), 0, st, a);
-  else if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_fwd2_kernel<true>, fgrid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(emu_attn_fwd2_kernel<false>, fgrid, dim3(256), 0, st, a);
+  else if (drop_p > 0.f) hipLaunchKernelGGL((emu_attn_fwd2_kernel<true, 3>), fgrid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 3>), fgrid, dim3(256), 0, st, a);
   return check_launch("attention_fwd_emu");
 }
 }  // namespace
@@ -981,6 +1003,42 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
   if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
   return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st);
+}
+
+// ---- 16-bit-operand evaluation attention (BASELINE configs[4] "fp16 MFMA attention"): the pipelined forward over TWO bf16 planes per
+// operand (hi + lo: 16 significant bits, the f32 exponent range - no scaling, no overflow at trained sigma gates), three MFMA
+// products per product, f32 softmax and accumulation.  No dropout, no LSE.
+extern "C" long hoisdf_attention_bf16x2_workspace(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  return (long)((2 * plane_elems(B, H, pad128(Lq)) + 4 * plane_elems(B, H, pad128(Lk))) * sizeof(__bf16));
+}
+
+extern "C" int hoisdf_attention_fwd_bf16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                           int B, int H, int Lq, int Lk, int kv_len, void* workspace, long workspace_bytes, void* stream) {
+  if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, 0.f, "attention_fwd_bf16x2")) return rc;
+  HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
+                 HOISDF_ERR_INVALID, "attention_fwd_bf16x2: bad output / workspace");
+  const long need = hoisdf_attention_bf16x2_workspace(B, H, Lq, Lk);
+  HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_fwd_bf16x2: workspace %ld < %ld bytes", workspace_bytes, need);
+  const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
+  hipStream_t st = as_stream(stream);
+  __bf16* w = reinterpret_cast<__bf16*>(workspace);
+  const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
+  Planes pq{}, pk{}, pv{};
+  pq.r[0] = w; pq.r[1] = w + nq; w += 2 * nq;
+  pk.r[0] = w; pk.r[1] = w + nk; w += 2 * nk;
+  pv.t[0] = w; pv.t[1] = w + nk;
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
+  EmuAttn a{};
+  for (int i = 0; i < 2; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
+  a.out = o; a.lse = nullptr; a.ldo = ldo;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
+  a.drop_p = 0.f; a.inv_keep = 1.f; a.thresh = 0; a.seed = 0;
+  const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
+  hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 2>), fgrid, dim3(256), 0, st, a);
+  return check_launch("attention_fwd_bf16x2");
 }
 
 // (internal, common.h) the plane addresses of a forward workspace as targets of linear_fwd_emu_qkv: q_part for a GEMM over the

@@ -1148,12 +1148,22 @@ def _attn_fwd_f16(q, k, v, H, kv_len):
     for t, L in ((q, Lq), (k, Lk), (v, Lk)):
         assert t.stride(2) == 1 and t.stride(0) == L * t.stride(1), "attention operands must be row-uniform views"
     from ._lib import lib
-    nbytes = lib().hoisdf_attention_f16_workspace(B, H, Lk)
-    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
-    call("hoisdf_attention_fwd_f16", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, B, H, Lq, Lk,
+    if _ATTN16_LEGACY:              # HOISDF_ATTN16=f16: round 2's f16 hi + lo kernel (A/B runs)
+        nbytes = lib().hoisdf_attention_f16_workspace(B, H, Lk)
+        ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+        call("hoisdf_attention_fwd_f16", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, B, H, Lq, Lk,
+             kv_len, _p(ws), nbytes, _st())
+        return o
+    # round 5: bf16 hi + lo operands on the pipelined forward (hoisdf_attention_fwd_bf16x2)
+    nbytes = lib().hoisdf_attention_bf16x2_workspace(B, H, Lq, Lk)
+    ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+    call("hoisdf_attention_fwd_bf16x2", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, B, H, Lq, Lk,
          kv_len, _p(ws), nbytes, _st())
     return o
+
+
+_ATTN16_LEGACY = __import__("os").environ.get("HOISDF_ATTN16", "bf16x2") == "f16"
 
 
 def _use_f16(drop_p, *tensors) -> bool:

@@ -367,6 +367,16 @@ int hoisdf_attention_fwd_f16(const float* q, int ldq, const float* k, int ldk, c
                              float* o, int ldo, int B, int H, int Lq, int Lk, int kv_len, void* workspace,
                              long workspace_bytes, void* stream);
 
+/* The 16-bit-operand evaluation attention on the pipelined forward (round 5; what cfg.attention_f16_eval selects by default):
+ * Q, K, V and the probabilities as bf16 hi + lo pairs (two planes per operand: 16 significant bits, the f32 exponent range - none of
+ * the f16 scheme's power-of-two scaling, no overflow at trained sigma gates), three v_mfma_f32_32x32x16_bf16
+ * products per product, f32 softmax state and accumulation.  Same layouts and kv_len semantics as hoisdf_attention_fwd; no dropout,
+ * no lse.  reference: nn.MultiheadAttention forward inside the encoder layers (common/nets/transformer.py:269), BASELINE.json
+ * configs[4].  workspace: hoisdf_attention_bf16x2_workspace(B, H, Lq, Lk) bytes, 16-byte aligned. */
+long hoisdf_attention_bf16x2_workspace(int B, int H, int Lq, int Lk);
+int hoisdf_attention_fwd_bf16x2(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                int B, int H, int Lq, int Lk, int kv_len, void* workspace, long workspace_bytes, void* stream);
+
 /* ---- fp32 attention emulated on the bf16 MFMA pipe ("bf16x3"; cfg.attention_emu, default) -------------------------------
  * reference: nn.MultiheadAttention inside the encoder layers (common/nets/transformer.py:269,286-302), forward + autograd
  * backward.  Same contracts, argument meaning, LSE convention (log2 domain) and dropout mask as hoisdf_attention_fwd / _bwd;

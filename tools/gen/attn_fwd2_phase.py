@@ -63,7 +63,53 @@ def phase_pv():
     return emit("FWD2_PV", "VB", slots)
 
 
+PROD2 = [(1, 0), (0, 1), (0, 0)]                               # two planes per operand (bf16 hi + lo): three products
+
+
+def phase_s2():
+    """FWD2_S2: the 12 MFMAs of S(t + 1) over two planes with the softmax / two-way split of tile t (8 pairs x 3 units)"""
+    work = {}
+    add = lambda s, w: work.setdefault(s, []).append(w)
+    for j in range(1, 4):
+        for p in range(2):
+            add(3 * (j - 1) + 1 + p, f"kf[{j & 1}][{p}] = KFRAG(KB, {p}, {j})")
+    units = []
+    for pr in range(8):
+        units += [f"PE1({pr})", f"PE2({pr})", f"PE3B({pr})"]
+    for i, u in enumerate(units):
+        add(i * 12 // len(units), u)
+    slots = []
+    for j in range(4):
+        for k, (x, y) in enumerate(PROD2):
+            m = 3 * j + k
+            slots.append((f"s_nxt = MB(kf[{j & 1}][{x}], qf[{j}][{y}], s_nxt)", "; ".join(work.get(m, []))))
+    return emit("FWD2_S2", "KB", slots)
+
+
+def phase_pv2():
+    work = {}
+    add = lambda s, w: work.setdefault(s, []).append(w)
+    for g in range(1, 4):
+        jj, dt = g >> 1, g & 1
+        for p in range(2):
+            add(3 * (g - 1) + 1 + p, f"vf[{g & 1}][{p}] = VFRAG(VB, {p}, {dt}, {jj})")
+    for i in range(4): add(3 + i, f"PM({i})")        # (asm reads of the S accumulator: kept >= 3 MFMAs behind the last S MFMA)
+    units = [f"STK({p})" for p in range(2)] + [f"STV({p})" for p in range(2)] + [f"LDK({p})" for p in range(2)] + [f"LDV({p})" for p in range(2)]
+    for i, u in enumerate(units):
+        add(i * 12 // len(units), u)
+    slots = []
+    for g in range(4):
+        jj, dt = g >> 1, g & 1
+        for k, (x, y) in enumerate(PROD2):
+            m = 3 * g + k
+            slots.append((f"o[{dt}] = MB(vf[{g & 1}][{x}], pw[{jj}][{y}], o[{dt}])", "; ".join(work.get(m, []))))
+    return emit("FWD2_PV2", "VB", slots)
+
+
 if __name__ == "__main__":
     print("// generated by tools/gen/attn_fwd2_phase.py - the pinned half-iterations of emu_attn_fwd2_kernel (one MFMA + the units behind it)")
     print(phase_s())
     print(phase_pv())
+    print("// two planes per operand (bf16 hi + lo, three products per product): the 16-bit-operand evaluation kernel of BASELINE configs[4]")
+    print(phase_s2())
+    print(phase_pv2())
