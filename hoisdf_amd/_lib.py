@@ -37,7 +37,8 @@ class SdfWeights(C.Structure):
     _fields_ = [("C", C.c_int), ("sdfin_w0", C.c_void_p), ("sdfin_b0", C.c_void_p), ("sdfin_w1", C.c_void_p),
                 ("sdfin_b1", C.c_void_p), ("dec_w0", C.c_void_p), ("dec_b0", C.c_void_p), ("dec_ld0", C.c_int),
                 ("dec_w1", C.c_void_p), ("dec_b1", C.c_void_p), ("dec_w2", C.c_void_p), ("dec_b2", C.c_void_p),
-                ("dec_w3", C.c_void_p), ("dec_b3", C.c_void_p), ("dec_w4", C.c_void_p), ("dec_b4", C.c_void_p)]
+                ("dec_w3", C.c_void_p), ("dec_b3", C.c_void_p), ("dec_w4", C.c_void_p), ("dec_b4", C.c_void_p),
+                ("emu_img", C.c_void_p * 6), ("emu_img_t", C.c_void_p * 6)]
 
 
 class EncoderLayerDesc(C.Structure):
@@ -96,7 +97,8 @@ MLP_MAX_LAYERS = 4
 class Mlp(C.Structure):
     """include/hoisdf.h hoisdf_mlp"""
     _fields_ = [("n_layers", C.c_int), ("act_last", C.c_int), ("dims", C.c_int * (MLP_MAX_LAYERS + 1)),
-                ("w", C.c_void_p * MLP_MAX_LAYERS), ("b", C.c_void_p * MLP_MAX_LAYERS)]
+                ("w", C.c_void_p * MLP_MAX_LAYERS), ("b", C.c_void_p * MLP_MAX_LAYERS),
+                ("img", C.c_void_p * MLP_MAX_LAYERS), ("img_t", C.c_void_p * MLP_MAX_LAYERS)]
 
 
 class EmuPrepItem(C.Structure):

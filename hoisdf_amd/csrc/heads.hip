@@ -38,7 +38,7 @@ void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, c
   for (int i = 0; i < m->n_layers; ++i) {
     float* out = i < last ? s.h[i] : y;
     const int ldo = i < last ? m->dims[i + 1] : ldy;
-    lin_fwd(c, in, ldin, m->w[i], m->dims[i], nullptr, m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i]);
+    lin_fwd(c, in, ldin, m->w[i], m->dims[i], m->img[i], m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i]);
     in = out; ldin = ldo;
   }
 }
@@ -54,7 +54,7 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
     float* gin = i > 0 ? c.ws->floats(M * m->dims[i]) : dx;
     const int ldgin = i > 0 ? m->dims[i] : lddx;
     if (!c.dry && c.ok() && !gin) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-    lin_bwd_input(c, g, ldg, s.bits[i], 0.f, m->w[i], m->dims[i], nullptr, gin, ldgin, M, m->dims[i + 1], m->dims[i], i == 0 ? accumulate_dx : 0);
+    lin_bwd_input(c, g, ldg, s.bits[i], 0.f, m->w[i], m->dims[i], m->img_t[i], gin, ldgin, M, m->dims[i + 1], m->dims[i], i == 0 ? accumulate_dx : 0);
     g = gin; ldg = ldgin;
   }
 }

@@ -30,11 +30,12 @@ inline long emu_scratch_bytes(int C) {
 }
 
 // one layer: fp32 emulated on the bf16 MFMA pipe (default, large point sets) or the exact-f32 MFMA GEMM.  K_pad >= K: columns K .. K_pad - 1 of x are zero padding (they meet zero weights in the image).
+// `given`: the caller's cached image of this weight (hoisdf_sdf_weights.emu_img), NULL = built into emu_img right here
 int layer(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, long M, int N, int K,
-          int K_pad, float drop_p, uint64_t seed, void* emu_img, void* stream) {
+          int K_pad, float drop_p, uint64_t seed, void* emu_img, const void* given, void* stream) {
   if (emu_img && M >= EMU_MIN_ROWS_Q && hoisdf_linear_emu_supported(x, ldx, K_pad) && (K_pad + 15) / 16 == (K + 15) / 16) {
-    if (int rc = hoisdf_linear_emu_prepare(W, ldw, N, K, 0, emu_img, stream)) return rc;
-    return hoisdf_linear_fwd_emu(x, ldx, emu_img, b, y, ldy, M, N, K_pad, 1, drop_p, seed, nullptr, stream);
+    if (!given) { if (int rc = hoisdf_linear_emu_prepare(W, ldw, N, K, 0, emu_img, stream)) return rc; }
+    return hoisdf_linear_fwd_emu(x, ldx, given ? given : emu_img, b, y, ldy, M, N, K_pad, 1, drop_p, seed, nullptr, stream);
   }
   return hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, stream);
 }
@@ -85,22 +86,22 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   }
   float* x0 = cat + X0_COL;
   // K2: linear_sdfin (main/model.py:63-69): C -> 512 -> 256, ReLU after both; the second layer lands in x0[:, 0:256]
-  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, img, stream);
+  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, img, w->emu_img[0], stream);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, img, stream);
+  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, img, w->emu_img[1], stream);
   if (rc) return rc;
   // K3: posenc + xyz into x0[:, 256:289], pad columns 289..291 zeroed (common/utils/sdf_utils.py:96-141)
   rc = hoisdf_posenc_fwd(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, stream);
   if (rc) return rc;
   // K4: decoder (common/nets/sdf_net.py:87-122); dropout(p) after every hidden ReLU when the module is in train() mode
   // (the reference's detached training-time queries run with it on), stream ids seed + layer
-  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, img, stream);   // the three pad columns of x0 are zero
+  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, img, w->emu_img[2], stream);   // the three pad columns of x0 are zero
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, stream);
+  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, w->emu_img[3], stream);
   if (rc) return rc;
-  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, stream);
+  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, w->emu_img[4], stream);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, stream);
+  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, w->emu_img[5], stream);
   if (rc) return rc;
   return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
 }
@@ -257,14 +258,14 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   }
   float* x0 = dry ? nullptr : s.cat + X0_COL;
   // linear_sdfin: C -> 512 -> 256, ReLU after both (main/model.py:63-69)
-  lin_fwd(c, s.feat, C, w->sdfin_w0, C, nullptr, w->sdfin_b0, s.ha, HID0, n, HID0, C, 1, 0.f, 0, s.ba);
-  lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, nullptr, w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf);
+  lin_fwd(c, s.feat, C, w->sdfin_w0, C, w->emu_img[0], w->sdfin_b0, s.ha, HID0, n, HID0, C, 1, 0.f, 0, s.ba);
+  lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, w->emu_img[1], w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf);
   if (!dry && c.ok()) c.rc = hoisdf_posenc_fwd(points, n, s.cat, CAT_LD, X0_COL + LAT, pe, stream);
   // decoder (common/nets/sdf_net.py:87-122); layer i draws dropout stream seed + i
-  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, nullptr, w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3);   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
-  lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, nullptr, w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1);
-  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, nullptr, w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2);
-  lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, nullptr, w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3);
+  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, w->emu_img[2], w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3);   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
+  lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, w->emu_img[3], w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1);
+  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, w->emu_img[4], w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2);
+  lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, w->emu_img[5], w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3);
   if (!dry && c.ok()) c.rc = hoisdf_sdf_head_fwd(s.h3, HID0, w->dec_w4, w->dec_b4, s.raw, sdf, n, HID0, clamp, stream);
   return c.rc;
 }
@@ -280,22 +281,22 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   float* dha = ws.floats(n * HID0); float* dfeat = ws.floats(n * (long)C);
   if (!dry && (!dh3 || !dh2 || !dcat || !dh0 || !dha || !dfeat)) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
   if (!dry) c.rc = hoisdf_sdf_head_bwd(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, stream);
-  lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, nullptr, dh2, HID0, n, HID0, HID0, 0);
+  lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0);
   lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0);
-  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, nullptr, dcat, CAT_LD, n, HID0, CAT_LD, 0);
+  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, w->emu_img_t[4], dcat, CAT_LD, n, HID0, CAT_LD, 0);
   lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD);
-  lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, nullptr, dh0, HID0, n, H1 + 1, HID0, 0);
+  lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, w->emu_img_t[3], dh0, HID0, n, H1 + 1, HID0, 0);
   lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0);
   // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is [512][292]
   // (contracted over the padded row so that it takes the bf16 pipe like the forward; the three pad columns come out zero)
   float* dx0 = dry ? nullptr : dcat + X0_COL;
   const float* x0 = dry ? nullptr : s.cat + X0_COL;
-  lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, nullptr, dx0, CAT_LD, n, HID0, X0, 1);
+  lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, w->emu_img_t[2], dx0, CAT_LD, n, HID0, X0, 1);
   lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0, X0 + 3);
   // linear_sdfin: its output sits in x0[:, 0:256] (positional encoding / xyz columns carry no gradient)
-  lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, nullptr, dha, HID0, n, LAT, HID0, 0);
+  lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, w->emu_img_t[1], dha, HID0, n, LAT, HID0, 0);
   lin_bwd_weight(c, dx0, CAT_LD, s.bf, 0.f, s.ha, HID0, G->d_sdfin_w1, G->d_sdfin_b1, n, LAT, HID0);
-  lin_bwd_input(c, dha, HID0, s.ba, 0.f, w->sdfin_w0, C, nullptr, dfeat, C, n, HID0, C, 0);
+  lin_bwd_input(c, dha, HID0, s.ba, 0.f, w->sdfin_w0, C, w->emu_img_t[0], dfeat, C, n, HID0, C, 0);
   lin_bwd_weight(c, dha, HID0, s.ba, 0.f, s.feat, C, G->d_sdfin_w0, G->d_sdfin_b0, n, HID0, C);
   if (!dry && c.ok() && dpyr)
     c.rc = hoisdf_project_gather_bwd(dpyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, dfeat, C, stream);

@@ -628,6 +628,8 @@ class SdfQueryWeights:
         self.sdfin, self.decoder = sdfin, decoder
         self._key = None
         self._keep = None
+        self._fold = None
+        self._images = None
         self.struct = None
 
     def _params(self):
@@ -640,33 +642,67 @@ class SdfQueryWeights:
 
     @torch.no_grad()
     def get(self):
-        from ._lib import SdfWeights
+        from ._lib import SdfWeights, EmuPrepItem, lib
         ps = self._params()
-        key = (_WEIGHT_GEN[0],) + tuple((p.data_ptr(), p._version) for p in ps)
+        key = (_WEIGHT_GEN[0], _GEMM_EMU) + tuple((p.data_ptr(), p._version) for p in ps)
         if key == self._key:
             return self.struct
         d, dev = self.decoder, ps[0].device
-        W = [weight_norm(getattr(d, f"linh{i}").weight_v.detach(), getattr(d, f"linh{i}").weight_g.detach()) for i in range(4)]
-        w1 = torch.zeros(224, 512, device=dev)
-        w1[:223] = W[1]
-        b1 = torch.zeros(224, device=dev)
-        b1[:223] = d.linh1.bias.detach()
-        w2 = torch.zeros(512, 516, device=dev)
-        w2[:, :223] = W[2][:, :223]
-        w2[:, 224:513] = W[2][:, 223:]
         s0, s1 = self.sdfin.layers[0], self.sdfin.layers[1]
+        Cc = s0.weight.shape[1]
+        if self._keep is None or self._keep[0].device != dev or self._keep[0].data_ptr() != s0.weight.data_ptr():
+            # persistent homes of the folded / re-laid matrices: the descriptor (and the device table of the image builder) keeps
+            # its addresses across optimizer steps
+            z = lambda *sh: torch.zeros(*sh, device=dev)
+            self._fold = dict(W0=z(512, 289), w1=z(224, 512), b1=z(224), w2=z(512, 516), W3=z(512, 512), tmp=z(512, 512))
+            self._images = None
+        f = self._fold
+        lh = [getattr(d, f"linh{i}") for i in range(4)]
+        assert lh[0].weight_v.shape == (512, 289) and lh[1].weight_v.shape == (223, 512) and lh[2].weight_v.shape == (512, 512) and \
+            lh[3].weight_v.shape == (512, 512) and s0.weight.shape[0] == 512 and s1.weight.shape == (256, 512), \
+            "hoisdf_sdf_query_fwd is built for the released layer sizes (512/256/223)"
+        # weight-norm fold straight into the layouts of include/hoisdf.h hoisdf_sdf_weights (row 223 of w1 / b1 and the pad columns of
+        # w2 stay zero: the skip concatenation is the 516-wide row itself)
+        for l, out, ld in ((lh[0], f["W0"], 289), (lh[1], f["w1"], 512), (lh[2], f["tmp"], 512), (lh[3], f["W3"], 512)):
+            v, g = l.weight_v.detach().contiguous(), l.weight_g.detach().contiguous()
+            _chk(v, g)
+            call("hoisdf_weightnorm_fwd", _p(v), _p(g), _p(out), ld, None, v.shape[0], v.shape[1], _st())
+        f["w2"][:, :223] = f["tmp"][:, :223]
+        f["w2"][:, 224:513] = f["tmp"][:, 223:]
+        f["b1"][:223] = lh[1].bias.detach()
         keep = [s0.weight.detach().contiguous(), s0.bias.detach().contiguous(), s1.weight.detach().contiguous(),
-                s1.bias.detach().contiguous(), W[0].contiguous(), d.linh0.bias.detach().contiguous(), w1, b1, w2,
-                d.linh2.bias.detach().contiguous(), W[3].contiguous(), d.linh3.bias.detach().contiguous(),
+                s1.bias.detach().contiguous(), f["W0"], lh[0].bias.detach().contiguous(), f["w1"], f["b1"], f["w2"],
+                lh[2].bias.detach().contiguous(), f["W3"], lh[3].bias.detach().contiguous(),
                 d.linh4.weight.detach().reshape(-1).contiguous(), d.linh4.bias.detach().contiguous()]
         _chk(*keep)
         st = SdfWeights()
-        st.C = keep[0].shape[1]
+        st.C = Cc
         (st.sdfin_w0, st.sdfin_b0, st.sdfin_w1, st.sdfin_b1, st.dec_w0, st.dec_b0, st.dec_w1, st.dec_b1, st.dec_w2, st.dec_b2,
          st.dec_w3, st.dec_b3, st.dec_w4, st.dec_b4) = (t.data_ptr() for t in keep)
         st.dec_ld0 = keep[4].stride(0)
-        assert keep[0].shape[0] == 512 and keep[2].shape == (256, 512) and keep[4].shape == (512, 289) and \
-            keep[10].shape == (512, 512), "hoisdf_sdf_query_fwd is built for the released layer sizes (512/256/223)"
+        if _GEMM_EMU:
+            # the bf16x3 images of the six matrices, both orientations, rebuilt by ONE launch per fold (a training step used to build
+            # 48 of them one by one inside hoisdf_sdf_query_fwd / _train_fwd / _bwd)
+            mats = [(keep[0], 512, Cc, Cc), (keep[2], 256, 512, 512), (keep[4], 512, 289, 289), (keep[6], 224, 512, 512),
+                    (keep[8], 512, 516, 516), (keep[10], 512, 512, 512)]                # (W, N, K, ldw)
+            if self._images is None:
+                imgs, arr, blk = [], (EmuPrepItem * 12)(), 0
+                for tr in (0, 1):
+                    for i, (W, N, K, ldw) in enumerate(mats):
+                        nb = lib().hoisdf_linear_emu_image_bytes(K if tr else N, N if tr else K)
+                        img = torch.empty(nb, device=dev, dtype=torch.uint8)
+                        it = arr[6 * tr + i]
+                        it.W, it.image, it.first_block = W.data_ptr(), img.data_ptr(), blk
+                        it.ldw, it.N, it.K, it.transpose = ldw, N, K, tr
+                        blk += lib().hoisdf_linear_emu_prepare_blocks(N, K, tr)
+                        imgs.append(img)
+                table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+                self._images = (imgs, table, blk, [m_[0].data_ptr() for m_ in mats])
+            imgs, table, blk, ptrs = self._images
+            assert ptrs == [m_[0].data_ptr() for m_ in mats]
+            call("hoisdf_linear_emu_prepare_batch", _p(table), 12, blk, _st())
+            for i in range(6):
+                st.emu_img[i], st.emu_img_t[i] = imgs[i].data_ptr(), imgs[6 + i].data_ptr()
         self._key, self._keep, self.struct = key, keep, st
         return st
 
@@ -1713,7 +1749,9 @@ def vote_loss(off, cls, pts, gt_mm, radius: float):
 # ---------------------------------------------------------------------------------------------
 # K1 + K7 + K8 and K11 + K12 as single C calls (include/hoisdf.h hoisdf_tokens_*, hoisdf_heads_vote_*)
 # ---------------------------------------------------------------------------------------------
-def _mlp_struct(weights, biases, act_last: bool):
+def _mlp_struct(weights, biases, act_last: bool, rows: int = 0, images: str = ""):
+    """``images``: "f" -> the cached forward weight images ride along (hoisdf_mlp.img), "b" -> the transposed ones of the grad-input
+    GEMMs (img_t), for chains over ``rows`` rows that take the emulated GEMM; the C side builds whatever is missing itself."""
     from ._lib import Mlp, MLP_MAX_LAYERS
     n = len(weights)
     if not 1 <= n <= MLP_MAX_LAYERS:
@@ -1721,11 +1759,24 @@ def _mlp_struct(weights, biases, act_last: bool):
     m = Mlp()
     m.n_layers, m.act_last = n, int(act_last)
     m.dims[0] = weights[0].shape[1]
+    keep = []
+    cached = images and _GEMM_EMU and rows >= _GEMM_EMU_MIN_ROWS
     for i, (w, b) in enumerate(zip(weights, biases)):
         if not w.is_contiguous() or w.shape[1] != m.dims[i]:
             raise ValueError("hoisdf_mlp needs dense weights chained dims[i] -> dims[i + 1]")
         m.dims[i + 1] = w.shape[0]
         m.w[i], m.b[i] = w.data_ptr(), b.data_ptr()
+        if cached and w.data_ptr() % 16 == 0:
+            # forward: contraction = dims[i]; grad-input: contraction = dims[i + 1] (layer 0's input gradient included: hoisdf_tokens_bwd asks for it)
+            if images == "f" and w.shape[1] % 4 == 0:
+                img = _emu_image(w, False)
+                m.img[i] = img.data_ptr()
+                keep.append(img)
+            elif images == "b" and w.shape[0] % 4 == 0:
+                img = _emu_image(w, True)
+                m.img_t[i] = img.data_ptr()
+                keep.append(img)
+    m._keep = keep                  # the images stay alive as long as the struct does
     return m
 
 
@@ -1758,8 +1809,8 @@ class _Tokens(torch.autograd.Function):
         _chk(tok, feat2, cam, center, pe, sdf, beta, *ws_, *bs_)
         if feat2.stride(0) != feat2.shape[1]:
             feat2 = feat2.contiguous()
-        m = _mlp_struct(ws_, bs_, True)
         M = B * P
+        m = _mlp_struct(ws_, bs_, True, M, "f")
         n_saved = lib().hoisdf_tokens_saved_bytes(C.addressof(m), M, 0)
         n_ws = lib().hoisdf_tokens_workspace_bytes(C.addressof(m), M, 0)
         saved = torch.empty(n_saved, device=tok.device, dtype=torch.uint8)
@@ -1780,9 +1831,9 @@ class _Tokens(torch.autograd.Function):
         ws_, bs_ = ctx.saved_tensors[4:4 + n], ctx.saved_tensors[4 + n:]
         dev = dtok.device
         dtok = dtok.contiguous()
-        m = _mlp_struct(ws_, bs_, True)
-        G, dws, dbs = _mlp_grads(ws_, bs_, dev)
         M = B * P
+        m = _mlp_struct(ws_, bs_, True, M, "b")
+        G, dws, dbs = _mlp_grads(ws_, bs_, dev)
         dfeat = torch.empty_like(feat2)
         dbeta = _zeros(1, dev)
         n_ws = lib().hoisdf_tokens_workspace_bytes(C.addressof(m), M, 1)
@@ -1817,7 +1868,7 @@ class _HeadsVote(torch.autograd.Function):
         L, B, P, E = enc.shape
         J = cw[-1].shape[0]
         dev = enc.device
-        mv, mc = _mlp_struct(vw, vb, False), _mlp_struct(cw, cb, False)
+        mv, mc = _mlp_struct(vw, vb, False, L * B * P, "f"), _mlp_struct(cw, cb, False, L * B * P, "f")
         n_saved = lib().hoisdf_heads_vote_saved_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J)
         n_ws = lib().hoisdf_heads_vote_workspace_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J, 0)
         saved = torch.empty(n_saved, device=dev, dtype=torch.uint8)
@@ -1839,7 +1890,7 @@ class _HeadsVote(torch.autograd.Function):
         vw, vb, cw, cb = wb[:nv], wb[nv:2 * nv], wb[2 * nv:2 * nv + nc], wb[2 * nv + nc:]
         L, B, P, E = enc.shape
         dev = enc.device
-        mv, mc = _mlp_struct(vw, vb, False), _mlp_struct(cw, cb, False)
+        mv, mc = _mlp_struct(vw, vb, False, L * B * P, "b"), _mlp_struct(cw, cb, False, L * B * P, "b")
         Gv, dvw, dvb = _mlp_grads(vw, vb, dev)
         Gc, dcw, dcb = _mlp_grads(cw, cb, dev)
         n_ws = lib().hoisdf_heads_vote_workspace_bytes(C.addressof(mv), C.addressof(mc), L, B, P, J, 1)

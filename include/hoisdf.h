@@ -226,6 +226,12 @@ typedef struct hoisdf_sdf_weights {
   const float *dec_w2, *dec_b2;           /* [512][516], [512] */
   const float *dec_w3, *dec_b3;           /* [512][512], [512] */
   const float *dec_w4, *dec_b4;           /* [512], [1] */
+  /* optional (NULL = built per call in the workspace): bf16x3 slab images (hoisdf_linear_emu_prepare) of the six matrices
+   * sdfin_w0, sdfin_w1, dec_w0 .. dec_w3 in this order - emu_img for the forward GEMMs, emu_img_t (transpose = 1) for the
+   * grad-input GEMMs of hoisdf_sdf_query_bwd.  The caller rebuilds them whenever it re-folds the weights (one
+   * hoisdf_linear_emu_prepare_batch launch); a training step otherwise builds 48 images inside these entries. */
+  const void* emu_img[6];
+  const void* emu_img_t[6];
 } hoisdf_sdf_weights;
 long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat);
 int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
@@ -570,6 +576,11 @@ typedef struct hoisdf_mlp {
   int dims[HOISDF_MLP_MAX_LAYERS + 1];
   const float* w[HOISDF_MLP_MAX_LAYERS];
   const float* b[HOISDF_MLP_MAX_LAYERS];
+  /* optional (NULL = built per call in the workspace): the bf16x3 slab images of w[i] (hoisdf_linear_emu_prepare, transpose 0 for
+   * the forward, transpose 1 for the grad-input GEMM) when the caller keeps them cached across calls - a training step otherwise
+   * rebuilds ~30 of them inside these entries */
+  const void* img[HOISDF_MLP_MAX_LAYERS];
+  const void* img_t[HOISDF_MLP_MAX_LAYERS];
 } hoisdf_mlp;
 typedef struct hoisdf_mlp_grads {
   float* dw[HOISDF_MLP_MAX_LAYERS];
