@@ -7,7 +7,8 @@ CASES = {
     # name: (C entry, kernel substring, shape)
     "attn_bwd_f32_32x2048x2048": ("hoisdf_attention_bwd", "attn_bwd_fused_kernel", (32, 2048, 2048)),
     "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd2_kernel", (32, 2048, 2048)),
-    "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd_stag_kernel", (32, 2048, 2048)),
+    "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd4_kernel", (32, 2048, 2048)),
+    "attn_fwd_bf16x2_4x8192x8192": ("hoisdf_attention_fwd_bf16x2", "emu_attn_fwd2_kernel<false, 2>", (4, 8192, 8192)),
     "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 1024, 256)),
     "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 256, 1024)),
     "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu", "emu_kc2_kernel<true, false>", (65536, 1024, 256)),
@@ -28,6 +29,13 @@ if __name__ == "__main__":
         q = torch.randn(B, Lq, E, device=dev); kv = torch.randn(B, Lk, 2 * E, device=dev); do = torch.randn(B, Lq, E, device=dev)
         k, v = kv[:, :, :E], kv[:, :, E:]
         dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+        if entry == "hoisdf_attention_fwd_bf16x2":              # configs[4]: evaluation, no dropout
+            O.set_attention_f16_eval(True)
+            with torch.no_grad():
+                for _ in range(3):
+                    O._attn_fwd_f16(q, k, v, H, Lk)
+            torch.cuda.synchronize()
+            sys.exit(0)
         o, lse = O._attn_fwd(q, k, v, H, Lk, p, 1234)
         for _ in range(3):
             if entry == "hoisdf_attention_bwd":

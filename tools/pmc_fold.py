@@ -26,6 +26,7 @@ def main():
         f = rows(os.path.join(d, f"{case}.pass1.csv"), ksub)
         w = rows(os.path.join(d, f"{case}.pass2.csv"), ksub)
         b = rows(os.path.join(d, f"{case}.pass3.csv"), ksub)
+        q = rows(os.path.join(d, f"{case}.pass4.csv"), ksub)
         if not (f or w or b):
             continue
         mean = lambda xs, i: sum(x[i] for x in xs) / len(xs)
@@ -42,6 +43,11 @@ def main():
             e["mfma_busy"] = round(mean(b["SQ_VALU_MFMA_BUSY_CYCLES"], 0) / (1024.0 * act), 4)
             e["effective_clock_ghz"] = round(act / dur_ns, 3)
             e["duration_us_under_pmc"] = round(dur_ns / 1e3, 1)
+        if "SQ_WAVE_CYCLES" in q and "SQ_WAIT_ANY" in q:         # share of the wave cycles parked at s_waitcnt / s_barrier, issue-stalled, issuing
+            wc = mean(q["SQ_WAVE_CYCLES"], 0)
+            e["wave_wait_frac"] = round(mean(q["SQ_WAIT_ANY"], 0) / wc, 4)
+            if "SQ_WAIT_INST_ANY" in q: e["wave_issue_stall_frac"] = round(mean(q["SQ_WAIT_INST_ANY"], 0) / wc, 4)
+            if "SQ_ACTIVE_INST_ANY" in q: e["wave_issuing_frac"] = round(mean(q["SQ_ACTIVE_INST_ANY"], 0) / wc, 4)
         res.append(e)
     json.dump(res, sys.stdout, indent=1)
 
