@@ -14,6 +14,10 @@ struct EmuAttn {
   const __bf16 *d[3];              // dO rows
   const float* lse_in; const float* delta;
   float* out; float* lse; float* dq_part; float* dk; float* dv;
+  // the chained dQ accumulation of emu_attn_bwd4_kernel<*, true>: dq_part = ONE running sum [bh][Lq][64] that the key blocks of a
+  // (b, head) add to in key-block order, dq_flags [bh][key block][4 waves] = query tiles a wave has added, dq / ldq = the final output
+  float* dq; int* dq_flags; int ldq;
+  int chain_group;                 // key blocks per chain (consecutive blocks kb / chain_group share one running sum; >= 1)
   int ldo, ldk, ldv;
   int B, H, Lq, Lk, Lqp, Lkp, kv_len;
   float drop_p, inv_keep;
@@ -32,5 +36,6 @@ __device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
 
 // attention_emu_bwd4.hip: launches emu_attn_bwd4_kernel over planes that are already converted (the argument block of
 // hoisdf_attention_bwd_emu); returns a HOISDF status
-int attention_bwd4_emu_launch(const emu_attn::EmuAttn& a, hipStream_t st);
+// (chain: dQ through the ordered in-L2 running sum - a.dq_part one [bh][Lq][64] buffer, a.dq_flags zeroed - instead of partials)
+int attention_bwd4_emu_launch(const emu_attn::EmuAttn& a, bool chain, hipStream_t st);
 }  // namespace hoisdf

@@ -1132,10 +1132,37 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
-  static int form = -1;                       // HOISDF_EMU_ATTN_BWD=3: the round-3 form (8 waves x 16 keys, half-step barriers; A/B runs)
-  if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_BWD"); form = (e && atoi(e) == 3) ? 3 : 4; }
+  // HOISDF_EMU_ATTN_BWD: (default) the round-5 kernel with dQ summed across the key blocks through an ordered running sum in L2;
+  // "4p": the same kernel with the per-key-block partial buffer + reduce pass; "3": the round-3 kernel (8 waves x 16 keys) - A/B runs
+  static int form = -1;
+  if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_BWD"); form = !e ? 5 : (atoi(e) == 3 ? 3 : (e[0] == '4' && e[1] == 'p' ? 4 : 5)); }
+  if (form == 5) {
+    // HOISDF_EMU_ATTN_BWD_CHAIN=G (default 1 = one partial per key block + the reduce pass): chains of G key blocks add their dQ
+    // contributions to ONE running sum in order, through the XCD's L2.  An EXPERIMENT, off by default: G = 16 takes the launch from
+    // 1.61 to ~0.6 GB of HBM traffic with bit-identical results, at the SAME speed (2.150 vs 2.155 ms per call at B = 32, S = 2048;
+    // G = 4: 2.18, G = 2: 2.23, and slower at 512 queries: 0.83 vs 0.74) - the partial traffic was never what bounds this kernel (the
+    // board sits at its 1400 W cap, HBM at 0.8 TB/s) and the waits of the chain eat what the reduce pass cost.  It is also only
+    // correct while all key blocks of a (b, head) run on one XCD (observed dispatch behaviour, not a HIP guarantee).
+    static int G = -1;
+    if (G < 0) { const char* e = getenv("HOISDF_EMU_ATTN_BWD_CHAIN"); G = e ? atoi(e) : 1; if (G < 1) G = 1; }
+    const int nkb = cdiv(Lk, 128), nlive = cdiv(kv_len, 128), ngrp = cdiv(nlive, G);
+    // the counters sit behind the ngrp running sums (the region holds nkb partial slots: always room unless G = 1)
+    int* flags = reinterpret_cast<int*>(part + (size_t)ngrp * B * H * Lq * 64);
+    const size_t flag_bytes = (size_t)B * H * nkb * 4 * sizeof(int);
+    const bool chain = G > 1 && nlive > 1 && (size_t)(nkb - ngrp) * B * H * Lq * 64 * sizeof(float) >= flag_bytes;
+    if (chain) {
+      a.dq = dq; a.ldq = ldq; a.dq_flags = flags; a.chain_group = G;
+      if (hipMemsetAsync(flags, 0, flag_bytes, st) != hipSuccess) { set_error("attention_bwd_emu: clearing the chain counters failed"); return HOISDF_ERR_LAUNCH; }
+      if (int rc = attention_bwd4_emu_launch(a, true, st)) return rc;
+      if (ngrp == 1) return HOISDF_OK;          // (the chain's last block wrote dq itself)
+      const long n4c = (long)B * H * Lq * 16;
+      hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4c + 255) / 256)), dim3(256), 0, st, part, ngrp, dq, ldq, B, H, Lq);
+      return check_launch("attention_bwd_emu dq reduce");
+    }
+    if (int rc = attention_bwd4_emu_launch(a, false, st)) return rc;
+  } else
   if (form == 4) {
-    if (int rc = attention_bwd4_emu_launch(a, st)) return rc;
+    if (int rc = attention_bwd4_emu_launch(a, false, st)) return rc;
   } else {
     const dim3 grid(cdiv(Lk, 128) * 8 * cdiv(B * H, 8));
     if (drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd_stag_kernel<true>, grid, dim3(512), B3_LDS_BYTES, st, a);

@@ -72,7 +72,17 @@ __device__ __forceinline__ uint32_t cvt2(f32x2 v) { return __builtin_bit_cast(ui
 __device__ __forceinline__ f32x2 unpack2(uint32_t w) { return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)}; }
 }  // namespace
 
-template <bool DROP>
+// CHAIN (experiment, HOISDF_EMU_ATTN_BWD_CHAIN=G, off by default): fewer dQ partials.  The key blocks of a (b, head) run side by side
+// on ONE XCD (emu_block) and walk the query tiles at the same pace; within a chain of G consecutive key blocks, block kb adds its
+// contribution of a query tile to a running sum that block kb - 1 has already added to - wave w of block kb waits for wave w of block
+// kb - 1 through a counter in L2 (same XCD: plain stores + sc1 loads, no fences), reads the 8 rows x 64 d it owns, adds, writes.
+// Fixed order = run-to-run identical, and with G = 16 bit-identical to the reduce pass (same association).  Measured (B = 32,
+// S = 2048, whole call): G = 16 2.150 ms, G = 8 2.16, G = 4 2.18, G = 2 2.23, partials + reduce 2.155: the 1.07 GB of partial traffic
+// is not what bounds the kernel, and a chain costs its members a start-up skew (one L2 round trip per stage, idle time with one
+// workgroup per CU).  Kept as the measured answer to "halve the dQ partials" (profiles/r05_attn_bwd_dq_chain_ab.txt); correctness
+// relies on the observed block -> XCD placement, which HIP does not promise - hence not the default.
+// (Blocks wait on LOWER block indices only, which the dispatcher starts first; the wait is bounded all the same.)
+template <bool DROP, bool CHAIN>
 __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   float* const xbuf = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + X0_BYTES);
@@ -178,7 +188,15 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
 #define B4_STOREP(i_, BUF_) do { *reinterpret_cast<u32x4*>(lds + (BUF_) + (i_) * QD_PLANE + st_o) = sg[i_]; } while (0)
 #define B4_STORES(SB_) do { if (tid < 64) stats[(SB_) + tid] = rstat; } while (0)
 
-  float* const part = a.dq_part + ((size_t)ktile * a.B * a.H + bh) * a.Lq * D;
+  // CHAIN: key blocks [G grp, G grp + G) of a (b, head) form one chain; its running sum is partial number grp
+  const int nkb_live = (a.kv_len + 127) / 128;                  // key blocks that take part (the others have nq = 0)
+  const int G = CHAIN ? a.chain_group : 1, grp = ktile / G;
+  const bool ch_first = ktile - grp * G == 0, ch_last = ktile - grp * G == G - 1 || ktile == nkb_live - 1;
+  const bool ch_direct = CHAIN && nkb_live <= G;                // a single chain: its last block writes the caller's dq (scaled) itself
+  float* const part = a.dq_part + ((size_t)(CHAIN ? grp : ktile) * a.B * a.H + bh) * a.Lq * D;
+  int* const my_flag = CHAIN ? a.dq_flags + ((size_t)bh * nkb + ktile) * 4 + wave : nullptr;
+  const int* const up_flag = CHAIN && !ch_first ? a.dq_flags + ((size_t)bh * nkb + ktile - 1) * 4 + wave : nullptr;
+  float* const dq_out = CHAIN ? a.dq + (size_t)b * a.Lq * a.ldq + head * D : nullptr;
   if (nq > 0) {
     // ---- prologue: tiles 0 and 1 staged, tile 2 in registers --------------------------------------------------------------
 #pragma unroll
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
     if (DROP) hb = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + 4 * h)) + (uint32_t)(key >> 1) * 0x9E3779B9U;
 
     f32x16 s, dp, dq;
-    f32x4 xo0[2], xo1[2];
+    f32x4 xo0[2], xo1[2], xprev[2];
     bf16x8 fr[2][3], fq0[4];
     u32x4 pwv[3][2], gwv[3][2];
     f32x2 pe[8], pd[8], xx[8], ff[8];
@@ -256,7 +274,39 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
 #define XOS(i_)                                                                                                        \
   do {                                                                                                                 \
     const int q_ = (t - 2) * 32 + 8 * wave + 4 * (i_) + (lane >> 4);                                                   \
-    if (t >= 2 && q_ < a.Lq) *reinterpret_cast<f32x4*>(part + (unsigned)(q_ * D + 4 * (lane & 15))) = xo0[i_] + xo1[i_]; \
+    if (t >= 2 && q_ < a.Lq) {                                                                                         \
+      f32x4 v_ = xo0[i_] + xo1[i_];                                                                                    \
+      if (CHAIN) {                                                                                                     \
+        if (!ch_first) v_ = xprev[i_] + v_;                                                                            \
+        if (ch_last && ch_direct) *reinterpret_cast<f32x4*>(dq_out + (size_t)q_ * a.ldq + 4 * (lane & 15)) = v_ * 0.125f; \
+        else *reinterpret_cast<f32x4*>(part + (unsigned)(q_ * D + 4 * (lane & 15))) = v_;                              \
+      } else {                                                                                                         \
+        *reinterpret_cast<f32x4*>(part + (unsigned)(q_ * D + 4 * (lane & 15))) = v_;                                   \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+// CHAIN: wait until the same wave of the previous key block has added tile t - 2, then fetch its running sum (sc1: served by L2,
+// never a stale L1 line); later, once this wave's own stores are acknowledged, publish the count
+#define XOP()                                                                                                          \
+  do {                                                                                                                 \
+    if (CHAIN && !ch_first && t >= 2) {                                                                                \
+      int spins_ = 0;                                                                                                  \
+      while (__hip_atomic_load(up_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t - 1 && ++spins_ < (1 << 20))   \
+        __builtin_amdgcn_s_sleep(2);                                                                                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                               \
+        const int q_ = (t - 2) * 32 + 8 * wave + 4 * i_ + (lane >> 4);                                                 \
+        const float* src_ = part + (unsigned)(min(q_, a.Lq - 1) * D + 4 * (lane & 15));                                \
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(xprev[i_]) : "v"(src_) : "memory");                  \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define XOW() do { if (CHAIN && !ch_first && t >= 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xprev[0]), "+v"(xprev[1]) : : "memory"); } while (0)
+#define XSIG()                                                                                                         \
+  do {                                                                                                                 \
+    if (CHAIN && !ch_last && t >= 2) {                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+      if (lane == 0) __hip_atomic_store(my_flag, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   \
+    }                                                                                                                  \
   } while (0)
 #define CRC(r_) (((r_) & 3) + 8 * ((r_) >> 2))
 #define HA(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int r_ = 4 * (q_) + i_; uint32_t x_ = hbn + (uint32_t)CRC(r_) * 0x85EBCA77U; x_ ^= x_ >> 15; hx[r_] = x_; PIN2(hx[r_]); } } } while (0)
@@ -415,10 +465,16 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
 #undef XW
 #undef XOL
 #undef XOS
+#undef XOP
+#undef XOW
+#undef XSIG
 #define TW(g_) ((void)0)
 #define XW(g_) ((void)0)
 #define XOL(i_) ((void)0)
 #define XOS(i_) ((void)0)
+#define XOP() ((void)0)
+#define XOW() ((void)0)
+#define XSIG() ((void)0)
 #endif
 #if BWD4_ABL & 16           /* no fragment reads: MFMA skeleton */
 #undef FRQ
@@ -502,7 +558,9 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
     {                                             // the last tile's dQ (written in iteration nq)
       const int t = nq + 1;
       XOL(0); XOL(1);
+      XOP(); XOW();
       XOS(0); XOS(1);
+      XSIG();
     }
   }
   if (key < a.Lk) {
@@ -522,21 +580,27 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
   }
 }
 
-int attention_bwd4_emu_launch(const EmuAttn& a, hipStream_t st) {
+int attention_bwd4_emu_launch(const EmuAttn& a, bool chain, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)B4_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(emu_attn_bwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)B4_LDS_BYTES) != hipSuccess) {
-      set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", B4_LDS_BYTES);
-      return HOISDF_ERR_LAUNCH;
-    }
+    const void* ks[4] = {reinterpret_cast<const void*>(emu_attn_bwd4_kernel<true, true>), reinterpret_cast<const void*>(emu_attn_bwd4_kernel<false, true>),
+                         reinterpret_cast<const void*>(emu_attn_bwd4_kernel<true, false>), reinterpret_cast<const void*>(emu_attn_bwd4_kernel<false, false>)};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4_LDS_BYTES) != hipSuccess) {
+        set_error("attention_bwd_emu: cannot raise the dynamic LDS limit to %u bytes", B4_LDS_BYTES);
+        return HOISDF_ERR_LAUNCH;
+      }
     attr_set = true;
   }
   const dim3 grid(cdiv(a.Lk, 128) * 8 * cdiv(a.B * a.H, 8));
-  if (a.drop_p > 0.f) hipLaunchKernelGGL(emu_attn_bwd4_kernel<true>, grid, dim3(256), B4_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(emu_attn_bwd4_kernel<false>, grid, dim3(256), B4_LDS_BYTES, st, a);
+  const bool drop = a.drop_p > 0.f;
+  if (chain) {
+    if (drop) hipLaunchKernelGGL((emu_attn_bwd4_kernel<true, true>), grid, dim3(256), B4_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((emu_attn_bwd4_kernel<false, true>), grid, dim3(256), B4_LDS_BYTES, st, a);
+  } else {
+    if (drop) hipLaunchKernelGGL((emu_attn_bwd4_kernel<true, false>), grid, dim3(256), B4_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((emu_attn_bwd4_kernel<false, false>), grid, dim3(256), B4_LDS_BYTES, st, a);
+  }
   return check_launch("attention_bwd_emu (bwd4)");
 }
 

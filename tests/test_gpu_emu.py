@@ -402,3 +402,34 @@ def test_emulated_attention_dropout_mask_is_the_f32_kernels_mask():
         OO._ATTN_BWD_EMU = keep_bwd
     assert_close(res[0][0], res[1][0], rel=2e-5, what="dropout out")
     assert_close(res[0][1], res[1][1], rel=5e-5, what="dropout dqkv")
+
+def test_chained_dq_accumulation_is_bit_identical_to_the_partial_buffers():
+    """HOISDF_EMU_ATTN_BWD_CHAIN=16 (csrc/attention_emu_bwd4.hip CHAIN: the key blocks of a (b, head) add their dQ contributions to one
+    running sum in key-block order through L2 instead of 16 partial tiles + a reduce pass) gives the SAME bits as the default form -
+    same summation order - and the round-3 kernel (HOISDF_EMU_ATTN_BWD=3) the same values to rounding."""
+    import hashlib, os, subprocess, sys
+    code = (
+        "import torch, hashlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from hoisdf_amd import ops\n"
+        "g = torch.Generator(device='cuda'); g.manual_seed(5)\n"
+        "B, Lq, Lk, E, H, p = 3, 640, 1024, 256, 4, 0.1\n"
+        "q = torch.randn(B, Lq, E, device='cuda', generator=g); kv = torch.randn(B, Lk, 2 * E, device='cuda', generator=g)\n"
+        "do = torch.randn(B, Lq, E, device='cuda', generator=g)\n"
+        "k, v = kv[:, :, :E], kv[:, :, E:]\n"
+        "dq = torch.empty_like(q); dkv = torch.empty_like(kv)\n"
+        "o, lse = ops._attn_fwd_emu(q, k, v, H, 900, p, 77, keep=False)\n"
+        "ops._attn_bwd_emu(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, 900, p, 77)\n"
+        "torch.cuda.synchronize()\n"
+        "print('HASH', hashlib.sha1(dq.cpu().numpy().tobytes()).hexdigest(), hashlib.sha1(dkv.cpu().numpy().tobytes()).hexdigest(), float(dq.abs().max()))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for label, env in (("partials", {}), ("chain16", {"HOISDF_EMU_ATTN_BWD_CHAIN": "16"}), ("chain4", {"HOISDF_EMU_ATTN_BWD_CHAIN": "4"})):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("HASH")]
+        assert line, out.stderr[-2000:]
+        res[label] = line[0].split()[1:]
+    assert res["chain16"][:2] == res["partials"][:2], res                 # dq and dk / dv bit-identical
+    assert res["chain4"][1] == res["partials"][1]                         # dk / dv do not depend on the dq path
+    assert float(res["partials"][2]) > 0

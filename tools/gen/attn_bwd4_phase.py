@@ -19,9 +19,9 @@ Units of one family are ordered STAGE-major over element quads so that neighbour
     python tools/gen/attn_bwd4_phase.py > hoisdf_amd/csrc/attn_bwd4_phase.inc"""
 import sys
 PROD = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]          # (A plane, B plane): small terms first
-CAP = 20
+CAP = 22
 COST = {"FR": 6, "TR": 9, "HA": 14, "HB": 18, "HC": 22, "LQ": 6, "DL": 6, "PA": 34, "PB": 20, "PC": 14, "PD": 14, "PE": 10,
-        "QA": 22, "QB": 14, "QC": 14, "QD": 10, "TW": 22, "STQ": 8, "STS": 10, "LDG": 8, "LDS_": 6, "XOL": 14, "XOS": 12, "XW": 10}
+        "QA": 22, "QB": 14, "QC": 14, "QD": 10, "TW": 22, "STQ": 8, "STS": 10, "LDG": 8, "LDS_": 6, "XOL": 14, "XOS": 12, "XW": 10, "XOP": 20, "XOW": 4, "XSIG": 8}
 
 
 def staged(stages, extra=None):
@@ -86,24 +86,41 @@ def main():
         fixed(115 + p, f"fr[0][{p}] = FRQN({p}, 0)", "FR")                             # next tile's first S group
 
     # ---- floating units: (name, arg) chains with a window [first, last]; a unit never sits ahead of its predecessor in the chain ----
-    def place(chain, first, last, gap=1):
+    where = {}
+
+    def place(chain, first, last, gap=1, after=None):
+        """units of a dependency chain in order: each goes to the least loaded slot of a short look-ahead window that starts behind
+        its predecessor (gap = 1: a later slot; 0: the same slot is allowed) and shrinks so that the rest of the chain still fits.
+        ``after``: (name, arg) -> unit of another chain that must sit in an EARLIER slot (shared scratch registers)."""
         prev = first - gap
-        for name, arg in chain:
+        n = len(chain)
+        for k, (name, arg) in enumerate(chain):
             lo = max(first, prev + gap)
-            cands = [s for s in range(lo, last + 1) if load[s] + COST[name] <= CAP]
-            s = cands[0] if cands else min(range(lo, last + 1), key=lambda t: (load[t], t))
+            if after and after(name, arg) is not None:
+                lo = max(lo, where[after(name, arg)] + 1)
+            lo = min(lo, last)
+            hi = min(last - gap * (n - 1 - k), lo + 6)          # leave one slot per remaining unit
+            hi = max(hi, lo)
+            s = min(range(lo, hi + 1), key=lambda t: (load[t] + COST[name] > CAP, load[t], t))
             work[s].append(f"{name}({arg})" if arg is not None else f"{name}()")
             load[s] += COST[name]
-            prev = s if gap else s
+            where[(name, arg)] = s
+            prev = s
         return prev
 
-    place([("XOL", 0), ("XOL", 1)], 0, 1, gap=0)
-    place([("XOS", 0), ("XOS", 1)], 6, 20)
-    place([("STQ", i) for i in range(6)] + [("STS", None)] + [("LDG", i) for i in range(6)] + [("LDS_", None)], 2, 47, gap=0)
+    # dQ(t - 2): exchange-tile reads and the wait for / fetch of the previous key block's running sum right behind the barrier, the
+    # add + store ~40 MFMAs later (the L2 round trip is hidden), the publication of this wave's count ~50 later (store
+    # acknowledgement; its vmcnt(0) also covers the tile loads issued in between, which have landed by then)
+    place([("XOL", 0), ("XOL", 1), ("XOP", None)], 0, 2, gap=0)
+    # (ONE chain: a staging register is stored before it is re-loaded, and STS() moves the load offset)
+    place([("STQ", i) for i in range(6)] + [("STS", None)] + [("LDG", i) for i in range(6)] + [("LDS_", None)], 3, 38, gap=0)
+    place([("XOW", None), ("XOS", 0), ("XOS", 1)], 40, 47, gap=0)
+    place([("XSIG", None)], 92, 96)
     place([("LQ", g) for g in range(4)], 20, 25, gap=0)
     place(staged(["PA", "PB", "PC", "PD", "PE"]), 26, 70)                              # S complete at slot 23 (+2), pw before slot 72
     place([("DL", g) for g in range(4)], 44, 49, gap=0)
-    place(staged(["QA", "QB", "QC", "QD"], "TW"), 50, 94)                              # dP complete at slot 47 (+2), gw before slot 96
+    # dP complete at slot 47 (+2), gw before slot 96; the Q units of a quad reuse the scratch registers (xx, ff) of its P units
+    place(staged(["QA", "QB", "QC", "QD"], "TW"), 50, 94, after=lambda name, q: ("PE", q) if name == "QA" else None)
     place([("XW", g) for g in range(4)], 74, 90, gap=0)                                # dq complete at slot 71 (+2)
     place([(st, q) for st in ("HA", "HB", "HC") for q in range(4)], 92, 119)           # dropout decisions of the NEXT tile
 
