@@ -37,7 +37,12 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (
 # error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
 DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--gemm f32 --attention f32)
 DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # the default: 3-way exact bf16 split, 6 products, f32 accumulation
-PMC_FILE = "r04_pmc.json"
+PMC_FILE = "r05_pmc.json"
+# what a BARE v_mfma_f32_32x32x16_bf16 stream (registers only, one wave per SIMD) sustains on this power-capped board (1400 W) when the
+# operands are the bf16x3 pieces of N(0,1) values / uniform random values: 1542-1568 TF of the 2500 TF datasheet peak (2044-2100 TF on
+# zero / constant operands) - tools/ubench/mfma_data.hip, profiles/r05_mfma_rate_vs_operand_data.txt
+MEASURED_MFMA_CEILING_TFLOPS = 1555.0
+STEP_TRACE = "r05_bench_kernel_stats.csv"      # rocprofv3 kernel trace of this bench restricted to the timed steps (tools/trace_stats.py)
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
 
@@ -561,7 +566,10 @@ def main():
             res["roofline"]["traffic_note"] = f"no PMC record: {ex}"
         res["families"] = [{"kernel": fam, "arithmetic": v["cls"], "ms_per_step": round(v["total_ms"] / timed_steps, 3),
                             "launches_per_step": v["launches"] / timed_steps, "achieved_tflops": round(v["tflops"], 2),
-                            "peak_tflops": PEAK[v["cls"]][0], "frac": round(v["tflops"] / PEAK[v["cls"]][0], 4)}
+                            "peak_tflops": PEAK[v["cls"]][0], "frac": round(v["tflops"] / PEAK[v["cls"]][0], 4),
+                            # against what a bare MFMA stream sustains on such operands under this board's power cap (None: f32 MFMA)
+                            "frac_of_measured_mfma_ceiling": (round(v["tflops"] / (MEASURED_MFMA_CEILING_TFLOPS / {"emu": 6.0, "split": 3.0}[v["cls"]]), 4)
+                                                              if v["cls"] in ("emu", "split") else None)}
                            for fam, v in sorted(agg.items(), key=lambda kv: -kv[1]["total_ms"])]
         tot_ms = sum(v["total_ms"] for v in agg.values())
         tot_gf = sum(v["gflop"] for v in agg.values())
@@ -570,6 +578,31 @@ def main():
                            "mfma_kernel_ms_per_step": round(tot_ms / timed_steps, 3),
                            "tflops": round(tot_gf / tot_ms, 2) if tot_ms > 0 else 0.0,
                            "tflops_over_the_whole_step": round(tot_gf / timed_steps / 1e3 / (ms_per_step * 1e-3), 2)}
+        # the roof of this board for these operands (see MEASURED_MFMA_CEILING_TFLOPS): products per fp32-equivalent product as in PEAK
+        div = {"f32": None, "emu": 6.0, "split": 3.0}[d["cls"]]
+        if div:
+            res["roofline"]["measured_mfma_ceiling"] = {"tflops": round(MEASURED_MFMA_CEILING_TFLOPS / div, 1),
+                                                         "what": "bare v_mfma_f32_32x32x16_bf16 stream on bf16x3 pieces / random operands under the 1400 W cap, / products per product",
+                                                         "file": "profiles/r05_mfma_rate_vs_operand_data.txt"}
+            res["roofline"]["frac_of_measured_mfma_ceiling"] = round(d["tflops"] / (MEASURED_MFMA_CEILING_TFLOPS / div), 4)
+        # Amdahl: where the kernel time of a step goes (HIP hot path / the PyTorch-ROCm image encoder's libraries / ATen glue), from
+        # the committed rocprofv3 trace of this same command (single stream, 5 timed steps) - evidence quoted, not measured in this run
+        try:
+            import csv
+            split = {"hip_hot_path": 0.0, "encoder_libraries": 0.0, "aten_glue": 0.0}
+            with open(os.path.join(REPO, "profiles", STEP_TRACE), newline="") as f:
+                for r in csv.DictReader(f):
+                    n, ms = r["Name"], float(r["TotalNsPerStep"]) * 1e-6
+                    k = "hip_hot_path" if "hoisdf" in n else ("aten_glue" if ("at::native" in n or "rocclr" in n) else "encoder_libraries")
+                    split[k] += ms
+            res["hot_path"]["kernel_ms_per_step_by_owner"] = {k: round(v, 2) for k, v in split.items()}
+            res["hot_path"]["kernel_ms_per_step_by_owner"]["file"] = f"profiles/{STEP_TRACE}"
+            res["hot_path"]["amdahl_note"] = ("the image encoder (MIOpen / CK / ATen; out of the hot path by north_star) is %.0f %% of the step's "
+                                              "kernel time: hot-path work can still buy at most %.2fx" %
+                                              (100 * (split["encoder_libraries"] + split["aten_glue"]) / max(sum(split.values()), 1e-9),
+                                               sum(split.values()) / max(split["encoder_libraries"] + split["aten_glue"], 1e-9)))
+        except Exception as ex:
+            res["hot_path"]["kernel_ms_per_step_by_owner"] = f"no trace file: {ex}"
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),
                               "launches_per_step": v["launches"] / timed_steps, "avg_us": round(v["avg_us"], 2)}
                           for n, v in ks.items()}
