@@ -947,3 +947,29 @@ def test_coarse_heads_vote_entry_equals_the_op_chain(L, B, P):
         O.set_deterministic(keep_det)
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         assert torch.equal(a, b), f"output / gradient {i} differs: {float((a - b).abs().max()):.3e}"
+
+@pytest.mark.parametrize("M,D,p", [(700, 256, 0.0), (4096, 256, 0.1), (33, 64, 0.3)])
+def test_residual_dropout_matches_the_add_layernorm_mask(M, D, p):
+    """hoisdf_residual_dropout (the residual of the pre-norm layers, common/nets/transformer.py:304-331): y = x + dropout(r) with the
+    (seed, row, column) mask of hoisdf_add_layernorm_fwd - checked through LayerNorm of the same sum - and dr = mask(dy), dx = dy."""
+    O = ops()
+    import hoisdf_amd.ops as OO
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(M, D, generator=g).to(DEV).requires_grad_(True)
+    gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    seed = 991
+    y = OO._ResidualDropout.apply(x, r, p, seed)
+    ln = OO._AddLayerNorm.apply(x.detach(), r.detach(), gamma, beta, 1e-5, p, seed)          # LN(x + dropout(r)), same mask
+    assert_close(ln, torch.nn.functional.layer_norm(y.detach().double(), (D,)).float(), rel=2e-5, what="same mask as add_layernorm")
+    keep = ((y.detach() - x.detach()).abs() > 0) | (r.detach() == 0)
+    if p == 0.0:
+        assert torch.equal(y.detach(), x.detach() + r.detach())
+    else:
+        frac = 1.0 - float(keep.float().mean())
+        assert abs(frac - p) < 0.03, frac
+        assert_close((y.detach() - x.detach())[keep], r.detach()[keep] / (1.0 - p), rel=2e-6, what="kept elements scaled")
+    go = torch.randn(M, D, generator=g).to(DEV)
+    y.backward(go)
+    assert torch.equal(x.grad, go)
+    assert_close(r.grad, torch.where(keep, go / (1.0 - p), torch.zeros_like(go)) if p > 0 else go, rel=2e-6, what="dr")
