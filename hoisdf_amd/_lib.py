@@ -45,7 +45,7 @@ class EncoderLayerDesc(C.Structure):
     """include/hoisdf.h hoisdf_encoder_layer_desc"""
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("E", C.c_int), ("F", C.c_int), ("H", C.c_int), ("n_query", C.c_int),
                 ("n_inter", C.c_int), ("eps", C.c_float), ("drop_p", C.c_float), ("seed", C.c_uint64 * 4), ("attention", C.c_int),
-                ("attention_bwd_emulated", C.c_int), ("training", C.c_int)]
+                ("attention_bwd_emulated", C.c_int), ("training", C.c_int), ("x_mag", C.c_void_p)]
 
 
 _ENC_W = ("w_in", "b_in", "w_out", "b_out", "g1", "be1", "w1", "b1", "w2", "b2", "g2", "be2", "g3", "be3")
@@ -126,11 +126,14 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_emu_prepare": [_P, _I, _I, _I, _I, _P, _P],
     "hoisdf_linear_emu_prepare_batch": [_P, _I, _L, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
+    "hoisdf_linear_fwd_emu_mag": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
+    "hoisdf_linear_bwd_input_emu_mag": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
     "hoisdf_linear_fwd_emu_small": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_linear_bwd_input_emu_small": [_P, _I, _P, _F, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_weight_emu_small": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P],
     "hoisdf_linear_bwd_weight_emu": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P],
+    "hoisdf_linear_bwd_weight_emu_mag": [_P, _I, _P, _F, _P, _I, _P, _I, _P, _L, _I, _I, _P, _L, _P, _P, _P],
     "hoisdf_relu_dropout_bwd": [_P, _I, _P, _I, _P, _I, _L, _I, _F, _P],
     "hoisdf_posenc_fwd": [_P, _L, _P, _I, _I, _P, _P],
     "hoisdf_sdf_query_fwd": [_PYR, _P, _P, _L, _I, _P, _P, _F, _I, _I, _P, _P, _SDFW, _F, _F, _U64, _P, _P, _P, _P, _P, _L, _P],
@@ -203,6 +206,7 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_decoder_layer_saved_bytes": ([_P], C.c_long),
           "hoisdf_decoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_encoder_layer_saved_bytes": ([_P], C.c_long),
+          "hoisdf_encoder_layer_out_mag": ([_P, _P], C.c_void_p),
           "hoisdf_encoder_layer_workspace_bytes": ([_P, _I], C.c_long),
           "hoisdf_sdf_query_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_bwd_weight_workspace": ([_L, _I, _I], C.c_long),
@@ -211,6 +215,8 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_linear_bwd_weight_emu_workspace": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_linear_emu_small_max_rows": ([], C.c_int),
+          "hoisdf_linear_emu_pieces": ([], C.c_int),
+          "hoisdf_mag_words": ([], C.c_int),
           "hoisdf_linear_emu_small_supported": ([_P, _L, _P, _L, _L, _I, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
           "hoisdf_attention_bf16x2_workspace": ([_I, _I, _I, _I], C.c_long),

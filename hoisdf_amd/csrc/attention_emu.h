@@ -23,6 +23,7 @@ struct EmuAttn {
   float drop_p, inv_keep;
   uint32_t thresh;
   uint64_t seed;
+  uint32_t* mag;                   // magnitude words (common.h) of what the kernel writes: out (forward), dk / dv (backward); null = none
 };
 
 __device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {

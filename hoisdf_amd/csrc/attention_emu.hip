@@ -273,17 +273,21 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
 #undef FWD_LOAD
 #undef FWD_STORE
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  uint32_t omax = 0u;
   if (qrow < a.Lq) {
     const float inv = 1.f / ltot;
     float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * h) =
-            make_float4(o[t][4 * g + 0] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const float4 ov = make_float4(o[t][4 * g + 0] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 * t + 8 * g + 4 * h) = ov;
+        omax = max(omax, mag_bits4(ov));
+      }
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
   }
+  mag_publish_wave(a.mag, omax);
 }
 
 
@@ -571,17 +575,21 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #undef FWD2_TILE_STATS
 #undef FWD2_ITER
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  uint32_t omax = 0u;
   if (qrow < a.Lq) {
     const float inv = 1.f / ltot;
     float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * h) =
-            make_float4(o[tt][4 * g + 0] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const float4 ov = make_float4(o[tt][4 * g + 0] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * h) = ov;
+        omax = max(omax, mag_bits4(ov));
+      }
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
   }
+  mag_publish_wave(a.mag, omax);
 }
 
 
@@ -865,16 +873,21 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
 #undef B3_ADVANCE
 #undef B3_STAGE
 #undef B3_SOFTMAX
+  uint32_t gmax = 0u;
   if (key < a.Lk) {
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
-      *reinterpret_cast<float4*>(pk + 16 * dt + 4 * g) = make_float4(dk[dt][0] * LN2, dk[dt][1] * LN2, dk[dt][2] * LN2, dk[dt][3] * LN2);
-      *reinterpret_cast<float4*>(pv + 16 * dt + 4 * g) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+      const float4 gk = make_float4(dk[dt][0] * LN2, dk[dt][1] * LN2, dk[dt][2] * LN2, dk[dt][3] * LN2);
+      const float4 gv = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+      *reinterpret_cast<float4*>(pk + 16 * dt + 4 * g) = gk;
+      *reinterpret_cast<float4*>(pv + 16 * dt + 4 * g) = gv;
+      gmax = max(gmax, max(mag_bits4(gk), mag_bits4(gv)));
     }
   }
+  mag_publish_wave(a.mag, gmax);
 }
 
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]  (f32; 16 lanes per (q, head))
@@ -896,23 +909,27 @@ __global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __rest
 
 // dq[b][q][head * 64 + d] = 0.125 * sum_kb part[kb][bh][q][d] in key-block order (one float4 per thread)
 __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __restrict__ part, int nkb, float* __restrict__ dq,
-                                                                 int ldq, int B, int H, int Lq) {
+                                                                 int ldq, int B, int H, int Lq, uint32_t* __restrict__ mag) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;          // (bh, q, d / 4)
   const long n = (long)B * H * Lq * 16;
-  if (i >= n) return;
-  const int d4 = (int)(i & 15);
-  const long bq = i >> 4;
-  const int q = (int)(bq % Lq);
-  const int bh = (int)(bq / Lq), b = bh / H, head = bh - b * H;
-  const size_t stride = (size_t)B * H * Lq * D;
-  const float* p = part + ((size_t)bh * Lq + q) * D + d4 * 4;
-  float4 s = *reinterpret_cast<const float4*>(p);
-  for (int k = 1; k < nkb; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  uint32_t qmax = 0u;
+  if (i < n) {
+    const int d4 = (int)(i & 15);
+    const long bq = i >> 4;
+    const int q = (int)(bq % Lq);
+    const int bh = (int)(bq / Lq), b = bh / H, head = bh - b * H;
+    const size_t stride = (size_t)B * H * Lq * D;
+    const float* p = part + ((size_t)bh * Lq + q) * D + d4 * 4;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < nkb; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float4 r = make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+    *reinterpret_cast<float4*>(dq + ((size_t)b * Lq + q) * ldq + head * D + d4 * 4) = r;
+    qmax = mag_bits4(r);
   }
-  *reinterpret_cast<float4*>(dq + ((size_t)b * Lq + q) * ldq + head * D + d4 * 4) =
-      make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+  mag_publish_wave(mag, qmax);             // dq's share of the magnitude words of [dq | dk | dv] (common.h), when wanted
 }
 
 }  // namespace hoisdf
@@ -962,7 +979,7 @@ namespace {
 // the forward over planes that are in the workspace already (layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only
 // form: [Q rows | K rows | V^T])
 int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
-                    void* workspace, int keep, hipStream_t st) {
+                    void* workspace, int keep, hipStream_t st, uint32_t* o_mag) {
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
@@ -971,7 +988,7 @@ int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
   const Planes pv = carve(w, nk, keep != 0, true);
   EmuAttn a{};
   for (int i = 0; i < 3; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
-  a.out = o; a.lse = lse; a.ldo = ldo;
+  a.out = o; a.lse = lse; a.ldo = ldo; a.mag = o_mag;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   static int form = -1;                       // HOISDF_EMU_ATTN_FWD=1: the first (unpipelined) form (A/B runs)
@@ -987,6 +1004,13 @@ int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
 extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                         int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
                                         uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
+  return attention_fwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, workspace_bytes, keep,
+                               nullptr, stream);
+}
+// (internal, common.h) + o_mag: the magnitude words of o (zero on entry; null = not wanted)
+int hoisdf::attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                                  int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
+                                  long workspace_bytes, int keep, uint32_t* o_mag, void* stream) {
   if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
   HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
                  HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
@@ -1002,7 +1026,7 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
   if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
   if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
   if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
-  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st);
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st, o_mag);
 }
 
 // ---- 16-bit-operand evaluation attention (BASELINE configs[4] "fp16 MFMA attention"): the pipelined forward over TWO bf16 planes per
@@ -1061,11 +1085,11 @@ void hoisdf::attention_emu_plane_targets(void* workspace, int B, int H, int Lq, 
 }
 
 int hoisdf::attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
-                                     uint64_t seed, void* workspace, int keep, void* stream) {
+                                     uint64_t seed, void* workspace, int keep, void* stream, uint32_t* o_mag) {
   HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0 && B > 0 &&
                      H > 0 && Lq > 0 && Lk > 0 && kv_len > 0 && kv_len <= Lk && drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "attention_fwd_emu_planes: bad arguments");
-  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, as_stream(stream));
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, as_stream(stream), o_mag);
 }
 
 // backward workspace: dO rows (3 planes) + the dQ partials [ceil(Lk / 128)][B H][Lq][64] f32
@@ -1082,6 +1106,14 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
                                         int ldo, const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk,
                                         float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
                                         const void* fwd_workspace, void* workspace, long workspace_bytes, void* stream) {
+  return attention_bwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, dk, dv, B, H, Lq, Lk, kv_len, drop_p, seed,
+                               fwd_workspace, workspace, workspace_bytes, nullptr, stream);
+}
+// (internal, common.h) + g_mag: ONE array of magnitude words for dq, dk and dv together (zero on entry; null = not wanted)
+int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                                  const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                  int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
+                                  void* workspace, long workspace_bytes, uint32_t* g_mag, void* stream) {
   // with the forward's planes (fwd_workspace) q, k, v themselves are not read: they may be null; ldq / ldk / ldv still give the
   // layouts of dq / dk / dv
   if (int rc = check_emu(fwd_workspace && !q ? o : q, fwd_workspace && !k ? o : k, fwd_workspace && !v ? o : v, ldq, ldk, ldv, B, H, Lq,
@@ -1129,7 +1161,7 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   for (int i = 0; i < 3; ++i) {
     a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.v[i] = pv.r[i]; a.d[i] = pd.r[i];
   }
-  a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv;
+  a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv; a.mag = g_mag;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   // HOISDF_EMU_ATTN_BWD: (default) the round-5 kernel with dQ summed across the key blocks through an ordered running sum in L2;
@@ -1149,14 +1181,15 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
     // the counters sit behind the ngrp running sums (the region holds nkb partial slots: always room unless G = 1)
     int* flags = reinterpret_cast<int*>(part + (size_t)ngrp * B * H * Lq * 64);
     const size_t flag_bytes = (size_t)B * H * nkb * 4 * sizeof(int);
-    const bool chain = G > 1 && nlive > 1 && (size_t)(nkb - ngrp) * B * H * Lq * 64 * sizeof(float) >= flag_bytes;
+    const bool chain = G > 1 && nlive > 1 && (size_t)(nkb - ngrp) * B * H * Lq * 64 * sizeof(float) >= flag_bytes &&
+                       !g_mag;       // (a chain of all key blocks writes dq itself: nobody would fold its magnitude)
     if (chain) {
       a.dq = dq; a.ldq = ldq; a.dq_flags = flags; a.chain_group = G;
       if (hipMemsetAsync(flags, 0, flag_bytes, st) != hipSuccess) { set_error("attention_bwd_emu: clearing the chain counters failed"); return HOISDF_ERR_LAUNCH; }
       if (int rc = attention_bwd4_emu_launch(a, true, st)) return rc;
       if (ngrp == 1) return HOISDF_OK;          // (the chain's last block wrote dq itself)
       const long n4c = (long)B * H * Lq * 16;
-      hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4c + 255) / 256)), dim3(256), 0, st, part, ngrp, dq, ldq, B, H, Lq);
+      hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4c + 255) / 256)), dim3(256), 0, st, part, ngrp, dq, ldq, B, H, Lq, g_mag);
       return check_launch("attention_bwd_emu dq reduce");
     }
     if (int rc = attention_bwd4_emu_launch(a, false, st)) return rc;
@@ -1171,6 +1204,6 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
   }
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
-                     B, H, Lq);
+                     B, H, Lq, g_mag);
   return check_launch("attention_bwd_emu dq reduce");
 }

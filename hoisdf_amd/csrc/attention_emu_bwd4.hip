@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
       XSIG();
     }
   }
+  uint32_t gmax = 0u;
   if (key < a.Lk) {
     float* pk = a.dk + ((size_t)b * a.Lk + key) * a.ldk + head * D;
     float* pv = a.dv + ((size_t)b * a.Lk + key) * a.ldv + head * D;
@@ -572,12 +573,14 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
       for (int g = 0; g < 4; ++g) {
         // Q was pre-scaled by log2(e)/8: dK = dS^T.Q / 8 = (dS^T.Qs) * ln 2
         const float zk = kvalid ? LN2 : 0.f, zv = kvalid ? 1.f : 0.f;          // (masked keys: finite garbage x 0)
-        *reinterpret_cast<float4*>(pk + 32 * mt + 8 * g + 4 * h) =
-            make_float4(dk[mt][4 * g] * zk, dk[mt][4 * g + 1] * zk, dk[mt][4 * g + 2] * zk, dk[mt][4 * g + 3] * zk);
-        *reinterpret_cast<float4*>(pv + 32 * mt + 8 * g + 4 * h) =
-            make_float4(dv[mt][4 * g] * zv, dv[mt][4 * g + 1] * zv, dv[mt][4 * g + 2] * zv, dv[mt][4 * g + 3] * zv);
+        const float4 gk = make_float4(dk[mt][4 * g] * zk, dk[mt][4 * g + 1] * zk, dk[mt][4 * g + 2] * zk, dk[mt][4 * g + 3] * zk);
+        const float4 gv = make_float4(dv[mt][4 * g] * zv, dv[mt][4 * g + 1] * zv, dv[mt][4 * g + 2] * zv, dv[mt][4 * g + 3] * zv);
+        *reinterpret_cast<float4*>(pk + 32 * mt + 8 * g + 4 * h) = gk;
+        *reinterpret_cast<float4*>(pv + 32 * mt + 8 * g + 4 * h) = gv;
+        gmax = max(gmax, max(mag_bits4(gk), mag_bits4(gv)));
       }
   }
+  mag_publish_wave(a.mag, gmax);              // dk / dv's share of the magnitude words of [dq | dk | dv] (common.h), when wanted
 }
 
 int attention_bwd4_emu_launch(const EmuAttn& a, bool chain, hipStream_t st) {

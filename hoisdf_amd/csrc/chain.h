@@ -64,13 +64,15 @@ const void* image_of(Ctx& c, const void* given, const float* W, int ldw, int N, 
 // K_pad >= K (default K): columns K .. K_pad - 1 of x are zero padding; the emulated form contracts over K_pad (they meet the zero
 // fill of the weight image, which is built from the K real columns) so that a ragged K (289) still takes the bf16 pipe
 void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const void* img, const float* b, float* y, int ldy, long M, int N,
-             int K, int act, float p, uint64_t seed, uint32_t* bits, int K_pad = 0) {
+             int K, int act, float p, uint64_t seed, uint32_t* bits, int K_pad = 0, const uint32_t* x_mag = nullptr, uint32_t* y_mag = nullptr) {
+  // x_mag / y_mag: magnitude words of x (null: unknown) and for y (null: not wanted; zero on entry) - common.h; only the emulated
+  // tiled form reads / writes them: a caller that hands y_mag on must know that form ran (emu_rows of the same arguments)
   if (!c.ok()) return;
   if (K_pad < K || (K_pad + 15) / 16 != (K + 15) / 16) K_pad = K;
   if (emu_rows(c, M, x, ldx, K_pad)) {
     const void* im = image_of(c, img, W, ldw, N, K, 0);
     if (c.dry || !c.ok()) return;
-    c.rc = hoisdf_linear_fwd_emu(x, ldx, im, b, y, ldy, M, N, K_pad, act, p, seed, bits, c.stream);
+    c.rc = linear_fwd_emu_mag(x, ldx, im, b, y, ldy, M, N, K_pad, act, p, seed, bits, x_mag, y_mag, c.stream);
     return;
   }
   if (c.dry) return;
@@ -78,13 +80,13 @@ void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const voi
   c.rc = hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
 }
 void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* W, int ldw, const void* img_t, float* dx,
-                   int lddx, long M, int N, int K, int accumulate) {
+                   int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag = nullptr, uint32_t* dx_mag = nullptr) {
   if (!c.ok()) return;
   if (!bits) p = 0.f;
   if (emu_rows(c, M, dy, lddy, N)) {
     const void* im = image_of(c, img_t, W, ldw, N, K, 1);
     if (c.dry || !c.ok()) return;
-    c.rc = hoisdf_linear_bwd_input_emu(dy, lddy, bits, p, im, dx, lddx, M, N, K, accumulate, c.stream);
+    c.rc = linear_bwd_input_emu_mag(dy, lddy, bits, p, im, dx, lddx, M, N, K, accumulate, dy_mag, accumulate ? nullptr : dx_mag, c.stream);
     return;
   }
   if (c.dry) return;
@@ -94,8 +96,11 @@ void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, floa
 // dW / db zero on entry (the exact-f32 kernel accumulates, the emulated one overwrites)
 // K_pad > K: dW is a dense [N][K_pad] and columns K .. K_pad - 1 of x are zero padding - both forms contract the padded width
 // (the pad columns of dW come out zero)
+// dy_mag / x_mag (f16x2 form): magnitude words of dy / x; with either one given the grad-weight runs in the f16x2 form (a missing one
+// is measured by the library), with neither in the bf16x3 form, which needs no magnitudes (no weight image is involved: the two
+// forms coexist per call)
 void lin_bwd_weight(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* x, int ldx, float* dW, float* db, long M,
-                    int N, int K, int K_pad = 0) {
+                    int N, int K, int K_pad = 0, const uint32_t* dy_mag = nullptr, const uint32_t* x_mag = nullptr) {
   if (!c.ok()) return;
   if (!bits) p = 0.f;
   if (K_pad < K) K_pad = K;
@@ -106,7 +111,8 @@ void lin_bwd_weight(Ctx& c, const float* dy, int lddy, const uint32_t* bits, flo
     float* w = c.ws->floats(nws > 4 ? nws : 4);   // (scratch of consecutive calls is not recycled: earlier launches may still read theirs)
     if (!c.dry) {
       if (!w) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-      c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, c.stream);
+      if (dy_mag || x_mag) c.rc = linear_bwd_weight_emu_mag(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, dy_mag, x_mag, c.stream);
+      else c.rc = hoisdf_linear_bwd_weight_emu(dy, lddy, bits, p, x, ldx, dW, K_pad, db, M, N, K_pad, w, nws, c.stream);
     }
     return;
   }

@@ -83,12 +83,56 @@ struct QkvPlanes {
   float qscale;      // the query part is scaled before the split (softmax scale in the log2 domain)
 };
 int linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, const float* bias, long M, int N, int K, const QkvPlanes& pl,
-                       void* stream);
+                       void* stream, const uint32_t* x_mag = nullptr);
 // attention_emu.hip: where the planes of a forward workspace live (hoisdf_attention_emu_workspace(.., keep ? 2 : 0) bytes), and the
 // forward / backward over planes that are already there
 void attention_emu_plane_targets(void* workspace, int B, int H, int Lq, int Lk, int keep, QkvPlanes& q_part, QkvPlanes& kv_part);
 int attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
-                             void* workspace, int keep, void* stream);
+                             void* workspace, int keep, void* stream, uint32_t* o_mag = nullptr);
+// hoisdf_attention_fwd_emu / _bwd_emu with magnitude words (below) for o / for [dq | dk | dv] together
+int attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse, int B,
+                          int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes, int keep,
+                          uint32_t* o_mag, void* stream);
+int attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                          const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H,
+                          int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace, void* workspace,
+                          long workspace_bytes, uint32_t* g_mag, void* stream);
+
+// gemm_emu.hip, f16x2 form: is it on (HOISDF_EMU_FORM, process-wide); magnitude words of a row-major f32 matrix (emu_amax_words()
+// words, each the bits of a max |x| over a share of the matrix: the contraction's operand scale is derived from their maximum)
+bool emu_form_h2();
+int emu_amax_words();
+int emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st);
+
+// ---- magnitude words (f16x2 form).  A kernel that writes a matrix which a later contraction reads as its row operand can leave
+// that matrix's largest magnitude behind while it still holds the values: MAG_WORDS u32 words, zero before the producer(s) run,
+// each wave folds the bits of its max |value| into one of them with an unsigned atomic max (|x| as IEEE bits orders like |x|;
+// several producers may share an array - dQ / dK / dV of one [dq | dk | dv] matrix).  The consumer reads the MAG_WORDS words.
+// An operand without words gets hoisdf's own magnitude pass (emu_amax_launch: one more read of the matrix).
+constexpr int MAG_WORDS = 256;
+__device__ __forceinline__ uint32_t mag_bits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
+__device__ __forceinline__ uint32_t mag_bits4(const float4& v) {
+  return max(max(mag_bits(v.x), mag_bits(v.y)), max(mag_bits(v.z), mag_bits(v.w)));
+}
+__device__ __forceinline__ void mag_publish_wave(uint32_t* words, uint32_t m) {      // all 64 lanes of a wave; words may be null
+  if (!words) return;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(words + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MAG_WORDS - 1)), m);
+}
+// the entries below with magnitude words (null = none): x_mag / dy_mag describe the row operand, y_mag / dx_mag receive the output's
+int linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K, int act,
+                       float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag, uint32_t* y_mag, void* stream);
+int linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image, float* dx, int lddx,
+                             long M, int N, int K, int accumulate, const uint32_t* dy_mag, uint32_t* dx_mag, void* stream);
+int linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx, float* dW, int lddw,
+                              float* db, long M, int N, int K, float* workspace, long workspace_floats, const uint32_t* dy_mag,
+                              const uint32_t* x_mag, void* stream);
+int add_layernorm_fwd_mag(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M,
+                          int D, float eps, float drop_p, uint64_t seed, uint32_t* y_mag, void* stream);
+int add_layernorm_bwd_mag(const float* dy, const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,
+                          const float* dx_add, float* dx, float* dr, float* dgamma, float* dbeta, long M, int D, float drop_p, uint64_t seed,
+                          uint32_t* dx_mag, uint32_t* dr_mag, void* stream);
 
 bool deterministic_mode();
 bool gemm_emu_mode();             // hoisdf_set_gemm_emu: ... as fp32 emulated on the bf16 MFMA pipe (default on)

@@ -22,6 +22,9 @@
 // LDS-transposed 16-byte stores).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -63,6 +66,9 @@ struct EmuArgs {
   int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
   int tiles_m, tiles_n, vecC, beta;
   QkvPlanes qkv;                            // .on: the output tile goes into attention planes instead of C (common.h)
+  // f16x2 form: magnitude partials of A (max over a_amax_n words = max |A|, or an upper bound), the image's {scale, 1 / scale}
+  const uint32_t* a_amax; int a_amax_n; const float* b_scale;
+  uint32_t* amax_out;                       // magnitude words of C (common.h MAG_WORDS; any form; null = not wanted)
 };
 }  // namespace
 
@@ -114,12 +120,16 @@ __global__ __launch_bounds__(256) void emu_prep_weight_batch_kernel(const hoisdf
   if (idx < total) emu_prep_weight_unit(it.W, it.ldw, R, Kc, it.transpose, nslab, idx, static_cast<u32x4*>(it.image));
 }
 
-// C-tile epilogue shared by the two main-loop forms: bias, ReLU, dropout, 1-bit sign map, accumulate-into, LDS-transposed 16-byte stores
-__device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][NJ], u32x4* lds, int m0, int n0, int wm, int wn, int wave,
+// C-tile epilogue shared by all main-loop forms (tile TM_ x TN_, 2 x 2 waves, wave tile 128 x 32 NJ_): bias, ReLU, dropout, 1-bit
+// sign map, accumulate-into, LDS-transposed 16-byte stores
+template <int TM_, int TN_, int NJ_>
+__device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][NJ_], u32x4* lds, int m0, int n0, int wm, int wn, int wave,
                                              int lane, int l31, int kh, float post_scale) {
-  if (post_scale != 1.f) {                     // (grad-input, rotated form) 1 / keep of the forward's dropout, once per element
+  constexpr int WN_ = TN_ / 2;
+  static_assert(WN_ == NJ_ * 32, "wave tile");
+  if (post_scale != 1.f) {                     // (grad-input, rotated form) 1 / keep of the forward's dropout, once per element; (f16x2) the operand scales
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ_; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -128,9 +138,9 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
   // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); all waves are
   // past the main loop's last barrier, the staging buffer is free
   const int rbase = m0 + wm * 128 + 4 * kh;
-  const int cbase = n0 + wn * WN + l31;
+  const int cbase = n0 + wn * WN_ + l31;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  for (int j = 0; j < NJ_; ++j) {
     const int col = cbase + j * 32;
     const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
@@ -150,83 +160,98 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
         const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
         const uint32_t rk = drop_rowkey(g.seed, (uint32_t)row);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j][r] *= drop_scale(rk, (uint32_t)(cbase + j * 32), g.thresh, g.inv_keep);
+        for (int j = 0; j < NJ_; ++j) acc[i][j][r] *= drop_scale(rk, (uint32_t)(cbase + j * 32), g.thresh, g.inv_keep);
       }
   }
+  if (g.amax_out) {
+    // largest magnitude of the finished tile -> the output's magnitude words (common.h: the f16x2 form of the NEXT contraction scales
+    // its operand by it).  Rows / columns past M / N hold bias-only values: still a fair bound.
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ_; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, __builtin_fabsf(acc[i][j][r]));
+    mag_publish_wave(g.amax_out, __builtin_bit_cast(uint32_t, m));
+  }
   if (g.qkv.on) {
-    // attention-plane output (common.h QkvPlanes): the wave's 128 x 64 sub-tile is 128 consecutive tokens of one sample x one head
-    // of one part; per 32-row block through the wave-private LDS slice: row planes as 8 lanes x 16 bytes per token and piece,
+    // attention-plane output (common.h QkvPlanes): every 128 x 64 part of the wave's sub-tile is 128 consecutive tokens of one sample x
+    // one head of one part; per 32-row block through the wave-private LDS slice: row planes as 8 lanes x 16 bytes per token and piece,
     // transposed value planes as one d per lane, 8 consecutive tokens (16 bytes) per store
-    constexpr int ES = WN + 4;
+    constexpr int ES = 64 + 4;
     float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
-    const int row0 = m0 + wm * 128, cw = n0 + wn * WN;
-    if (row0 + 128 > g.M || cw + WN > g.N) return;           // (never: the launcher takes whole wave tiles only)
-    const int colg = g.qkv.col0 + cw;
-    const int part = colg / g.qkv.E, head = (colg - part * g.qkv.E) >> 6;
+    const int row0 = m0 + wm * 128, cw = n0 + wn * WN_;
+    if (row0 + 128 > g.M || cw + WN_ > g.N) return;           // (never: the launcher takes whole wave tiles only)
     const int b = row0 / g.qkv.L, s0 = row0 - b * g.qkv.L;
-    const size_t bh = (size_t)b * g.qkv.H + head;
-    const float sc = part == 0 ? g.qkv.qscale : 1.f;
-    __bf16* const r0 = static_cast<__bf16*>(g.qkv.r[part][0]);
-    __bf16* const r1 = static_cast<__bf16*>(g.qkv.r[part][1]);
-    __bf16* const r2 = static_cast<__bf16*>(g.qkv.r[part][2]);
-    const bool trn = part == 2 && g.qkv.vt[0] != nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int hh = 0; hh < NJ_ / 2; ++hh) {
+      const int colg = g.qkv.col0 + cw + hh * 64;
+      const int part = colg / g.qkv.E, head = (colg - part * g.qkv.E) >> 6;
+      const size_t bh = (size_t)b * g.qkv.H + head;
+      const float sc = part == 0 ? g.qkv.qscale : 1.f;
+      __bf16* const r0 = static_cast<__bf16*>(g.qkv.r[part][0]);
+      __bf16* const r1 = static_cast<__bf16*>(g.qkv.r[part][1]);
+      __bf16* const r2 = static_cast<__bf16*>(g.qkv.r[part][2]);
+      const bool trn = part == 2 && g.qkv.vt[0] != nullptr;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r] * sc;
-      if (r0) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 8;
-          const float4 u = *reinterpret_cast<const float4*>(w + rr * ES + cc);
-          const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc + 4);
-          bf16x8 p0, p1, p2;
-          split3x8(u, v, p0, p1, p2);
-          const size_t o = ((size_t)bh * g.qkv.Lp + s0 + i * 32 + rr) * 64 + cc;
-          *reinterpret_cast<bf16x8*>(r0 + o) = p0;
-          *reinterpret_cast<bf16x8*>(r1 + o) = p1;
-          *reinterpret_cast<bf16x8*>(r2 + o) = p2;
+          for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][2 * hh + j][r] * sc;
+        if (r0) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int rr = p * 8 + (lane >> 3), cc = (lane & 7) * 8;
+            const float4 u = *reinterpret_cast<const float4*>(w + rr * ES + cc);
+            const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc + 4);
+            bf16x8 p0, p1, p2;
+            split3x8(u, v, p0, p1, p2);
+            const size_t o = ((size_t)bh * g.qkv.Lp + s0 + i * 32 + rr) * 64 + cc;
+            *reinterpret_cast<bf16x8*>(r0 + o) = p0;
+            *reinterpret_cast<bf16x8*>(r1 + o) = p1;
+            *reinterpret_cast<bf16x8*>(r2 + o) = p2;
+          }
         }
-      }
-      if (trn) {
-        __bf16* const t0 = static_cast<__bf16*>(g.qkv.vt[0]);
-        __bf16* const t1 = static_cast<__bf16*>(g.qkv.vt[1]);
-        __bf16* const t2 = static_cast<__bf16*>(g.qkv.vt[2]);
+        if (trn) {
+          __bf16* const t0 = static_cast<__bf16*>(g.qkv.vt[0]);
+          __bf16* const t1 = static_cast<__bf16*>(g.qkv.vt[1]);
+          __bf16* const t2 = static_cast<__bf16*>(g.qkv.vt[2]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float* c0 = w + (8 * q) * ES + lane;
-          const float4 u = make_float4(c0[0], c0[ES], c0[2 * ES], c0[3 * ES]);
-          const float4 v = make_float4(c0[4 * ES], c0[5 * ES], c0[6 * ES], c0[7 * ES]);
-          bf16x8 p0, p1, p2;
-          split3x8(u, v, p0, p1, p2);
-          const size_t o = ((size_t)bh * 64 + lane) * g.qkv.Lp + s0 + i * 32 + 8 * q;
-          *reinterpret_cast<bf16x8*>(t0 + o) = p0;
-          *reinterpret_cast<bf16x8*>(t1 + o) = p1;
-          *reinterpret_cast<bf16x8*>(t2 + o) = p2;
+          for (int q = 0; q < 4; ++q) {
+            const float* c0 = w + (8 * q) * ES + lane;
+            const float4 u = make_float4(c0[0], c0[ES], c0[2 * ES], c0[3 * ES]);
+            const float4 v = make_float4(c0[4 * ES], c0[5 * ES], c0[6 * ES], c0[7 * ES]);
+            bf16x8 p0, p1, p2;
+            split3x8(u, v, p0, p1, p2);
+            const size_t o = ((size_t)bh * 64 + lane) * g.qkv.Lp + s0 + i * 32 + 8 * q;
+            *reinterpret_cast<bf16x8*>(t0 + o) = p0;
+            *reinterpret_cast<bf16x8*>(t1 + o) = p1;
+            *reinterpret_cast<bf16x8*>(t2 + o) = p2;
+          }
         }
       }
     }
     return;
   }
-  const bool full = (m0 + TM <= g.M) && (n0 + TN <= g.N);
+  const bool full = (m0 + TM_ <= g.M) && (n0 + TN_ <= g.N);
   if (full && g.vecC) {
-    // one row of blocks (32 x 64) per wave at a time through a wave-private LDS slice, read back row-wise: one
-    // global_store_dwordx4 covers four complete 256-byte row segments
-    constexpr int ES = WN + 4;
+    // one row of blocks (32 x WN_) per wave at a time through a wave-private LDS slice, read back row-wise: one
+    // global_store_dwordx4 covers complete 256-byte row segments
+    constexpr int ES = WN_ + 4, LPR = WN_ / 4, RPI = 64 / LPR;
     float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ_; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r];
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int rr = p * 4 + (lane >> 4), cc = (lane & 15) * 4;
+      for (int p = 0; p < 32 / RPI; ++p) {
+        const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
         float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
-        float4* cp = reinterpret_cast<float4*>(g.C + (size_t)(m0 + wm * 128 + i * 32 + rr) * g.ldc + n0 + wn * WN + cc);
+        float4* cp = reinterpret_cast<float4*>(g.C + (size_t)(m0 + wm * 128 + i * 32 + rr) * g.ldc + n0 + wn * WN_ + cc);
         if (g.beta) {
           const float4 old = *cp;
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
@@ -236,7 +261,7 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ_; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -250,32 +275,35 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
   }
   if (g.bits_out) {
     // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below: one ballot is two mask words.
-    // Each lane collects the words of "its" rows (lane and lane + 64 of the wave's 128 x 64 sub-tile) and writes them once.
-    uint32_t w00 = 0u, w01 = 0u, w10 = 0u, w11 = 0u;
+    // Each lane collects the words of "its" rows (lane and lane + 64 of the wave's 128-row sub-tile) and writes them once.
+    uint32_t wd[2][NJ_];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int j = 0; j < NJ_; ++j) wd[hh][j] = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = (i & 1) * 32 + (r & 3) + 8 * (r >> 2);      // row within a 64-row half, as held by lanes 0-31
-        const unsigned long long q0 = __ballot(acc[i][0][r] > 0.f);
-        const unsigned long long q1 = __ballot(acc[i][1][r] > 0.f);
-        if (i < 2) {
-          if (lane == rl) { w00 = (uint32_t)q0; w01 = (uint32_t)q1; }
-          if (lane == rl + 4) { w00 = (uint32_t)(q0 >> 32); w01 = (uint32_t)(q1 >> 32); }
-        } else {
-          if (lane == rl) { w10 = (uint32_t)q0; w11 = (uint32_t)q1; }
-          if (lane == rl + 4) { w10 = (uint32_t)(q0 >> 32); w11 = (uint32_t)(q1 >> 32); }
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j) {
+          const unsigned long long q = __ballot(acc[i][j][r] > 0.f);
+          if (lane == rl) wd[i >> 1][j] = (uint32_t)q;
+          if (lane == rl + 4) wd[i >> 1][j] = (uint32_t)(q >> 32);
         }
       }
-    const int wcol = (n0 + wn * WN) >> 5;
-    const int nvalid = g.N - (n0 + wn * WN);
+    const int wcol = (n0 + wn * WN_) >> 5;
+    const int nvalid = g.N - (n0 + wn * WN_);
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int row = m0 + wm * 128 + hh * 64 + lane;
-      const uint32_t v0 = hh ? w10 : w00, v1 = hh ? w11 : w01;
       if (row < g.M) {
-        if (nvalid > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol] = nvalid >= 32 ? v0 : (v0 & ((1u << nvalid) - 1u));
-        if (nvalid > 32) g.bits_out[(size_t)row * g.ldbits_out + wcol + 1] = nvalid >= 64 ? v1 : (v1 & ((1u << (nvalid - 32)) - 1u));
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j) {
+          const int nv = nvalid - 32 * j;
+          if (nv > 0) g.bits_out[(size_t)row * g.ldbits_out + wcol + j] = nv >= 32 ? wd[hh][j] : (wd[hh][j] & ((1u << nv) - 1u));
+        }
       }
     }
   }
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(NT, 2) void emu_kc_kernel(EmuArgs g) {
 #undef RD_B
 #undef MM1
 
-  emu_epilogue(g, acc, lds, m0, n0, wm, wn, wave, lane, l31, kh, 1.f);
+  emu_epilogue<TM, TN, NJ>(g, acc, lds, m0, n0, wm, wn, wave, lane, l31, kh, 1.f);
 }
 
 
@@ -615,7 +643,296 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #undef SYNC
 #undef STAGE_ALL
 #undef LOAD_ALL
-  emu_epilogue(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, MASK ? g.ascale : 1.f);
+  emu_epilogue<TM, TN, NJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, MASK ? g.ascale : 1.f);
+}
+
+
+// ============================================================================================================================
+// f16x2 form ("h2"): the same contractions from TWO f16 pieces per operand and THREE products.
+//   x s = hi + lo + r,  hi = f16(x s), lo = f16(x s - hi), |r| <= max(2^-22 |x s|, 2^-25) (on average 2^-24 |x s|): with the operand
+//   scaled by a power of two s so that max |x s| lies in [2^13, 2^14) every element within 2^-16 of the largest keeps 22 bits; below
+//   that lo is an f16 subnormal: an ABSOLUTE error of 2^-38 max |x|.  x y is accumulated in f32 from lo hi + hi lo + hi hi (each f16 x f16 product
+//   is exact in f32); the dropped lo lo term is <= 2^-22 |x y|, on average 2^-26 |x y| with a random sign - the rounding of an f32
+//   multiply-add.  Half the MFMA work of the bf16x3 form at the same matrix-pipe rate; the price is the scale: the largest
+//   magnitude of every operand has to be known when its contraction is launched (weights: found while the image is built;
+//   activations / gradients: magnitude words written by the producing kernel's epilogue, or by hoisdf's own magnitude pass).
+// Tile 256 x 256 x 16, 4 waves as 2 x 2, wave tile 128 x 128 = 4 x 4 MFMA blocks (256 accumulators in AGPRs, one workgroup per CU):
+// with half the MFMA work per byte the 256 x 128 tile of emu_kc2_kernel would ask the vector memory pipe for ~100 GB/s per CU.
+// Staging, LDS layout and the rotated, pinned phase are emu_kc2_kernel's (tools/gen/h2_phase.py -> h2_phase.inc).
+// Weight image: column tile tn (256 columns), slab s (16 k), plane p (hi, lo), chunk c (8 k), row r: 16 bytes at
+// ((((tn * nslab + s) * 2 + p) * 2 + c) * 256 + r) * 16; behind the last tile a 128-byte trailer: 16 magnitude words, then {s, 1 / s}.
+// ============================================================================================================================
+namespace {
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define MFH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+constexpr int HTM = 256, HTN = 256, HNJ = 4;
+constexpr int HA_U4 = 2 * 2 * HTM, HB_U4 = 2 * 2 * HTN, HSTAGE = HA_U4 + HB_U4;      // 16-byte units per stage (32 KB)
+constexpr int H_EPI_U4 = (4 * 32 * (HTN / 2 + 4) * 4 + 64) / 16;                       // the epilogue's four transposition slices + a few words
+constexpr int H_TRAILER = 128;
+constexpr int AMAX_BLOCKS = 512;
+
+// power-of-two operand scale from the largest magnitude (bits of |x|max): max |x| s in [2^13, 2^14); zero / denormal / huge maxima clamp
+__device__ __forceinline__ uint32_t h2_exp(uint32_t amax_bits) { return min(max((amax_bits >> 23) & 0xffu, 14u), 254u); }
+__device__ __forceinline__ float h2_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (267u - h2_exp(amax_bits)) << 23); }
+__device__ __forceinline__ float h2_inv_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (h2_exp(amax_bits) - 13u) << 23); }
+
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* red4) {      // 256 threads
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+}
+}  // namespace
+
+// magnitude words of a row-major f32 matrix: block b -> part[b] = bits of max |x| over its share (AMAX_BLOCKS blocks)
+__global__ __launch_bounds__(256) void emu_amax_kernel(const float* __restrict__ x, long ld, long M, int K, uint32_t* __restrict__ part) {
+  __shared__ uint32_t red4[4];
+  const int k4 = K >> 2;
+  const long n4 = M * k4;
+  uint32_t m = 0u;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256 * 4) {
+    uint32_t mm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long j = i + (long)u * gridDim.x * 256;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (j < n4) { const long r = j / k4; v = *reinterpret_cast<const u32x4*>(x + r * ld + (j - r * k4) * 4); }
+      mm[u] = max(max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu));
+    }
+    m = max(m, max(max(mm[0], mm[1]), max(mm[2], mm[3])));
+  }
+  m = block_max_u32(m, red4);
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+
+// ---- weight -> f16x2 image.  Pass 1: 16 magnitude words per weight into the trailer; pass 2: scale, split, write (+ {s, 1 / s}).
+__host__ __device__ __forceinline__ uint32_t* h2_trailer(void* image, int R, int Kc) {
+  return reinterpret_cast<uint32_t*>(static_cast<char*>(image) + (size_t)((R + HTN - 1) / HTN) * ((Kc + KS - 1) / KS) * HB_U4 * 16);
+}
+__device__ __forceinline__ void h2_weight_amax_unit(const float* __restrict__ W, int ldw, int N, int K, int part, uint32_t* trailer, uint32_t* red4) {
+  uint32_t m = 0u;
+  const long n = (long)N * K;
+  for (long i = (long)part * 256 + threadIdx.x; i < n; i += 16 * 256) {
+    const long r = i / K;
+    m = max(m, __builtin_bit_cast(uint32_t, W[r * ldw + (i - r * K)]) & 0x7fffffffu);
+  }
+  m = block_max_u32(m, red4);
+  if (threadIdx.x == 0) trailer[part] = m;
+}
+__device__ __forceinline__ void h2_prep_weight_unit(const float* __restrict__ W, int ldw, int R, int Kc, int transpose, int nslab,
+                                                    long idx, u32x4* __restrict__ img) {
+  uint32_t* tr = h2_trailer(img, R, Kc);
+  uint32_t am = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) am = max(am, tr[i]);
+  const float sc = h2_scale(am);
+  if (idx == 0) {                                  // (the whole trailer is defined: images compare equal byte for byte)
+    reinterpret_cast<float*>(tr)[16] = sc; reinterpret_cast<float*>(tr)[17] = h2_inv_scale(am);
+#pragma unroll
+    for (int i = 18; i < H_TRAILER / 4; ++i) tr[i] = 0u;
+  }
+  const int r = (int)(idx % HTN);
+  const int c = (int)((idx / HTN) % 2);
+  const int s = (int)((idx / (2 * HTN)) % nslab);
+  const int tn = (int)(idx / ((long)2 * HTN * nslab));
+  const int row = tn * HTN + r;
+  const int k0 = s * KS + c * 8;
+  f16x8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    float v = 0.f;
+    if (row < R && k < Kc) v = transpose ? W[(size_t)k * ldw + row] : W[(size_t)row * ldw + k];
+    v *= sc;
+    hi[i] = (_Float16)v;
+    lo[i] = (_Float16)(v - (float)hi[i]);
+  }
+  const size_t base = ((size_t)(tn * nslab + s) * 2) * 2 * HTN;
+  img[base + (0 * 2 + c) * HTN + r] = __builtin_bit_cast(u32x4, hi);
+  img[base + (1 * 2 + c) * HTN + r] = __builtin_bit_cast(u32x4, lo);
+}
+__global__ __launch_bounds__(256) void h2_weight_amax_kernel(const float* __restrict__ W, int ldw, int N, int K, int R, int Kc, void* image) {
+  __shared__ uint32_t red4[4];
+  h2_weight_amax_unit(W, ldw, N, K, blockIdx.x, h2_trailer(image, R, Kc), red4);
+}
+__global__ __launch_bounds__(256) void h2_weight_amax_batch_kernel(const hoisdf_emu_prep_item* __restrict__ items) {
+  __shared__ uint32_t red4[4];
+  const hoisdf_emu_prep_item it = items[blockIdx.x >> 4];
+  const int R = it.transpose ? it.K : it.N, Kc = it.transpose ? it.N : it.K;
+  h2_weight_amax_unit(it.W, it.ldw, it.N, it.K, blockIdx.x & 15, h2_trailer(it.image, R, Kc), red4);
+}
+__global__ __launch_bounds__(256) void h2_prep_weight_kernel(const float* __restrict__ W, int ldw, int R, int Kc, int transpose, int nslab,
+                                                             long total, u32x4* __restrict__ img) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) h2_prep_weight_unit(W, ldw, R, Kc, transpose, nslab, idx, img);
+}
+__global__ __launch_bounds__(256) void h2_prep_weight_batch_kernel(const hoisdf_emu_prep_item* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hoisdf_emu_prep_item it = items[lo];
+  const int R = it.transpose ? it.K : it.N, Kc = it.transpose ? it.N : it.K;
+  const int nslab = ((Kc + KS - 1) / KS);
+  const long total = (long)((R + HTN - 1) / HTN) * nslab * 2 * HTN;
+  const long idx = ((long)blockIdx.x - it.first_block) * 256 + threadIdx.x;
+  if (idx < total) h2_prep_weight_unit(it.W, it.ldw, R, Kc, it.transpose, nslab, idx, static_cast<u32x4*>(it.image));
+}
+
+template <bool MASK, bool KTAIL>
+__global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
+  __shared__ __attribute__((aligned(16))) u32x4 st0[H_EPI_U4 > HSTAGE ? H_EPI_U4 : HSTAGE];
+  __shared__ __attribute__((aligned(16))) u32x4 st1[HSTAGE];
+  __shared__ uint32_t red4[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+  const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
+  const int m0 = tm * HTM, n0 = tn * HTN;
+  const int nslab = (g.K + KS - 1) / KS;
+  const int last = nslab - 1;
+
+  // operand scales: A from its magnitude words, the weight's from the image trailer
+  uint32_t amb = 0u;
+  for (int i = tid; i < g.a_amax_n; i += NT) amb = max(amb, g.a_amax[i]);
+  amb = block_max_u32(amb, red4);
+  const float sA = h2_scale(amb);
+  const float post = h2_inv_scale(amb) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
+
+  f32x16 acc[4][HNJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < HNJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging roles, descriptors and LDS slots: emu_kc2_kernel's (item i = row i * 64 + wave * 16 + lane / 4, quad lane % 4)
+  const int rl = lane >> 2, qd = lane & 3, cq = qd >> 1;
+  const int rows_in = min(HTM, g.M - m0);
+  __amdgpu_buffer_rsrc_t rsa[4], rsm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rows_q = max(min(rows_in - i * 64, 64), 0);
+    rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)m0 + i * 64) * g.lda), 0,
+                                               rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+    rsm[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(MASK ? g.abits + ((size_t)m0 + i * 64) * g.ldbits : nullptr), 0,
+                                               MASK ? (int)((long)rows_q * g.ldbits * 4) : 0, 0x00020000);
+  }
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<u32x4*>(g.Bimg + (size_t)tn * nslab * HB_U4), 0, nslab * HB_U4 * 16, 0x00020000);
+  const int aoff = (int)((((long)wave * 16 + rl) * g.lda + 4 * qd) * 4);
+  const int moff = (int)(((long)wave * 16 + rl) * g.ldbits * 4);
+  const int wslot = 2 * (cq * HTM + ((wave * 16 + rl) ^ (cq << 2))) + (qd & 1);
+  const int aread = (wm * 128 + l31) ^ (kh << 2);
+  const int kq = g.K - 4 * qd;
+  f32x2 rp[8], fu[8];
+  uint32_t t0[8], t1[8];
+  u32x4 rb[4];
+  uint32_t rm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, mb = 0xfu;
+  bool kin = true;
+#define NOP_ ((void)0)
+#define HLDGA(i, sl)                                                                                                   \
+  do {                                                                                                                 \
+    const int k0_ = min((sl), last) * KS;                      /* (uniform) a pad slab re-reads the last one */        \
+    const f32x4 v_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa[i], aoff, k0_ * 4, 0));       \
+    rp[2 * (i)] = f32x2{v_[0], v_[1]}; rp[2 * (i) + 1] = f32x2{v_[2], v_[3]};                                          \
+    if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm[i], moff, (k0_ >> 5) * 4, 0);                           \
+  } while (0)
+#define HLDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (tid + (q) * NT) * 16, min((sl), last) * (HB_U4 * 16), 0)
+#define HUI(i, sl) do { if (MASK) mb = rm[i] >> ((((sl) & 1) << 4) + 4 * qd); if (KTAIL) kin = (sl) * KS < kq; } while (0)
+#define PK_SUB(d, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+// pair p = 2 i + j of item i: HC1 sign bitmap / k tail / scale, hi plane (v_cvt_pk_f16_f32, round to nearest) and its f32 image;
+// HC2 residual, lo plane
+#define HC1(p)                                                                                                         \
+  do {                                                                                                                 \
+    f32x2 v_ = rp[p];                                                                                                  \
+    if (MASK) {           /* (asm: see emu_kc2_kernel's U1) */                                                         \
+      float xa_, xb_;                                                                                                  \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xa_) : "v"(__builtin_amdgcn_sbfe((int)mb, 2 * ((p) & 1), 1)), "v"(v_.x));       \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xb_) : "v"(__builtin_amdgcn_sbfe((int)mb, 2 * ((p) & 1) + 1, 1)), "v"(v_.y));   \
+      v_ = f32x2{xa_, xb_};                                                                                            \
+    }                                                                                                                  \
+    if (KTAIL) { if (!kin) v_ = f32x2{0.f, 0.f}; }                                                                     \
+    v_ *= sA;                                                                                                          \
+    const f16x2 h_ = __builtin_convertvector(v_, f16x2);                                                               \
+    t0[p] = __builtin_bit_cast(uint32_t, h_); rp[p] = v_;                                                              \
+    fu[p] = __builtin_convertvector(h_, f32x2);                                                                        \
+  } while (0)
+#define HC2(p) do { f32x2 w_; PK_SUB(w_, rp[p], fu[p]); t1[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(w_, f16x2)); } while (0)
+#define HSTA(st, i, tp, pl) reinterpret_cast<u32x2*>(st)[wslot + (i) * 128 + (pl) * 4 * HTM] = u32x2{tp[2 * (i)], tp[2 * (i) + 1]}
+#define HSTB(st, q) (st)[HA_U4 + tid + (q) * NT] = rb[q]
+#define HLA(st, p, i) __builtin_bit_cast(f16x8, (st)[aread + ((p) * 2 + kh) * HTM + (i) * 32])
+#define HLB(st, p, j) __builtin_bit_cast(f16x8, (st)[HA_U4 + wn * 128 + l31 + ((p) * 2 + kh) * HTN + (j) * 32])
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define HM1(ax, bx, i, j, work) do { acc[i][j] = MFH(ax[i], bx[j], acc[i][j]); work; SB(); } while (0)
+#define HMM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < HNJ; ++j) acc[i][j] = MFH(ax[i], bx[j], acc[i][j])
+#include "h2_phase.inc"
+#define SYNC() do { SB(); __syncthreads(); SB(); } while (0)
+#define HSTAGE_ALL(st, sl)                                                                                             \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+      HUI(i, sl);                                                                                                      \
+      HC1(2 * i); HC2(2 * i); HC1(2 * i + 1); HC2(2 * i + 1);                                                          \
+      HSTA(st, i, t0, 0); HSTA(st, i, t1, 1);                                                                          \
+    }                                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) HSTB(st, q);                                                         \
+  } while (0)
+#define HLOAD_ALL(sl)                                                                                                  \
+  do {                                                                                                                 \
+    /* issue order pinned to a phase's (B pieces, then the items): the vmcnt waits inside the loop count BOTH histories */ \
+    SB();                                                                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) { HLDGB(q, sl); SB(); }                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) { HLDGA(i, sl); SB(); }                                              \
+  } while (0)
+
+  const int nslab2 = (nslab + 1) & ~1;
+  f16x8 aH[4], aL[4], bP[HNJ], bQ[HNJ], bL[HNJ];
+  HLOAD_ALL(0);
+  HSTAGE_ALL(st0, 0);
+  HLOAD_ALL(1);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { aL[i] = HLA(st0, 1, i); aH[i] = HLA(st0, 0, i); }
+#pragma unroll
+  for (int j = 0; j < HNJ; ++j) { bP[j] = HLB(st0, 0, j); bL[j] = HLB(st0, 1, j); }
+  HMM(aL, bP); HMM(aH, bL);                                    // lo hi, hi lo of slab 0
+  HSTAGE_ALL(st1, 1);
+  HLOAD_ALL(2);
+  SYNC();                                                      // aH / bP = hi fragments of slab 0
+  for (int s = 1; s + 1 < nslab2; s += 2) {
+    HPHASE(st1, st0, s, bP, bQ);
+    SYNC();
+    HPHASE(st0, st1, s + 1, bQ, bP);
+    SYNC();
+  }
+  HPHASE(st1, st0, nslab2 - 1, bP, bQ);
+  SB();
+  HMM(aH, bQ);                                                 // hi hi of the last slab
+  __syncthreads();
+#undef HLDGA
+#undef HLDGB
+#undef HUI
+#undef PK_SUB
+#undef HC1
+#undef HC2
+#undef HSTA
+#undef HSTB
+#undef HLA
+#undef HLB
+#undef SB
+#undef HM1
+#undef HMM
+#undef NOP_
+#undef HPHASE
+#undef SYNC
+#undef HSTAGE_ALL
+#undef HLOAD_ALL
+  emu_epilogue<HTM, HTN, HNJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, post);
 }
 
 
@@ -645,6 +962,7 @@ struct DwArgs {
   float* colsum; long colsum_split_stride;   // partial bias gradients [split][N] (or db), may be null
   int M, N, K;
   int splitk, m_per_split, tiles_n, tiles_k;
+  const uint32_t* dy_amax; int dy_amax_n; const uint32_t* x_amax; int x_amax_n;      // f16x2 form: magnitude words of dy and x
 };
 }  // namespace
 
@@ -1076,6 +1394,231 @@ __global__ __launch_bounds__(NT, 1) void emu_dw2_kernel(DwArgs g) {
   }
 }
 
+// ---- f16x2 form of the 256 x 256 grad-weight tile (see "f16x2 form" above): both f32 operands scaled by their own power of two and
+// split into hi + lo f16 pieces in the staging registers, three MFMA products per slab (tools/gen/dw2h_phase.py -> dw2h_phase.inc),
+// stage = two planes (32 KB), the bias gradient from the unscaled values, dW scaled back in the epilogue.  The largest magnitudes
+// come as magnitude words (common.h) from whoever produced dy and x, or from emu_amax_launch.
+template <bool MASK, bool HASDB>
+__global__ __launch_bounds__(NT, 1) void emu_dw2h_kernel(DwArgs g) {
+  constexpr int A_U4 = 2 * 2 * DT;                           // two planes x two chunks x 256 columns
+  constexpr int STG = 2 * A_U4;                              // dy + x: 16-byte units per stage (32 KB)
+  constexpr int EPI = (4 * 32 * (DT / 2 + 4) * 4 + 15) / 16; // the epilogue's four transposition slices
+  __shared__ __attribute__((aligned(16))) u32x4 lds_all[2 * STG > EPI ? 2 * STG : EPI];
+  __shared__ uint32_t red4[4];
+  u32x4* const s0 = lds_all;
+  u32x4* const s1 = lds_all + STG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int ntile = g.tiles_n * g.tiles_k;
+  const int bid = blockIdx.x;
+  const int split = (bid & 7) + 8 * (bid / (8 * ntile));      // every slice of one tile on the same XCD (shared L2)
+  const int t = (bid >> 3) % ntile;
+  if (split >= g.splitk) return;
+  const int tn = t / g.tiles_k, tk = t - tn * g.tiles_k;
+  const int n0 = tn * DT, k0 = tk * DT;
+  const int mbeg = split * g.m_per_split;
+  const int mend = min(g.M, mbeg + g.m_per_split);
+  const int nslab = (mend - mbeg + KS - 1) / KS;
+  // operand scales from the magnitude words (common.h): dy s_dy and x s_x in [2^13, 2^14) at their largest element
+  uint32_t am_dy = 0u, am_x = 0u;
+  for (int i = threadIdx.x; i < g.dy_amax_n; i += NT) am_dy = max(am_dy, g.dy_amax[i]);
+  for (int i = threadIdx.x; i < g.x_amax_n; i += NT) am_x = max(am_x, g.x_amax[i]);
+  am_dy = block_max_u32(am_dy, red4);
+  __syncthreads();
+  am_x = block_max_u32(am_x, red4);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging role of the wave: waves 0 / 1 the dy patch of chunk 0 / 1 (rows 0-7 / 8-15 of the slab), waves 2 / 3 the x patch
+  const bool isA = wave < 2;
+  const int c = wave & 1, cg = lane;
+  const int col0 = (isA ? n0 : k0) + 4 * cg;
+  const bool col_ok = col0 < (isA ? g.N : g.K);             // N, K multiples of 4: a column group is all in or all out
+  const long ld = uni64(isA ? g.lddy : g.ldx);
+  const char* opbase = reinterpret_cast<const char*>(g.dy) +
+                       (long)uni64(isA ? 0ul : (uint64_t)(reinterpret_cast<const char*>(g.x) - reinterpret_cast<const char*>(g.dy)));
+  // row e of the patch: one per-lane offset register + e * (row stride), added at the load (a scalar operand of the add); a lane whose
+  // columns lie past the operand starts 1 GB out of range and reads zeros
+  const int voff0 = col_ok ? (int)(((long)c * 8 * ld + col0) * 4) : 0x40000000;
+  const int boff0 = (MASK && isA && col_ok) ? (int)(((long)c * 8 * g.ldbits + (col0 >> 5)) * 4) : 0x40000000;
+  const int ldb4 = (int)(ld * 4), ldm4 = g.ldbits * 4;
+  const uint32_t notA = isA ? 0u : 0xffffffffu;              // x patches carry no bitmap
+  const int bsh = col0 & 31;                                 // the patch's four sign bits within its bitmap word
+  constexpr bool SWZ = true;
+  const int sw = SWZ ? (cg >> 1) & 3 : 0;
+  const int wbase = (isA ? 0 : A_U4) + c * DT + 4 * cg;       // unit of the patch's first column in plane 0 (column j: + (j ^ sw))
+  const int rsw = SWZ ? (l31 >> 3) & 3 : 0;
+  const int aread = (wm * 128 + l31) ^ rsw, bread = A_U4 + ((wn * 128 + l31) ^ rsw);
+  f32x2 rvL[8], rvH[8];                                       // the patch: columns 0-1 / 2-3 of its eight rows
+  uint32_t rm[8], mpk = 0xffffffffu;                          // bitmap words of the slab in flight; the 8 x 4 sign bits of the patch being converted
+  uint32_t t0[4], t1[4];
+  const float sc = isA ? h2_scale(am_dy) : h2_scale(am_x);   // (wave-uniform)
+  f32x2 rp_, fu_;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#define NOP_ ((void)0)
+// DLDG(hf, e, sl): half hf (columns 2 hf, 2 hf + 1) of row e of the patch of slab sl through the slab's descriptor [first row of the
+// slab, end of the slice);
+// DLDM(e, sl): its bitmap word
+#define DSLAB(sl)                                                                                                      \
+    const int ms_ = mbeg + (sl) * KS;                                                                                  \
+    const int left_ = max(mend - ms_, 0);                     /* (uniform) rows of the slice from this slab on */
+#define DLDG(hf, e, sl)                                                                                                \
+  do {                                                                                                                 \
+    DSLAB(sl)                                                                                                          \
+    const __amdgpu_buffer_rsrc_t r_ = __builtin_amdgcn_make_buffer_rsrc(                                               \
+        const_cast<char*>(opbase + (size_t)ms_ * ld * 4), 0, (int)min((long)left_ * ld * 4, 0x3fffffffL), 0x00020000); \
+    const f32x2 v_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_, voff0 + (e) * ldb4 + (hf) * 8, 0, 0)); \
+    if ((hf) == 0) rvL[e] = v_; else rvH[e] = v_;                                                                      \
+  } while (0)
+#define DLDM(e, sl)                                                                                                    \
+  do {                                                                                                                 \
+    if (MASK) {                                                                                                        \
+      DSLAB(sl)                                                                                                        \
+      const __amdgpu_buffer_rsrc_t b_ = __builtin_amdgcn_make_buffer_rsrc(                                             \
+          const_cast<uint32_t*>(g.bits + (size_t)ms_ * g.ldbits), 0, (int)min((long)left_ * g.ldbits * 4, 0x3fffffffL), 0x00020000); \
+      rm[e] = __builtin_amdgcn_raw_buffer_load_b32(b_, boff0 + (e) * ldm4, 0, 0);                                      \
+    }                                                                                                                  \
+  } while (0)
+#define PK_SUB(d, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+// the conversion of rows 2 pr, 2 pr + 1 of column j of the patch: DU1 bitmap + first plane (column 0 first packs the two rows' four
+// sign bits into mpk - nibble e = row e - which frees the word registers for the next slab's words), DU2 first residual, DU3 second
+// plane, DU4 second residual + third plane
+#define DU1(j, pr)                                                                                                     \
+  do {                                                                                                                 \
+    f32x2 v_ = (j) < 2 ? f32x2{rvL[2 * (pr)][(j) & 1], rvL[2 * (pr) + 1][(j) & 1]} : f32x2{rvH[2 * (pr)][(j) & 1], rvH[2 * (pr) + 1][(j) & 1]}; \
+    if (MASK) {                                                                                                        \
+      if ((j) == 0) {                                                                                                  \
+        const uint32_t n0_ = ((rm[2 * (pr)] | notA) >> bsh) & 0xfu, n1_ = ((rm[2 * (pr) + 1] | notA) >> bsh) & 0xfu;   \
+        mpk = ((pr) == 0 ? 0u : mpk) | (n0_ << (8 * (pr))) | (n1_ << (8 * (pr) + 4));                                  \
+      }                                                                                                                \
+      float xa_, xb_;     /* (asm: see emu_kc2_kernel's U1) */                                                         \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xa_) : "v"(__builtin_amdgcn_sbfe((int)mpk, 8 * (pr) + (j), 1)), "v"(v_.x));    \
+      asm("v_and_b32 %0, %1, %2" : "=v"(xb_) : "v"(__builtin_amdgcn_sbfe((int)mpk, 8 * (pr) + 4 + (j), 1)), "v"(v_.y)); \
+      v_ = f32x2{xa_, xb_};                                                                                            \
+    }                                                                                                                  \
+    if (HASDB) csum[j] += v_.x + v_.y;                                                                                 \
+    v_ *= sc;                                                                                                          \
+    const f16x2 h_ = __builtin_convertvector(v_, f16x2);      /* v_cvt_pk_f16_f32, round to nearest */                 \
+    t0[pr] = __builtin_bit_cast(uint32_t, h_); rp_ = v_;                                                               \
+    fu_ = __builtin_convertvector(h_, f32x2);                                                                          \
+  } while (0)
+#define DU2(j, pr) do { f32x2 w_; PK_SUB(w_, rp_, fu_); t1[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(w_, f16x2)); } while (0)
+#define DSTA(st, j, pl) (st)[wbase + ((j) ^ sw) + (pl) * 2 * DT] = ((pl) == 0 ? u32x4{t0[0], t0[1], t0[2], t0[3]} : u32x4{t1[0], t1[1], t1[2], t1[3]})
+#define DLA(st, p, i) __builtin_bit_cast(f16x8, (st)[aread + ((p) * 2 + kh) * DT + (i) * 32])
+#define DLB(st, p, j) __builtin_bit_cast(f16x8, (st)[bread + ((p) * 2 + kh) * DT + (j) * 32])
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define M1(ax, bx, i, j, work) do { acc[i][j] = MFH(ax[i], bx[j], acc[i][j]); work; SB(); } while (0)
+#define MM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = MFH(ax[i], bx[j], acc[i][j])
+#define SYNC() do { SB(); __syncthreads(); SB(); } while (0)
+#include "dw2h_phase.inc"
+#define DSTAGE_ALL(st)                                                                                                 \
+  do {                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+      _Pragma("unroll") for (int pr = 0; pr < 4; ++pr) { DU1(j, pr); DU2(j, pr); }                                     \
+      DSTA(st, j, 0); DSTA(st, j, 1);                                                                                  \
+    }                                                                                                                  \
+  } while (0)
+#define DLOAD_ALL(sl) _Pragma("unroll") for (int e = 0; e < 8; ++e) { DLDG(0, e, sl); DLDG(1, e, sl); }
+#define DLOADM_ALL(sl) _Pragma("unroll") for (int e = 0; e < 8; ++e) DLDM(e, sl)
+
+  // the slab count is rounded up to an even number (a pad slab reads zeros through its empty descriptor); phases after the head
+  // come in pairs plus one.
+  const int nslab2 = (max(nslab, 1) + 1) & ~1;
+  f16x8 aH[4], aL[4], bP[4], bQ[4], bL[4];
+  DLOAD_ALL(0);
+  DLOADM_ALL(0);
+  DSTAGE_ALL(s0);
+  DLOAD_ALL(1);
+  DLOADM_ALL(1);
+  __syncthreads();
+  // head (left to the compiler): the first half of slab 0, slab 1 -> s1, slab 2 requested
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { aL[i] = DLA(s0, 1, i); aH[i] = DLA(s0, 0, i); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { bP[j] = DLB(s0, 0, j); bL[j] = DLB(s0, 1, j); }
+  MM(aL, bP); MM(aH, bL);                                     // lo hi, hi lo of slab 0; aH / bP = its hi pieces stay for the next phase
+  DSTAGE_ALL(s1);
+  DLOAD_ALL(2);
+  DLOADM_ALL(2);
+  SYNC();
+  for (int s = 1; s + 1 < nslab2; s += 2) {
+    DHPHASE(s1, s0, s, bP, bQ);
+    SYNC();
+    DHPHASE(s0, s1, s + 1, bQ, bP);
+    SYNC();
+  }
+  DHPHASE(s1, s0, nslab2 - 1, bP, bQ);
+  SB();
+  MM(aH, bQ);                                                 // hi hi of the last slab
+  __syncthreads();
+#undef DSLAB
+#undef DLDG
+#undef DLDM
+#undef DLOADM_ALL
+#undef PK_SUB
+#undef DU1
+#undef DU2
+#undef DSTA
+#undef DLA
+#undef DLB
+#undef SB
+#undef M1
+#undef MM
+#undef SYNC
+#undef DHPHASE
+#undef DSTAGE_ALL
+#undef DLOAD_ALL
+#undef NOP_
+  const float unscale = h2_inv_scale(am_dy) * h2_inv_scale(am_x);
+  const float post = MASK ? g.ascale : 1.f;
+  u32x4* lds = lds_all;
+  // bias gradient partial: the two chunk threads of a column group add up through LDS
+  if (HASDB && tk == 0) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (isA) *reinterpret_cast<f32x4*>(&red[c * DT + 4 * cg]) = csum * post;
+    __syncthreads();
+    if (tid < DT) {
+      const int n = n0 + tid;
+      if (n < g.N) g.colsum[(size_t)split * g.colsum_split_stride + n] = red[tid] + red[DT + tid];
+    }
+    __syncthreads();
+  }
+  // epilogue: one row of 32 x 32 blocks (32 x 128) at a time through the wave's private LDS slice
+  float* Cb = g.C + (size_t)split * g.c_split_stride;
+  const bool full = (n0 + DT <= g.N) && (k0 + DT <= g.K) && (g.K % 4 == 0);
+  constexpr int WK = DT / 2, ES = WK + 4, LPR = WK / 4, RPI = 64 / LPR;
+  float* w = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r] * (MASK ? post * unscale : unscale);
+#pragma unroll
+    for (int p = 0; p < 32 / RPI; ++p) {
+      const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
+      const int row = n0 + wm * 128 + i * 32 + rr, col = k0 + wn * WK + cc;
+      const float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
+      if (full) {
+        *reinterpret_cast<float4*>(Cb + (size_t)row * g.K + col) = v;
+      } else if (row < g.N) {
+        float* cp = Cb + (size_t)row * g.K + col;
+        if (col + 0 < g.K) cp[0] = v.x;
+        if (col + 1 < g.K) cp[1] = v.y;
+        if (col + 2 < g.K) cp[2] = v.z;
+        if (col + 3 < g.K) cp[3] = v.w;
+      }
+    }
+  }
+}
+
 // out[i] = sum_s part[s * stride + i], deterministic: a block owns 256 consecutive floats (64 lanes x float4), its 16 waves sum
 // the slices s = w, w + 16, ... in order (16 independent 1 KB streams per block keep the loads in flight) and the 16 partial sums
 // are combined in wave order through LDS.  n must be a multiple of 4 (N * K and N are).
@@ -1121,6 +1664,38 @@ __global__ __launch_bounds__(1024) void emu_reduce_partials_kernel(const float* 
 namespace {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// HOISDF_EMU_FORM: "h2" (default) = the f16x2 form, "b3" = bf16x3 (six products).  Process-wide: it fixes the weight-image format.
+bool form_h2() {
+  static int f = -1;
+  if (f < 0) { const char* e = getenv("HOISDF_EMU_FORM"); f = (e && (e[0] == 'b' || e[0] == 'B')) ? 0 : 1; }
+  return f == 1;
+}
+
+// magnitude words for an operand nobody measured: a ring of word arrays per stream (stream order makes the reuse safe)
+uint32_t* amax_ring_slot(hipStream_t st) {
+  struct Ring { uint32_t* base; unsigned next; };
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, Ring> rings;
+  constexpr unsigned SLOTS = 64;
+  std::lock_guard<std::mutex> lk(mu);
+  Ring& r = rings[st];
+  if (!r.base) {
+    if (hipMalloc(reinterpret_cast<void**>(&r.base), (size_t)SLOTS * AMAX_BLOCKS * 4) != hipSuccess) { r.base = nullptr; return nullptr; }
+    r.next = 0;
+  }
+  return r.base + (size_t)(r.next++ % SLOTS) * AMAX_BLOCKS;
+}
+}  // namespace
+
+// magnitude words of a row-major matrix into `part` (AMAX_BLOCKS words)
+int hoisdf::emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st) {
+  hipLaunchKernelGGL(emu_amax_kernel, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, part);
+  return check_launch("emu_amax");
+}
+int hoisdf::emu_amax_words() { return AMAX_BLOCKS; }
+bool hoisdf::emu_form_h2() { return form_h2(); }
+
+namespace {
 int launch_emu(EmuArgs g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -1133,9 +1708,28 @@ int launch_emu(EmuArgs g, hipStream_t st) {
     }
     attr_set = true;
   }
+  g.vecC = al16(g.C) && (g.ldc % 4 == 0);
+  if (g.beta) g.amax_out = nullptr;           // (the tile is added to what is there: its own magnitude says nothing)
+  if (form_h2()) {
+    g.tiles_m = cdiv(g.M, HTM);
+    g.tiles_n = cdiv(g.N, HTN);
+    g.b_scale = reinterpret_cast<const float*>(h2_trailer(const_cast<u32x4*>(g.Bimg), g.N, g.K)) + 16;
+    if (!g.a_amax) {
+      uint32_t* part = amax_ring_slot(st);
+      if (!part) { set_error("linear_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      if (int rc = emu_amax_launch(g.A, g.lda, g.M, g.K, part, st)) return rc;
+      g.a_amax = part; g.a_amax_n = AMAX_BLOCKS;
+    }
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
+    const bool kt = g.K % KS != 0 || (cdiv(g.K, KS) & 1);
+    if (g.abits && kt) hipLaunchKernelGGL((emu_h2_kernel<true, true>), grid, block, 0, st, g);
+    else if (g.abits) hipLaunchKernelGGL((emu_h2_kernel<true, false>), grid, block, 0, st, g);
+    else if (kt) hipLaunchKernelGGL((emu_h2_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((emu_h2_kernel<false, false>), grid, block, 0, st, g);
+    return check_launch("linear_emu (f16x2)");
+  }
   g.tiles_m = cdiv(g.M, TM);
   g.tiles_n = cdiv(g.N, TN);
-  g.vecC = al16(g.C) && (g.ldc % 4 == 0);
   const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
   static int form = -1;                       // HOISDF_EMU_KC=1: the first main-loop form (A/B runs); default: the rotated form
   if (form < 0) { const char* e = getenv("HOISDF_EMU_KC"); form = (e && atoi(e) == 1) ? 1 : 2; }
@@ -1157,6 +1751,7 @@ using namespace hoisdf;
 
 extern "C" long hoisdf_linear_emu_image_bytes(int rows, int K) {
   if (rows <= 0 || K <= 0) return 0;
+  if (form_h2()) return (long)cdiv(rows, HTN) * cdiv(K, KS) * HB_U4 * 16 + H_TRAILER;
   return (long)cdiv(rows, TN) * cdiv(K, KS) * B_U4 * 16;
 }
 
@@ -1165,6 +1760,13 @@ extern "C" int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, 
   HOISDF_REQUIRE(al16(image), HOISDF_ERR_INVALID, "linear_emu_prepare: the image must be 16-byte aligned");
   const int R = transpose ? K : N, Kc = transpose ? N : K;
   const int nslab = cdiv(Kc, KS);
+  if (form_h2()) {
+    const long total = (long)cdiv(R, HTN) * nslab * 2 * HTN;
+    hipLaunchKernelGGL(h2_weight_amax_kernel, dim3(16), dim3(256), 0, as_stream(stream), W, ldw, N, K, R, Kc, image);
+    hipLaunchKernelGGL(h2_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldw, R, Kc,
+                       transpose, nslab, total, static_cast<u32x4*>(image));
+    return check_launch("linear_emu_prepare (f16x2)");
+  }
   const long total = (long)cdiv(R, TN) * nslab * 2 * TN;
   hipLaunchKernelGGL(emu_prep_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), W, ldw, R, Kc,
                      transpose, nslab, total, static_cast<u32x4*>(image));
@@ -1174,6 +1776,7 @@ extern "C" int hoisdf_linear_emu_prepare(const float* W, int ldw, int N, int K, 
 extern "C" long hoisdf_linear_emu_prepare_blocks(int N, int K, int transpose) {
   if (N <= 0 || K <= 0) return 0;
   const int R = transpose ? K : N, Kc = transpose ? N : K;
+  if (form_h2()) return ((long)cdiv(R, HTN) * cdiv(Kc, KS) * 2 * HTN + 255) / 256;
   return ((long)cdiv(R, TN) * cdiv(Kc, KS) * 2 * TN + 255) / 256;
 }
 
@@ -1181,6 +1784,11 @@ extern "C" int hoisdf_linear_emu_prepare_batch(const hoisdf_emu_prep_item* d_ite
   HOISDF_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < (1L << 31), HOISDF_ERR_INVALID, "linear_emu_prepare_batch: bad sizes");
   if (n == 0 || total_blocks == 0) return HOISDF_OK;
   HOISDF_REQUIRE(d_items, HOISDF_ERR_INVALID, "linear_emu_prepare_batch: null table");
+  if (form_h2()) {
+    hipLaunchKernelGGL(h2_weight_amax_batch_kernel, dim3((unsigned)n * 16), dim3(256), 0, as_stream(stream), d_items);
+    hipLaunchKernelGGL(h2_prep_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), d_items, n);
+    return check_launch("linear_emu_prepare_batch (f16x2)");
+  }
   hipLaunchKernelGGL(emu_prep_weight_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), d_items, n);
   return check_launch("linear_emu_prepare_batch");
 }
@@ -1191,6 +1799,19 @@ extern "C" int hoisdf_linear_emu_supported(const float* a, long lda, int Kc) {
 
 extern "C" int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M,
                                      int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream) {
+  return linear_fwd_emu_mag(x, ldx, w_image, bias, y, ldy, M, N, K, act, drop_p, seed, relu_bits, nullptr, nullptr, stream);
+}
+extern "C" int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M,
+                                         int N, int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag,
+                                         uint32_t* y_mag, void* stream) {
+  return linear_fwd_emu_mag(x, ldx, w_image, bias, y, ldy, M, N, K, act, drop_p, seed, relu_bits, x_mag, y_mag, stream);
+}
+extern "C" int hoisdf_mag_words(void) { return MAG_WORDS; }
+extern "C" int hoisdf_linear_emu_pieces(void) { return form_h2() ? 2 : 3; }
+
+int hoisdf::linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K,
+                               int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag, uint32_t* y_mag,
+                               void* stream) {
   HOISDF_REQUIRE(M == 0 || (x && w_image && y), HOISDF_ERR_INVALID, "linear_fwd_emu: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && M < (1L << 31), HOISDF_ERR_INVALID,
                  "linear_fwd_emu: bad sizes M=%ld N=%d K=%d ldx=%d ldy=%d", M, N, K, ldx, ldy);
@@ -1203,12 +1824,13 @@ extern "C" int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_imag
   g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
+  g.a_amax = x_mag; g.a_amax_n = x_mag ? MAG_WORDS : 0; g.amax_out = y_mag;
   return launch_emu(g, as_stream(stream));
 }
 
 // hoisdf_linear_fwd_emu whose output goes into attention planes (common.h QkvPlanes; internal: the coarse layer entries use it)
 int hoisdf::linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, const float* bias, long M, int N, int K,
-                               const QkvPlanes& pl, void* stream) {
+                               const QkvPlanes& pl, void* stream, const uint32_t* x_mag) {
   HOISDF_REQUIRE(x && w_image && M > 0 && N > 0 && K > 0 && ldx >= K && M < (1L << 31), HOISDF_ERR_INVALID, "linear_fwd_emu_qkv: bad arguments");
   HOISDF_REQUIRE(hoisdf_linear_emu_supported(x, ldx, K), HOISDF_ERR_INVALID, "linear_fwd_emu_qkv: x alignment / K");
   HOISDF_REQUIRE(pl.on && pl.L > 0 && pl.L % 128 == 0 && M % pl.L == 0 && N % 64 == 0 && pl.E % 64 == 0 && pl.Lp >= pl.L &&
@@ -1218,12 +1840,24 @@ int hoisdf::linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, con
   g.A = x; g.lda = ldx; g.Bimg = static_cast<const u32x4*>(w_image);
   g.C = nullptr; g.ldc = N; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.inv_keep = 1.f; g.qkv = pl;
+  g.a_amax = x_mag; g.a_amax_n = x_mag ? MAG_WORDS : 0;
   return launch_emu(g, as_stream(stream));
 }
 
 extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                            const void* wt_image, float* dx, int lddx, long M, int N, int K, int accumulate,
                                            void* stream) {
+  return linear_bwd_input_emu_mag(dy, lddy, relu_bits, drop_p, wt_image, dx, lddx, M, N, K, accumulate, nullptr, nullptr, stream);
+}
+extern "C" int hoisdf_linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
+                                               const void* wt_image, float* dx, int lddx, long M, int N, int K, int accumulate,
+                                               const uint32_t* dy_mag, uint32_t* dx_mag, void* stream) {
+  return linear_bwd_input_emu_mag(dy, lddy, relu_bits, drop_p, wt_image, dx, lddx, M, N, K, accumulate, dy_mag, dx_mag, stream);
+}
+
+int hoisdf::linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image, float* dx,
+                                     int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag, uint32_t* dx_mag,
+                                     void* stream) {
   HOISDF_REQUIRE(M == 0 || (dy && wt_image && dx), HOISDF_ERR_INVALID, "linear_bwd_input_emu: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && lddx >= K && M < (1L << 31) && drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_input_emu: bad sizes");
@@ -1237,6 +1871,7 @@ extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint
   g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N;
   g.inv_keep = 1.f;
   g.beta = accumulate ? 1 : 0;
+  g.a_amax = dy_mag; g.a_amax_n = dy_mag ? MAG_WORDS : 0; g.amax_out = dx_mag;
   return launch_emu(g, as_stream(stream));
 }
 
@@ -1281,9 +1916,33 @@ extern "C" long hoisdf_linear_bwd_weight_emu_workspace(long M, int N, int K) {
   return (long)splitk * ((long)N * K + N);
 }
 
+namespace {
+int bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx, float* dW, int lddw,
+                   float* db, long M, int N, int K, float* workspace, long workspace_floats, bool h2, const uint32_t* dy_mag,
+                   const uint32_t* x_mag, void* stream);
+}
 extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
                                             int ldx, float* dW, int lddw, float* db, long M, int N, int K, float* workspace,
                                             long workspace_floats, void* stream) {
+  return bwd_weight_emu(dy, lddy, relu_bits, drop_p, x, ldx, dW, lddw, db, M, N, K, workspace, workspace_floats, false, nullptr, nullptr, stream);
+}
+// the f16x2 form (when the process runs it, hoisdf_linear_emu_pieces() == 2, and the tile is the 256-wide one; otherwise as above):
+// dy_mag / x_mag = magnitude words of the two operands, NULL = measured here
+extern "C" int hoisdf_linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x,
+                                                int ldx, float* dW, int lddw, float* db, long M, int N, int K, float* workspace,
+                                                long workspace_floats, const uint32_t* dy_mag, const uint32_t* x_mag, void* stream) {
+  return bwd_weight_emu(dy, lddy, relu_bits, drop_p, x, ldx, dW, lddw, db, M, N, K, workspace, workspace_floats, form_h2(), dy_mag, x_mag, stream);
+}
+int hoisdf::linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx,
+                                      float* dW, int lddw, float* db, long M, int N, int K, float* workspace, long workspace_floats,
+                                      const uint32_t* dy_mag, const uint32_t* x_mag, void* stream) {
+  return bwd_weight_emu(dy, lddy, relu_bits, drop_p, x, ldx, dW, lddw, db, M, N, K, workspace, workspace_floats, form_h2(), dy_mag, x_mag, stream);
+}
+
+namespace {
+int bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx, float* dW, int lddw,
+                   float* db, long M, int N, int K, float* workspace, long workspace_floats, bool h2, const uint32_t* dy_mag,
+                   const uint32_t* x_mag, void* stream) {
   HOISDF_REQUIRE(dW && (M == 0 || (dy && x)), HOISDF_ERR_INVALID, "linear_bwd_weight_emu: null pointer");
   HOISDF_REQUIRE(M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw == K && M < (1L << 31) && drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_weight_emu: bad sizes (a dense dW, lddw == K, is required)");
@@ -1322,7 +1981,26 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   const dim3 grid((unsigned)(ntile * 8 * cdiv(g.splitk, 8))), block(NT);
   const unsigned lb = 2u * (3 * 2 * DT + 3 * 2 * dtk) * 16u;
   const int form = dw_old_form() ? 1 : 2;     // HOISDF_EMU_DW=1: the first main-loop form for the 256-wide tiles (A/B runs)
-  if (dtk == 256 && form == 2) {
+  if (dtk == 256 && form == 2 && h2) {
+    g.dy_amax = dy_mag; g.dy_amax_n = MAG_WORDS; g.x_amax = x_mag; g.x_amax_n = MAG_WORDS;
+    if (!dy_mag) {
+      uint32_t* part = amax_ring_slot(st);
+      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      if (int rc = emu_amax_launch(dy, lddy, M, N, part, st)) return rc;
+      g.dy_amax = part; g.dy_amax_n = AMAX_BLOCKS;
+    }
+    if (!x_mag) {
+      uint32_t* part = amax_ring_slot(st);
+      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      if (int rc = emu_amax_launch(x, ldx, M, K, part, st)) return rc;
+      g.x_amax = part; g.x_amax_n = AMAX_BLOCKS;
+    }
+    const bool hasdb = g.colsum != nullptr;
+    if (relu_bits && hasdb) hipLaunchKernelGGL((emu_dw2h_kernel<true, true>), grid, block, 0, st, g);
+    else if (relu_bits) hipLaunchKernelGGL((emu_dw2h_kernel<true, false>), grid, block, 0, st, g);
+    else if (hasdb) hipLaunchKernelGGL((emu_dw2h_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((emu_dw2h_kernel<false, false>), grid, block, 0, st, g);
+  } else if (dtk == 256 && form == 2) {
     const bool hasdb = g.colsum != nullptr;
     if (relu_bits && hasdb) hipLaunchKernelGGL((emu_dw2_kernel<true, true>), grid, block, 0, st, g);
     else if (relu_bits) hipLaunchKernelGGL((emu_dw2_kernel<true, false>), grid, block, 0, st, g);
@@ -1345,3 +2023,4 @@ extern "C" int hoisdf_linear_bwd_weight_emu(const float* dy, int lddy, const uin
   }
   return HOISDF_OK;
 }
+}  // namespace

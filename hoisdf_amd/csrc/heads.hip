@@ -32,20 +32,36 @@ void mlp_carve(const hoisdf_mlp* m, long M, Bump& b, MlpSaved& s) {
     s.bits[i] = act ? static_cast<uint32_t*>(b.take(M * bits_words(m->dims[i + 1]) * 4)) : nullptr;
   }
 }
+// n zero-filled magnitude-word arrays (common.h) from the workspace for the operands a chain hands from one contraction to the next;
+// null when the contractions are not in the f16x2 form (or in a measuring pass, which only reserves the bytes)
+uint32_t* chain_mags(Ctx& c, int n) {
+  if (!c.emu || !emu_form_h2()) return nullptr;
+  uint32_t* p = static_cast<uint32_t*>(c.ws->take((long)n * MAG_WORDS * 4));
+  if (c.dry || !p || !c.ok()) return nullptr;
+  if (hipMemsetAsync(p, 0, (size_t)n * MAG_WORDS * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return nullptr; }
+  return p;
+}
 void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, const MlpSaved& s, float* y, int ldy) {
   const int last = m->n_layers - 1;
   const float* in = x; int ldin = ldx;
+  uint32_t* mg = chain_mags(c, m->n_layers);
+  const uint32_t* in_mag = nullptr;
   for (int i = 0; i < m->n_layers; ++i) {
     float* out = i < last ? s.h[i] : y;
     const int ldo = i < last ? m->dims[i + 1] : ldy;
-    lin_fwd(c, in, ldin, m->w[i], m->dims[i], m->img[i], m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i]);
-    in = out; ldin = ldo;
+    // (the tiled emulated form is the one that writes the words: the same test lin_fwd makes)
+    uint32_t* out_mag = mg && i < last && emu_rows(c, M, in, ldin, m->dims[i]) ? mg + i * MAG_WORDS : nullptr;
+    lin_fwd(c, in, ldin, m->w[i], m->dims[i], m->img[i], m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i], 0,
+            in_mag, out_mag);
+    in = out; ldin = ldo; in_mag = out_mag;
   }
 }
 // dy [M][ld] = gradient of the last layer's (post-activation) output; dx (optional) receives / accumulates the input gradient
 void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const float* x, int ldx, long M, const MlpSaved& s, const float* dy,
                   int lddy, float* dx, int lddx, int accumulate_dx) {
   const float* g = dy; int ldg = lddy;
+  uint32_t* mg = chain_mags(c, m->n_layers);
+  const uint32_t* g_mag = nullptr;
   for (int i = m->n_layers - 1; i >= 0; --i) {
     const float* in = i > 0 ? s.h[i - 1] : x;
     const int ldin = i > 0 ? m->dims[i] : ldx;
@@ -54,8 +70,10 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
     float* gin = i > 0 ? c.ws->floats(M * m->dims[i]) : dx;
     const int ldgin = i > 0 ? m->dims[i] : lddx;
     if (!c.dry && c.ok() && !gin) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-    lin_bwd_input(c, g, ldg, s.bits[i], 0.f, m->w[i], m->dims[i], m->img_t[i], gin, ldgin, M, m->dims[i + 1], m->dims[i], i == 0 ? accumulate_dx : 0);
-    g = gin; ldg = ldgin;
+    uint32_t* gin_mag = mg && i > 0 && emu_rows(c, M, g, ldg, m->dims[i + 1]) ? mg + i * MAG_WORDS : nullptr;
+    lin_bwd_input(c, g, ldg, s.bits[i], 0.f, m->w[i], m->dims[i], m->img_t[i], gin, ldgin, M, m->dims[i + 1], m->dims[i], i == 0 ? accumulate_dx : 0,
+                  g_mag, gin_mag);
+    g = gin; ldg = ldgin; g_mag = gin_mag;
   }
 }
 bool grads_ok(const hoisdf_mlp* m, const hoisdf_mlp_grads* G) {

@@ -237,12 +237,13 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, long M,
                                                          int D, float eps, float drop_p, float inv_keep,
-                                                         uint64_t seed, uint32_t thresh, int rpg, int take) {
+                                                         uint64_t seed, uint32_t thresh, int rpg, int take, uint32_t* __restrict__ y_mag) {
   // rpg > 0 (hoisdf_layernorm_rows_fwd): only the first `take` rows of every group of `rpg` input rows are normalised;
   // y / mean / rstd are compact ([groups * take]), M counts the compact rows
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t ymax = 0u;                               // y's magnitude words (common.h), when wanted
   for (; orow < M; orow += (long)gridDim.x * 4) {
     const long row = rpg > 0 ? (orow / take) * rpg + orow % take : orow;       // input row
     float4 v[4];
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
         o.z = (v[i].z - mu) * rs * g.z + bb.z;
         o.w = (v[i].w - mu) * rs * g.w + bb.w;
         *reinterpret_cast<float4*>(y + (size_t)orow * D + u * 4) = o;
+        ymax = max(ymax, mag_bits4(o));
       }
     }
     if (lane == 0) {
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
       if (rstd) rstd[orow] = rs;
     }
   }
+  mag_publish_wave(y_mag, ymax);
 }
 
 // backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dr = dx * mask/(1-p).
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dr, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, long M, int D, float drop_p,
                                                          float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds, const float* __restrict__ dx_add,
-                                                         int rpg, int take) {
+                                                         int rpg, int take, uint32_t* __restrict__ dx_mag, uint32_t* __restrict__ dr_mag) {
   // rpg > 0 (hoisdf_layernorm_rows_bwd): M counts ALL input rows; dy / mean / rstd are compact - only rows t < take of a
   // group carry a gradient, the others just pass dx_add through (or get 0)
   const int lane = threadIdx.x & 63;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); }
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t xmax = 0u, rmax = 0u;            // magnitude words of dx / dr (common.h), when wanted
   for (; row < M; row += (long)gridDim.x * 4) {
     long crow = row;                        // row of dy / mean / rstd
     if (rpg > 0) {
@@ -328,9 +332,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int u = lane + 64 * i;
-          if (u < nu)
-            *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) =
-                dx_add ? *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + u * 4) : make_float4(0, 0, 0, 0);
+          if (u < nu) {
+            const float4 e = dx_add ? *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + u * 4) : make_float4(0, 0, 0, 0);
+            *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = e;
+            xmax = max(xmax, mag_bits4(e));
+          }
         }
         continue;
       }
@@ -383,6 +389,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
           ox.x += e.x; ox.y += e.y; ox.z += e.z; ox.w += e.w;
         }
         *reinterpret_cast<float4*>(dx + (size_t)row * D + u * 4) = ox;
+        xmax = max(xmax, mag_bits4(ox));
         if (dr) {
           if (drop_p > 0.f) {
             const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(u * 4);
@@ -392,10 +399,13 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
             o.w *= drop_scale(rk, e + 3, thresh, inv_keep);
           }
           *reinterpret_cast<float4*>(dr + (size_t)row * D + u * 4) = o;
+          rmax = max(rmax, mag_bits4(o));
         }
       }
     }
   }
+  mag_publish_wave(dx_mag, xmax);
+  mag_publish_wave(dr_mag, rmax);
   // reduce the 4 waves of the block through LDS, then one atomic per column per block
   __shared__ float red[2][4][1024];
   const int w = threadIdx.x >> 6;
@@ -564,12 +574,16 @@ extern "C" int hoisdf_token_build_bwd_ordered(const float* dtok, const float* fe
 extern "C" int hoisdf_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
                                         float* y, float* mean, float* rstd, long M, int D, float eps, float drop_p,
                                         uint64_t seed, void* stream) {
+  return add_layernorm_fwd_mag(x, r, gamma, beta, y, mean, rstd, M, D, eps, drop_p, seed, nullptr, stream);
+}
+int hoisdf::add_layernorm_fwd_mag(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                  long M, int D, float eps, float drop_p, uint64_t seed, uint32_t* y_mag, void* stream) {
   HOISDF_REQUIRE(x && gamma && beta && y && M >= 0, HOISDF_ERR_INVALID, "add_layernorm_fwd: null pointer");
   HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
                  "add_layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
   if (M == 0) return HOISDF_OK;
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
-                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0);
+                     mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0, y_mag);
   return check_launch("add_layernorm_fwd");
 }
 
@@ -594,7 +608,7 @@ extern "C" int hoisdf_layernorm_rows_fwd(const float* x, const float* gamma, con
   const long M = groups * take;
   if (M == 0) return HOISDF_OK;
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, (const float*)nullptr, gamma,
-                     beta, y, mean, rstd, M, D, eps, 0.f, 1.f, (uint64_t)0, 0u, rows_per_group, take);
+                     beta, y, mean, rstd, M, D, eps, 0.f, 1.f, (uint64_t)0, 0u, rows_per_group, take, (uint32_t*)nullptr);
   return check_launch("layernorm_rows_fwd");
 }
 
@@ -602,6 +616,11 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
                                         const float* mean, const float* rstd, const float* dx_add, float* dx, float* dr,
                                         float* dgamma, float* dbeta, long M, int D, float drop_p, uint64_t seed,
                                         void* stream) {
+  return add_layernorm_bwd_mag(dy, x, r, gamma, mean, rstd, dx_add, dx, dr, dgamma, dbeta, M, D, drop_p, seed, nullptr, nullptr, stream);
+}
+int hoisdf::add_layernorm_bwd_mag(const float* dy, const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,
+                                  const float* dx_add, float* dx, float* dr, float* dgamma, float* dbeta, long M, int D, float drop_p,
+                                  uint64_t seed, uint32_t* dx_mag, uint32_t* dr_mag, void* stream) {
   HOISDF_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && M >= 0, HOISDF_ERR_INVALID,
                  "add_layernorm_bwd: null pointer");
   HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
@@ -611,7 +630,7 @@ extern "C" int hoisdf_add_layernorm_bwd(const float* dy, const float* x, const f
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
                      dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
-                     det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0);
+                     det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0, dx_mag, dr_mag);
   return check_launch("add_layernorm_bwd");
 }
 
@@ -628,6 +647,6 @@ extern "C" int hoisdf_layernorm_rows_bwd(const float* dy, const float* x, const 
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, (const float*)nullptr, gamma,
                      mean, rstd, dx, (float*)nullptr, dgamma, dbeta, M, D, 0.f, 1.f, (uint64_t)0, 0u,
-                     det_scratch((size_t)blocks * 2 * D), dx_add, rows_per_group, take);
+                     det_scratch((size_t)blocks * 2 * D), dx_add, rows_per_group, take, (uint32_t*)nullptr, (uint32_t*)nullptr);
   return check_launch("layernorm_rows_bwd");
 }

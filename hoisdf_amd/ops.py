@@ -467,16 +467,25 @@ def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
     return None
 
 
-def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None):
-    """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the emulated form overwrites."""
+# grad-weight form when no magnitude words are at hand: "b3" (bf16x3, needs none) or "h2" (f16x2, the library measures both operands)
+_EMU_DW_FORM = __import__("os").environ.get("HOISDF_EMU_DW_FORM", "b3")
+
+
+def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None, form=None, dy_mag=None, x_mag=None):
+    """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the emulated form overwrites.
+    form "h2" / magnitude words given: hoisdf_linear_bwd_weight_emu_mag (f16x2 where the process runs that form)."""
     if (_GEMM_EMU and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
             and dW.data_ptr() % 16 == 0):
         from ._lib import lib
         nws = lib().hoisdf_linear_bwd_weight_emu_workspace(M, N, K)
         ws = torch.empty(max(nws, 4), device=dW.device, dtype=torch.float32)
-        call("hoisdf_linear_bwd_weight_emu", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
-             _p(ws), nws, _st())
+        if (form or _EMU_DW_FORM) == "h2" or dy_mag is not None or x_mag is not None:
+            call("hoisdf_linear_bwd_weight_emu_mag", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
+                 _p(ws), nws, _p(dy_mag), _p(x_mag), _st())
+        else:
+            call("hoisdf_linear_bwd_weight_emu", _p(dy2), lddy, _p(bits), float(p), _p(x2), ldx, _p(dW), K, _p(db), M, N, K,
+                 _p(ws), nws, _st())
         return
     if M == 0:
         return                      # an empty row set: dW / db stay zero (what the f32 entry does)
@@ -1530,6 +1539,11 @@ class _EncoderLayerC(torch.autograd.Function):
                              training=int(any(ctx.needs_input_grad)))
         for i in range(4):                                     # attention, after out-projection, FFN hidden, after the FFN
             d.seed[i] = next_seed() if p > 0 else 0
+        # magnitude words of x (f16x2 form): left by the layer below next to its saved activations (kept alive with them)
+        xm = getattr(x, "_hoisdf_mag", None)
+        if xm is not None and xm[2] == x._version:
+            d.x_mag = xm[0]
+            ctx.x_mag_owner = xm[1]
         w = EncoderLayerWeights(**{n: t.data_ptr() for n, t in zip(_ENC_W_NAMES, params)})
         _EncoderLayerC._images(w, (w_in, w_out, w1, w2), False, B * nq, B * S, E, nq == S)
         dp, wp = C.addressof(d), C.addressof(w)
@@ -1541,6 +1555,10 @@ class _EncoderLayerC(torch.autograd.Function):
         x2 = torch.empty(B, nq, E, device=dev)
         y = torch.empty(B, ni, E, device=dev)
         call("hoisdf_encoder_layer_fwd", _p(x), wp, dp, _p(x2), _p(y), _p(saved), n_saved, _p(ws), n_ws, _st())
+        if saved is not None:
+            om = lib().hoisdf_encoder_layer_out_mag(dp, _p(saved))
+            if om:
+                x2._hoisdf_mag = (om, saved, x2._version)
         ctx.save_for_backward(x, x2, saved, *params)
         ctx.desc = d
         return x2, y

@@ -145,6 +145,35 @@ typedef struct hoisdf_emu_prep_item {
 long hoisdf_linear_emu_prepare_blocks(int N, int K, int transpose);
 int hoisdf_linear_emu_prepare_batch(const hoisdf_emu_prep_item* d_items, int n, long total_blocks, void* stream);
 int hoisdf_linear_emu_supported(const float* a, long lda, int contraction);
+/* ---- the two arithmetic forms of the emulated entries (process-wide; environment HOISDF_EMU_FORM, read at first use) -----------
+ * "b3"  bf16x3: the exact three-piece split described above, six products per product, any operand range.
+ * "h2"  f16x2 (default since round 5): every operand is scaled by a power of two s that puts its largest magnitude in
+ *       [2^13, 2^14) and split into TWO f16 pieces, x s = hi + lo + r with |r| <= max(2^-22 |x s|, 2^-25): 22 significant bits
+ *       (on average 2^-24 relative, the rounding of an f32 operation) for every element within 2^-16 of the matrix's largest, an
+ *       ABSOLUTE error of 2^-38 max |x| below that (the low piece is an f16 subnormal there); each product is accumulated in f32 from
+ *       THREE f16 MFMA products (lo hi + hi lo + hi hi; the dropped lo lo term is <= 2^-22 of the product) and the result is scaled
+ *       back.  Half the matrix-pipe work of b3.  Error against fp64 on the model's operands: that of b3 and of the exact-f32 entries
+ *       (tests/test_gpu_emu.py, test_gpu_bench_geometry.py); what it gives up is RELATIVE accuracy of elements more than 2^16 below
+ *       the largest one of the same operand matrix (their error stays 2^-38 of that largest one).
+ *       The scale needs the operand's largest magnitude at launch time: weights carry theirs in the image; for the row operand
+ *       the caller may pass "magnitude words" that the producing kernel left behind (hoisdf_mag_words() u32 words, zero-filled
+ *       before the producer(s) ran; every wave of a producer folds the IEEE bits of its max |value| into one word with an unsigned
+ *       atomic max: the *_mag entries below do that for their output when y_mag / dx_mag is given - not with accumulate = 1).
+ *       Without words (x_mag = NULL, and in the plain entries) the library measures the operand itself: one more read of it.
+ * hoisdf_linear_emu_pieces() = 2 (h2) or 3 (b3).  The image format follows the form: images are built and consumed in one process. */
+int hoisdf_linear_emu_pieces(void);
+int hoisdf_mag_words(void);
+int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
+                              int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag,
+                              uint32_t* y_mag, void* stream);
+int hoisdf_linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image,
+                                    float* dx, int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag,
+                                    uint32_t* dx_mag, void* stream);
+/* grad-weight in the f16x2 form (h2 processes, 256-wide tiles; otherwise identical to hoisdf_linear_bwd_weight_emu, whose
+ * bf16x3 arithmetic needs no magnitudes and stays available in either process form): dy_mag / x_mag as above, NULL = measured. */
+int hoisdf_linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx,
+                                     float* dW, int lddw, float* db, long M, int N, int K, float* workspace, long workspace_floats,
+                                     const uint32_t* dy_mag, const uint32_t* x_mag, void* stream);
 int hoisdf_linear_fwd_emu(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
                           int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, void* stream);
 int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image,
@@ -464,7 +493,12 @@ typedef struct hoisdf_encoder_layer_desc {
   int attention;                /* 0: exact-f32 kernels; 2: emulated-fp32 forward (hoisdf_attention_fwd_emu) */
   int attention_bwd_emulated;   /* with attention == 2: the order-fixed emulated backward instead of the f32 fused one */
   int training;                 /* 0: nothing is saved (saved may be NULL), hoisdf_encoder_layer_bwd cannot follow */
+  const uint32_t* x_mag;        /* optional: magnitude words of x (f16x2 form, see hoisdf_linear_fwd_emu_mag; NULL = the layer measures
+                                 * x itself), e.g. hoisdf_encoder_layer_out_mag of the layer below; must stay valid until the backward */
 } hoisdf_encoder_layer_desc;
+/* where a training forward left the magnitude words of x_out inside `saved` (NULL when the layer's contractions do not run in the
+ * f16x2 form): the x_mag of the next layer's descriptor */
+const uint32_t* hoisdf_encoder_layer_out_mag(const hoisdf_encoder_layer_desc* d, const void* saved);
 typedef struct hoisdf_encoder_layer_weights {
   const float *w_in, *b_in;     /* [3E][E], [3E]: packed q | k | v in-projection */
   const float *w_out, *b_out;   /* [E][E], [E] */

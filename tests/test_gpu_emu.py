@@ -1,11 +1,15 @@
-"""-m gpu: the fp32-emulating linear kernels (csrc/gemm_emu.hip: exact three-way bf16 split of both f32 operands, six bf16
-MFMA products, f32 accumulation) are held to the bars of the exact-f32 MFMA kernel:
+"""-m gpu: the fp32-emulating linear kernels (csrc/gemm_emu.hip; default form "h2": two scaled f16 pieces per operand, three f16
+MFMA products, f32 accumulation; form "b3", HOISDF_EMU_FORM=b3: exact three-way bf16 split, six products - this file runs its
+linear-layer tests under both, the second in a child process) are held to the bars of the exact-f32 MFMA kernel:
   * against fp64 at the exact kernel's tolerance (2e-6 of the tensor's max on rows spanning 8 decades, ragged shapes, ReLU +
     dropout through the sign bitmap, accumulate-into);
   * element-wise error against fp64, normalised by sum |a||b|, no larger than the exact-f32 kernel's on the same inputs;
   * exactness of the split itself (x0 + x1 + x2 == x bit for bit) on values across the whole f32 exponent range."""
 import ctypes as C
 import math
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -17,6 +21,12 @@ DEV = "cuda"
 def ops():
     from hoisdf_amd import ops as O
     return O
+
+
+def pieces():
+    """2: the f16x2 form, 3: bf16x3 (process-wide, HOISDF_EMU_FORM)"""
+    from hoisdf_amd._lib import lib
+    return lib().hoisdf_linear_emu_pieces()
 
 
 def assert_close(a, b, rel, what=""):
@@ -119,6 +129,46 @@ def test_emulated_grad_weight_matches_fp64(M, N, K, act, p):
     O._gemm_bwd_weight(gy, N, None, 0.0, x.detach(), K, dW3, db3, M, N, K)
     assert not torch.equal(dW1, dW3)
     assert_close(dW1, dW3, rel=2e-6, what="emulated vs exact-f32 dW")
+
+
+@pytest.mark.parametrize("M,N,K,masked", [(8192, 256, 256, False), (16384, 1024, 256, True), (9000, 224, 516, True), (70000, 256, 1024, False),
+                                          (8200, 64, 992, False), (8200, 512, 252, True), (8300, 256, 128, True)])
+def test_f16x2_grad_weight_matches_fp64(M, N, K, masked):
+    """hoisdf_linear_bwd_weight_emu_mag (emu_dw2h_kernel: both operands scaled and split into two f16 pieces in the staging registers,
+    three products): dW, db against fp64 at the exact kernel's 2e-6 with rows spanning 6 decades, ragged edges, the sign bitmap;
+    magnitudes measured by the library or handed over as magnitude words (same results bit for bit); K <= 128 keeps the bf16x3
+    tile.  Two runs are bit-identical."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    from hoisdf_amd._lib import lib
+    g = torch.Generator().manual_seed(M + N + K)
+    decades = lambda n: torch.pow(10.0, -6.0 * torch.rand(n, 1, generator=g))
+    x = (torch.randn(M, K, generator=g) * decades(M)).to(DEV)
+    gy = (torch.randn(M, N, generator=g) * 1e-4 * decades(M)).to(DEV)
+    gy[::7] = 0.0
+    bits, p, scale = None, 0.0, torch.ones(M, N, device=DEV, dtype=torch.float64)
+    if masked:
+        keep = torch.rand(M, N, generator=g) < 0.6
+        nw = (N + 31) // 32
+        pad = torch.zeros(M, nw * 32, dtype=torch.bool); pad[:, :N] = keep
+        words = (pad.view(M, nw, 32).long() << torch.arange(32)).sum(-1)
+        bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
+        p = 0.2
+        scale = keep.to(DEV).double() / (1 - p)
+    dye = gy.double() * scale
+    outs = []
+    nw_ = lib().hoisdf_mag_words()
+    ymag = torch.zeros(nw_, dtype=torch.int32, device=DEV); ymag[3] = gy.abs().max().view(torch.int32)
+    xmag = torch.zeros(nw_, dtype=torch.int32, device=DEV); xmag[200] = x.abs().max().view(torch.int32)
+    for kw in (dict(form="h2"), dict(form="h2"), dict(dy_mag=ymag, x_mag=xmag), dict(dy_mag=ymag)):
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        O._gemm_bwd_weight(gy, N, bits, p, x, K, dW, db, M, N, K, **kw)
+        outs.append((dW, db))
+    assert_close(outs[0][0], dye.t() @ x.double(), rel=2e-6, what="dW")
+    assert_close(outs[0][1], dye.sum(0), rel=2e-6, what="db")
+    for dW, db in outs[1:]:
+        assert torch.equal(dW, outs[0][0]) and torch.equal(db, outs[0][1])
 
 
 @pytest.mark.parametrize("M,N,K,act,p", [(544, 256, 256, False, 0.0), (544, 1024, 256, True, 0.1), (544, 256, 1024, False, 0.0),
@@ -240,6 +290,8 @@ def test_emulated_linear_is_no_less_accurate_than_the_exact_f32_kernel(M, N, K):
 def test_three_way_bf16_split_is_exact_over_the_f32_range():
     """x0 + x1 + x2 == x bit for bit (every normal f32 whose lowest piece stays a normal bf16, i.e. |x| >= 2^-110): checked
     through the kernel itself - an identity weight makes y[m][n] = x[m][n] as x0 + x1 + x2 with nothing else to add."""
+    if pieces() != 3:
+        pytest.skip("the exact split is the bf16x3 form's (test_the_bf16x3_form_meets_the_same_bars runs this under HOISDF_EMU_FORM=b3)")
     O = ops()
     g = torch.Generator().manual_seed(3)
     M, K = 2048, 256
@@ -251,6 +303,79 @@ def test_three_way_bf16_split_is_exact_over_the_f32_range():
     y = torch.empty(M, K, device=DEV)
     O._gemm_fwd(x, K, eye, None, y, K, M, K, K, 0, 0.0, 0, None)
     assert torch.equal(y, x)
+
+
+def test_f16x2_split_keeps_its_stated_accuracy():
+    """the f16x2 form through the kernel itself (identity weight: y = (hi + lo) / s): every element within max(2^-22 |x|,
+    2^-38 max |x|) of itself (include/hoisdf.h: two 11-bit pieces; below 2^-16 max |x| the low piece is an f16 subnormal and the
+    error turns absolute); the scale follows the largest magnitude wherever it sits in the f32 range."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    g = torch.Generator().manual_seed(5)
+    M, K = 2048, 256
+    for top in (-60, 0, 17, 90):
+        mant = torch.rand(M, K, generator=g) + 1.0
+        expo = torch.randint(top - 45, top + 1, (M, K), generator=g).float()
+        sign = torch.where(torch.rand(M, K, generator=g) < 0.5, -1.0, 1.0)
+        x = (sign * mant * torch.pow(2.0, expo)).to(DEV)
+        x[::9] = 0.0
+        y = torch.empty(M, K, device=DEV)
+        O._gemm_fwd(x, K, torch.eye(K, device=DEV), None, y, K, M, K, K, 0, 0.0, 0, None)
+        amax = float(x.abs().max())
+        err = (y.double() - x.double()).abs()
+        bound = torch.maximum(x.double().abs() * 2.0 ** -22, torch.full_like(err, amax * 2.0 ** -38))
+        assert bool((err <= bound).all()), (top, float((err / bound).max()))
+
+
+def test_magnitude_words_travel_from_producer_to_consumer():
+    """hoisdf_linear_fwd_emu_mag / _bwd_input_emu_mag: the words a contraction leaves for its output hold max |y| (never less, and
+    within the padding rows' bias-only values of it); a consumer given those words computes bit-identically to one that measures
+    the operand itself whenever both find the same power of two."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    from hoisdf_amd._lib import call, lib
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 4100, 512, 256
+    x = torch.randn(M, K, generator=g).to(DEV)
+    W1 = (torch.randn(N, K, generator=g) / 16).to(DEV)
+    W2 = (torch.randn(K, N, generator=g) / 16).to(DEV)
+    nw = lib().hoisdf_mag_words()
+    ymag = torch.zeros(nw, dtype=torch.int32, device=DEV)
+    zmag = torch.zeros(nw, dtype=torch.int32, device=DEV)
+    y = torch.empty(M, N, device=DEV); z = torch.empty(M, K, device=DEV); z0 = torch.empty(M, K, device=DEV)
+    st = O._st()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    call("hoisdf_linear_fwd_emu_mag", p(x), K, p(O._emu_image(W1, False)), None, p(y), N, M, N, K, 1, 0.0, 0, None, None, p(ymag), st)
+    got = float(ymag.view(torch.float32).max())
+    assert got == float(y.abs().max()), (got, float(y.abs().max()))
+    call("hoisdf_linear_fwd_emu_mag", p(y), N, p(O._emu_image(W2, False)), None, p(z), K, M, K, N, 0, 0.0, 0, None, p(ymag), p(zmag), st)
+    call("hoisdf_linear_fwd_emu", p(y), N, p(O._emu_image(W2, False)), None, p(z0), K, M, K, N, 0, 0.0, 0, None, st)
+    assert torch.equal(z, z0)
+    assert float(zmag.view(torch.float32).max()) == float(z.abs().max())
+    assert_close(z, torch.relu(x.double() @ W1.double().t()) @ W2.double().t(), rel=2e-6, what="two chained contractions")
+    # grad-input with the words of dy; accumulate = 1 leaves dx_mag alone
+    dx = torch.empty(M, K, device=DEV); dx0 = torch.empty(M, K, device=DEV)
+    dmag = torch.zeros(nw, dtype=torch.int32, device=DEV)
+    call("hoisdf_linear_bwd_input_emu_mag", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx), K, M, N, K, 0, p(ymag), p(dmag), st)
+    call("hoisdf_linear_bwd_input_emu", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx0), K, M, N, K, 0, st)
+    assert torch.equal(dx, dx0) and float(dmag.view(torch.float32).max()) == float(dx.abs().max())
+    dmag.zero_()
+    call("hoisdf_linear_bwd_input_emu_mag", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx), K, M, N, K, 1, p(ymag), p(dmag), st)
+    assert int(dmag.abs().max()) == 0
+    assert_close(dx, 2 * dx0.double(), rel=1e-6, what="accumulate")
+
+
+def test_the_bf16x3_form_meets_the_same_bars():
+    """the linear-layer tests of this file once more with HOISDF_EMU_FORM=b3 (the form is fixed per process: a child runs them)"""
+    if os.environ.get("HOISDF_EMU_FORM_CHILD"):
+        pytest.skip("already the child")
+    env = dict(os.environ, HOISDF_EMU_FORM="b3" if pieces() == 2 else "h2", HOISDF_EMU_FORM_CHILD="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "linear or split or image or batch", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout
 
 
 def test_emulated_image_cache_follows_weight_updates_and_owners():

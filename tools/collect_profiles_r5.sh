@@ -14,13 +14,13 @@ HOISDF_ATTN16=f16 python bench.py --config 4 --no-cpu-baseline --exact-f32 0 > $
 python bench.py --branch-mix --no-cpu-baseline --exact-f32 0 > $O/bench_branch_mix.json 2> /dev/null
 cd /tmp
 for cfg in default config4; do
-  extra=""; [ $cfg = config4 ] && extra="--config 4"
+  extra=""; marker=""; [ $cfg = config4 ] && extra="--config 4" && marker="vote_loss_fwd_kernel"
   HOISDF_TWO_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- \
       python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --exact-f32 0 --no-kernel-timing $extra > $O/bench_${cfg}_under_rocprof.json 2> /dev/null
   T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
   S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
   [ -n "$S" ] && cp $S $O/${cfg}_rocprof_stats_raw.csv
-  [ -n "$T" ] && python $R/tools/trace_stats.py $T 3 5 > $O/${cfg}_kernel_stats.csv 2> $O/${cfg}_timed_window.txt
+  [ -n "$T" ] && python $R/tools/trace_stats.py $T 3 5 $marker > $O/${cfg}_kernel_stats.csv 2> $O/${cfg}_timed_window.txt
   rm -rf $O/trace
 done
 cd $R

@@ -4,19 +4,21 @@
 rocprofv3 --stats aggregates the whole process, including MIOpen's find-mode warm-up (which runs its
 naive reference convolutions a few hundred times).  The timed region is delimited with the AdamW launches
 (hoisdf::adamw_chunks_kernel, one per step): bench.py does `warmup` untimed steps, then `steps` timed ones, each ending with the same number of
-optimizer kernels.  usage: trace_stats.py <kernel_trace.csv> <warmup> <steps> > stats.csv"""
+optimizer kernels.  An inference trace (configs[3]/[4]: no optimizer) names another once-per-step kernel as the marker instead.
+usage: trace_stats.py <kernel_trace.csv> <warmup> <steps> [marker substring] > stats.csv"""
 import csv, sys
 from collections import defaultdict
 
 
 def main():
     path, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    markers = sys.argv[4:] or ["adamw_chunks_kernel", "FusedAdam"]
     rows = []
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    opt = [i for i, r in enumerate(rows) if "adamw_chunks_kernel" in r[2] or "FusedAdam" in r[2]]
+    opt = [i for i, r in enumerate(rows) if any(m in r[2] for m in markers)]
     assert opt and len(opt) % (warmup + steps) == 0, (len(opt), warmup, steps)
     per = len(opt) // (warmup + steps)
     first = opt[per * warmup - 1] + 1            # first dispatch after the last warm-up optimizer kernel
