@@ -14,7 +14,7 @@ HEADER = open(_lib.HEADER_PATH).read()
 def header_functions():
     body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
     fns = {}
-    for m in re.finditer(r"\b(?:int|long|void|const char\*)\s+(hoisdf_\w+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long|void|const char\*|const uint32_t\*)\s+(hoisdf_\w+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("void", "") else len(args.split(","))
         fns[m.group(1)] = n
