@@ -36,12 +36,18 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (
 # linear layers and the attention forward) fp32 emulated with EXACT 3-way bf16 operand splits, 6 products, f32 accumulation:
 # error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
 DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--gemm f32 --attention f32)
-DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # the default: 3-way exact bf16 split, 6 products, f32 accumulation
+DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # HOISDF_EMU_FORM=b3: 3-way exact bf16 split, 6 products, f32 accumulation
+# the default since round 5: the linear layers in the f16x2 form (two scaled f16 pieces per operand, 3 products: include/hoisdf.h),
+# the attention contractions bf16x3 as before
+DTYPE_EMU_H2 = "f32 (emulated contractions, f32 accumulate: linear layers f16x2 = scaled hi + lo f16 pieces x 3 products, attention bf16x3 x 6 products)"
 PMC_FILE = "r05_pmc.json"
 # what a BARE v_mfma_f32_32x32x16_bf16 stream (registers only, one wave per SIMD) sustains on this power-capped board (1400 W) when the
 # operands are the bf16x3 pieces of N(0,1) values / uniform random values: 1542-1568 TF of the 2500 TF datasheet peak (2044-2100 TF on
 # zero / constant operands) - tools/ubench/mfma_data.hip, profiles/r05_mfma_rate_vs_operand_data.txt
 MEASURED_MFMA_CEILING_TFLOPS = 1555.0
+# the same probe with v_mfma_f32_32x32x16_f16 on the hi / lo f16 pieces of N(0,1) values: 1345-1380 TF (tools/ubench/mfma_data_f16.hip,
+# profiles/r05_mfma_rate_vs_operand_data_f16.txt)
+MEASURED_MFMA_CEILING_F16_TFLOPS = 1365.0
 STEP_TRACE = "r05_bench_kernel_stats.csv"      # rocprofv3 kernel trace of this bench restricted to the timed steps (tools/trace_stats.py)
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
@@ -74,6 +80,10 @@ class KernelTimer:
         "hoisdf_linear_fwd_emu": lambda a: 2.0 * a[6] * a[7] * a[8],
         "hoisdf_linear_bwd_input_emu": lambda a: 2.0 * a[7] * a[8] * a[9],
         "hoisdf_linear_bwd_weight_emu": lambda a: 2.0 * a[9] * a[10] * a[11],
+        # the same entries with magnitude words (f16x2 form): the words are appended to the argument lists
+        "hoisdf_linear_fwd_emu_mag": lambda a: 2.0 * a[6] * a[7] * a[8],
+        "hoisdf_linear_bwd_input_emu_mag": lambda a: 2.0 * a[7] * a[8] * a[9],
+        "hoisdf_linear_bwd_weight_emu_mag": lambda a: 2.0 * a[9] * a[10] * a[11],
         # the one-wave-per-tile emulated form for < 2048 rows: the argument lists of the exact-f32 entries (no workspace)
         "hoisdf_linear_fwd_emu_small": lambda a: 2.0 * a[7] * a[8] * a[9],
         "hoisdf_linear_bwd_input_emu_small": lambda a: 2.0 * a[8] * a[9] * a[10],
@@ -94,6 +104,7 @@ class KernelTimer:
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_attention_fwd_bf16x2": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
+             "hoisdf_linear_fwd_emu_mag": (6, 7, 8), "hoisdf_linear_bwd_input_emu_mag": (7, 8, 9), "hoisdf_linear_bwd_weight_emu_mag": (9, 10, 11),
              "hoisdf_linear_fwd_emu_small": (7, 8, 9), "hoisdf_linear_bwd_input_emu_small": (8, 9, 10),
              "hoisdf_linear_bwd_weight_emu_small": (9, 10, 11),
              }
@@ -170,6 +181,7 @@ def main():
     ap.add_argument("--n-obj", type=int, default=None)
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bf16x3-leg", type=int, default=1, help="also time 10 steps with HOISDF_EMU_FORM=b3 in a child process (outside the timed region) into `bf16x3_linear_layers`")
     ap.add_argument("--exact-f32", type=int, default=1, help="also time 10 steps of the exact-f32 path (outside the timed region) into `exact_f32`")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=7, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
@@ -464,25 +476,30 @@ def main():
         workload = (f"BASELINE configs[4]: dense eval, batch 8 over 2 GPUs = {args.batch}/GPU, {args.n_hand}+{args.n_obj} "
                     f"query points through sdf_infer, f16-MFMA attention (hi+lo split operands, f32 softmax/accumulate), "
                     f"{enc}, inference only")
+    h2_form = _lib.lib().hoisdf_linear_emu_pieces() == 2          # the linear layers' emulation form of this process (HOISDF_EMU_FORM)
     res = {
         "metric": "samples/sec (img + 2048 SDF queries) fwd+bwd at 1/2/4/8 MI355X" if args.config == 1 else
                   f"samples/sec, inference (BASELINE configs[{args.config}])",
         "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": (DTYPE_EMU if (args.gemm == "emu" or args.attention == "emu") else DTYPE_F32) if args.config != 4 else
-                 "f32 (attention contractions: f16 hi+lo split operands x3 products, f32 accumulate / softmax; linear layers " +
-                 ("bf16x3-emulated fp32)" if args.gemm == "emu" else "exact f32)"),
+        "dtype": ((DTYPE_EMU_H2 if (h2_form and args.gemm == "emu") else DTYPE_EMU) if (args.gemm == "emu" or args.attention == "emu") else DTYPE_F32)
+                 if args.config != 4 else
+                 "f32 (attention contractions: bf16 hi+lo split operands x3 products, f32 accumulate / softmax; linear layers " +
+                 (("f16x2-emulated fp32)" if h2_form else "bf16x3-emulated fp32)") if args.gemm == "emu" else "exact f32)"),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": args.config,
                    "global_batch": world * args.batch, "points": args.n_hand + args.n_obj,
                    "parallelism": f"dp{world}", ("final_loss" if train else "checksum"): float(last.detach())},
     }
     res["config"]["arithmetic"] = {
-        "linear_layers": {"emu": "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate",
+        "linear_layers": {"emu": ("fp32 emulated on the f16 MFMA pipe (f16x2 form, HOISDF_EMU_FORM=h2): both f32 operands scaled by a power of two "
+                                  "(largest magnitude -> [2^13, 2^14)) and split into hi + lo f16 pieces, 3 products, f32 accumulate; the scale's "
+                                  "magnitudes travel from the producing kernel's epilogue to the consuming contraction" if h2_form else
+                                  "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate"),
                           "f32": "exact-f32 MFMA"}[args.gemm],
-        "attention": {"emu": "forward and backward emulated fp32 (as the linear layers; the 17-query decoder attention exact-f32)"
+        "attention": {"emu": "forward and backward emulated fp32 in the bf16x3 form (exact 3-way bf16 split, 6 products; the 17-query decoder attention exact-f32)"
                              if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
-                             "forward emulated fp32 (as the linear layers), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
+                             "forward emulated fp32 (bf16x3), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
                       "f32": "exact-f32 MFMA", "f16": "f16-MFMA eval kernel (BASELINE configs[4]): f16 hi+lo operands, 3 products"}[
                           "f16" if cfg.attention_f16_eval else ("f32" if args.attention == "f32" else "emu")],
         "accuracy_evidence": "tests/test_gpu_emu.py, tools/emu_accuracy.py: error vs fp64 <= the exact-f32 kernels' and hipBLASLt fp32's"}
@@ -502,8 +519,12 @@ def main():
             ("attn_fwd_kernel", ["hoisdf_attention_fwd"], "f32"),
             ("gemm_f32_kernel (linear fwd + grad-input + grad-weight)",
              ["hoisdf_linear_fwd", "hoisdf_linear_bwd_input", "hoisdf_linear_bwd_weight"] + ([] if sq_emu else sq), "f32"),
-            ("emu_kc2_kernel (linear fwd + grad-input; emu_kc_kernel with HOISDF_EMU_KC=1)", ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu"] + (sq if sq_emu else []), "emu"),
-            ("emu_dw2_kernel (linear grad-weight, + ordered reduce; emu_dw_kernel<128> for K <= 128)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
+            ("emu_h2_kernel (linear fwd + grad-input, f16x2 form: 256 x 128 tile, 256 x 256 for masked grad-input over >= 768)" if h2_form else
+             "emu_kc2_kernel (linear fwd + grad-input; emu_kc_kernel with HOISDF_EMU_KC=1)",
+             ["hoisdf_linear_fwd_emu", "hoisdf_linear_bwd_input_emu", "hoisdf_linear_fwd_emu_mag", "hoisdf_linear_bwd_input_emu_mag"] + (sq if sq_emu else []),
+             "h2" if h2_form else "emu"),
+            ("emu_dw2_kernel (linear grad-weight, bf16x3, + ordered reduce; emu_dw_kernel<128> for K <= 128)", ["hoisdf_linear_bwd_weight_emu"], "emu"),
+            ("emu_dw2h_kernel (linear grad-weight, f16x2 form, + ordered reduce)", ["hoisdf_linear_bwd_weight_emu_mag"], "h2" if h2_form else "emu"),
             ("emu_small_kernel / emu_small_dw_kernel (linear layers of < 2048 rows: decoder stack, heads; latency-bound)",
              ["hoisdf_linear_fwd_emu_small", "hoisdf_linear_bwd_input_emu_small", "hoisdf_linear_bwd_weight_emu_small"], "emu"),
             ("emu_attn_fwd2_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
@@ -513,8 +534,11 @@ def main():
             ("attn_fwd_f16_kernel (round 2, HOISDF_ATTN16=f16; + operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
         ]
         PEAK = {"f32": (PEAK_F32_TFLOPS, "f32 MFMA peak (= f32 vector peak), MI355X_MICROARCH.md:41"),
+                "h2": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense f16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent product (scaled hi + lo f16 pieces; MI355X_MICROARCH.md:42)"),
                 "emu": (round(PEAK_F16_TFLOPS / 6.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product (MI355X_MICROARCH.md:42)"),
                 "split": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per product (hi + lo operand pairs)")}
+        # what a bare MFMA stream sustains on such operands under this board's power cap, per fp32-equivalent product
+        CEIL = {"emu": MEASURED_MFMA_CEILING_TFLOPS / 6.0, "split": MEASURED_MFMA_CEILING_TFLOPS / 3.0, "h2": MEASURED_MFMA_CEILING_F16_TFLOPS / 3.0}
         agg = {}
         for fam, members, cls in FAMS:
             ms = sum(ks[m]["total_ms"] for m in members if m in ks)
@@ -568,8 +592,7 @@ def main():
                             "launches_per_step": v["launches"] / timed_steps, "achieved_tflops": round(v["tflops"], 2),
                             "peak_tflops": PEAK[v["cls"]][0], "frac": round(v["tflops"] / PEAK[v["cls"]][0], 4),
                             # against what a bare MFMA stream sustains on such operands under this board's power cap (None: f32 MFMA)
-                            "frac_of_measured_mfma_ceiling": (round(v["tflops"] / (MEASURED_MFMA_CEILING_TFLOPS / {"emu": 6.0, "split": 3.0}[v["cls"]]), 4)
-                                                              if v["cls"] in ("emu", "split") else None)}
+                            "frac_of_measured_mfma_ceiling": (round(v["tflops"] / CEIL[v["cls"]], 4) if v["cls"] in CEIL else None)}
                            for fam, v in sorted(agg.items(), key=lambda kv: -kv[1]["total_ms"])]
         tot_ms = sum(v["total_ms"] for v in agg.values())
         tot_gf = sum(v["gflop"] for v in agg.values())
@@ -579,12 +602,13 @@ def main():
                            "tflops": round(tot_gf / tot_ms, 2) if tot_ms > 0 else 0.0,
                            "tflops_over_the_whole_step": round(tot_gf / timed_steps / 1e3 / (ms_per_step * 1e-3), 2)}
         # the roof of this board for these operands (see MEASURED_MFMA_CEILING_TFLOPS): products per fp32-equivalent product as in PEAK
-        div = {"f32": None, "emu": 6.0, "split": 3.0}[d["cls"]]
-        if div:
-            res["roofline"]["measured_mfma_ceiling"] = {"tflops": round(MEASURED_MFMA_CEILING_TFLOPS / div, 1),
-                                                         "what": "bare v_mfma_f32_32x32x16_bf16 stream on bf16x3 pieces / random operands under the 1400 W cap, / products per product",
-                                                         "file": "profiles/r05_mfma_rate_vs_operand_data.txt"}
-            res["roofline"]["frac_of_measured_mfma_ceiling"] = round(d["tflops"] / (MEASURED_MFMA_CEILING_TFLOPS / div), 4)
+        if d["cls"] in CEIL:
+            res["roofline"]["measured_mfma_ceiling"] = {"tflops": round(CEIL[d["cls"]], 1),
+                                                         "what": ("bare v_mfma_f32_32x32x16_f16 stream on the hi / lo f16 pieces of N(0,1) operands" if d["cls"] == "h2" else
+                                                                  "bare v_mfma_f32_32x32x16_bf16 stream on bf16x3 pieces / random operands") +
+                                                                 " under the 1400 W cap, / products per product",
+                                                         "file": "profiles/r05_mfma_rate_vs_operand_data_f16.txt" if d["cls"] == "h2" else "profiles/r05_mfma_rate_vs_operand_data.txt"}
+            res["roofline"]["frac_of_measured_mfma_ceiling"] = round(d["tflops"] / CEIL[d["cls"]], 4)
         # Amdahl: where the kernel time of a step goes (HIP hot path / the PyTorch-ROCm image encoder's libraries / ATen glue), from
         # the committed rocprofv3 trace of this same command (single stream, 5 timed steps) - evidence quoted, not measured in this run
         try:
@@ -608,6 +632,23 @@ def main():
                           for n, v in ks.items()}
     if exact is not None:
         res["exact_f32"] = exact
+    # ---- the same step with the linear layers in the bf16x3 form (exact three-way operand split, six products: the round-4 arithmetic),
+    # OUTSIDE the timed region.  The form is fixed per process (it is the weight-image format): a child process on this GPU, rank 0 at
+    # N = 1 only.
+    if train and world == 1 and args.bf16x3_leg and h2_form and args.gemm == "emu" and not args.branch_mix and args.config == 1:
+        import subprocess
+        env = dict(os.environ, HOISDF_EMU_FORM="b3")
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--exact-f32", "0",
+               "--no-kernel-timing", "--bf16x3-leg", "0", "--batch", str(args.batch), "--n-hand", str(args.n_hand), "--n-obj", str(args.n_obj),
+               "--resnet", str(args.resnet)]
+        try:
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+            res["bf16x3_linear_layers"] = {"what": "the same train step with HOISDF_EMU_FORM=b3 (linear layers bf16x3: exact 3-way split, 6 products), "
+                                                   "10 steps in a child process after the timed region", "dtype": line["dtype"],
+                                           "value": line["value"], "unit": "samples/s", "ms_per_step": line["ms_per_step"]}
+        except Exception as ex:
+            res["bf16x3_linear_layers"] = f"child run failed: {ex}"
     if comm is not None:
         res["comm"] = comm
     if world == 1 and not args.no_cpu_baseline:

@@ -126,6 +126,7 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_emu_prepare": [_P, _I, _I, _I, _I, _P, _P],
     "hoisdf_linear_emu_prepare_batch": [_P, _I, _L, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
+    "hoisdf_mag_measure": [_P, _L, _L, _I, _P, _P],
     "hoisdf_linear_fwd_emu_mag": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_input_emu_mag": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],

@@ -103,6 +103,7 @@ int attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, cons
 bool emu_form_h2();
 int emu_amax_words();
 int emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st);
+int emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st);      // into magnitude words (below)
 
 // ---- magnitude words (f16x2 form).  A kernel that writes a matrix which a later contraction reads as its row operand can leave
 // that matrix's largest magnitude behind while it still holds the values: MAG_WORDS u32 words, zero before the producer(s) run,
@@ -128,6 +129,12 @@ int linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bit
 int linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx, float* dW, int lddw,
                               float* db, long M, int N, int K, float* workspace, long workspace_floats, const uint32_t* dy_mag,
                               const uint32_t* x_mag, void* stream);
+int project_gather_fwd_mag(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows, int rows_per_sample,
+                           const float* center, const float* cam_intr, float scale, int img_h, int img_w, float* feat, int ldf, float* cam_out,
+                           float* uv_out, uint32_t* feat_mag, void* stream);
+int posenc_fwd_mag(const float* points, long n_rows, float* x0, int ldx0, int col0, float* pe, uint32_t* x0_mag, void* stream);
+int sdf_head_bwd_mag(const float* dsdf, const float* sdf_raw, const float* h, int ldh, const float* w, float* dh, int lddh, float* dw,
+                     float* db, long n_rows, int K, float clamp, uint32_t* dh_mag, void* stream);
 int add_layernorm_fwd_mag(const float* x, const float* r, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long M,
                           int D, float eps, float drop_p, uint64_t seed, uint32_t* y_mag, void* stream);
 int add_layernorm_bwd_mag(const float* dy, const float* x, const float* r, const float* gamma, const float* mean, const float* rstd,

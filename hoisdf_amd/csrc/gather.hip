@@ -82,10 +82,11 @@ __device__ __forceinline__ int level_of(const PyrDev& P, int u) {
 
 __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, float* __restrict__ feat,
                                                          int ldf, float* __restrict__ cam_out,
-                                                         float* __restrict__ uv_out) {
+                                                         float* __restrict__ uv_out, uint32_t* __restrict__ feat_mag) {
   const int lane = threadIdx.x & 63;
   long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long stride = (long)gridDim.x * 4;
+  uint32_t fmax = 0u;                               // feat's magnitude words (common.h), when wanted
   for (; r < a.n_rows; r += stride) {
     int b;
     float cam[3], uv[2], g[2];
@@ -113,8 +114,10 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, f
         acc.x += v.x * t.w11; acc.y += v.y * t.w11; acc.z += v.z * t.w11; acc.w += v.w * t.w11;
       }
       out[u] = acc;
+      fmax = max(fmax, mag_bits4(acc));
     }
   }
+  mag_publish_wave(feat_mag, fmax);
 }
 
 __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, const float* __restrict__ dfeat,
@@ -430,6 +433,12 @@ extern "C" int hoisdf_project_gather_fwd(const hoisdf_pyramid* pyr, const float*
                                          const float* center, const float* cam_intr, float scale, int img_h,
                                          int img_w, float* feat, int ldf, float* cam_out, float* uv_out,
                                          void* stream) {
+  return project_gather_fwd_mag(pyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w, feat, ldf, cam_out,
+                                uv_out, nullptr, stream);
+}
+int hoisdf::project_gather_fwd_mag(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
+                                   int rows_per_sample, const float* center, const float* cam_intr, float scale, int img_h, int img_w,
+                                   float* feat, int ldf, float* cam_out, float* uv_out, uint32_t* feat_mag, void* stream) {
   HOISDF_REQUIRE(pyr && feat, HOISDF_ERR_INVALID, "project_gather_fwd: null pointer");
   if (int rc = check_proj(points, n_rows, rows_per_sample, sample_idx, center, cam_intr, scale,
                           "project_gather_fwd")) return rc;
@@ -449,7 +458,7 @@ extern "C" int hoisdf_project_gather_fwd(const hoisdf_pyramid* pyr, const float*
   ProjArgs a{points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale,
              (float)(img_w - 1) * 0.5f, (float)(img_h - 1) * 0.5f};
   hipLaunchKernelGGL(gather_fwd_kernel, dim3(grid_for_rows(n_rows)), dim3(256), 0, as_stream(stream), P, a,
-                     feat, ldf, cam_out, uv_out);
+                     feat, ldf, cam_out, uv_out, feat_mag);
   return check_launch("gather_fwd");
 }
 

@@ -687,6 +687,7 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* red4) { 
 }  // namespace
 
 // magnitude words of a row-major f32 matrix: block b -> part[b] = bits of max |x| over its share (AMAX_BLOCKS blocks)
+template <bool WORDS>      // WORDS: folded into MAG_WORDS zero-filled magnitude words (common.h) instead of one plain word per block
 __global__ __launch_bounds__(256) void emu_amax_kernel(const float* __restrict__ x, long ld, long M, int K, uint32_t* __restrict__ part) {
   __shared__ uint32_t red4[4];
   const int k4 = K >> 2;
@@ -704,7 +705,10 @@ __global__ __launch_bounds__(256) void emu_amax_kernel(const float* __restrict__
     m = max(m, max(max(mm[0], mm[1]), max(mm[2], mm[3])));
   }
   m = block_max_u32(m, red4);
-  if (threadIdx.x == 0) part[blockIdx.x] = m;
+  if (threadIdx.x == 0) {
+    if (WORDS) atomicMax(part + (blockIdx.x & (MAG_WORDS - 1)), m);
+    else part[blockIdx.x] = m;
+  }
 }
 
 // ---- weight -> f16x2 image.  Pass 1: 16 magnitude words per weight into the trailer; pass 2: scale, split, write (+ {s, 1 / s}).
@@ -782,17 +786,23 @@ __global__ __launch_bounds__(256) void h2_prep_weight_batch_kernel(const hoisdf_
   if (idx < total) h2_prep_weight_unit(it.W, it.ldw, R, Kc, it.transpose, nslab, idx, static_cast<u32x4*>(it.image));
 }
 
-template <bool MASK, bool KTAIL>
-__global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
-  __shared__ __attribute__((aligned(16))) u32x4 st0[H_EPI_U4 > HSTAGE ? H_EPI_U4 : HSTAGE];
-  __shared__ __attribute__((aligned(16))) u32x4 st1[HSTAGE];
+// NJ = 4: tile 256 x 256 (one workgroup per CU); NJ = 2: tile 256 x 128, wave tile 128 x 64, two workgroups per CU (few or narrow
+// tiles: the prologue / epilogue of one workgroup under the main loop of the other) - it reads one half of the image's 256-row blocks
+template <bool MASK, bool KTAIL, int NJ>
+__global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) {
+  constexpr int TN_ = 64 * NJ;                                        // tile width
+  constexpr int BST = 2 * 2 * TN_;                                    // 16-byte units of the weight operand per stage
+  constexpr int STG = HA_U4 + BST;
+  constexpr int EPI = (4 * 32 * (TN_ / 2 + 4) * 4 + 64) / 16;         // the epilogue's four transposition slices + a few words
+  __shared__ __attribute__((aligned(16))) u32x4 st0[EPI > STG ? EPI : STG];
+  __shared__ __attribute__((aligned(16))) u32x4 st1[STG];
   __shared__ uint32_t red4[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
   const int t = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
   const int tm = t / g.tiles_n, tn = t - tm * g.tiles_n;
-  const int m0 = tm * HTM, n0 = tn * HTN;
+  const int m0 = tm * HTM, n0 = tn * TN_;
   const int nslab = (g.K + KS - 1) / KS;
   const int last = nslab - 1;
 
@@ -803,11 +813,11 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
   const float sA = h2_scale(amb);
   const float post = h2_inv_scale(amb) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
 
-  f32x16 acc[4][HNJ];
+  f32x16 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < HNJ; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -823,8 +833,11 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
     rsm[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(MASK ? g.abits + ((size_t)m0 + i * 64) * g.ldbits : nullptr), 0,
                                                MASK ? (int)((long)rows_q * g.ldbits * 4) : 0, 0x00020000);
   }
+  // the image is laid out in 256-row blocks (HB_U4 units per slab): a 128-wide tile reads rows (tn & 1) * 128 .. + 127 of its block
+  const int tb = NJ == 4 ? tn : tn >> 1, r0 = NJ == 4 ? 0 : (tn & 1) * 128;
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<u32x4*>(g.Bimg + (size_t)tn * nslab * HB_U4), 0, nslab * HB_U4 * 16, 0x00020000);
+      const_cast<u32x4*>(g.Bimg + (size_t)tb * nslab * HB_U4), 0, nslab * HB_U4 * 16, 0x00020000);
+  const int boff = NJ == 4 ? tid * 16 : ((tid >> 7) * HTN + r0 + (tid & 127)) * 16;     // piece q: + q * (NJ == 4 ? NT : 2 * HTN) units
   const int aoff = (int)((((long)wave * 16 + rl) * g.lda + 4 * qd) * 4);
   const int moff = (int)(((long)wave * 16 + rl) * g.ldbits * 4);
   const int wslot = 2 * (cq * HTM + ((wave * 16 + rl) ^ (cq << 2))) + (qd & 1);
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
   const int kq = g.K - 4 * qd;
   f32x2 rp[8], fu[8];
   uint32_t t0[8], t1[8];
-  u32x4 rb[4];
+  u32x4 rb[NJ];
   uint32_t rm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, mb = 0xfu;
   bool kin = true;
 #define NOP_ ((void)0)
@@ -843,7 +856,7 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
     rp[2 * (i)] = f32x2{v_[0], v_[1]}; rp[2 * (i) + 1] = f32x2{v_[2], v_[3]};                                          \
     if (MASK) rm[i] = __builtin_amdgcn_raw_buffer_load_b32(rsm[i], moff, (k0_ >> 5) * 4, 0);                           \
   } while (0)
-#define HLDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, (tid + (q) * NT) * 16, min((sl), last) * (HB_U4 * 16), 0)
+#define HLDGB(q, sl) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rsb, boff + (q) * ((NJ == 4 ? NT : 2 * HTN) * 16), min((sl), last) * (HB_U4 * 16), 0)
 #define HUI(i, sl) do { if (MASK) mb = rm[i] >> ((((sl) & 1) << 4) + 4 * qd); if (KTAIL) kin = (sl) * KS < kq; } while (0)
 #define PK_SUB(d, a, b) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
 // pair p = 2 i + j of item i: HC1 sign bitmap / k tail / scale, hi plane (v_cvt_pk_f16_f32, round to nearest) and its f32 image;
@@ -867,10 +880,10 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
 #define HSTA(st, i, tp, pl) reinterpret_cast<u32x2*>(st)[wslot + (i) * 128 + (pl) * 4 * HTM] = u32x2{tp[2 * (i)], tp[2 * (i) + 1]}
 #define HSTB(st, q) (st)[HA_U4 + tid + (q) * NT] = rb[q]
 #define HLA(st, p, i) __builtin_bit_cast(f16x8, (st)[aread + ((p) * 2 + kh) * HTM + (i) * 32])
-#define HLB(st, p, j) __builtin_bit_cast(f16x8, (st)[HA_U4 + wn * 128 + l31 + ((p) * 2 + kh) * HTN + (j) * 32])
+#define HLB(st, p, j) __builtin_bit_cast(f16x8, (st)[HA_U4 + wn * (TN_ / 2) + l31 + ((p) * 2 + kh) * TN_ + (j) * 32])
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define HM1(ax, bx, i, j, work) do { acc[i][j] = MFH(ax[i], bx[j], acc[i][j]); work; SB(); } while (0)
-#define HMM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < HNJ; ++j) acc[i][j] = MFH(ax[i], bx[j], acc[i][j])
+#define HMM(ax, bx) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = MFH(ax[i], bx[j], acc[i][j])
 #include "h2_phase.inc"
 #define SYNC() do { SB(); __syncthreads(); SB(); } while (0)
 #define HSTAGE_ALL(st, sl)                                                                                             \
@@ -880,18 +893,18 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
       HC1(2 * i); HC2(2 * i); HC1(2 * i + 1); HC2(2 * i + 1);                                                          \
       HSTA(st, i, t0, 0); HSTA(st, i, t1, 1);                                                                          \
     }                                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) HSTB(st, q);                                                         \
+    _Pragma("unroll") for (int q = 0; q < NJ; ++q) HSTB(st, q);                                                        \
   } while (0)
 #define HLOAD_ALL(sl)                                                                                                  \
   do {                                                                                                                 \
     /* issue order pinned to a phase's (B pieces, then the items): the vmcnt waits inside the loop count BOTH histories */ \
     SB();                                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) { HLDGB(q, sl); SB(); }                                              \
+    _Pragma("unroll") for (int q = 0; q < NJ; ++q) { HLDGB(q, sl); SB(); }                                             \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) { HLDGA(i, sl); SB(); }                                              \
   } while (0)
 
   const int nslab2 = (nslab + 1) & ~1;
-  f16x8 aH[4], aL[4], bP[HNJ], bQ[HNJ], bL[HNJ];
+  f16x8 aH[4], aL[4], bP[NJ], bQ[NJ], bL[NJ];
   HLOAD_ALL(0);
   HSTAGE_ALL(st0, 0);
   HLOAD_ALL(1);
@@ -899,18 +912,19 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { aL[i] = HLA(st0, 1, i); aH[i] = HLA(st0, 0, i); }
 #pragma unroll
-  for (int j = 0; j < HNJ; ++j) { bP[j] = HLB(st0, 0, j); bL[j] = HLB(st0, 1, j); }
+  for (int j = 0; j < NJ; ++j) { bP[j] = HLB(st0, 0, j); bL[j] = HLB(st0, 1, j); }
   HMM(aL, bP); HMM(aH, bL);                                    // lo hi, hi lo of slab 0
   HSTAGE_ALL(st1, 1);
   HLOAD_ALL(2);
   SYNC();                                                      // aH / bP = hi fragments of slab 0
+#define HPH(cur, nxt, s, bC, bN) do { if constexpr (NJ == 4) { HPHASE(cur, nxt, s, bC, bN); } else { HPHASE2(cur, nxt, s, bC, bN); } } while (0)
   for (int s = 1; s + 1 < nslab2; s += 2) {
-    HPHASE(st1, st0, s, bP, bQ);
+    HPH(st1, st0, s, bP, bQ);
     SYNC();
-    HPHASE(st0, st1, s + 1, bQ, bP);
+    HPH(st0, st1, s + 1, bQ, bP);
     SYNC();
   }
-  HPHASE(st1, st0, nslab2 - 1, bP, bQ);
+  HPH(st1, st0, nslab2 - 1, bP, bQ);
   SB();
   HMM(aH, bQ);                                                 // hi hi of the last slab
   __syncthreads();
@@ -929,10 +943,12 @@ __global__ __launch_bounds__(NT, 1) void emu_h2_kernel(EmuArgs g) {
 #undef HMM
 #undef NOP_
 #undef HPHASE
+#undef HPHASE2
+#undef HPH
 #undef SYNC
 #undef HSTAGE_ALL
 #undef HLOAD_ALL
-  emu_epilogue<HTM, HTN, HNJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, post);
+  emu_epilogue<HTM, TN_, NJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, post);
 }
 
 
@@ -1687,10 +1703,22 @@ uint32_t* amax_ring_slot(hipStream_t st) {
 }
 }  // namespace
 
+// HOISDF_MAG_TRACE=1: every operand the library had to measure itself, on stderr (who asked, rows x columns) - which producers to teach
+static void mag_trace(const char* who, long M, int K) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HOISDF_MAG_TRACE"); on = (e && atoi(e) != 0) ? 1 : 0; }
+  if (on) fprintf(stderr, "[hoisdf mag] measured by the library: %s operand %ld x %d\n", who, M, K);
+}
 // magnitude words of a row-major matrix into `part` (AMAX_BLOCKS words)
 int hoisdf::emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st) {
-  hipLaunchKernelGGL(emu_amax_kernel, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, part);
+  hipLaunchKernelGGL(emu_amax_kernel<false>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, part);
   return check_launch("emu_amax");
+}
+// the same pass into magnitude words (MAG_WORDS, zero on entry): for an operand several contractions will read
+int hoisdf::emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st) {
+  mag_trace("a chain, once for all its readers:", M, K);
+  hipLaunchKernelGGL(emu_amax_kernel<true>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, words);
+  return check_launch("emu_amax (words)");
 }
 int hoisdf::emu_amax_words() { return AMAX_BLOCKS; }
 bool hoisdf::emu_form_h2() { return form_h2(); }
@@ -1711,21 +1739,37 @@ int launch_emu(EmuArgs g, hipStream_t st) {
   g.vecC = al16(g.C) && (g.ldc % 4 == 0);
   if (g.beta) g.amax_out = nullptr;           // (the tile is added to what is there: its own magnitude says nothing)
   if (form_h2()) {
+    // tile width: 256 x 128, two workgroups per CU (the prologue / epilogue of one under the main loop of the other; finer tiles for
+    // the 16 384 / 49 152-row shapes) except for the masked grad-input over a long contraction, where the 256 x 256 tile's halved
+    // staging work per MFMA wins (tools/mb_kc2.py, profiles/r05_h2_tile_widths.txt: 65536 x 1024 x 256 forward + ReLU + dropout
+    // 180 vs 149 TF, 49152 x 512 x 512 247 vs 212, 65536 x 256 x 256 176 vs 159; masked grad-input over 1024: 172 vs 181).
+    // HOISDF_H2_TILE=128 / 256 forces one (A/B runs).
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("HOISDF_H2_TILE"); const int v = e ? atoi(e) : 0; forced = (v == 128 || v == 256) ? v : 0; }
+    const bool wide_ok = cdiv(g.M, HTM) * cdiv(g.N, HTN) >= 208 && g.N % HTN == 0;
+    const bool narrow = forced ? forced == 128 : !(g.abits && g.K >= 768 && wide_ok);
+    const int tw = narrow ? 128 : HTN;
     g.tiles_m = cdiv(g.M, HTM);
-    g.tiles_n = cdiv(g.N, HTN);
+    g.tiles_n = cdiv(g.N, tw);
     g.b_scale = reinterpret_cast<const float*>(h2_trailer(const_cast<u32x4*>(g.Bimg), g.N, g.K)) + 16;
     if (!g.a_amax) {
       uint32_t* part = amax_ring_slot(st);
       if (!part) { set_error("linear_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      mag_trace(g.beta ? "grad-input (+=)" : g.abits ? "grad-input (masked)" : g.qkv.on ? "in-projection" : "forward / grad-input", g.M, g.K);
       if (int rc = emu_amax_launch(g.A, g.lda, g.M, g.K, part, st)) return rc;
       g.a_amax = part; g.a_amax_n = AMAX_BLOCKS;
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
     const bool kt = g.K % KS != 0 || (cdiv(g.K, KS) & 1);
-    if (g.abits && kt) hipLaunchKernelGGL((emu_h2_kernel<true, true>), grid, block, 0, st, g);
-    else if (g.abits) hipLaunchKernelGGL((emu_h2_kernel<true, false>), grid, block, 0, st, g);
-    else if (kt) hipLaunchKernelGGL((emu_h2_kernel<false, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((emu_h2_kernel<false, false>), grid, block, 0, st, g);
+    if (narrow) {
+      if (g.abits && kt) hipLaunchKernelGGL((emu_h2_kernel<true, true, 2>), grid, block, 0, st, g);
+      else if (g.abits) hipLaunchKernelGGL((emu_h2_kernel<true, false, 2>), grid, block, 0, st, g);
+      else if (kt) hipLaunchKernelGGL((emu_h2_kernel<false, true, 2>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((emu_h2_kernel<false, false, 2>), grid, block, 0, st, g);
+    } else if (g.abits && kt) hipLaunchKernelGGL((emu_h2_kernel<true, true, 4>), grid, block, 0, st, g);
+    else if (g.abits) hipLaunchKernelGGL((emu_h2_kernel<true, false, 4>), grid, block, 0, st, g);
+    else if (kt) hipLaunchKernelGGL((emu_h2_kernel<false, true, 4>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((emu_h2_kernel<false, false, 4>), grid, block, 0, st, g);
     return check_launch("linear_emu (f16x2)");
   }
   g.tiles_m = cdiv(g.M, TM);
@@ -1807,6 +1851,17 @@ extern "C" int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_
   return linear_fwd_emu_mag(x, ldx, w_image, bias, y, ldy, M, N, K, act, drop_p, seed, relu_bits, x_mag, y_mag, stream);
 }
 extern "C" int hoisdf_mag_words(void) { return MAG_WORDS; }
+// the magnitude words of a matrix nobody left words for: one read of x (hosts that chain the *_mag entries themselves call this once per
+// operand instead of letting every consumer measure it again)
+extern "C" int hoisdf_mag_measure(const float* x, long ldx, long M, int K, uint32_t* words, void* stream) {
+  HOISDF_REQUIRE(words && (M == 0 || x) && M >= 0 && K > 0 && ldx >= K, HOISDF_ERR_INVALID, "mag_measure: bad arguments");
+  HOISDF_REQUIRE(M == 0 || hoisdf_linear_emu_supported(x, ldx, K), HOISDF_ERR_INVALID, "mag_measure: x must be 16-byte aligned with ldx and K multiples of 4");
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(words, 0, MAG_WORDS * sizeof(uint32_t), st) != hipSuccess) { set_error("mag_measure: memset failed"); return HOISDF_ERR_LAUNCH; }
+  if (M == 0) return HOISDF_OK;
+  hipLaunchKernelGGL(emu_amax_kernel<true>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ldx, M, K, words);
+  return check_launch("mag_measure");
+}
 extern "C" int hoisdf_linear_emu_pieces(void) { return form_h2() ? 2 : 3; }
 
 int hoisdf::linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K,
@@ -1986,12 +2041,14 @@ int bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float d
     if (!dy_mag) {
       uint32_t* part = amax_ring_slot(st);
       if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      mag_trace("grad-weight dy", M, N);
       if (int rc = emu_amax_launch(dy, lddy, M, N, part, st)) return rc;
       g.dy_amax = part; g.dy_amax_n = AMAX_BLOCKS;
     }
     if (!x_mag) {
       uint32_t* part = amax_ring_slot(st);
       if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      mag_trace("grad-weight x", M, K);
       if (int rc = emu_amax_launch(x, ldx, M, K, part, st)) return rc;
       g.x_amax = part; g.x_amax_n = AMAX_BLOCKS;
     }

@@ -16,14 +16,15 @@ namespace {
 constexpr int MLP_MAX = HOISDF_MLP_MAX_LAYERS;
 inline long bits_words(int N) { return (N + 31) / 32; }
 
-struct MlpSaved { float* h[MLP_MAX]; uint32_t* bits[MLP_MAX]; };
+struct MlpSaved { float* h[MLP_MAX]; uint32_t* bits[MLP_MAX]; uint32_t* mag; };
 
 bool mlp_ok(const hoisdf_mlp* m) {
   if (!m || m->n_layers < 1 || m->n_layers > MLP_MAX) return false;
   for (int i = 0; i <= m->n_layers; ++i) if (m->dims[i] <= 0) return false;
   return true;
 }
-// hidden activations h[i] (output of layer i, i < last) and the ReLU sign maps of every activated layer
+// hidden activations h[i] (output of layer i, i < last) and the ReLU sign maps of every activated layer; magnitude words (common.h)
+// of the operands of the chain's contractions: array 0 = the input x (when the chain measured it itself), i = h[i - 1]
 void mlp_carve(const hoisdf_mlp* m, long M, Bump& b, MlpSaved& s) {
   const int last = m->n_layers - 1;
   for (int i = 0; i < m->n_layers; ++i) {
@@ -31,26 +32,34 @@ void mlp_carve(const hoisdf_mlp* m, long M, Bump& b, MlpSaved& s) {
     const bool act = i < last || m->act_last;
     s.bits[i] = act ? static_cast<uint32_t*>(b.take(M * bits_words(m->dims[i + 1]) * 4)) : nullptr;
   }
+  s.mag = static_cast<uint32_t*>(b.take((long)m->n_layers * MAG_WORDS * 4));
 }
-// n zero-filled magnitude-word arrays (common.h) from the workspace for the operands a chain hands from one contraction to the next;
-// null when the contractions are not in the f16x2 form (or in a measuring pass, which only reserves the bytes)
-uint32_t* chain_mags(Ctx& c, int n) {
-  if (!c.emu || !emu_form_h2()) return nullptr;
+inline bool chain_mags_on(const Ctx& c, long M) { return c.emu && emu_form_h2() && M >= EMU_MIN_ROWS; }
+// n zero-filled magnitude-word arrays from the workspace (null: not in the f16x2 form; a measuring pass only reserves the bytes)
+uint32_t* chain_mags(Ctx& c, long M, int n) {
+  if (!chain_mags_on(c, M)) return nullptr;
   uint32_t* p = static_cast<uint32_t*>(c.ws->take((long)n * MAG_WORDS * 4));
   if (c.dry || !p || !c.ok()) return nullptr;
   if (hipMemsetAsync(p, 0, (size_t)n * MAG_WORDS * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return nullptr; }
   return p;
 }
-void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, const MlpSaved& s, float* y, int ldy) {
+// x_mag: the caller's magnitude words of x; null = measured here ONCE (array 0 of s.mag) for the layer-0 contraction and, in the
+// backward, its grad-weight.  The backward must be given the same x_mag.
+void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, const MlpSaved& s, float* y, int ldy, const uint32_t* x_mag = nullptr) {
   const int last = m->n_layers - 1;
   const float* in = x; int ldin = ldx;
-  uint32_t* mg = chain_mags(c, m->n_layers);
-  const uint32_t* in_mag = nullptr;
+  uint32_t* mg = chain_mags_on(c, M) && !c.dry && s.mag && c.ok() ? s.mag : nullptr;
+  if (mg && hipMemsetAsync(mg, 0, (size_t)m->n_layers * MAG_WORDS * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return; }
+  const uint32_t* in_mag = mg ? x_mag : nullptr;
+  if (mg && !in_mag && emu_rows(c, M, x, ldx, m->dims[0])) {
+    if ((c.rc = emu_mag_measure(x, ldx, M, m->dims[0], mg, c.st)) != HOISDF_OK) return;
+    in_mag = mg;
+  }
   for (int i = 0; i < m->n_layers; ++i) {
     float* out = i < last ? s.h[i] : y;
     const int ldo = i < last ? m->dims[i + 1] : ldy;
     // (the tiled emulated form is the one that writes the words: the same test lin_fwd makes)
-    uint32_t* out_mag = mg && i < last && emu_rows(c, M, in, ldin, m->dims[i]) ? mg + i * MAG_WORDS : nullptr;
+    uint32_t* out_mag = mg && i < last && emu_rows(c, M, in, ldin, m->dims[i]) ? mg + (i + 1) * MAG_WORDS : nullptr;
     lin_fwd(c, in, ldin, m->w[i], m->dims[i], m->img[i], m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i], 0,
             in_mag, out_mag);
     in = out; ldin = ldo; in_mag = out_mag;
@@ -58,14 +67,23 @@ void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, c
 }
 // dy [M][ld] = gradient of the last layer's (post-activation) output; dx (optional) receives / accumulates the input gradient
 void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const float* x, int ldx, long M, const MlpSaved& s, const float* dy,
-                  int lddy, float* dx, int lddx, int accumulate_dx) {
+                  int lddy, float* dx, int lddx, int accumulate_dx, const uint32_t* x_mag = nullptr) {
   const float* g = dy; int ldg = lddy;
-  uint32_t* mg = chain_mags(c, m->n_layers);
+  const int last = m->n_layers - 1;
+  uint32_t* mg = chain_mags(c, M, m->n_layers + 1);         // array i = the gradient entering layer i (i = n_layers: dy)
+  const bool fwd_mags = mg && s.mag;
   const uint32_t* g_mag = nullptr;
-  for (int i = m->n_layers - 1; i >= 0; --i) {
+  if (mg && emu_rows(c, M, dy, lddy, m->dims[last + 1])) {   // dy feeds two contractions: measured once
+    if ((c.rc = emu_mag_measure(dy, lddy, M, m->dims[last + 1], mg + (last + 1) * MAG_WORDS, c.st)) != HOISDF_OK) return;
+    g_mag = mg + (last + 1) * MAG_WORDS;
+  }
+  for (int i = last; i >= 0; --i) {
     const float* in = i > 0 ? s.h[i - 1] : x;
     const int ldin = i > 0 ? m->dims[i] : ldx;
-    lin_bwd_weight(c, g, ldg, s.bits[i], 0.f, in, ldin, G->dw[i], G->db[i], M, m->dims[i + 1], m->dims[i]);
+    // the words of the layer's input: h[i - 1]'s from the forward's epilogue; x's from the caller or from the forward's own pass
+    const uint32_t* in_mag = !fwd_mags ? nullptr : i > 0 ? (emu_rows(c, M, i > 1 ? s.h[i - 2] : x, i > 1 ? m->dims[i - 1] : ldx, m->dims[i - 1]) ? s.mag + i * MAG_WORDS : nullptr)
+                                                         : (x_mag ? x_mag : (emu_rows(c, M, x, ldx, m->dims[0]) ? s.mag : nullptr));
+    lin_bwd_weight(c, g, ldg, s.bits[i], 0.f, in, ldin, G->dw[i], G->db[i], M, m->dims[i + 1], m->dims[i], 0, g_mag, g_mag ? in_mag : nullptr);
     if (i == 0 && !dx) break;
     float* gin = i > 0 ? c.ws->floats(M * m->dims[i]) : dx;
     const int ldgin = i > 0 ? m->dims[i] : lddx;
@@ -75,6 +93,10 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
                   g_mag, gin_mag);
     g = gin; ldg = ldgin; g_mag = gin_mag;
   }
+}
+// the words mlp_forward(m, x) left for x in its saved block (null when it did not measure)
+const uint32_t* enc_mag(const Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, const MlpSaved& s) {
+  return chain_mags_on(c, M) && !c.dry && s.mag && emu_rows(c, M, x, ldx, m->dims[0]) ? s.mag : nullptr;
 }
 bool grads_ok(const hoisdf_mlp* m, const hoisdf_mlp_grads* G) {
   if (!G) return false;
@@ -211,7 +233,7 @@ static int heads_vote_backward(const hoisdf_mlp* mv, const hoisdf_mlp* mc, const
   }
   const int E = mv->dims[0];
   mlp_backward(c, mv, Gv, enc, E, M, s.vote, doff, 3 * J, denc, E, 0);
-  mlp_backward(c, mc, Gc, enc, E, M, s.cl, dcls, J, denc, E, 1);
+  mlp_backward(c, mc, Gc, enc, E, M, s.cl, dcls, J, denc, E, 1, enc_mag(c, mv, enc, E, M, s.vote));
   if (c.ok() && !dry && ws.overflow) { set_error("heads_vote_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
   return c.rc;
 }
@@ -248,7 +270,7 @@ extern "C" int hoisdf_heads_vote_fwd(const float* enc, const hoisdf_mlp* vote, c
   Ctx c{as_stream(stream), stream, &ws, false, gemm_emu_mode()};
   const int E = vote->dims[0];
   mlp_forward(c, vote, enc, E, M, s.vote, s.off, 3 * J);
-  mlp_forward(c, cls, enc, E, M, s.cl, s.cls, J);
+  mlp_forward(c, cls, enc, E, M, s.cl, s.cls, J, enc_mag(c, vote, enc, E, M, s.vote));        // (enc is measured once, by the first chain)
   if (c.ok()) c.rc = hoisdf_vote_loss_fwd(s.off, s.cls, pts, joint_gt_mm, radius, joints, s.stats, l3d_sum, bce_sum, near_sum, L, B, P, J, stream);
   if (c.ok() && (sv.overflow || ws.overflow)) c.rc = HOISDF_ERR_WORKSPACE;
   if (c.rc == HOISDF_ERR_WORKSPACE) set_error("heads_vote_fwd: workspace (%ld bytes) too small", workspace_bytes);

@@ -3,6 +3,8 @@
 // and residual+dropout+LayerNorm.
 // All are one-pass, coalesced (16-byte lanes where the row width allows), with wave-level
 // reductions; none is reshaped into a GEMM.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -12,9 +14,10 @@ namespace hoisdf {
 // then xyz; common/utils/sdf_utils.py:113-126 (freq bands 2^linspace(0,4,5) = 1,2,4,8,16).
 __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ pts, long n_rows,
                                                      float* __restrict__ x0, int ldx0, int col0,
-                                                     float* __restrict__ pe) {
+                                                     float* __restrict__ pe, uint32_t* __restrict__ x0_mag) {
   long idx = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per (row, slot<36)
   const long total = n_rows * 36;
+  uint32_t vmax = 0u;                                    // magnitude words (common.h) of what goes into x0, when wanted
   for (; idx < total; idx += (long)gridDim.x * 256) {
     const long r = idx / 36;
     const int s = (int)(idx - r * 36);
@@ -29,7 +32,9 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ p
       val = pts[r * 3 + (s - 30)];
     }
     if (x0 && col0 + s < ldx0) x0[(size_t)r * ldx0 + col0 + s] = val;   // s in [33,36) zero-fills the pad
+    vmax = max(vmax, mag_bits(val));
   }
+  mag_publish_wave(x0_mag, vmax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
                                                            const float* __restrict__ h, int ldh,
                                                            const float* __restrict__ w, float* __restrict__ dh,
                                                            int lddh, float* __restrict__ dw, float* __restrict__ db,
-                                                           long n_rows, int K, float clampv, DetScratch ds) {
+                                                           long n_rows, int K, float clampv, DetScratch ds, uint32_t* __restrict__ dh_mag) {
   // each wave walks rows with a grid stride (two rows in flight) and keeps a private dw accumulator per lane
   // slot; the four waves of a block are summed in LDS so every block issues ONE atomic per column (the same 512
   // addresses are hit by every block: per-wave atomics serialised 2048 adds per address, 238 us -> see DESIGN.md)
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dwa[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};   // K <= 512: 2 float4 per lane
   float dba = 0.f;
+  uint32_t hmax = 0u;                                    // dh's magnitude words (common.h), when wanted
   const long stride = (long)gridDim.x * 4;
   for (long r0 = (long)blockIdx.x * 4 + wave; r0 < n_rows; r0 += 2 * stride) {
     const long r1 = r0 + stride;
@@ -125,14 +131,17 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
         const float4 a0 = *reinterpret_cast<const float4*>(h0 + c);
         const float4 a1 = *reinterpret_cast<const float4*>(h1 + c);
         const float4 ww = *reinterpret_cast<const float4*>(w + c);
-        *reinterpret_cast<float4*>(dh + (size_t)r0 * lddh + c) = make_float4(g0 * ww.x, g0 * ww.y, g0 * ww.z, g0 * ww.w);
-        if (two) *reinterpret_cast<float4*>(dh + (size_t)r1 * lddh + c) = make_float4(g1 * ww.x, g1 * ww.y, g1 * ww.z, g1 * ww.w);
+        const float4 d0 = make_float4(g0 * ww.x, g0 * ww.y, g0 * ww.z, g0 * ww.w), d1 = make_float4(g1 * ww.x, g1 * ww.y, g1 * ww.z, g1 * ww.w);
+        *reinterpret_cast<float4*>(dh + (size_t)r0 * lddh + c) = d0;
+        if (two) *reinterpret_cast<float4*>(dh + (size_t)r1 * lddh + c) = d1;
+        hmax = max(hmax, max(mag_bits4(d0), mag_bits4(d1)));          // (g1 = 0 without a second row)
         dwa[i].x += g0 * a0.x + g1 * a1.x; dwa[i].y += g0 * a0.y + g1 * a1.y;
         dwa[i].z += g0 * a0.z + g1 * a1.z; dwa[i].w += g0 * a0.w + g1 * a1.w;
       }
     }
     dba += g0 + g1;
   }
+  mag_publish_wave(dh_mag, hmax);
 #pragma unroll
   for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&red[wave][lane * 4 + i * 256]) = dwa[i];
   if (lane == 0) red[wave][512] = dba;
@@ -471,6 +480,9 @@ static int row_grid(long n_rows) {
 
 extern "C" int hoisdf_posenc_fwd(const float* points, long n_rows, float* x0, int ldx0, int col0, float* pe,
                                  void* stream) {
+  return posenc_fwd_mag(points, n_rows, x0, ldx0, col0, pe, nullptr, stream);
+}
+int hoisdf::posenc_fwd_mag(const float* points, long n_rows, float* x0, int ldx0, int col0, float* pe, uint32_t* x0_mag, void* stream) {
   HOISDF_REQUIRE(points && (x0 || pe) && n_rows >= 0, HOISDF_ERR_INVALID, "posenc_fwd: bad arguments");
   HOISDF_REQUIRE(!x0 || (col0 >= 0 && col0 + 33 <= ldx0), HOISDF_ERR_INVALID,
                  "posenc_fwd: col0=%d + 33 exceeds ldx0=%d", col0, ldx0);
@@ -479,7 +491,7 @@ extern "C" int hoisdf_posenc_fwd(const float* points, long n_rows, float* x0, in
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(posenc_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), points, n_rows, x0,
-                     ldx0, col0, pe);
+                     ldx0, col0, pe, x0_mag);
   return check_launch("posenc");
 }
 
@@ -514,6 +526,10 @@ extern "C" int hoisdf_sdf_head_fwd(const float* h, int ldh, const float* w, cons
 extern "C" int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, const float* h, int ldh,
                                    const float* w, float* dh, int lddh, float* dw, float* db, long n_rows, int K,
                                    float clamp, void* stream) {
+  return sdf_head_bwd_mag(dsdf, sdf_raw, h, ldh, w, dh, lddh, dw, db, n_rows, K, clamp, nullptr, stream);
+}
+int hoisdf::sdf_head_bwd_mag(const float* dsdf, const float* sdf_raw, const float* h, int ldh, const float* w, float* dh, int lddh, float* dw,
+                             float* db, long n_rows, int K, float clamp, uint32_t* dh_mag, void* stream) {
   HOISDF_REQUIRE(dsdf && sdf_raw && h && w && dh && dw && db && n_rows >= 0, HOISDF_ERR_INVALID,
                  "sdf_head_bwd: null pointer");
   HOISDF_REQUIRE(K > 0 && K <= 512 && (K & 3) == 0 && (ldh & 3) == 0 && (lddh & 3) == 0 && ldh >= K && lddh >= K,
@@ -522,7 +538,7 @@ extern "C" int hoisdf_sdf_head_bwd(const float* dsdf, const float* sdf_raw, cons
   int blocks = row_grid(n_rows);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sdf_head_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dsdf, sdf_raw, h, ldh, w,
-                     dh, lddh, dw, db, n_rows, K, clamp, det_scratch((size_t)blocks * (K + 1)));
+                     dh, lddh, dw, db, n_rows, K, clamp, det_scratch((size_t)blocks * (K + 1)), dh_mag);
   return check_launch("sdf_head_bwd");
 }
 
@@ -627,7 +643,9 @@ int hoisdf::add_layernorm_bwd_mag(const float* dy, const float* x, const float* 
                  "add_layernorm_bwd: D=%d must be a multiple of 4 and <= 1024", D);
   if (M == 0) return HOISDF_OK;
   int blocks = row_grid(M);
-  if (blocks > 512) blocks = 512;
+  static int cap = -1;                          // HOISDF_LN_BWD_BLOCKS: blocks of the backward (A/B runs; default 1024 = 4 per CU)
+  if (cap < 0) { const char* e = getenv("HOISDF_LN_BWD_BLOCKS"); cap = e && atoi(e) > 0 ? atoi(e) : 1024; }
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
                      dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
                      det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0, dx_mag, dr_mag);

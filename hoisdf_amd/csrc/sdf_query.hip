@@ -31,21 +31,27 @@ inline long emu_scratch_bytes(int C) {
 
 // one layer: fp32 emulated on the bf16 MFMA pipe (default, large point sets) or the exact-f32 MFMA GEMM.  K_pad >= K: columns K .. K_pad - 1 of x are zero padding (they meet zero weights in the image).
 // `given`: the caller's cached image of this weight (hoisdf_sdf_weights.emu_img), NULL = built into emu_img right here
+// x_mag / y_mag (f16x2 form): magnitude words (common.h) of x (null: measured) and for y (zero on entry); *y_has says whether the
+// emulated kernel ran and filled them
 int layer(const float* x, int ldx, const float* W, int ldw, const float* b, float* y, int ldy, long M, int N, int K,
-          int K_pad, float drop_p, uint64_t seed, void* emu_img, const void* given, void* stream) {
+          int K_pad, float drop_p, uint64_t seed, void* emu_img, const void* given, void* stream, const uint32_t* x_mag = nullptr,
+          uint32_t* y_mag = nullptr, bool* y_has = nullptr) {
+  if (y_has) *y_has = false;
   if (emu_img && M >= EMU_MIN_ROWS_Q && hoisdf_linear_emu_supported(x, ldx, K_pad) && (K_pad + 15) / 16 == (K + 15) / 16) {
     if (!given) { if (int rc = hoisdf_linear_emu_prepare(W, ldw, N, K, 0, emu_img, stream)) return rc; }
-    return hoisdf_linear_fwd_emu(x, ldx, given ? given : emu_img, b, y, ldy, M, N, K_pad, 1, drop_p, seed, nullptr, stream);
+    if (y_has) *y_has = y_mag != nullptr;
+    return linear_fwd_emu_mag(x, ldx, given ? given : emu_img, b, y, ldy, M, N, K_pad, 1, drop_p, seed, nullptr, x_mag, y_mag, stream);
   }
   return hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, stream);
 }
+constexpr long QMAG_BYTES = 5L * MAG_WORDS * 4;       // magnitude words of feat, ha, cat, h0, h2 behind the image scratch
 }  // namespace
 
 extern "C" long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat) {
   if (n_rows <= 0 || C <= 0) return 0;
   long fl = align64(n_rows * HID0) * 2 + align64(n_rows * CAT_LD);
   if (need_feat) fl += align64(n_rows * (long)C);
-  return fl * (long)sizeof(float) + emu_scratch_bytes(C);
+  return fl * (long)sizeof(float) + emu_scratch_bytes(C) + QMAG_BYTES;
 }
 
 extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
@@ -70,38 +76,46 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   float* hb = ha + align64(n_rows * HID0);
   float* cat = hb + align64(n_rows * HID0);
   float* feat_ws = cat + align64(n_rows * CAT_LD);
-  void* img = gemm_emu_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - emu_scratch_bytes(C)))
+  void* img = gemm_emu_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - emu_scratch_bytes(C) - QMAG_BYTES))
                                                       : nullptr;
+  // magnitude words (f16x2 form) handed from each kernel to the contraction that reads its output
+  uint32_t* qm = (img && emu_form_h2()) ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (need - QMAG_BYTES)) : nullptr;
+  auto mg = [&](int i) -> uint32_t* { return qm ? qm + i * MAG_WORDS : nullptr; };
+  if (qm && hipMemsetAsync(qm, 0, QMAG_BYTES, as_stream(stream)) != hipSuccess) { set_error("sdf_query_fwd: memset failed"); return HOISDF_ERR_LAUNCH; }
+  const uint32_t* m_feat = nullptr; bool has = false;
   int rc;
   // K1 (unless the caller shares its gathered rows)
   const float* feat = feat_in;
   if (!feat) {
     float* f = feat_out ? feat_out : feat_ws;
-    rc = hoisdf_project_gather_fwd(pyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w,
-                                   f, C, cam_out, nullptr, stream);
+    rc = project_gather_fwd_mag(pyr, points, sample_idx, n_rows, rows_per_sample, center, cam_intr, scale, img_h, img_w,
+                                f, C, cam_out, nullptr, mg(0), stream);
     if (rc) return rc;
-    feat = f;
+    feat = f; m_feat = mg(0);
   } else if (cam_out) {
     HOISDF_REQUIRE(false, HOISDF_ERR_INVALID, "sdf_query_fwd: cam_out needs the gather to run here (feat_in given)");
   }
   float* x0 = cat + X0_COL;
   // K2: linear_sdfin (main/model.py:63-69): C -> 512 -> 256, ReLU after both; the second layer lands in x0[:, 0:256]
-  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, img, w->emu_img[0], stream);
+  rc = layer(feat, C, w->sdfin_w0, C, w->sdfin_b0, ha, HID0, n_rows, HID0, C, C, 0.f, 0, img, w->emu_img[0], stream, m_feat, mg(1), &has);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, img, w->emu_img[1], stream);
+  bool has_cat = false;
+  rc = layer(ha, HID0, w->sdfin_w1, HID0, w->sdfin_b1, x0, CAT_LD, n_rows, LAT, HID0, HID0, 0.f, 0, img, w->emu_img[1], stream, has ? mg(1) : nullptr, mg(2), &has_cat);
   if (rc) return rc;
   // K3: posenc + xyz into x0[:, 256:289], pad columns 289..291 zeroed (common/utils/sdf_utils.py:96-141)
-  rc = hoisdf_posenc_fwd(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, stream);
+  rc = posenc_fwd_mag(points, n_rows, cat, CAT_LD, X0_COL + LAT, pe, has_cat ? mg(2) : nullptr, stream);
   if (rc) return rc;
   // K4: decoder (common/nets/sdf_net.py:87-122); dropout(p) after every hidden ReLU when the module is in train() mode
   // (the reference's detached training-time queries run with it on), stream ids seed + layer
-  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, img, w->emu_img[2], stream);   // the three pad columns of x0 are zero
+  // (cat's words: x0's columns are complete here; layer 1 adds its columns' before layer 2 reads the whole row)
+  rc = layer(x0, CAT_LD, w->dec_w0, w->dec_ld0, w->dec_b0, ha, HID0, n_rows, HID0, X0, X0 + 3, drop_p, seed, img, w->emu_img[2], stream, has_cat ? mg(2) : nullptr, mg(3), &has);   // the three pad columns of x0 are zero
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, w->emu_img[3], stream);
+  bool has1 = false;
+  rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, w->emu_img[3], stream, has ? mg(3) : nullptr, has_cat ? mg(2) : nullptr, &has1);
   if (rc) return rc;
-  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, w->emu_img[4], stream);
+  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, w->emu_img[4], stream, has_cat && has1 ? mg(2) : nullptr, mg(4), &has);
   if (rc) return rc;
-  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, w->emu_img[5], stream);
+  rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, w->emu_img[5], stream, has ? mg(4) : nullptr, nullptr, nullptr);
   if (rc) return rc;
   return hoisdf_sdf_head_fwd(hb, HID0, w->dec_w4, w->dec_b4, sdf_raw, sdf, n_rows, HID0, clamp, stream);
 }
@@ -227,7 +241,11 @@ extern "C" int hoisdf_sdf_infer(const hoisdf_pyramid* pyr, const float* center, 
 #include "chain.h"
 
 namespace {
-struct TrainSaved { float *feat, *ha, *cat, *h0, *h2, *h3, *raw; uint32_t *ba, *bf, *b0, *b1, *b2, *b3; };
+struct TrainSaved { float *feat, *ha, *cat, *h0, *h2, *h3, *raw; uint32_t *ba, *bf, *b0, *b1, *b2, *b3; uint32_t* mag; };
+// magnitude words (common.h) of the forward's contraction operands, kept for the grad-weights: feat, ha, cat (x0 is a column slice of
+// it: both contractions read the one array, filled in the order the columns are written), h0, h2
+enum { TM_FEAT = 0, TM_HA = 1, TM_CAT = 2, TM_H0 = 3, TM_H2 = 4, TM_N = 5 };
+inline bool train_mags(const Ctx& c, long n) { return c.emu && emu_form_h2() && n >= EMU_MIN_ROWS; }
 inline long bits_words(int N) { return (N + 31) / 32; }
 void train_carve(long n, int C, Bump& b, TrainSaved& s) {
   s.feat = b.floats(n * C); s.ha = b.floats(n * HID0); s.cat = b.floats(n * CAT_LD); s.h0 = b.floats(n * HID0); s.h2 = b.floats(n * HID0);
@@ -235,6 +253,7 @@ void train_carve(long n, int C, Bump& b, TrainSaved& s) {
   s.ba = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.bf = static_cast<uint32_t*>(b.take(n * bits_words(LAT) * 4));
   s.b0 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b1 = static_cast<uint32_t*>(b.take(n * bits_words(H1 + 1) * 4));
   s.b2 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b3 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4));
+  s.mag = static_cast<uint32_t*>(b.take((long)TM_N * MAG_WORDS * 4));
 }
 }  // namespace
 
@@ -252,20 +271,24 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   TrainSaved s;
   const int C = w ? w->C : 1;
   train_carve(n, C, saved, s);
+  const bool mags = train_mags(c, n) && !dry && s.mag;
+  auto mg = [&](int i) -> uint32_t* { return mags ? s.mag + i * MAG_WORDS : nullptr; };
   if (!dry) {
-    c.rc = hoisdf_project_gather_fwd(pyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, s.feat, C, cam_out, nullptr, stream);
+    if (mags) c.rc = hipMemsetAsync(s.mag, 0, (size_t)TM_N * MAG_WORDS * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
+    if (c.ok()) c.rc = project_gather_fwd_mag(pyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, s.feat, C, cam_out, nullptr, mg(TM_FEAT), stream);
     if (c.ok()) c.rc = hipMemsetAsync(s.cat, 0, sizeof(float) * n * CAT_LD, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;   // pad columns
   }
   float* x0 = dry ? nullptr : s.cat + X0_COL;
   // linear_sdfin: C -> 512 -> 256, ReLU after both (main/model.py:63-69)
-  lin_fwd(c, s.feat, C, w->sdfin_w0, C, w->emu_img[0], w->sdfin_b0, s.ha, HID0, n, HID0, C, 1, 0.f, 0, s.ba);
-  lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, w->emu_img[1], w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf);
-  if (!dry && c.ok()) c.rc = hoisdf_posenc_fwd(points, n, s.cat, CAT_LD, X0_COL + LAT, pe, stream);
+  lin_fwd(c, s.feat, C, w->sdfin_w0, C, w->emu_img[0], w->sdfin_b0, s.ha, HID0, n, HID0, C, 1, 0.f, 0, s.ba, 0, mg(TM_FEAT), mg(TM_HA));
+  lin_fwd(c, s.ha, HID0, w->sdfin_w1, HID0, w->emu_img[1], w->sdfin_b1, x0, CAT_LD, n, LAT, HID0, 1, 0.f, 0, s.bf, 0, mg(TM_HA), mg(TM_CAT));
+  if (!dry && c.ok()) c.rc = posenc_fwd_mag(points, n, s.cat, CAT_LD, X0_COL + LAT, pe, mg(TM_CAT), stream);
   // decoder (common/nets/sdf_net.py:87-122); layer i draws dropout stream seed + i
-  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, w->emu_img[2], w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3);   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
-  lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, w->emu_img[3], w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1);
-  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, w->emu_img[4], w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2);
-  lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, w->emu_img[5], w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3);
+  // (the words of cat: x0's columns are complete here; layer 1 adds its own columns' before layer 2 reads the whole row)
+  lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, w->emu_img[2], w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3, mg(TM_CAT), mg(TM_H0));   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
+  lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, w->emu_img[3], w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1, 0, mg(TM_H0), mg(TM_CAT));
+  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, w->emu_img[4], w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2, 0, mg(TM_CAT), mg(TM_H2));
+  lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, w->emu_img[5], w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3, 0, mg(TM_H2), nullptr);
   if (!dry && c.ok()) c.rc = hoisdf_sdf_head_fwd(s.h3, HID0, w->dec_w4, w->dec_b4, s.raw, sdf, n, HID0, clamp, stream);
   return c.rc;
 }
@@ -280,24 +303,31 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   float* dh3 = ws.floats(n * HID0); float* dh2 = ws.floats(n * HID0); float* dcat = ws.floats(n * CAT_LD); float* dh0 = ws.floats(n * HID0);
   float* dha = ws.floats(n * HID0); float* dfeat = ws.floats(n * (long)C);
   if (!dry && (!dh3 || !dh2 || !dcat || !dh0 || !dha || !dfeat)) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
-  if (!dry) c.rc = hoisdf_sdf_head_bwd(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, stream);
-  lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0);
-  lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0);
-  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, w->emu_img_t[4], dcat, CAT_LD, n, HID0, CAT_LD, 0);
-  lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD);
-  lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, w->emu_img_t[3], dh0, HID0, n, H1 + 1, HID0, 0);
-  lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0);
+  // magnitude words of the gradients that feed contractions: dh3, dh2, dcat, dh0, dha (dx0 is accumulated into: measured by its consumers)
+  enum { BM_DH3 = 0, BM_DH2 = 1, BM_DCAT = 2, BM_DH0 = 3, BM_DHA = 4, BM_N = 5 };
+  uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)BM_N * MAG_WORDS * 4));
+  const bool mags = train_mags(c, n) && !dry && bmag && s.mag;
+  auto mg = [&](int i) -> uint32_t* { return mags ? bmag + i * MAG_WORDS : nullptr; };
+  auto fm = [&](int i) -> const uint32_t* { return mags ? s.mag + i * MAG_WORDS : nullptr; };
+  if (mags) c.rc = hipMemsetAsync(bmag, 0, (size_t)BM_N * MAG_WORDS * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
+  if (!dry && c.ok()) c.rc = sdf_head_bwd_mag(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, mg(BM_DH3), stream);
+  lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0, mg(BM_DH3), mg(BM_DH2));
+  lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0, 0, mg(BM_DH3), fm(TM_H2));
+  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, w->emu_img_t[4], dcat, CAT_LD, n, HID0, CAT_LD, 0, mg(BM_DH2), mg(BM_DCAT));
+  lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD, 0, mg(BM_DH2), fm(TM_CAT));
+  lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, w->emu_img_t[3], dh0, HID0, n, H1 + 1, HID0, 0, mg(BM_DCAT), mg(BM_DH0));
+  lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0, 0, mg(BM_DCAT), fm(TM_H0));
   // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is [512][292]
   // (contracted over the padded row so that it takes the bf16 pipe like the forward; the three pad columns come out zero)
   float* dx0 = dry ? nullptr : dcat + X0_COL;
   const float* x0 = dry ? nullptr : s.cat + X0_COL;
-  lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, w->emu_img_t[2], dx0, CAT_LD, n, HID0, X0, 1);
-  lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0, X0 + 3);
+  lin_bwd_input(c, dh0, HID0, s.b0, drop_p, w->dec_w0, w->dec_ld0, w->emu_img_t[2], dx0, CAT_LD, n, HID0, X0, 1, mg(BM_DH0), nullptr);
+  lin_bwd_weight(c, dh0, HID0, s.b0, drop_p, x0, CAT_LD, G->d_dec_w0, G->d_dec_b0, n, HID0, X0, X0 + 3, mg(BM_DH0), fm(TM_CAT));
   // linear_sdfin: its output sits in x0[:, 0:256] (positional encoding / xyz columns carry no gradient)
-  lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, w->emu_img_t[1], dha, HID0, n, LAT, HID0, 0);
-  lin_bwd_weight(c, dx0, CAT_LD, s.bf, 0.f, s.ha, HID0, G->d_sdfin_w1, G->d_sdfin_b1, n, LAT, HID0);
-  lin_bwd_input(c, dha, HID0, s.ba, 0.f, w->sdfin_w0, C, w->emu_img_t[0], dfeat, C, n, HID0, C, 0);
-  lin_bwd_weight(c, dha, HID0, s.ba, 0.f, s.feat, C, G->d_sdfin_w0, G->d_sdfin_b0, n, HID0, C);
+  lin_bwd_input(c, dx0, CAT_LD, s.bf, 0.f, w->sdfin_w1, HID0, w->emu_img_t[1], dha, HID0, n, LAT, HID0, 0, nullptr, mg(BM_DHA));
+  lin_bwd_weight(c, dx0, CAT_LD, s.bf, 0.f, s.ha, HID0, G->d_sdfin_w1, G->d_sdfin_b1, n, LAT, HID0, 0, nullptr, fm(TM_HA));
+  lin_bwd_input(c, dha, HID0, s.ba, 0.f, w->sdfin_w0, C, w->emu_img_t[0], dfeat, C, n, HID0, C, 0, mg(BM_DHA), nullptr);
+  lin_bwd_weight(c, dha, HID0, s.ba, 0.f, s.feat, C, G->d_sdfin_w0, G->d_sdfin_b0, n, HID0, C, 0, mg(BM_DHA), fm(TM_FEAT));
   if (!dry && c.ok() && dpyr)
     c.rc = hoisdf_project_gather_bwd(dpyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, dfeat, C, stream);
   if (c.ok() && !dry && ws.overflow) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }

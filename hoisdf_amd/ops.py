@@ -447,8 +447,38 @@ def _emu_image(W: torch.Tensor, transpose: bool) -> torch.Tensor:
     return ent[0]
 
 
-def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
+_H2 = [None]
+
+
+def _h2() -> bool:
+    """the process runs the f16x2 form of the emulated contractions (include/hoisdf.h, HOISDF_EMU_FORM)"""
+    if _H2[0] is None:
+        from ._lib import lib
+        _H2[0] = lib().hoisdf_linear_emu_pieces() == 2
+    return _H2[0]
+
+
+def _mag_measure(a2, lda, M, K):
+    """magnitude words (f16x2 form) of an operand whose producer left none: one read of it (hoisdf_mag_measure), so that the
+    contractions that consume it - forward and grad-weight of a layer, grad-input and grad-weight of its backward - do not each
+    measure it again.  None outside the f16x2 form."""
+    if not _h2():
+        return None
+    from ._lib import lib
+    words = torch.empty(lib().hoisdf_mag_words(), device=a2.device, dtype=torch.int32)
+    call("hoisdf_mag_measure", _p(a2), lda, M, K, _p(words), _st())
+    return words
+
+
+def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits, x_mag=None):
+    """-> the magnitude words of x2 that the emulated f16x2 contraction used (given or measured here; None otherwise)"""
     if _emu_ok(M, x2, ldx, K):
+        if _h2():
+            if x_mag is None:
+                x_mag = _mag_measure(x2, ldx, M, K)
+            call("hoisdf_linear_fwd_emu_mag", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
+                 float(drop_p), seed, _p(bits), _p(x_mag), None, _st())
+            return x_mag
         call("hoisdf_linear_fwd_emu", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _st())
         return None
@@ -457,8 +487,15 @@ def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits):
     return None
 
 
-def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate):
+def _gemm_bwd_input(dy2, lddy, bits, p, W, dx, lddx, M, N, K, accumulate, dy_mag=None):
+    """-> the magnitude words of dy2 the f16x2 contraction used (given or measured here; None otherwise)"""
     if _emu_ok(M, dy2, lddy, N):
+        if _h2():
+            if dy_mag is None:
+                dy_mag = _mag_measure(dy2, lddy, M, N)
+            call("hoisdf_linear_bwd_input_emu_mag", _p(dy2), lddy, _p(bits), float(p), _p(_emu_image(W, True)), _p(dx), lddx, M, N, K,
+                 int(accumulate), _p(dy_mag), None, _st())
+            return dy_mag
         call("hoisdf_linear_bwd_input_emu", _p(dy2), lddy, _p(bits), float(p), _p(_emu_image(W, True)), _p(dx), lddx, M, N, K,
              int(accumulate), _st())
         return None
@@ -473,7 +510,10 @@ _EMU_DW_FORM = __import__("os").environ.get("HOISDF_EMU_DW_FORM", "b3")
 
 def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None, dy_scale=None, form=None, dy_mag=None, x_mag=None):
     """dW / db are zero-filled by the caller (the f32 kernel accumulates into them); the emulated form overwrites.
-    form "h2" / magnitude words given: hoisdf_linear_bwd_weight_emu_mag (f16x2 where the process runs that form)."""
+    form "h2" / magnitude words given (x_scale / dy_scale: what _gemm_fwd / _gemm_bwd_input returned for the same operands):
+    hoisdf_linear_bwd_weight_emu_mag (f16x2 where the process runs that form)."""
+    x_mag = x_mag if x_mag is not None else x_scale
+    dy_mag = dy_mag if dy_mag is not None else dy_scale
     if (_GEMM_EMU and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
             and dW.data_ptr() % 16 == 0):

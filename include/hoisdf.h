@@ -163,6 +163,8 @@ int hoisdf_linear_emu_supported(const float* a, long lda, int contraction);
  * hoisdf_linear_emu_pieces() = 2 (h2) or 3 (b3).  The image format follows the form: images are built and consumed in one process. */
 int hoisdf_linear_emu_pieces(void);
 int hoisdf_mag_words(void);
+/* the words of a matrix whose producer left none: zero-fills `words` and folds max |x| of the M x K matrix into them (one read of x) */
+int hoisdf_mag_measure(const float* x, long ldx, long M, int K, uint32_t* words, void* stream);
 int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
                               int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag,
                               uint32_t* y_mag, void* stream);

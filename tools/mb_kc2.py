@@ -4,7 +4,8 @@ hand-interleaved): per-shape time, and bit-equality of the outputs (same product
 import sys, os, math, subprocess, json, hashlib
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 SHAPES = [(65536, 1024, 256), (65536, 256, 1024), (65536, 768, 256), (65536, 256, 256), (294912, 256, 256), (49152, 1024, 992),
-          (49152, 512, 512), (49152, 512, 256), (16384, 1024, 992), (49152, 512, 292), (294912, 60, 256), (1000, 200, 60), (777, 131, 20)]
+          (49152, 512, 512), (49152, 512, 256), (49152, 256, 256), (16384, 1024, 992), (16384, 512, 512), (16384, 256, 512), (49152, 512, 292),
+          (294912, 60, 256), (1000, 200, 60)]
 
 
 def child():
