@@ -39,7 +39,8 @@ def test_attention_backward_asm_mfma_hazard_audit(tmp_path):
 def test_generated_schedules_are_current():
     """the committed *_phase.inc files are what their generators print"""
     # (kc2_phase.inc holds several variants of tools/gen/kc2_phase.py <variant>: not a one-to-one print)
-    for gen, inc in (("attn_bwd4_phase.py", "attn_bwd4_phase.inc"), ("attn_fwd2_phase.py", "attn_fwd2_phase.inc"), ("dw2_phase.py", "dw2_phase.inc")):
+    for gen, inc in (("attn_bwd4_phase.py", "attn_bwd4_phase.inc"), ("attn_fwd2_phase.py", "attn_fwd2_phase.inc"), ("dw2_phase.py", "dw2_phase.inc"),
+                     ("h2_phase.py", "h2_phase.inc"), ("dw2h_phase.py", "dw2h_phase.inc")):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", gen)], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         have = open(os.path.join(ROOT, "hoisdf_amd", "csrc", inc)).read()

@@ -9,10 +9,14 @@ CASES = {
     "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd2_kernel", (32, 2048, 2048)),
     "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd4_kernel", (32, 2048, 2048)),
     "attn_fwd_bf16x2_4x8192x8192": ("hoisdf_attention_fwd_bf16x2", "emu_attn_fwd2_kernel<false, 2>", (4, 8192, 8192)),
-    "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 1024, 256)),
-    "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu", "emu_kc2_kernel<false, false>", (65536, 256, 1024)),
-    "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu", "emu_kc2_kernel<true, false>", (65536, 1024, 256)),
-    "linear_bwd_weight_emu_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw2_kernel<true, true>", (65536, 1024, 256)),
+    # the f16x2 form of the linear layers (default; what the Python path calls: the *_mag entries after one hoisdf_mag_measure per operand)
+    "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu_mag", "emu_h2_kernel<false, false, 2>", (65536, 1024, 256)),
+    "linear_fwd_emu_65536x256x1024": ("hoisdf_linear_fwd_emu_mag", "emu_h2_kernel<false, false, 2>", (65536, 256, 1024)),
+    "linear_fwd_emu_65536x256x256": ("hoisdf_linear_fwd_emu_mag", "emu_h2_kernel<false, false, 2>", (65536, 256, 256)),
+    "linear_bwd_input_emu_65536x1024x256": ("hoisdf_linear_bwd_input_emu_mag", "emu_h2_kernel<true, false, 4>", (65536, 1024, 256)),
+    "linear_bwd_weight_emu_65536x1024x256": ("hoisdf_linear_bwd_weight_emu_mag", "emu_dw2h_kernel<true, true>", (65536, 1024, 256)),
+    # the bf16x3 grad-weight (no magnitudes needed: what runs where no words are at hand)
+    "linear_bwd_weight_b3_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw2_kernel<true, true>", (65536, 1024, 256)),
     "linear_fwd_f32_65536x1024x256": ("hoisdf_linear_fwd", "gemm_f32_kernel<true, true, false, false>", (65536, 1024, 256)),
 }
 if __name__ == "__main__":
@@ -50,7 +54,7 @@ if __name__ == "__main__":
         dy = torch.randn(M, N, device=dev)
         y = torch.empty(M, N, device=dev); dx = torch.empty(M, K, device=dev); dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
         bits = torch.empty(M, (N + 31) // 32, dtype=torch.int32, device=dev)
-        O.set_gemm_emu("_emu" in case)
+        O.set_gemm_emu("_emu" in case or "_b3_" in case)
         O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.0, 0, bits)
         for _ in range(3):
             if "linear_fwd" in case:
@@ -58,5 +62,5 @@ if __name__ == "__main__":
             elif "bwd_input" in case:
                 O._gemm_bwd_input(dy, N, bits, 0.0, W, dx, K, M, N, K, 0)
             else:
-                O._gemm_bwd_weight(dy, N, bits, 0.0, x, K, dW, db, M, N, K)
+                O._gemm_bwd_weight(dy, N, bits, 0.0, x, K, dW, db, M, N, K, form="b3" if "_b3_" in case else "h2")
     torch.cuda.synchronize()
