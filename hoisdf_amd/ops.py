@@ -467,7 +467,18 @@ def _mag_measure(a2, lda, M, K):
     from ._lib import lib
     words = torch.empty(lib().hoisdf_mag_words(), device=a2.device, dtype=torch.int32)
     call("hoisdf_mag_measure", _p(a2), lda, M, K, _p(words), _st())
+    a2._hoisdf_words = (words, a2._version, a2.data_ptr(), lda, M, K)
     return words
+
+
+def _mag_known(a2, lda, M, K):
+    """the words an earlier contraction over this very tensor object measured (same storage version, same view).  Only the grad-weight
+    looks here - it finds what the grad-input of the same layer just measured for dy, or the forward for x: operands nothing writes in
+    between (the C entries write through raw pointers, which torch's version counter does not see: forward / grad-input always measure)"""
+    t = getattr(a2, "_hoisdf_words", None)
+    if t is not None and t[1:] == (a2._version, a2.data_ptr(), lda, M, K):
+        return t[0]
+    return None
 
 
 def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits, x_mag=None):
@@ -514,6 +525,9 @@ def _gemm_bwd_weight(dy2, lddy, bits, p, x2, ldx, dW, db, M, N, K, x_scale=None,
     hoisdf_linear_bwd_weight_emu_mag (f16x2 where the process runs that form)."""
     x_mag = x_mag if x_mag is not None else x_scale
     dy_mag = dy_mag if dy_mag is not None else dy_scale
+    if _h2() and form != "b3":
+        x_mag = x_mag if x_mag is not None else _mag_known(x2, ldx, M, K)
+        dy_mag = dy_mag if dy_mag is not None else _mag_known(dy2, lddy, M, N)
     if (_GEMM_EMU and M >= _GEMM_EMU_DW_MIN_ROWS and min(N, K) >= _GEMM_EMU_DW_MIN_WIDTH and N % 4 == 0 and K % 4 == 0
             and lddy % 4 == 0 and ldx % 4 == 0 and dW.stride(0) == K and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
             and dW.data_ptr() % 16 == 0):
