@@ -159,8 +159,11 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_bf16x2": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P],
+    "hoisdf_attention_fwd_emu_mag": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P, _P, _P, _P],
     "hoisdf_attention_bwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
                                  _L, _P],
+    "hoisdf_attention_bwd_emu_mag": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
+                                 _L, _P, _P, _P, _P, _P],
     "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                    _U64, _P],

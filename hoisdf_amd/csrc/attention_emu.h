@@ -23,6 +23,9 @@ struct EmuAttn {
   float drop_p, inv_keep;
   uint32_t thresh;
   uint64_t seed;
+  const uint32_t* d_mag;           // f16x2 backward: magnitude words of dO
+  float* dq_scale;                 // f16x2 backward: one float the kernel leaves for the dQ reduce pass (0.125 / (sK sS))
+  const uint32_t *in_mag, *in_mag_kv;   // f16x2 form: magnitude words of the matrices the Q planes / the K and V planes were made from (their scales)
   uint32_t* mag;                   // magnitude words (common.h) of what the kernel writes: out (forward), dk / dv (backward); null = none
 };
 
@@ -39,4 +42,6 @@ __device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
 // hoisdf_attention_bwd_emu); returns a HOISDF status
 // (chain: dQ through the ordered in-L2 running sum - a.dq_part one [bh][Lq][64] buffer, a.dq_flags zeroed - instead of partials)
 int attention_bwd4_emu_launch(const emu_attn::EmuAttn& a, bool chain, hipStream_t st);
+// attention_emu_bwd4h.hip: the f16x2 form (two f16 planes per operand in a.q / a.k / a.v / a.d, scales from a.in_mag / a.in_mag_kv / a.d_mag)
+int attention_bwd4h_emu_launch(const emu_attn::EmuAttn& a, hipStream_t st);
 }  // namespace hoisdf

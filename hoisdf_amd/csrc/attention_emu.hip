@@ -98,13 +98,21 @@ __device__ __forceinline__ void split8(const f32x16& s, int jj, float mul, bf16x
 // ---- conversion pre-pass: f32 [B][L][ld] (head slice) -> three bf16 planes, row-major [bh][Lp][64] and / or transposed
 // [bh][64][Lp]; rows >= L are zero.  One block per (bh, 64-row tile): a thread owns 16 consecutive d of one row (4 threads per
 // row: 256-byte coalesced reads, 128-byte coalesced row-major writes); the transposed copies go through an LDS tile.
+// F16 (the f16x2 form of the attention, round 5): TWO planes of f16 bits - hi = f16(x scale s), lo = f16(x scale s - hi) with s the
+// power of two that the magnitude words `mag` (common.h) of the source matrix give; the third plane pointers are not touched.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <bool F16>
 __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __restrict__ src, int ld, int L, int Lp, int B, int H,
                                                                float scale, __bf16* __restrict__ r0, __bf16* __restrict__ r1,
                                                                __bf16* __restrict__ r2, __bf16* __restrict__ t0,
-                                                               __bf16* __restrict__ t1, __bf16* __restrict__ t2) {
+                                                               __bf16* __restrict__ t1, __bf16* __restrict__ t2,
+                                                               const uint32_t* __restrict__ mag) {
   constexpr int TP = 72;
   __shared__ __attribute__((aligned(16))) __bf16 tile[3][64 * TP];
+  __shared__ uint32_t red4[4];
   const int tid = threadIdx.x;
+  if (F16) scale *= mag_scale(mag_words_max(mag, MAG_WORDS, red4));
   const int nb = Lp / 64;
   const int kb = blockIdx.x % nb, bh = blockIdx.x / nb, b = bh / H, head = bh - b * H;
   const int r = tid >> 2, dc = (tid & 3) * 16;
@@ -118,10 +126,18 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
     float4 w = valid ? *reinterpret_cast<const float4*>(sr + 8 * i + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     u.x *= scale; u.y *= scale; u.z *= scale; u.w *= scale;
     w.x *= scale; w.y *= scale; w.z *= scale; w.w *= scale;
-    bf16x8 p0, p1, p2;
-    SPLIT1(u.x, 0); SPLIT1(u.y, 1); SPLIT1(u.z, 2); SPLIT1(u.w, 3);
-    SPLIT1(w.x, 4); SPLIT1(w.y, 5); SPLIT1(w.z, 6); SPLIT1(w.w, 7);
-    pa[i][0] = p0; pa[i][1] = p1; pa[i][2] = p2;
+    if (F16) {
+      const float e_[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)e_[j]; lo[j] = (_Float16)(e_[j] - (float)hi[j]); }
+      pa[i][0] = __builtin_bit_cast(bf16x8, hi); pa[i][1] = __builtin_bit_cast(bf16x8, lo); pa[i][2] = pa[i][1];
+    } else {
+      bf16x8 p0, p1, p2;
+      SPLIT1(u.x, 0); SPLIT1(u.y, 1); SPLIT1(u.z, 2); SPLIT1(u.w, 3);
+      SPLIT1(w.x, 4); SPLIT1(w.y, 5); SPLIT1(w.z, 6); SPLIT1(w.w, 7);
+      pa[i][0] = p0; pa[i][1] = p1; pa[i][2] = p2;
+    }
   }
   if (r0) {
     const size_t o = ((size_t)bh * Lp + row) * D + dc;
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<bf16x8*>(r0 + o + 8 * i) = pa[i][0];
       *reinterpret_cast<bf16x8*>(r1 + o + 8 * i) = pa[i][1];
-      if (r2) *reinterpret_cast<bf16x8*>(r2 + o + 8 * i) = pa[i][2];          // (two-plane callers pass null third planes)
+      if (!F16 && r2) *reinterpret_cast<bf16x8*>(r2 + o + 8 * i) = pa[i][2];  // (two-plane callers pass null third planes)
     }
   }
   if (t0) {                                                // block-uniform
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
       for (int e = 0; e < 8; ++e) {
         tile[0][(dc + 8 * i + e) * TP + r] = pa[i][0][e];
         tile[1][(dc + 8 * i + e) * TP + r] = pa[i][1][e];
-        tile[2][(dc + 8 * i + e) * TP + r] = pa[i][2][e];
+        if (!F16) tile[2][(dc + 8 * i + e) * TP + r] = pa[i][2][e];
       }
     __syncthreads();
     const int d = tid >> 2, rc = (tid & 3) * 16;           // 16 consecutive rows of d-row d
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<u32x4*>(t0 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[0][d * TP + rc + 8 * i]);
       *reinterpret_cast<u32x4*>(t1 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[1][d * TP + rc + 8 * i]);
-      if (t2) *reinterpret_cast<u32x4*>(t2 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[2][d * TP + rc + 8 * i]);
+      if (!F16 && t2) *reinterpret_cast<u32x4*>(t2 + o + 8 * i) = *reinterpret_cast<const u32x4*>(&tile[2][d * TP + rc + 8 * i]);
     }
   }
 }
@@ -307,8 +323,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // NPL = planes per operand: 3 = fp32-equivalent (six products per product); 2 = bf16 hi + lo operands, three products - the 16-bit-operand
 // evaluation kernel of BASELINE configs[4] (hoisdf_attention_fwd_bf16x2; ~2^-17 relative operand error, f32 softmax and accumulation)
-template <bool DROP, int NPL>
+// F16 (with NPL = 2): the f16x2 form - the planes hold f16 hi + lo pieces of Q s, K s, V s (s = the power of two from a.in_mag, the
+// magnitude words of the [q | k | v] matrix; emu_attn_convert_kernel<true>), the products run on v_mfma_f32_32x32x16_f16.  The scores
+// come out multiplied by s^2: the softmax works on them as they are (running maximum, rescale threshold and exponent argument carry
+// the factor 1 / s^2 in one fused multiply-add); P is formed as 2^6 P (<= 2^14 at the lazy rescale's 2^8 head room) so that its f16
+// pieces keep 22 bits down to 2^-22 of the row's largest probability; the row sum carries the same 2^6 and O = acc / (l s).
+template <bool DROP, int NPL, bool F16>
 __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
+  static_assert(!F16 || NPL == 2, "the f16 form has two planes");
+  __shared__ uint32_t red4_[4];
   __shared__ __attribute__((aligned(16))) __bf16 Kb0[3 * ROWS_T];
   __shared__ __attribute__((aligned(16))) __bf16 Kb1[3 * ROWS_T];
   __shared__ __attribute__((aligned(16))) __bf16 Vb0[3 * TRN_T];
@@ -319,8 +342,19 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   if (!emu_block((a.Lq + 127) / 128, a.B * a.H, qtile, bh)) return;
   const int b = bh / a.H, head = bh - b * a.H;
   const int qrow = qtile * 128 + wave * 32 + c;
-  const __bf16* kp[3] = {a.k[0] + (size_t)bh * a.Lkp * D, a.k[1] + (size_t)bh * a.Lkp * D, a.k[2] + (size_t)bh * a.Lkp * D};
-  const __bf16* vp[3] = {a.vt[0] + (size_t)bh * D * a.Lkp, a.vt[1] + (size_t)bh * D * a.Lkp, a.vt[2] + (size_t)bh * D * a.Lkp};
+  const __bf16* kp[3] = {a.k[0] + (size_t)bh * a.Lkp * D, a.k[1] + (size_t)bh * a.Lkp * D, a.k[NPL == 3 ? 2 : 1] + (size_t)bh * a.Lkp * D};
+  const __bf16* vp[3] = {a.vt[0] + (size_t)bh * D * a.Lkp, a.vt[1] + (size_t)bh * D * a.Lkp, a.vt[NPL == 3 ? 2 : 1] + (size_t)bh * D * a.Lkp};
+  // f16 form: cs = 1 / s^2 takes the accumulated scores to the log2-domain scores, vinv = 1 / s takes the accumulated output back
+  float cs = 1.f, vinv = 1.f;
+  constexpr float PB = F16 ? 6.f : 0.f;                     // P is formed as 2^PB P
+  if (F16) {
+    const float iq_ = mag_inv_scale(mag_words_max(a.in_mag, MAG_WORDS, red4_));
+    __syncthreads();
+    const float ik_ = mag_inv_scale(mag_words_max(a.in_mag_kv, MAG_WORDS, red4_));
+    cs = iq_ * ik_; vinv = ik_;
+  }
+  const float thr8 = F16 ? 8.f / cs : 8.f;                  // the lazy rescale's threshold in accumulator units
+  float mneg = INFINITY;                                    // f16 form: PB - m cs (the exponent argument is fma(score, cs, mneg))
 
   bf16x8 qf[4][3];                        // Q^T fragments: k-step j <-> d = 16 j + 8 h .. + 7 of the lane's query
 #pragma unroll
@@ -352,14 +386,25 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define PK_SUB(d, x, y) asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(y))
 // ---- units of the S phase: scores 2 pr, 2 pr + 1 of tile t -> probabilities -> (dropout) -> three bf16 planes
-#define PE1(pr) do { e_[pr] = f32x2{__builtin_amdgcn_exp2f(s_cur[2 * (pr)] - m), __builtin_amdgcn_exp2f(s_cur[2 * (pr) + 1] - m)}; } while (0)
+#define PE1(pr)                                                                                                        \
+  do {                                                                                                                 \
+    if constexpr (F16) e_[pr] = f32x2{__builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[2 * (pr)], cs, mneg)),               \
+                                     __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[2 * (pr) + 1], cs, mneg))};           \
+    else e_[pr] = f32x2{__builtin_amdgcn_exp2f(s_cur[2 * (pr)] - m), __builtin_amdgcn_exp2f(s_cur[2 * (pr) + 1] - m)}; \
+  } while (0)
 #define PE2(pr)                                                                                                        \
   do {                                                                                                                 \
     ps += e_[pr].x + e_[pr].y;                                                                                         \
     if (DROP) e_[pr] = f32x2{e_[pr].x * dsc[2 * (pr)], e_[pr].y * dsc[2 * (pr) + 1]};                                   \
-    const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(e_[pr], bf16x2));                         \
-    w0[pr] = h_;                                                                                                       \
-    f_[pr] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                  \
+    if constexpr (F16) {                                                                                               \
+      const f16x2 hh_ = __builtin_convertvector(e_[pr], f16x2);                                                        \
+      w0[pr] = __builtin_bit_cast(uint32_t, hh_);                                                                      \
+      f_[pr] = __builtin_convertvector(hh_, f32x2);                                                                    \
+    } else {                                                                                                           \
+      const uint32_t h_ = __builtin_bit_cast(uint32_t, __builtin_convertvector(e_[pr], bf16x2));                       \
+      w0[pr] = h_;                                                                                                     \
+      f_[pr] = f32x2{__builtin_bit_cast(float, h_ << 16), __builtin_bit_cast(float, h_ & 0xffff0000u)};                \
+    }                                                                                                                  \
   } while (0)
 #define PE3(pr)                                                                                                        \
   do {                                                                                                                 \
@@ -382,7 +427,8 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #define PE3B(pr)                                                                                                       \
   do {                                                                                                                 \
     f32x2 r_; PK_SUB(r_, e_[pr], f_[pr]);                                                                              \
-    w1[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r_, bf16x2));                                        \
+    if constexpr (F16) w1[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r_, f16x2));                      \
+    else w1[pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r_, bf16x2));                                   \
     if (((pr) & 3) == 3) {                                                                                             \
       pw[(pr) >> 2][0] = __builtin_bit_cast(bf16x8, u32x4{w0[(pr) - 3], w0[(pr) - 2], w0[(pr) - 1], w0[pr]});          \
       pw[(pr) >> 2][1] = __builtin_bit_cast(bf16x8, u32x4{w1[(pr) - 3], w1[(pr) - 2], w1[(pr) - 1], w1[pr]});          \
@@ -470,6 +516,11 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
 #else
 #define FWD2_SYNC() __syncthreads()
 #endif
+#pragma push_macro("MB")
+#undef MB
+#define MB(a_, b_, c_)                                                                                                             \
+  (F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a_)), __builtin_bit_cast(f16x8, (b_)), (c_), 0, 0, 0) \
+       : __builtin_amdgcn_mfma_f32_32x32x16_bf16((a_), (b_), (c_), 0, 0, 0))
 #include "attn_fwd2_phase.inc"
 
   // ---- prologue: K(0), V(0), K(1) staged; K(2), V(1) in registers; S(0) and its statistics
@@ -507,11 +558,12 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
       PM(0); PM(1); PM(2); PM(3);                                                                                      \
     }                                                                                                                  \
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));                                                                            \
-    if (__any(mt > m + 8.f)) {                                                                                         \
+    if (__any(mt > m + thr8)) {                                                                                        \
       const float mn = fmaxf(m, mt);                                                                                   \
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);                                                              \
+      const float alpha = __builtin_amdgcn_exp2f(F16 ? (m - mn) * cs : m - mn);                                        \
       lsum *= alpha;                                                                                                   \
       m = mn;                                                                                                          \
+      mneg = PB - m * cs;                                                                                              \
       _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int r = 0; r < 16; ++r) o[t_][r] *= alpha; \
     }                                                                                                                  \
     if (DO_HASH) { _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) { PH1(pr); PH2(pr); PH3(pr); } }                    \
@@ -577,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   uint32_t omax = 0u;
   if (qrow < a.Lq) {
-    const float inv = 1.f / ltot;
+    const float inv = vinv / ltot;
     float* op = a.out + ((size_t)b * a.Lq + qrow) * a.ldo + head * D;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -587,10 +639,11 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
         *reinterpret_cast<float4*>(op + 32 * tt + 8 * g + 4 * h) = ov;
         omax = max(omax, mag_bits4(ov));
       }
-    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
+    if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = (F16 ? m * cs - PB : m) + log2f(ltot);       // log2 domain
   }
   mag_publish_wave(a.mag, omax);
 }
+#pragma pop_macro("MB")
 
 
 namespace {
@@ -908,8 +961,10 @@ __global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __rest
 }
 
 // dq[b][q][head * 64 + d] = 0.125 * sum_kb part[kb][bh][q][d] in key-block order (one float4 per thread)
+// scale: null = 0.125 (the bf16x3 backward: Q pre-scaled by log2(e) / 8 ...); the f16x2 backward leaves 0.125 / (sK sS) there
 __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __restrict__ part, int nkb, float* __restrict__ dq,
-                                                                 int ldq, int B, int H, int Lq, uint32_t* __restrict__ mag) {
+                                                                 int ldq, int B, int H, int Lq, uint32_t* __restrict__ mag,
+                                                                 const float* __restrict__ scale) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;          // (bh, q, d / 4)
   const long n = (long)B * H * Lq * 16;
   uint32_t qmax = 0u;
@@ -925,7 +980,8 @@ __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __
       const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const float4 r = make_float4(s.x * 0.125f, s.y * 0.125f, s.z * 0.125f, s.w * 0.125f);
+    const float sc = scale ? *scale : 0.125f;
+    const float4 r = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
     *reinterpret_cast<float4*>(dq + ((size_t)b * Lq + q) * ldq + head * D + d4 * 4) = r;
     qmax = mag_bits4(r);
   }
@@ -948,10 +1004,13 @@ inline Planes carve(__bf16*& w, size_t n, bool rows, bool trn) {
   for (int i = 0; i < 3; ++i) { p.t[i] = trn ? w : nullptr; if (trn) w += n; }
   return p;
 }
-int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, const Planes& p, hipStream_t st) {
+// mag != null: the f16x2 planes of a matrix with those magnitude words (two planes, scaled); null: the bf16 planes
+int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, const Planes& p, hipStream_t st, const uint32_t* mag = nullptr) {
   const long nblk = (long)B * H * (Lp / 64);
-  hipLaunchKernelGGL(emu_attn_convert_kernel, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, p.r[0], p.r[1],
-                     p.r[2], p.t[0], p.t[1], p.t[2]);
+  if (mag) hipLaunchKernelGGL(emu_attn_convert_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, p.r[0], p.r[1],
+                              p.r[2], p.t[0], p.t[1], p.t[2], mag);
+  else hipLaunchKernelGGL(emu_attn_convert_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, p.r[0], p.r[1],
+                          p.r[2], p.t[0], p.t[1], p.t[2], mag);
   return check_launch("attention_emu_convert");
 }
 int check_emu(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, int B, int H, int Lq, int Lk, int kv_len,
@@ -978,8 +1037,9 @@ extern "C" long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int
 namespace {
 // the forward over planes that are in the workspace already (layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only
 // form: [Q rows | K rows | V^T])
+// in_mag != null: the planes are the f16x2 ones (two planes, made with those magnitude words): the f16 kernel
 int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
-                    void* workspace, int keep, hipStream_t st, uint32_t* o_mag) {
+                    void* workspace, int keep, hipStream_t st, uint32_t* o_mag, const uint32_t* in_mag = nullptr, const uint32_t* in_mag_kv = nullptr) {
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
@@ -988,15 +1048,18 @@ int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
   const Planes pv = carve(w, nk, keep != 0, true);
   EmuAttn a{};
   for (int i = 0; i < 3; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
-  a.out = o; a.lse = lse; a.ldo = ldo; a.mag = o_mag;
+  a.out = o; a.lse = lse; a.ldo = ldo; a.mag = o_mag; a.in_mag = in_mag; a.in_mag_kv = in_mag_kv ? in_mag_kv : in_mag;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   static int form = -1;                       // HOISDF_EMU_ATTN_FWD=1: the first (unpipelined) form (A/B runs)
   if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_FWD"); form = (e && atoi(e) == 1) ? 1 : 2; }
   const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
-  if (form == 1) hipLaunchKernelGGL(emu_attn_fwd_kernel, fgrid, dim3(256), 0, st, a);
-  else if (drop_p > 0.f) hipLaunchKernelGGL((emu_attn_fwd2_kernel<true, 3>), fgrid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 3>), fgrid, dim3(256), 0, st, a);
+  if (in_mag) {
+    if (drop_p > 0.f) hipLaunchKernelGGL((emu_attn_fwd2_kernel<true, 2, true>), fgrid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 2, true>), fgrid, dim3(256), 0, st, a);
+  } else if (form == 1) hipLaunchKernelGGL(emu_attn_fwd_kernel, fgrid, dim3(256), 0, st, a);
+  else if (drop_p > 0.f) hipLaunchKernelGGL((emu_attn_fwd2_kernel<true, 3, false>), fgrid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 3, false>), fgrid, dim3(256), 0, st, a);
   return check_launch("attention_fwd_emu");
 }
 }  // namespace
@@ -1005,12 +1068,22 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
                                         int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
                                         uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
   return attention_fwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, workspace_bytes, keep,
-                               nullptr, stream);
+                               nullptr, stream, nullptr, nullptr);
+}
+// the f16x2 form of the forward (qkv_mag = magnitude words of the matrix q, k, v are column slices of: one common power-of-two scale,
+// two f16 planes per operand, three products per product; include/hoisdf.h); o_mag receives o's words when given
+extern "C" int hoisdf_attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                                            int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
+                                            uint64_t seed, void* workspace, long workspace_bytes, int keep, const uint32_t* qkv_mag,
+                                            const uint32_t* kv_mag, uint32_t* o_mag, void* stream) {
+  HOISDF_REQUIRE(qkv_mag, HOISDF_ERR_INVALID, "attention_fwd_emu_mag: the magnitude words of q / k / v are required (hoisdf_mag_measure)");
+  return attention_fwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, workspace_bytes, keep,
+                               o_mag, stream, qkv_mag, kv_mag);
 }
 // (internal, common.h) + o_mag: the magnitude words of o (zero on entry; null = not wanted)
 int hoisdf::attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                                   int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
-                                  long workspace_bytes, int keep, uint32_t* o_mag, void* stream) {
+                                  long workspace_bytes, int keep, uint32_t* o_mag, void* stream, const uint32_t* qkv_mag, const uint32_t* kv_mag) {
   if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
   HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
                  HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
@@ -1023,10 +1096,13 @@ int hoisdf::attention_fwd_emu_mag(const float* q, int ldq, const float* k, int l
   const Planes pq = carve(w, nq, true, false);
   const Planes pk = carve(w, nk, true, false);
   const Planes pv = carve(w, nk, keep != 0, true);
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
-  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st, o_mag);
+  // qkv_mag: the magnitude words of the matrix q, k and v are column slices of - the f16x2 form (one scale for the three)
+  // (kv_mag: k and v come from another matrix than q - its words; null: the same)
+  if (qkv_mag && !kv_mag) kv_mag = qkv_mag;
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, qkv_mag)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, kv_mag)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, kv_mag)) return rc;
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st, o_mag, qkv_mag, kv_mag);
 }
 
 // ---- 16-bit-operand evaluation attention (BASELINE configs[4] "fp16 MFMA attention"): the pipelined forward over TWO bf16 planes per
@@ -1061,7 +1137,7 @@ extern "C" int hoisdf_attention_fwd_bf16x2(const float* q, int ldq, const float*
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = 0.f; a.inv_keep = 1.f; a.thresh = 0; a.seed = 0;
   const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
-  hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 2>), fgrid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 2, false>), fgrid, dim3(256), 0, st, a);
   return check_launch("attention_fwd_bf16x2");
 }
 
@@ -1107,13 +1183,27 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
                                         float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
                                         const void* fwd_workspace, void* workspace, long workspace_bytes, void* stream) {
   return attention_bwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, dk, dv, B, H, Lq, Lk, kv_len, drop_p, seed,
-                               fwd_workspace, workspace, workspace_bytes, nullptr, stream);
+                               fwd_workspace, workspace, workspace_bytes, nullptr, stream, nullptr, nullptr, nullptr);
+}
+// the backward in the f16x2 form (emu_attn_bwd4h_kernel): qkv_mag / kv_mag as in hoisdf_attention_fwd_emu_mag, do_mag = the magnitude
+// words of dout; fwd_workspace = the planes a forward OF THE SAME FORM kept (keep = 1), or NULL (q, k, v are converted here)
+extern "C" int hoisdf_attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                                            int ldo, const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk,
+                                            float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
+                                            const void* fwd_workspace, void* workspace, long workspace_bytes, const uint32_t* qkv_mag,
+                                            const uint32_t* kv_mag, const uint32_t* do_mag, uint32_t* g_mag, void* stream) {
+  HOISDF_REQUIRE(qkv_mag && do_mag, HOISDF_ERR_INVALID, "attention_bwd_emu_mag: the magnitude words of q / k / v and of dout are required");
+  return attention_bwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, dk, dv, B, H, Lq, Lk, kv_len, drop_p, seed,
+                               fwd_workspace, workspace, workspace_bytes, g_mag, stream, qkv_mag, kv_mag, do_mag);
 }
 // (internal, common.h) + g_mag: ONE array of magnitude words for dq, dk and dv together (zero on entry; null = not wanted)
 int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                                   const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                                   int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
-                                  void* workspace, long workspace_bytes, uint32_t* g_mag, void* stream) {
+                                  void* workspace, long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* qkv_mag,
+                                  const uint32_t* kv_mag, const uint32_t* do_mag) {
+  const bool h2 = qkv_mag && do_mag;                 // the f16x2 form: two scaled f16 planes per operand (emu_attn_bwd4h_kernel)
+  if (h2 && !kv_mag) kv_mag = qkv_mag;
   // with the forward's planes (fwd_workspace) q, k, v themselves are not read: they may be null; ldq / ldk / ldv still give the
   // layouts of dq / dk / dv
   if (int rc = check_emu(fwd_workspace && !q ? o : q, fwd_workspace && !k ? o : k, fwd_workspace && !v ? o : v, ldq, ldk, ldv, B, H, Lq,
@@ -1149,11 +1239,11 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
     pq = carve(f, nq, true, false); pk = carve(f, nk, true, false); pv = carve(f, nk, true, true);
   } else {
     pq = carve(w, nq, true, false); pk = carve(w, nk, true, false); pv = carve(w, nk, true, false);
-    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st)) return rc;
-    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st)) return rc;
-    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st)) return rc;
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, h2 ? qkv_mag : nullptr)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, h2 ? kv_mag : nullptr)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, h2 ? kv_mag : nullptr)) return rc;
   }
-  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, pd, st)) return rc;
+  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, pd, st, h2 ? do_mag : nullptr)) return rc;
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(emu_attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, o, ldo, dout, lddo, delta, B, H, Lq);
   if (int rc = check_launch("attention_emu_delta")) return rc;
@@ -1164,6 +1254,15 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
   a.lse_in = lse; a.delta = delta; a.dq_part = part; a.dk = dk; a.dv = dv; a.ldk = ldk; a.ldv = ldv; a.mag = g_mag;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
+  if (h2) {
+    a.in_mag = qkv_mag; a.in_mag_kv = kv_mag; a.d_mag = do_mag;
+    a.dq_scale = reinterpret_cast<float*>(pd.r[2]);          // (the third dO plane is free in this form: the reduce pass's factor lives there)
+    if (int rc = attention_bwd4h_emu_launch(a, st)) return rc;
+    const long n4h = (long)B * H * Lq * 16;
+    hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4h + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
+                       B, H, Lq, g_mag, (const float*)a.dq_scale);
+    return check_launch("attention_bwd_emu dq reduce");
+  }
   // HOISDF_EMU_ATTN_BWD: (default) the round-5 kernel with dQ summed across the key blocks through an ordered running sum in L2;
   // "4p": the same kernel with the per-key-block partial buffer + reduce pass; "3": the round-3 kernel (8 waves x 16 keys) - A/B runs
   static int form = -1;
@@ -1189,7 +1288,7 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
       if (int rc = attention_bwd4_emu_launch(a, true, st)) return rc;
       if (ngrp == 1) return HOISDF_OK;          // (the chain's last block wrote dq itself)
       const long n4c = (long)B * H * Lq * 16;
-      hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4c + 255) / 256)), dim3(256), 0, st, part, ngrp, dq, ldq, B, H, Lq, g_mag);
+      hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4c + 255) / 256)), dim3(256), 0, st, part, ngrp, dq, ldq, B, H, Lq, g_mag, (const float*)nullptr);
       return check_launch("attention_bwd_emu dq reduce");
     }
     if (int rc = attention_bwd4_emu_launch(a, false, st)) return rc;
@@ -1204,6 +1303,6 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
   }
   const long n4 = (long)B * H * Lq * 16;
   hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,
-                     B, H, Lq, g_mag);
+                     B, H, Lq, g_mag, (const float*)nullptr);
   return check_launch("attention_bwd_emu dq reduce");
 }

@@ -92,11 +92,13 @@ int attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq
 // hoisdf_attention_fwd_emu / _bwd_emu with magnitude words (below) for o / for [dq | dk | dv] together
 int attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse, int B,
                           int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes, int keep,
-                          uint32_t* o_mag, void* stream);
+                          uint32_t* o_mag, void* stream, const uint32_t* qkv_mag = nullptr,       // qkv_mag: the f16x2 form of the forward
+                          const uint32_t* kv_mag = nullptr);                                     // (k, v from another matrix than q: its words)
 int attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                           const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H,
                           int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace, void* workspace,
-                          long workspace_bytes, uint32_t* g_mag, void* stream);
+                          long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* qkv_mag = nullptr,
+                          const uint32_t* kv_mag = nullptr, const uint32_t* do_mag = nullptr);      // all three: the f16x2 form
 
 // gemm_emu.hip, f16x2 form: is it on (HOISDF_EMU_FORM, process-wide); magnitude words of a row-major f32 matrix (emu_amax_words()
 // words, each the bits of a max |x| over a share of the matrix: the contraction's operand scale is derived from their maximum)
@@ -120,6 +122,23 @@ __device__ __forceinline__ void mag_publish_wave(uint32_t* words, uint32_t m) { 
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(words + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MAG_WORDS - 1)), m);
+}
+// power-of-two operand scale from the largest magnitude (bits of |x|max): max |x| s in [2^13, 2^14); zero / denormal / huge maxima clamp
+__device__ __forceinline__ uint32_t mag_exp(uint32_t amax_bits) { return min(max((amax_bits >> 23) & 0xffu, 14u), 254u); }
+__device__ __forceinline__ float mag_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (267u - mag_exp(amax_bits)) << 23); }
+__device__ __forceinline__ float mag_inv_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (mag_exp(amax_bits) - 13u) << 23); }
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* red4) {      // 256 threads; red4 = four shared words
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+}
+// the maximum over an array of magnitude words, by a 256-thread block (all threads call it)
+__device__ __forceinline__ uint32_t mag_words_max(const uint32_t* words, int n, uint32_t* red4) {
+  uint32_t m = 0u;
+  for (int i = threadIdx.x; i < n; i += 256) m = max(m, words[i]);
+  return block_max_u32(m, red4);
 }
 // the entries below with magnitude words (null = none): x_mag / dy_mag describe the row operand, y_mag / dx_mag receive the output's
 int linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K, int act,

@@ -666,24 +666,15 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define MFH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-constexpr int HTM = 256, HTN = 256, HNJ = 4;
-constexpr int HA_U4 = 2 * 2 * HTM, HB_U4 = 2 * 2 * HTN, HSTAGE = HA_U4 + HB_U4;      // 16-byte units per stage (32 KB)
-constexpr int H_EPI_U4 = (4 * 32 * (HTN / 2 + 4) * 4 + 64) / 16;                       // the epilogue's four transposition slices + a few words
+constexpr int HTM = 256, HTN = 256;
+constexpr int HA_U4 = 2 * 2 * HTM, HB_U4 = 2 * 2 * HTN;      // 16-byte units of the activation stage / of one 256-row image block per slab
 constexpr int H_TRAILER = 128;
 constexpr int AMAX_BLOCKS = 512;
 
-// power-of-two operand scale from the largest magnitude (bits of |x|max): max |x| s in [2^13, 2^14); zero / denormal / huge maxima clamp
-__device__ __forceinline__ uint32_t h2_exp(uint32_t amax_bits) { return min(max((amax_bits >> 23) & 0xffu, 14u), 254u); }
-__device__ __forceinline__ float h2_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (267u - h2_exp(amax_bits)) << 23); }
-__device__ __forceinline__ float h2_inv_scale(uint32_t amax_bits) { return __builtin_bit_cast(float, (h2_exp(amax_bits) - 13u) << 23); }
-
-__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* red4) {      // 256 threads
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return max(max(red4[0], red4[1]), max(red4[2], red4[3]));
-}
+// (the power-of-two operand scale from the magnitude words and the 256-thread block maximum live in common.h: the attention kernels use them too)
+__device__ __forceinline__ uint32_t h2_exp(uint32_t amax_bits) { return mag_exp(amax_bits); }
+__device__ __forceinline__ float h2_scale(uint32_t amax_bits) { return mag_scale(amax_bits); }
+__device__ __forceinline__ float h2_inv_scale(uint32_t amax_bits) { return mag_inv_scale(amax_bits); }
 }  // namespace
 
 // magnitude words of a row-major f32 matrix: block b -> part[b] = bits of max |x| over its share (AMAX_BLOCKS blocks)
@@ -1710,18 +1701,18 @@ static void mag_trace(const char* who, long M, int K) {
   if (on) fprintf(stderr, "[hoisdf mag] measured by the library: %s operand %ld x %d\n", who, M, K);
 }
 // magnitude words of a row-major matrix into `part` (AMAX_BLOCKS words)
-int hoisdf::emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st) {
+int emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st) {
   hipLaunchKernelGGL(emu_amax_kernel<false>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, part);
   return check_launch("emu_amax");
 }
 // the same pass into magnitude words (MAG_WORDS, zero on entry): for an operand several contractions will read
-int hoisdf::emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st) {
+int emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st) {
   mag_trace("a chain, once for all its readers:", M, K);
   hipLaunchKernelGGL(emu_amax_kernel<true>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, words);
   return check_launch("emu_amax (words)");
 }
-int hoisdf::emu_amax_words() { return AMAX_BLOCKS; }
-bool hoisdf::emu_form_h2() { return form_h2(); }
+int emu_amax_words() { return AMAX_BLOCKS; }
+bool emu_form_h2() { return form_h2(); }
 
 namespace {
 int launch_emu(EmuArgs g, hipStream_t st) {

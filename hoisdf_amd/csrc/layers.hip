@@ -39,7 +39,15 @@ int rows_copy_add(float* dst, long dst_gs, const float* src, long src_gs, int gr
 struct Geo {
   int B, S, E, F, H, nq, ni; bool full; long M, Ms; float eps, p; int att, att_bwd_emu;
   bool fused_qkv;      // the in-projection writes the attention planes directly (linear_fwd_emu_qkv): no f32 q / k / v, no conversion pass
+  bool att_h2;         // the attention forward in the f16x2 form: the in-projection writes f32 q / k / v and leaves their magnitude words, the
+                       // conversion pass makes two scaled f16 planes per operand from them (attention_fwd_emu_mag)
 };
+// HOISDF_ATTN_FORM=b3: the attention forward of the layers stays in the bf16x3 form (A/B runs)
+bool attn_h2_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HOISDF_ATTN_FORM"); on = (e && (e[0] == 'b' || e[0] == 'B')) ? 0 : 1; }
+  return on == 1;
+}
 // HOISDF_QKV_PLANES=0: the in-projection writes f32 q / k / v and the attention entry converts them (the round-3 flow; A/B runs)
 bool qkv_planes_enabled() {
   static int on = -1;
@@ -52,7 +60,7 @@ bool qkv_planes_enabled() {
 struct SavedForms {
   std::mutex mu;
   std::unordered_map<const void*, int> form;
-  void put(const void* saved, bool fused) { std::lock_guard<std::mutex> l(mu); if (form.size() > 4096) form.clear(); form[saved] = fused ? 1 : 0; }
+  void put(const void* saved, int flags) { std::lock_guard<std::mutex> l(mu); if (form.size() > 4096) form.clear(); form[saved] = flags; }
   int take(const void* saved) {
     std::lock_guard<std::mutex> l(mu);
     auto it = form.find(saved);
@@ -79,7 +87,9 @@ int geometry(const hoisdf_encoder_layer_desc* d, Geo& g) {
   g.att_bwd_emu = g.att == 2 && d->attention_bwd_emulated && d->training;
   // emulated attention forward (and, in training, the emulated backward over the kept planes: nothing else reads q / k / v),
   // heads of 64, whole 128-token wave tiles per sample, the in-projection on the emulated GEMM
-  g.fused_qkv = qkv_planes_enabled() && g.att == 2 && (g.att_bwd_emu || !d->training) && g.E == g.H * 64 && g.S % 128 == 0 &&
+  // (f16x2 attention: where the layer's contractions run in the f16x2 form - the same test as layer_mags() below)
+  g.att_h2 = attn_h2_enabled() && g.att == 2 && g.E == g.H * 64 && gemm_emu_mode() && emu_form_h2() && g.M >= EMU_MIN_ROWS;
+  g.fused_qkv = !g.att_h2 && qkv_planes_enabled() && g.att == 2 && (g.att_bwd_emu || !d->training) && g.E == g.H * 64 && g.S % 128 == 0 &&
                 g.nq % 128 == 0 && gemm_emu_mode() && g.M >= EMU_MIN_ROWS;
   return HOISDF_OK;
 }
@@ -90,7 +100,7 @@ struct Saved {
   void* planes; long planes_bytes;
   uint32_t* mag;       // magnitude words (common.h) of o, x1, h, x_out: 4 x MAG_WORDS, zeroed by the forward before its first launch
 };
-enum { MAG_O = 0, MAG_X1 = 1, MAG_H = 2, MAG_XOUT = 3, MAG_FWD = 4 };
+enum { MAG_O = 0, MAG_X1 = 1, MAG_H = 2, MAG_XOUT = 3, MAG_QKV = 4, MAG_KV = 5, MAG_FWD = 6 };   // (QKV: [q | k | v], or q alone next to KV = [k | v])
 void carve_saved(const Geo& g, Bump& b, Saved& s) {
   const int E = g.E;
   s.qkv = s.qbuf = s.kvbuf = s.xq = nullptr;
@@ -102,7 +112,7 @@ void carve_saved(const Geo& g, Bump& b, Saved& s) {
   s.o = b.floats(g.M * E); s.lse = b.floats((long)g.B * g.H * g.nq); s.a = b.floats(g.M * E); s.x1 = b.floats(g.M * E);
   s.h = b.floats(g.M * g.F); s.bits = static_cast<uint32_t*>(b.take(g.M * ((g.F + 31) / 32) * 4)); s.f = b.floats(g.M * E);
   s.st = b.floats(6 * g.M);
-  s.planes_bytes = g.att_bwd_emu ? hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 2) : 0;
+  s.planes_bytes = g.att_bwd_emu ? hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 2) : 0;     // (bf16x3 or, with att_h2, f16x2 planes: the backward runs in the forward's form)
   s.planes = s.planes_bytes ? b.take(s.planes_bytes) : nullptr;
   s.mag = static_cast<uint32_t*>(b.take((long)MAG_FWD * MAG_WORDS * 4));
 }
@@ -148,13 +158,13 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
       }
     }
   } else if (g.full) {
-    lin_fwd(c, x, E, w->w_in, E, w->img_in, w->b_in, s.qkv, 3 * E, g.Ms, 3 * E, E, 0, 0.f, 0, nullptr, 0, xm, nullptr);
+    lin_fwd(c, x, E, w->w_in, E, w->img_in, w->b_in, s.qkv, 3 * E, g.Ms, 3 * E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_QKV) : nullptr);
     q = s.qkv; k = s.qkv + E; v = s.qkv + 2 * E; ldq = ldkv = 3 * E;
   } else {
     if (!dry && c.ok()) c.rc = rows_copy_add(s.xq, (long)g.nq * E, x, (long)g.S * E, g.B, g.nq, E, 0, c.st);
     xq2 = s.xq;
-    lin_fwd(c, s.xq, E, w->w_in, E, w->img_in_q, w->b_in, s.qbuf, E, g.M, E, E, 0, 0.f, 0, nullptr, 0, xm, nullptr);
-    lin_fwd(c, x, E, w->w_in + (size_t)E * E, E, w->img_in_kv, w->b_in ? w->b_in + E : nullptr, s.kvbuf, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr, 0, xm, nullptr);
+    lin_fwd(c, s.xq, E, w->w_in, E, w->img_in_q, w->b_in, s.qbuf, E, g.M, E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_QKV) : nullptr);
+    lin_fwd(c, x, E, w->w_in + (size_t)E * E, E, w->img_in_kv, w->b_in ? w->b_in + E : nullptr, s.kvbuf, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_KV) : nullptr);
     q = s.qbuf; k = s.kvbuf; v = s.kvbuf + E; ldq = E; ldkv = 2 * E;
   }
   const uint32_t* o_mag = g.att == 2 ? mg(MAG_O) : nullptr;        // (the exact-f32 attention leaves none: the out-projection measures o itself)
@@ -164,8 +174,11 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
   } else if (g.att == 2) {
     if (!dry && c.ok()) {
       if (!aw) c.rc = HOISDF_ERR_WORKSPACE;
-      else c.rc = attention_fwd_emu_mag(q, ldq, k, ldkv, v, ldkv, s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], aw, ab,
-                                        s.planes ? 1 : 0, mg(MAG_O), stream);
+      else {
+        const uint32_t* qm = g.att_h2 ? mg(MAG_QKV) : nullptr;              // (null without the words: the bf16x3 form)
+        c.rc = attention_fwd_emu_mag(q, ldq, k, ldkv, v, ldkv, s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], aw, ab,
+                                     s.planes ? 1 : 0, mg(MAG_O), stream, qm, qm && !g.full ? mg(MAG_KV) : nullptr);
+      }
     }
   } else if (!dry && c.ok()) {
     c.rc = hoisdf_attention_fwd(q, ldq, k, ldkv, v, ldkv, s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], stream);
@@ -211,7 +224,7 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   if (!dry && (!dx1 || !df || !dh || !dxq || !da || !dO || !delta)) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
   if (!dry && !dx2) { set_error("encoder_layer_bwd: no upstream gradient (g_x_out and g_y both null)"); return HOISDF_ERR_INVALID; }
   // magnitude words of df, dh, da, [dq | dk | dv] (or dq and [dk | dv]) (common.h): written by the kernel that produces the matrix, read by the contraction that consumes it
-  enum { MAG_DF = 0, MAG_DH = 1, MAG_DA = 2, MAG_DQKV = 3, MAG_DKV = 4, MAG_BWD = 5 };
+  enum { MAG_DF = 0, MAG_DH = 1, MAG_DA = 2, MAG_DQKV = 3, MAG_DKV = 4, MAG_DO = 5, MAG_BWD = 6 };
   uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)MAG_BWD * MAG_WORDS * 4));
   const bool mags = layer_mags(c, g) && (dry || bmag);
   auto mg = [&](int i) -> uint32_t* { return mags && bmag ? bmag + i * MAG_WORDS : nullptr; };
@@ -224,17 +237,21 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   lin_bwd_weight(c, dh, F, s.bits, g.p, s.x1, E, G->dw1, G->db1, M, F, E, 0, mg(MAG_DH), fm(MAG_X1));
   const float* xq2 = g.full ? x : s.xq;
   if (!dry && c.ok()) c.rc = add_layernorm_bwd_mag(dx1, xq2, s.a, w->g1, st, st + M, nullptr, dxq, da, G->dg1, G->dbe1, M, E, g.p, d->seed[1], nullptr, mg(MAG_DA), stream);
-  lin_bwd_input(c, da, E, nullptr, 0.f, w->w_out, E, w->img_t_out, dO, E, M, E, E, 0, mg(MAG_DA), nullptr);
+  lin_bwd_input(c, da, E, nullptr, 0.f, w->w_out, E, w->img_t_out, dO, E, M, E, E, 0, mg(MAG_DA), g.att_h2 ? mg(MAG_DO) : nullptr);
   lin_bwd_weight(c, da, E, nullptr, 0.f, s.o, E, G->dw_out, G->db_out, M, E, E, 0, mg(MAG_DA), g.att == 2 ? fm(MAG_O) : nullptr);
   const bool amag = mags && g.att_bwd_emu && g.full;       // (separate q / kv matrices: the two kernels' words would have to be told apart)
   auto attn_bwd = [&](const float* q, int ldq, const float* k, const float* v, int ldkv, float* dq, float* dk, float* dv) {
     if (g.att_bwd_emu) {
-      const long ab = hoisdf_attention_bwd_emu_workspace(g.B, g.H, g.nq, g.S, 1);
+      const long ab = hoisdf_attention_bwd_emu_workspace(g.B, g.H, g.nq, g.S, s.planes ? 1 : 0);
       void* aw = ws.take(ab);
       if (dry || !c.ok()) return;
       if (!aw) { c.rc = HOISDF_ERR_WORKSPACE; return; }
+      // (f16x2 form: the words of the projected matrices from the forward, dO's from the out-projection's grad-input)
+      const uint32_t* qm = g.att_h2 && mags ? fm(MAG_QKV) : nullptr;
+      if (g.att_h2 && !qm) { set_error("encoder_layer_bwd: the forward ran the f16x2 attention but the magnitude words are not available"); c.rc = HOISDF_ERR_INVALID; return; }
       c.rc = attention_bwd_emu_mag(q, ldq, k, ldkv, v, ldkv, s.o, E, dO, E, s.lse, delta, dq, dk, dv, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0],
-                                   s.planes, aw, ab, amag ? mg(MAG_DQKV) : nullptr, stream);
+                                   s.planes, aw, ab, amag ? mg(MAG_DQKV) : nullptr, stream, qm, qm && !g.full ? fm(MAG_KV) : nullptr,
+                                   qm ? mg(MAG_DO) : nullptr);
     } else if (!dry && c.ok()) {
       c.rc = hoisdf_attention_bwd(q, ldq, k, ldkv, v, ldkv, s.o, E, dO, E, s.lse, delta, dq, dk, dv, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], stream);
     }
@@ -312,7 +329,7 @@ extern "C" int hoisdf_encoder_layer_fwd(const float* x, const hoisdf_encoder_lay
   static char none;                                  // (a real pass never measures: a null buffer is an empty one)
   if (!sv.base) { sv.base = &none; sv.cap = 0; }
   if (!ws.base) { ws.base = &none; ws.cap = 0; }
-  if (d->training) saved_forms().put(saved, g.fused_qkv);
+  if (d->training) saved_forms().put(saved, (g.fused_qkv ? 1 : 0) | (g.att_h2 ? 2 : 0));
   const int rc = forward(x, w, d, g, x_out, y_out, sv, ws, false, stream);
   if (rc == HOISDF_ERR_WORKSPACE) set_error("encoder_layer_fwd: workspace (%ld bytes) or saved buffer (%ld bytes) too small", workspace_bytes, saved_bytes);
   return rc;
@@ -330,7 +347,7 @@ extern "C" int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, cons
   HOISDF_REQUIRE(d->training, HOISDF_ERR_INVALID, "encoder_layer_bwd: the forward call must have run with training = 1");
   HOISDF_REQUIRE(al16(x) && al16(dx) && al16(saved) && al16(workspace), HOISDF_ERR_INVALID, "encoder_layer_bwd: buffers must be 16-byte aligned");
   const int recorded = saved_forms().take(saved);              // what the forward of THIS saved buffer decided (-1: unknown host, recompute)
-  if (recorded >= 0) g.fused_qkv = recorded != 0;
+  if (recorded >= 0) { g.fused_qkv = (recorded & 1) != 0; g.att_h2 = (recorded & 2) != 0; }
   Bump sv(const_cast<void*>(saved), saved_bytes), ws(workspace, workspace_bytes);
   const int rc = backward(x, x_out, w, d, g, sv, g_x_out, g_y, dx, grads, ws, false, stream);
   if (rc == HOISDF_OK && sv.overflow) { set_error("encoder_layer_bwd: saved buffer too small"); return HOISDF_ERR_WORKSPACE; }

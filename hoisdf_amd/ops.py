@@ -1122,8 +1122,17 @@ def _planes_key(q, k, v, H, kv_len):
 _EMU_PLANES = {}
 
 
-def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False):
-    """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it"""
+_ATTN_FORM_H2 = __import__("os").environ.get("HOISDF_ATTN_FORM", "h2")[:1].lower() != "b"
+
+
+def _attn_h2(rows: int) -> bool:
+    """the encoder layers' attention forward runs in the f16x2 form (csrc/layers.hip geometry(): where their linear layers do)"""
+    return _ATTN_FORM_H2 and _GEMM_EMU and _h2() and rows >= _GEMM_EMU_MIN_ROWS
+
+
+def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv_mag=None):
+    """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it.
+    qkv_mag: magnitude words of the matrix q, k, v are slices of -> the f16x2 form of the forward (no planes kept)"""
     from ._lib import lib
     B, Lq, E = q.shape
     Lk = k.shape[1]
@@ -1134,6 +1143,10 @@ def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False):
     ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    if qkv_mag is not None:
+        call("hoisdf_attention_fwd_emu_mag", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk,
+             kv_len, float(drop_p), seed, _p(ws), nbytes, 0, _p(qkv_mag), _p(kv_mag), None, _st())
+        return o, lse
     call("hoisdf_attention_fwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk,
          kv_len, float(drop_p), seed, _p(ws), nbytes, int(keep), _st())
     if keep:
@@ -1143,7 +1156,8 @@ def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False):
     return o, lse
 
 
-def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
+def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed, qkv_mag=None, kv_mag=None):
+    """qkv_mag (and kv_mag when k, v come from another matrix than q): the f16x2 form of the backward (the words the forward used)"""
     from ._lib import lib
     B, Lq, E = q.shape
     Lk = k.shape[1]
@@ -1154,6 +1168,12 @@ def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed):
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
     if kept is not None:
         kept.record_stream(torch.cuda.current_stream(q.device))
+    if qkv_mag is not None:
+        do_mag = _mag_measure(do, E, B * Lq, E)
+        call("hoisdf_attention_bwd_emu_mag", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E, _p(lse),
+             _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _p(qkv_mag),
+             _p(kv_mag), _p(do_mag), None, _st())
+        return
     call("hoisdf_attention_bwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E, _p(lse),
          _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _st())
 
@@ -1169,14 +1189,18 @@ def _emu_bwd() -> bool:
     return _ATTN_BWD_EMU or deterministic()
 
 
-def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False):
+def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv_mag=None):
+    if mode == 2 and qkv_mag is not None:
+        return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, qkv_mag=qkv_mag, kv_mag=kv_mag)
     if mode == 2:
         return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=keep and _emu_bwd())
     return _attn_fwd(q, k, v, H, kv_len, drop_p, seed)
 
 
-def _attn_bwd_mode(mode, *a):
-    return (_attn_bwd_emu if (mode == 2 and _emu_bwd()) else _attn_bwd)(*a)
+def _attn_bwd_mode(mode, *a, qkv_mag=None, kv_mag=None):
+    if mode == 2 and _emu_bwd():
+        return _attn_bwd_emu(*a, qkv_mag=qkv_mag, kv_mag=kv_mag)
+    return _attn_bwd(*a)
 
 
 class _AttentionSelf(torch.autograd.Function):
@@ -1451,11 +1475,18 @@ class _EncoderLayer(torch.autograd.Function):
             q = qbuf.view(B, nq, E)
             kv3 = kvbuf.view(B, S, 2 * E)
             k, v = kv3[:, :, :E], kv3[:, :, E:]
+        qm = kvm = None
         if _use_f16(p, x, w_in, w_out, w1, w2):
             # gradient-free eval with cfg.attention_f16_eval: the f16-operand kernel (no LSE: nothing is saved for a backward)
             o, lse = _attn_fwd_f16(q, k, v, H, S), None
         else:
-            o, lse = _attn_fwd_mode(split, q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad))
+            if split == 2 and _attn_h2(B * nq) and E == 64 * H:
+                # the f16x2 form of the forward, as the coarse entry runs it: the scales from the magnitudes of the projected matrices
+                if full:
+                    qm = _mag_measure(qkv, 3 * E, B * S, 3 * E)
+                else:
+                    qm, kvm = _mag_measure(qbuf, E, B * nq, E), _mag_measure(kvbuf, 2 * E, B * S, 2 * E)
+            o, lse = _attn_fwd_mode(split, q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad), qkv_mag=qm, kv_mag=kvm)
         M = B * nq
         a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
         xq2 = xq.view(M, E)
@@ -1480,6 +1511,7 @@ class _EncoderLayer(torch.autograd.Function):
         ctx.save_for_backward(x, qkv if full else qbuf, qkv if full else kvbuf, o, lse, a, x1, h, bits, f, x2, st, w_in,
                               w_out, w1, w2, g1, g2, g3)
         ctx.meta = (B, S, E, nq, full, float(p), H, (s_attn, s_ln1, s_ffn, s_ln2), split, ni)
+        ctx.attn_mags = (qm, kvm)
         return x2.view(B, nq, E), y.view(B, ni, E)
 
     @staticmethod
@@ -1526,7 +1558,8 @@ class _EncoderLayer(torch.autograd.Function):
         do = torch.empty(M, E, device=dev)
         _lin_bwd_input(da, None, 0.0, w_out, do, False)
         _lin_bwd_weight(da, None, 0.0, o.view(M, E), dw_out, db_out)
-        bwd = lambda *a_: _attn_bwd_mode(split, *a_)
+        qm, kvm = ctx.attn_mags                                       # (the f16x2 forward's words: the backward runs in the same form)
+        bwd = lambda *a_: _attn_bwd_mode(split, *a_, qkv_mag=qm, kv_mag=kvm)
         do3 = do.view(B, nq, E)
         if full:
             qkv3 = qs.view(B, S, 3 * E)

@@ -429,11 +429,32 @@ long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int mode);
 int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                              float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
                              long workspace_bytes, int keep, void* stream);
+/* the forward in the f16x2 form (round 5; see "the two arithmetic forms" at hoisdf_linear_fwd_emu_mag): qkv_mag = the magnitude
+ * words of the matrix q (and, with kv_mag = NULL, k and v) are column slices of, kv_mag = those of the matrix k and v come from when
+ * that is another one (hoisdf_mag_measure, or the y_mag of the in-projection): one power-of-two scale per matrix; two f16 planes per
+ * operand, three v_mfma_f32_32x32x16_f16 products per product, P carried as 2^6 P.  Same contracts, LSE convention and dropout mask
+ * as hoisdf_attention_fwd_emu.  Accuracy: the operand pieces keep 22 bits, so a score s (log2 domain) carries an absolute error of
+ * ~2^-22 |s| where the bf16x3 form has f32 rounding only - indistinguishable at the |s| <~ 100 of trained attention, 4x the bf16x3
+ * form's output error at |s| ~ 2000.  The planes it keeps (keep = 1) are f16x2 planes - only a backward of the same form reads them.
+ * o_mag (optional) receives the words of o. */
+int hoisdf_attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                 float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
+                                 long workspace_bytes, int keep, const uint32_t* qkv_mag, const uint32_t* kv_mag, uint32_t* o_mag,
+                                 void* stream);
 long hoisdf_attention_bwd_emu_workspace(int B, int H, int Lq, int Lk, int kept);
 int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                              const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                              int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
                              void* workspace, long workspace_bytes, void* stream);
+/* the backward in the f16x2 form (emu_attn_bwd4h_kernel, round 5): Q, K, V, dO and P as two scaled f16 pieces (three products per
+ * product), dS as three (its magnitude follows P: five products in dQ and dK) - 76 instead of 120 MFMAs per query tile; one pass, no
+ * atomics, run-to-run identical like hoisdf_attention_bwd_emu.  qkv_mag / kv_mag: as hoisdf_attention_fwd_emu_mag; do_mag: the
+ * magnitude words of dout (all required; hoisdf_mag_measure).  fwd_workspace: the planes a forward OF THIS FORM kept, or NULL. */
+int hoisdf_attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
+                                 const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
+                                 int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
+                                 void* workspace, long workspace_bytes, const uint32_t* qkv_mag, const uint32_t* kv_mag,
+                                 const uint32_t* do_mag, uint32_t* g_mag, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
 int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,

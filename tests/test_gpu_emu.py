@@ -501,6 +501,92 @@ def test_emulated_attention_is_as_accurate_as_the_exact_f32_kernels(B, Lq, Lk, k
         assert float(dkve[:, kv:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,Lq,Lk,kv,amp", [(2, 2048, 2048, 2048, 1.0), (2, 300, 300, 230, 1.0), (1, 1536, 2048, 1536, 4.0), (3, 33, 700, 700, 1e-3),
+                                            (1, 512, 2048, 2048, 1.0)])
+def test_f16x2_attention_forward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv, amp):
+    """hoisdf_attention_fwd_emu_mag (emu_attn_fwd2_kernel<DROP, 2, true>: Q, K, V as scaled hi + lo f16 planes, three f16 MFMA products,
+    P carried as 2^6 P) against float64 softmax attention: output within the bf16x3 kernel's bar (2e-5 of max) and no further from fp64
+    than 1.5 x the bf16x3 kernel's distance; the LSE (log2 domain) agrees with the bf16x3 kernel's; operands of very different overall
+    magnitude (amp: peaked - scores up to ~250 in the log2 domain - and flat softmaxes) ride on the scale from the magnitude words; with
+    dropout the mask is the same function.  (The 22-bit operand pieces put ~2^-22 |score| of absolute error on a score: at amp = 30,
+    scores of ~2000, the output is 5e-5 of its maximum off - include/hoisdf.h says so; trained attention stays below ~100.)"""
+    O = ops()
+    from hoisdf_amd._lib import call, lib
+    E, H = 256, 4
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = (torch.randn(B, Lq, E, generator=g) * amp).to(DEV)
+    kvm = (torch.randn(B, Lk, 2 * E, generator=g) * amp).to(DEV)
+    kvm[..., :E] *= 0.5
+    k, v = kvm[..., :E], kvm[..., E:]
+    ref = _ref_attn64(q.double().cpu().contiguous(), k.double().cpu().contiguous(), v.double().cpu().contiguous(), H, kv)
+    # the words of "the matrix q, k, v are slices of": measured (hoisdf_mag_measure) for [k | v], folded with q's maximum by hand
+    mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=DEV)
+    call("hoisdf_mag_measure", C.c_void_p(kvm.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
+    mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
+    ob, lb = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0)
+    oh, lh = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, qkv_mag=mag)
+    oh2, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, qkv_mag=mag)
+    assert torch.equal(oh, oh2) and not torch.equal(oh, ob)
+    assert_close(oh, ref, rel=2e-5, what="f16x2 out")
+    mx = float(ref.abs().max())
+    eh = float((oh.double().cpu() - ref).abs().max()) / mx
+    eb = float((ob.double().cpu() - ref).abs().max()) / mx
+    assert eh <= 1.5 * eb + 2e-7, (eh, eb)
+    assert float((lh - lb).abs().max()) <= 2e-5 * max(1.0, float(lb.abs().max()))
+    # dropout: the same keep decisions as the bf16x3 kernel (same seed): outputs agree to rounding
+    od, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.1, 4321)
+    oe, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.1, 4321, qkv_mag=mag)
+    assert_close(oe, od.double(), rel=2e-5, what="f16x2 out with dropout")
+
+
+@pytest.mark.parametrize("B,Lq,Lk,kv,p", [(2, 2048, 2048, 2048, 0.0), (2, 300, 300, 230, 0.0), (1, 1536, 2048, 1536, 0.1), (3, 33, 700, 700, 0.0),
+                                          (1, 512, 2048, 2048, 0.1)])
+def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv, p):
+    """hoisdf_attention_bwd_emu_mag (emu_attn_bwd4h_kernel: two f16 pieces for Q, K, V, dO, P, three for dS; 76 MFMAs per query tile)
+    against float64 autograd of softmax attention: dq, dk, dv within the bf16x3 kernel's bar (5e-5 of max) and no further from fp64 than
+    2.5 x the bf16x3 kernel's distance; masked keys get exactly zero; two runs bit-identical; with dropout the same mask as the bf16x3
+    kernel (gradients agree to rounding)."""
+    O = ops()
+    from hoisdf_amd._lib import call, lib
+    E, H = 256, 4
+    g = torch.Generator().manual_seed(Lq + Lk + 1)
+    q = torch.randn(B, Lq, E, generator=g).to(DEV)
+    kvm = torch.randn(B, Lk, 2 * E, generator=g).to(DEV)
+    go = (torch.randn(B, Lq, E, generator=g) * 1e-3).to(DEV)
+    k, v = kvm[..., :E], kvm[..., E:]
+    mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=DEV)
+    call("hoisdf_mag_measure", C.c_void_p(kvm.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
+    mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
+
+    def run(h2, seed=99):
+        if h2:
+            o, lse = O._attn_fwd_emu(q, k, v, H, kv, p, seed, qkv_mag=mag)
+        else:
+            o, lse = O._attn_fwd_emu(q, k, v, H, kv, p, seed)
+        dq = torch.empty_like(q); dkv = torch.empty_like(kvm)
+        O._attn_bwd_emu(q, k, v, o, lse, go, dq, dkv[..., :E], dkv[..., E:], H, kv, p, seed, **(dict(qkv_mag=mag) if h2 else {}))
+        return dq, dkv
+    dqh, dkvh = run(True)
+    dqh2, dkvh2 = run(True)
+    dqb, dkvb = run(False)
+    assert torch.equal(dqh, dqh2) and torch.equal(dkvh, dkvh2) and not torch.equal(dqh, dqb)
+    if kv < Lk:
+        assert float(dkvh[:, kv:].abs().max()) == 0.0
+    if p == 0.0:
+        q64, kv64 = q.double().cpu().requires_grad_(True), kvm.double().cpu().requires_grad_(True)
+        ref = _ref_attn64(q64, kv64[..., :E].contiguous(), kv64[..., E:].contiguous(), H, kv)
+        ref.backward(go.double().cpu())
+        for name, gh, gb, r in (("dq", dqh, dqb, q64.grad), ("dkv", dkvh, dkvb, kv64.grad)):
+            assert_close(gh, r, rel=5e-5, what="f16x2 " + name)
+            mx = float(r.abs().max())
+            eh = float((gh.double().cpu() - r).abs().max()) / mx
+            eb = float((gb.double().cpu() - r).abs().max()) / mx
+            assert eh <= 2.5 * eb + 2e-7, (name, eh, eb)          # (22-bit operand pieces against exact ones: 2e-6 vs 1e-6 of max on dq)
+    else:
+        assert_close(dqh, dqb.double(), rel=5e-5, what="dq with dropout")
+        assert_close(dkvh, dkvb.double(), rel=5e-5, what="dkv with dropout")
+
+
 def test_emulated_attention_dropout_mask_is_the_f32_kernels_mask():
     """same (seed, query, key) hash as attention.hip: with dropout on, the emulated forward / backward agree with the exact-f32
     kernels to rounding (the SAME elements are dropped), and the backward is the adjoint of the forward in V (same mask)."""

@@ -94,7 +94,10 @@ def phase_pv2():
         for p in range(2):
             add(3 * (g - 1) + 1 + p, f"vf[{g & 1}][{p}] = VFRAG(VB, {p}, {dt}, {jj})")
     for i in range(4): add(3 + i, f"PM({i})")        # (asm reads of the S accumulator: kept >= 3 MFMAs behind the last S MFMA)
-    units = [f"STK({p})" for p in range(2)] + [f"STV({p})" for p in range(2)] + [f"LDK({p})" for p in range(2)] + [f"LDV({p})" for p in range(2)]
+    stage = [f"STK({p})" for p in range(2)] + [f"STV({p})" for p in range(2)] + [f"LDK({p})" for p in range(2)] + [f"LDV({p})" for p in range(2)]
+    units = []
+    for pr in range(8):                          # the dropout decisions of tile t + 1 (DROP only: empty macros otherwise), the staging spread between them
+        units += [f"PH1({pr})", f"PH2({pr})", f"PH3({pr})", stage[pr]]
     for i, u in enumerate(units):
         add(i * 12 // len(units), u)
     slots = []
