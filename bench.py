@@ -37,9 +37,9 @@ PEAK_F16_TFLOPS = 2500.0         # MI355X_MICROARCH.md:42: dense f16/bf16 MFMA (
 # error vs fp64 at or below the exact-f32 kernels' and the vendor fp32 GEMM's (tests/test_gpu_emu.py, tools/emu_accuracy.py)
 DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--gemm f32 --attention f32)
 DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # HOISDF_EMU_FORM=b3: 3-way exact bf16 split, 6 products, f32 accumulation
-# the default since round 5: the linear layers in the f16x2 form (two scaled f16 pieces per operand, 3 products: include/hoisdf.h),
-# the attention contractions bf16x3 as before
-DTYPE_EMU_H2 = "f32 (emulated contractions, f32 accumulate: linear layers f16x2 = scaled hi + lo f16 pieces x 3 products, attention bf16x3 x 6 products)"
+# the default since round 5: linear layers AND the encoder attention in the f16x2 form (two scaled f16 pieces per operand, 3 products:
+# include/hoisdf.h); HOISDF_EMU_FORM=b3 brings the bf16x3 arithmetic back for both
+DTYPE_EMU_H2 = "f32 (emulated contractions, f32 accumulate, f16x2 form: operands as scaled hi + lo f16 pieces x 3 products; the attention backward's dS as three pieces x 5)"
 PMC_FILE = "r05_pmc.json"
 # what a BARE v_mfma_f32_32x32x16_bf16 stream (registers only, one wave per SIMD) sustains on this power-capped board (1400 W) when the
 # operands are the bf16x3 pieces of N(0,1) values / uniform random values: 1542-1568 TF of the 2500 TF datasheet peak (2044-2100 TF on
@@ -74,6 +74,9 @@ class KernelTimer:
         # emulated fp32 attention: (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         "hoisdf_attention_fwd_emu": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
         "hoisdf_attention_bwd_emu": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
+        # the f16x2 form: the same argument lists with the magnitude words appended
+        "hoisdf_attention_fwd_emu_mag": lambda a: 4.0 * a[9] * a[10] * a[11] * a[13] * 64,
+        "hoisdf_attention_bwd_emu_mag": lambda a: 10.0 * a[15] * a[16] * a[17] * a[19] * 64,
         # (q,ldq,k,ldk,v,ldv,o,ldo,lse,B,H,Lq,Lk,kv_len,...) / (q,..,o,ldo,do,lddo,lse,delta,dq,dk,dv,B,H,Lq,Lk,kv_len,...)
         # fp32 emulated on the bf16 pipe: (x, ldx, image, bias, y, ldy, M, N, K, ...) / (dy, lddy, bits, p, image, dx, lddx, M, N, K, ...);
         # algorithmic FLOPs (the six bf16 products per product are not counted)
@@ -103,6 +106,7 @@ class KernelTimer:
              "hoisdf_attention_fwd": (9, 11, 13), "hoisdf_attention_bwd": (15, 17, 19),
              "hoisdf_attention_fwd_f16": (8, 10, 12), "hoisdf_attention_fwd_bf16x2": (8, 10, 12), "hoisdf_sdf_query_fwd": (3, 3, 3),
              "hoisdf_attention_fwd_emu": (9, 11, 13), "hoisdf_attention_bwd_emu": (15, 17, 19),
+             "hoisdf_attention_fwd_emu_mag": (9, 11, 13), "hoisdf_attention_bwd_emu_mag": (15, 17, 19),
              "hoisdf_linear_fwd_emu": (6, 7, 8), "hoisdf_linear_bwd_input_emu": (7, 8, 9), "hoisdf_linear_bwd_weight_emu": (9, 10, 11),
              "hoisdf_linear_fwd_emu_mag": (6, 7, 8), "hoisdf_linear_bwd_input_emu_mag": (7, 8, 9), "hoisdf_linear_bwd_weight_emu_mag": (9, 10, 11),
              "hoisdf_linear_fwd_emu_small": (7, 8, 9), "hoisdf_linear_bwd_input_emu_small": (8, 9, 10),
@@ -181,7 +185,7 @@ def main():
     ap.add_argument("--n-obj", type=int, default=None)
     ap.add_argument("--resnet", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bf16x3-leg", type=int, default=1, help="also time 10 steps with HOISDF_EMU_FORM=b3 in a child process (outside the timed region) into `bf16x3_linear_layers`")
+    ap.add_argument("--bf16x3-leg", type=int, default=1, help="also time 10 steps with HOISDF_EMU_FORM=b3 in a child process (outside the timed region) into `bf16x3`")
     ap.add_argument("--exact-f32", type=int, default=1, help="also time 10 steps of the exact-f32 path (outside the timed region) into `exact_f32`")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-every", type=int, default=7, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
@@ -497,7 +501,9 @@ def main():
                                   "magnitudes travel from the producing kernel's epilogue to the consuming contraction" if h2_form else
                                   "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate"),
                           "f32": "exact-f32 MFMA"}[args.gemm],
-        "attention": {"emu": "forward and backward emulated fp32 in the bf16x3 form (exact 3-way bf16 split, 6 products; the 17-query decoder attention exact-f32)"
+        "attention": {"emu": ("forward and backward emulated fp32 in the f16x2 form (scaled hi + lo f16 planes of Q, K, V, dO, P: 3 products; dS three pieces: 5 products; "
+                              "HOISDF_ATTN_FORM=b3: the bf16x3 kernels; the 17-query decoder attention exact-f32)" if (h2_form and os.environ.get("HOISDF_ATTN_FORM", "h2")[:1].lower() != "b") else
+                              "forward and backward emulated fp32 in the bf16x3 form (exact 3-way bf16 split, 6 products; the 17-query decoder attention exact-f32)")
                              if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
                              "forward emulated fp32 (bf16x3), backward exact-f32 MFMA fused kernel (HOISDF_ATTN_BWD=f32)",
                       "f32": "exact-f32 MFMA", "f16": "f16-MFMA eval kernel (BASELINE configs[4]): f16 hi+lo operands, 3 products"}[
@@ -528,17 +534,23 @@ def main():
             ("emu_small_kernel / emu_small_dw_kernel (linear layers of < 2048 rows: decoder stack, heads; latency-bound)",
              ["hoisdf_linear_fwd_emu_small", "hoisdf_linear_bwd_input_emu_small", "hoisdf_linear_bwd_weight_emu_small"], "emu"),
             ("emu_attn_fwd2_kernel (+ bf16x3 conversion passes)", ["hoisdf_attention_fwd_emu"], "emu"),
+            ("emu_attn_fwd2_kernel<DROP, 2, true> (f16x2 form: scaled hi + lo f16 planes, three products; + magnitude / conversion passes)",
+             ["hoisdf_attention_fwd_emu_mag"], "h2"),
+            ("emu_attn_bwd4h_kernel (f16x2 form, fused dK, dV, dQ: 76 MFMAs per tile = 3.8 products per product; + magnitude / dO conversion / delta / dQ reduce passes)",
+             ["hoisdf_attention_bwd_emu_mag"], "h2b"),
             ("emu_attn_bwd4_kernel (fused dK, dV, dQ; + dO conversion / delta / dQ reduce passes; emu_attn_bwd_stag_kernel with HOISDF_EMU_ATTN_BWD=3)",
              ["hoisdf_attention_bwd_emu"], "emu"),
             ("emu_attn_fwd2_kernel<NPL = 2> (bf16 hi + lo operands, three products; + conversion passes)", ["hoisdf_attention_fwd_bf16x2"], "split"),
             ("attn_fwd_f16_kernel (round 2, HOISDF_ATTN16=f16; + operand split pass)", ["hoisdf_attention_fwd_f16"], "split"),
         ]
         PEAK = {"f32": (PEAK_F32_TFLOPS, "f32 MFMA peak (= f32 vector peak), MI355X_MICROARCH.md:41"),
+                "h2b": (round(PEAK_F16_TFLOPS / 3.8, 1), "dense f16 MFMA peak 2500 TFLOP/s / 3.8 products per product (S, dP, dV: 3; dQ, dK: 5 - dS carries three f16 pieces)"),
                 "h2": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense f16 MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent product (scaled hi + lo f16 pieces; MI355X_MICROARCH.md:42)"),
                 "emu": (round(PEAK_F16_TFLOPS / 6.0, 1), "dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent product (MI355X_MICROARCH.md:42)"),
                 "split": (round(PEAK_F16_TFLOPS / 3.0, 1), "dense 16-bit MFMA peak 2500 TFLOP/s / 3 products per product (hi + lo operand pairs)")}
         # what a bare MFMA stream sustains on such operands under this board's power cap, per fp32-equivalent product
-        CEIL = {"emu": MEASURED_MFMA_CEILING_TFLOPS / 6.0, "split": MEASURED_MFMA_CEILING_TFLOPS / 3.0, "h2": MEASURED_MFMA_CEILING_F16_TFLOPS / 3.0}
+        CEIL = {"emu": MEASURED_MFMA_CEILING_TFLOPS / 6.0, "split": MEASURED_MFMA_CEILING_TFLOPS / 3.0, "h2": MEASURED_MFMA_CEILING_F16_TFLOPS / 3.0,
+                "h2b": MEASURED_MFMA_CEILING_F16_TFLOPS / 3.8}
         agg = {}
         for fam, members, cls in FAMS:
             ms = sum(ks[m]["total_ms"] for m in members if m in ks)
@@ -604,10 +616,10 @@ def main():
         # the roof of this board for these operands (see MEASURED_MFMA_CEILING_TFLOPS): products per fp32-equivalent product as in PEAK
         if d["cls"] in CEIL:
             res["roofline"]["measured_mfma_ceiling"] = {"tflops": round(CEIL[d["cls"]], 1),
-                                                         "what": ("bare v_mfma_f32_32x32x16_f16 stream on the hi / lo f16 pieces of N(0,1) operands" if d["cls"] == "h2" else
+                                                         "what": ("bare v_mfma_f32_32x32x16_f16 stream on the hi / lo f16 pieces of N(0,1) operands" if d["cls"] in ("h2", "h2b") else
                                                                   "bare v_mfma_f32_32x32x16_bf16 stream on bf16x3 pieces / random operands") +
                                                                  " under the 1400 W cap, / products per product",
-                                                         "file": "profiles/r05_mfma_rate_vs_operand_data_f16.txt" if d["cls"] == "h2" else "profiles/r05_mfma_rate_vs_operand_data.txt"}
+                                                         "file": "profiles/r05_mfma_rate_vs_operand_data_f16.txt" if d["cls"] in ("h2", "h2b") else "profiles/r05_mfma_rate_vs_operand_data.txt"}
             res["roofline"]["frac_of_measured_mfma_ceiling"] = round(d["tflops"] / CEIL[d["cls"]], 4)
         # Amdahl: where the kernel time of a step goes (HIP hot path / the PyTorch-ROCm image encoder's libraries / ATen glue), from
         # the committed rocprofv3 trace of this same command (single stream, 5 timed steps) - evidence quoted, not measured in this run
@@ -632,7 +644,7 @@ def main():
                           for n, v in ks.items()}
     if exact is not None:
         res["exact_f32"] = exact
-    # ---- the same step with the linear layers in the bf16x3 form (exact three-way operand split, six products: the round-4 arithmetic),
+    # ---- the same step in the bf16x3 form (exact three-way operand split, six products: the round-4 arithmetic),
     # OUTSIDE the timed region.  The form is fixed per process (it is the weight-image format): a child process on this GPU, rank 0 at
     # N = 1 only.
     if train and world == 1 and args.bf16x3_leg and h2_form and args.gemm == "emu" and not args.branch_mix and args.config == 1:
@@ -644,11 +656,11 @@ def main():
         try:
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-            res["bf16x3_linear_layers"] = {"what": "the same train step with HOISDF_EMU_FORM=b3 (linear layers bf16x3: exact 3-way split, 6 products), "
-                                                   "10 steps in a child process after the timed region", "dtype": line["dtype"],
+            res["bf16x3"] = {"what": "the same train step with HOISDF_EMU_FORM=b3 (linear layers and attention in the bf16x3 form: exact 3-way split, "
+                                     "6 products - the round-4 arithmetic), 10 steps in a child process after the timed region", "dtype": line["dtype"],
                                            "value": line["value"], "unit": "samples/s", "ms_per_step": line["ms_per_step"]}
         except Exception as ex:
-            res["bf16x3_linear_layers"] = f"child run failed: {ex}"
+            res["bf16x3"] = f"child run failed: {ex}"
     if comm is not None:
         res["comm"] = comm
     if world == 1 and not args.no_cpu_baseline:

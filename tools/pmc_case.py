@@ -8,6 +8,9 @@ CASES = {
     "attn_bwd_f32_32x2048x2048": ("hoisdf_attention_bwd", "attn_bwd_fused_kernel", (32, 2048, 2048)),
     "attn_fwd_emu_32x2048x2048": ("hoisdf_attention_fwd_emu", "emu_attn_fwd2_kernel", (32, 2048, 2048)),
     "attn_bwd_emu_32x2048x2048": ("hoisdf_attention_bwd_emu", "emu_attn_bwd4_kernel", (32, 2048, 2048)),
+    # the f16x2 form of the encoder attention (default in the layers)
+    "attn_fwd_h2_32x2048x2048": ("hoisdf_attention_fwd_emu_mag", "emu_attn_fwd2_kernel<true, 2, true>", (32, 2048, 2048)),
+    "attn_bwd_h2_32x2048x2048": ("hoisdf_attention_bwd_emu_mag", "emu_attn_bwd4h_kernel", (32, 2048, 2048)),
     "attn_fwd_bf16x2_4x8192x8192": ("hoisdf_attention_fwd_bf16x2", "emu_attn_fwd2_kernel<false, 2>", (4, 8192, 8192)),
     # the f16x2 form of the linear layers (default; what the Python path calls: the *_mag entries after one hoisdf_mag_measure per operand)
     "linear_fwd_emu_65536x1024x256": ("hoisdf_linear_fwd_emu_mag", "emu_h2_kernel<false, false, 2>", (65536, 1024, 256)),
@@ -38,6 +41,20 @@ if __name__ == "__main__":
             with torch.no_grad():
                 for _ in range(3):
                     O._attn_fwd_f16(q, k, v, H, Lk)
+            torch.cuda.synchronize()
+            sys.exit(0)
+        if "_h2_" in case:
+            import ctypes as C
+            from hoisdf_amd._lib import call, lib
+            mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=dev)
+            call("hoisdf_mag_measure", C.c_void_p(kv.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
+            mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
+            o, lse = O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, qkv_mag=mag)
+            for _ in range(3):
+                if entry == "hoisdf_attention_fwd_emu_mag":
+                    O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, qkv_mag=mag)
+                else:
+                    O._attn_bwd_emu(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, Lk, p, 1234, qkv_mag=mag)
             torch.cuda.synchronize()
             sys.exit(0)
         o, lse = O._attn_fwd(q, k, v, H, Lk, p, 1234)
