@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--bf16x3-leg", type=int, default=1, help="also time 10 steps with HOISDF_EMU_FORM=b3 in a child process (outside the timed region) into `bf16x3`")
     ap.add_argument("--exact-f32", type=int, default=1, help="also time 10 steps of the exact-f32 path (outside the timed region) into `exact_f32`")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--time-every", type=int, default=7, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
+    ap.add_argument("--time-every", type=int, default=20, help="record per-kernel HIP events on every n-th timed step (such a step runs single-stream with ~1400 event records: ~10 ms slower than a plain one)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce even with one rank (single-GPU check of the N>1 path)")
     ap.add_argument("--shape-report", action="store_true", help="per-shape kernel table on stderr")

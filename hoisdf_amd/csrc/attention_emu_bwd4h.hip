@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
     uint32_t hb = 0;
     const uint32_t dthr = a.thresh & 0xffff0000u;
     const int hsh = (key & 1) ? 0 : 16;
-    if (DROP) hb = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + 4 * h)) + (uint32_t)(key >> 1) * 0x9E3779B9U;
+    const bool kodd = (key & 1) != 0;
+    if (DROP) hb = drop_rowkey(a.seed, (uint32_t)(bh * a.Lq + 4 * h)) + (uint32_t)(key >> 1) * 0x9E3779B9U + (kodd ? 16u * 0x85EBCA77U : 0u);    // (odd key: the pair's hashes of queries CR(8..15))
 
     f32x16 s, dp, dq;
     f32x4 xo0[2], xo1[2], xprev[2];
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
     u32x4 pwv[2][2], gwv[3][2];
     f32x2 pe[8], pd[8], xx[8], ff[8];
     float dsc[16], lq[16], dl[16];
-    uint32_t hx[16];
+    uint32_t hy[8];                         // the lane's half of the pair's sixteen hashes (see HA)
+    float dmine[8], dsend[8];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dsc[r] = 1.f;
 #pragma unroll
@@ -309,9 +311,37 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
     }                                                                                                                  \
   } while (0)
 #define CRC(r_) (((r_) & 3) + 8 * ((r_) >> 2))
-#define HA(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int r_ = 4 * (q_) + i_; uint32_t x_ = hbn + (uint32_t)CRC(r_) * 0x85EBCA77U; x_ ^= x_ >> 15; hx[r_] = x_; PIN2(hx[r_]); } } } while (0)
-#define HB(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int r_ = 4 * (q_) + i_; hx[r_] *= 0x2C1B3C6DU; PIN2(hx[r_]); } } } while (0)
-#define HC(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int r_ = 4 * (q_) + i_; const uint32_t x_ = hx[r_] ^ (hx[r_] >> 12); dsc[r_] = (x_ << hsh) >= dthr ? a.inv_keep : 0.f; PIN2(dsc[r_]); } } } while (0)
+// Dropout decisions, one hash per KEY PAIR (common.h drop_hash: the low 16 bits decide the even key, the high ones the odd key): the two
+// lanes of a key pair (lane, lane ^ 1) need the same sixteen hashes (one per query of the tile), so each computes EIGHT - the even lane
+// those of queries CR(0..7), the odd lane those of CR(8..15): hb carries the 16-row offset -, decides them for itself and for its
+// partner, and the partner's decisions travel through a DPP quad permute.  Units: HA / HB / HC over e = 4 q .. 4 q + 3 (q = 0, 1),
+// HD puts the sixteen factors in their places.
+#define HA(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int e_ = 4 * (q_) + i_; uint32_t x_ = hbn + (uint32_t)CRC(e_) * 0x85EBCA77U; x_ ^= x_ >> 15; hy[e_] = x_; PIN2(hy[e_]); } } } while (0)
+#define HB(q_) do { if (DROP) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const int e_ = 4 * (q_) + i_; hy[e_] *= 0x2C1B3C6DU; PIN2(hy[e_]); } } } while (0)
+#define HC(q_)                                                                                                         \
+  do {                                                                                                                 \
+    if (DROP) {                                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                               \
+        const int e_ = 4 * (q_) + i_;                                                                                  \
+        const uint32_t x_ = hy[e_] ^ (hy[e_] >> 12);                                                                   \
+        dmine[e_] = (x_ << hsh) >= dthr ? a.inv_keep : 0.f;                                                            \
+        dsend[e_] = (x_ << (hsh ^ 16)) >= dthr ? a.inv_keep : 0.f;                                                     \
+        PIN2(dmine[e_]); PIN2(dsend[e_]);                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+#define HD(q_)                                                                                                         \
+  do {                                                                                                                 \
+    if (DROP) {                                                                                                        \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                               \
+        const int e_ = 4 * (q_) + i_;                                                                                  \
+        const float got_ = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, dsend[e_]), 0xB1, 0xF, 0xF, true));   /* quad_perm [1, 0, 3, 2]: from lane ^ 1 */ \
+        dsc[e_] = kodd ? got_ : dmine[e_];                                                                             \
+        dsc[8 + e_] = kodd ? dmine[e_] : got_;                                                                         \
+        PIN2(dsc[e_]); PIN2(dsc[8 + e_]);                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
     // P units: P = exp2(S - lse) (keys past kv_len are NOT masked here: their dK / dV rows are written as zeros at the end and their
     // K^T fragments are zero, so nothing they produce is used), Pd = P * dropout scale, three-way split of Pd -> pw
 #define LQ(g_) do { const f32x4 v_ = *reinterpret_cast<const f32x4*>(stats + st_cur + 8 * (g_) + 4 * h); lq[4 * (g_)] = PBIAS - v_.x; lq[4 * (g_) + 1] = PBIAS - v_.y; lq[4 * (g_) + 2] = PBIAS - v_.z; lq[4 * (g_) + 3] = PBIAS - v_.w; } while (0)     /* lq = 13 - lse: P is formed as 2^13 P */
@@ -407,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
 
     // dropout decisions of tile 0 (the loop computes tile t + 1's behind the dK products of tile t)
     uint32_t hbn = hb;
-    HA(0); HA(1); HA(2); HA(3); HB(0); HB(1); HB(2); HB(3); HC(0); HC(1); HC(2); HC(3);
+    HA(0); HA(1); HB(0); HB(1); HC(0); HC(1); HD(0); HD(1);
 #pragma unroll
     for (int p = 0; p < 2; ++p) fr[0][p] = FRQ(p, 0);
     for (int t = 0; t <= nq; ++t) {

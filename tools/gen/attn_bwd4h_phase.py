@@ -18,7 +18,7 @@ P2 = [(1, 0), (0, 1), (0, 0)]                                    # (A plane, B p
 P23 = [(1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]                   # A two pieces, B (dS) three pieces
 N = 76
 CAP = 34
-COST = {"FR": 6, "TR": 9, "HA": 14, "HB": 18, "HC": 22, "LQ": 10, "DL": 10, "PA": 34, "PB": 20, "PC": 14, "PD": 10,
+COST = {"FR": 6, "TR": 9, "HA": 14, "HB": 18, "HC": 30, "HD": 20, "LQ": 10, "DL": 10, "PA": 34, "PB": 20, "PC": 14, "PD": 10,
         "QA": 26, "QB": 14, "QC": 14, "QD": 10, "TW": 22, "STQ": 8, "STS": 10, "LDG": 8, "LDS_": 6, "XOL": 14, "XOS": 12, "XW": 10, "XOP": 20, "XOW": 4, "XSIG": 8}
 S0, P0, Q0, V0, K0 = 0, 12, 24, 44, 56
 
@@ -118,7 +118,8 @@ def main():
     # dP complete at slot 23 (+2), gw before slot 56; the Q units of a quad reuse the scratch registers (xx, ff) of its P units
     place(staged(["QA", "QB", "QC", "QD"], "TW"), 26, 54, after=lambda name, q: ("PD", q) if name == "QA" else None)
     place([("XW", g) for g in range(4)], 46, 56, gap=0)                                # dq complete at slot 43 (+2)
-    place([(st, q) for st in ("HA", "HB", "HC") for q in range(4)], 56, 75)            # dropout decisions of the NEXT tile
+    # dropout decisions of the NEXT tile: a lane computes eight of its key pair's sixteen hashes (quads 0, 1), HD exchanges and places them
+    place([(st, q) for st in ("HA", "HB", "HC", "HD") for q in range(2)], 57, 75)
 
     lines = ["#define BWD4H_ITER()", "  do {"]
     for m in range(N):
