@@ -546,6 +546,8 @@ def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv
     against float64 autograd of softmax attention: dq, dk, dv within the bf16x3 kernel's bar (5e-5 of max) and no further from fp64 than
     2.5 x the bf16x3 kernel's distance; masked keys get exactly zero; two runs bit-identical; with dropout the same mask as the bf16x3
     kernel (gradients agree to rounding)."""
+    if pieces() != 2:
+        pytest.skip("the Python helpers measure magnitudes only in f16x2 processes")
     O = ops()
     from hoisdf_amd._lib import call, lib
     E, H = 256, 4
