@@ -433,7 +433,10 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
     // K phase: this wave's partial dQ^T(t - 1) [d 32 x q 32] -> X[khalf][q][d]
 #define XW(g_) do { *reinterpret_cast<f32x4*>(xbuf + x_b + (xw0 ^ (8 * (g_)))) = f32x4{dq[4 * (g_)], dq[4 * (g_) + 1], dq[4 * (g_) + 2], dq[4 * (g_) + 3]}; } while (0)
 #define B4_SYNC() __syncthreads()
-#include "attn_bwd4h_phase.inc"
+#ifndef BWD4H_INC
+#define BWD4H_INC "attn_bwd4h_phase.inc"
+#endif
+#include BWD4H_INC
 
     // dropout decisions of tile 0 (the loop computes tile t + 1's behind the dK products of tile t)
     uint32_t hbn = hb;

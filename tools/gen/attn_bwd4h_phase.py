@@ -13,11 +13,13 @@ useful a-priori bound: five products per product in the two contractions that re
 The floating units (softmax, split, dropout decisions, exchange, staging) are placed by the load balancer of attn_bwd4_phase.py inside
 the windows their data allows.
     python tools/gen/attn_bwd4h_phase.py > hoisdf_amd/csrc/attn_bwd4h_phase.inc"""
+import os
 import sys
 P2 = [(1, 0), (0, 1), (0, 0)]                                    # (A plane, B plane) of two-piece operands: small terms first
 P23 = [(1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]                   # A two pieces, B (dS) three pieces
 N = 76
-CAP = 34
+CAP = int(os.environ.get("BWD4H_CAP", "34"))          # (A/B runs: the committed schedule is CAP = 34, look-ahead 4)
+AHEAD = int(os.environ.get("BWD4H_AHEAD", "4"))
 COST = {"FR": 6, "TR": 9, "HA": 14, "HB": 18, "HC": 30, "HD": 20, "LQ": 10, "DL": 10, "PA": 34, "PB": 20, "PC": 14, "PD": 10,
         "QA": 26, "QB": 14, "QC": 14, "QD": 10, "TW": 22, "STQ": 8, "STS": 10, "LDG": 8, "LDS_": 6, "XOL": 14, "XOS": 12, "XW": 10, "XOP": 20, "XOW": 4, "XSIG": 8}
 S0, P0, Q0, V0, K0 = 0, 12, 24, 44, 56
@@ -98,7 +100,7 @@ def main():
             if after and after(name, arg) is not None:
                 lo = max(lo, where[after(name, arg)] + 1)
             lo = min(lo, last)
-            hi = min(last - gap * (n - 1 - k), lo + 4)
+            hi = min(last - gap * (n - 1 - k), lo + AHEAD)
             hi = max(hi, lo)
             s = min(range(lo, hi + 1), key=lambda t: (load[t] + COST[name] > CAP, load[t], t))
             work[s].append(f"{name}({arg})" if arg is not None else f"{name}()")
