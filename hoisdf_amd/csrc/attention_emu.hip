@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
     const float iq_ = mag_inv_scale(mag_words_max(a.in_mag, MAG_WORDS, red4_));
     __syncthreads();
     const float ik_ = mag_inv_scale(mag_words_max(a.in_mag_kv, MAG_WORDS, red4_));
-    cs = iq_ * ik_; vinv = ik_;
+    cs = fmaxf(iq_ * ik_, 0x1p-100f); vinv = ik_;           // (floored: operands below ~2^-37 have scores of exactly zero either way)
   }
   const float thr8 = F16 ? 8.f / cs : 8.f;                  // the lazy rescale's threshold in accumulator units
   float mneg = INFINITY;                                    // f16 form: PB - m cs (the exponent argument is fma(score, cs, mneg))

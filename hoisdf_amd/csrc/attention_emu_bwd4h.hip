@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
   __syncthreads();
   const uint32_t ad_ = mag_words_max(a.d_mag, MAG_WORDS, red4_);
   const float iq = mag_inv_scale(aq_), ik = mag_inv_scale(ak_), id = mag_inv_scale(ad_);
-  const float cs = iq * ik;                                  // accumulated scores -> log2-domain scores
+  const float cs = fmaxf(iq * ik, 0x1p-100f);                                // accumulated scores -> log2-domain scores
   constexpr float PBIAS = 13.f;                              // P is formed as 2^13 P
   constexpr float K1 = 0x1p-36f;                             // dS' = Pd' dP_acc 2^-36 - P' delta (sD sV 2^-36): dS sS with sS = sD sV 2^-23
   const float k2a = mag_scale(ad_) * 0x1p-18f, k2b = mag_scale(ak_) * 0x1p-18f;      // (two factors: sD sV alone can leave the f32 range)
