@@ -965,7 +965,9 @@ __global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __rest
 __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __restrict__ part, int nkb, float* __restrict__ dq,
                                                                  int ldq, int B, int H, int Lq, uint32_t* __restrict__ mag,
                                                                  const float* __restrict__ scale) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;          // (bh, q, d / 4)
+  // blocks walk the (bh, q) rows from the LAST one down: the backward kernel wrote the high heads' partials last, so they are the ones
+  // still in the 256 MB memory-side cache
+  const long i = (long)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x;          // (bh, q, d / 4)
   const long n = (long)B * H * Lq * 16;
   uint32_t qmax = 0u;
   if (i < n) {
@@ -976,9 +978,15 @@ __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __
     const size_t stride = (size_t)B * H * Lq * D;
     const float* p = part + ((size_t)bh * Lq + q) * D + d4 * 4;
     float4 s = *reinterpret_cast<const float4*>(p);
-    for (int k = 1; k < nkb; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * stride);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    // eight partials in flight per thread, added in key-block order (the sum is the serial loop's, bit for bit)
+    for (int k0 = 1; k0 < nkb; k0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = k0 + j < nkb ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(k0 + j) * stride)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < nkb) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
     }
     const float sc = scale ? *scale : 0.125f;
     const float4 r = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
