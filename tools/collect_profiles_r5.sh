@@ -16,7 +16,7 @@ cd /tmp
 for cfg in default config4; do
   extra=""; marker=""; [ $cfg = config4 ] && extra="--config 4" && marker="vote_loss_fwd_kernel"
   HOISDF_TWO_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- \
-      python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --exact-f32 0 --no-kernel-timing $extra > $O/bench_${cfg}_under_rocprof.json 2> /dev/null
+      python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --exact-f32 0 --bf16x3-leg 0 --no-kernel-timing $extra > $O/bench_${cfg}_under_rocprof.json 2> /dev/null
   T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
   S=$(find $O/trace -name "*kernel_stats.csv" | head -1)
   [ -n "$S" ] && cp $S $O/${cfg}_rocprof_stats_raw.csv
