@@ -328,6 +328,41 @@ def test_f16x2_split_keeps_its_stated_accuracy():
         assert bool((err <= bound).all()), (top, float((err / bound).max()))
 
 
+def test_f16x2_form_at_the_ends_of_the_f32_range():
+    """the operand scale is a power of two clamped so that neither it nor its inverse leaves the normal f32 range (common.h
+    mag_scale / mag_inv_scale): an all-zero operand gives exactly bias, an operand whose maximum sits just under FLT_MAX or in
+    the last normal binades comes back through an identity weight finite and within the form's bound; forward, grad-input and
+    grad-weight alike."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    g = torch.Generator().manual_seed(11)
+    M, K = 2048, 256
+    eye = torch.eye(K, device=DEV)
+    bias = torch.randn(K, generator=g).to(DEV)
+    y = torch.empty(M, K, device=DEV)
+    O._gemm_fwd(torch.zeros(M, K, device=DEV), K, eye, bias, y, K, M, K, K, 0, 0.0, 0, None)
+    assert torch.equal(y, bias.expand(M, K))
+    dw = torch.zeros(K, K, device=DEV); db = torch.zeros(K, device=DEV)
+    O._gemm_bwd_weight(torch.zeros(M, K, device=DEV), K, None, 0.0, torch.randn(M, K, generator=g).to(DEV), K, dw, db, M, K, K, form="h2")
+    assert float(dw.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+    for top in (127, -110, -126):
+        x = ((torch.rand(M, K, generator=g) * 2 - 1) * 2.0 ** top).to(DEV)
+        x[3, 5] = 1.999 * 2.0 ** top
+        O._gemm_fwd(x, K, eye, None, y, K, M, K, K, 0, 0.0, 0, None)
+        assert bool(torch.isfinite(y).all())
+        amax = float(x.double().abs().max())
+        err = (y.double() - x.double()).abs()
+        bound = torch.maximum(x.double().abs() * 2.0 ** -22, torch.full_like(err, max(amax * 2.0 ** -38, 2.0 ** -149)))
+        if top > -120:                       # (below: the clamped scale leaves fewer than 22 bits, stated in include/hoisdf.h)
+            assert bool((err <= bound).all()), (top, float((err / bound).max()))
+        else:
+            assert float(err.max()) <= amax * 2.0 ** -9, (top, float(err.max()) / amax)
+        dx = torch.empty(M, K, device=DEV)
+        O._gemm_bwd_input(x, K, None, 0.0, eye, dx, K, M, K, K, False)
+        assert bool(torch.isfinite(dx).all()) and float((dx.double() - x.double()).abs().max()) <= amax * 2.0 ** -9
+
+
 def test_magnitude_words_travel_from_producer_to_consumer():
     """hoisdf_linear_fwd_emu_mag / _bwd_input_emu_mag: the words a contraction leaves for its output hold max |y| (never less, and
     within the padding rows' bias-only values of it); a consumer given those words computes bit-identically to one that measures
