@@ -574,9 +574,10 @@ def test_f16x2_attention_forward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv,
     assert_close(oe, od.double(), rel=2e-5, what="f16x2 out with dropout")
 
 
-@pytest.mark.parametrize("B,Lq,Lk,kv,p", [(2, 2048, 2048, 2048, 0.0), (2, 300, 300, 230, 0.0), (1, 1536, 2048, 1536, 0.1), (3, 33, 700, 700, 0.0),
-                                          (1, 512, 2048, 2048, 0.1)])
-def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv, p):
+@pytest.mark.parametrize("B,Lq,Lk,kv,p,gamp", [(2, 2048, 2048, 2048, 0.0, 1e-3), (2, 300, 300, 230, 0.0, 1e-3), (1, 1536, 2048, 1536, 0.1, 1e-3),
+                                               (3, 33, 700, 700, 0.0, 1e-3), (1, 512, 2048, 2048, 0.1, 1e-3),
+                                               (2, 300, 300, 230, 0.0, 1e-30), (2, 300, 300, 230, 0.0, 1e20)])
+def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv, p, gamp):
     """hoisdf_attention_bwd_emu_mag (emu_attn_bwd4h_kernel: two f16 pieces for Q, K, V, dO, P, three for dS; 76 MFMAs per query tile)
     against float64 autograd of softmax attention: dq, dk, dv within the bf16x3 kernel's bar (5e-5 of max) and no further from fp64 than
     2.5 x the bf16x3 kernel's distance; masked keys get exactly zero; two runs bit-identical; with dropout the same mask as the bf16x3
@@ -589,7 +590,7 @@ def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv
     g = torch.Generator().manual_seed(Lq + Lk + 1)
     q = torch.randn(B, Lq, E, generator=g).to(DEV)
     kvm = torch.randn(B, Lk, 2 * E, generator=g).to(DEV)
-    go = (torch.randn(B, Lq, E, generator=g) * 1e-3).to(DEV)
+    go = (torch.randn(B, Lq, E, generator=g) * gamp).to(DEV)          # (gamp: output gradients at both ends of the f32 range too)
     k, v = kvm[..., :E], kvm[..., E:]
     mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=DEV)
     call("hoisdf_mag_measure", C.c_void_p(kvm.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
