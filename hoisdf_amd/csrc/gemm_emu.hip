@@ -236,6 +236,7 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
     return;
   }
   const bool full = (m0 + TM_ <= g.M) && (n0 + TN_ <= g.N);
+  const bool stream_c = !g.beta && (long)g.M * g.N >= (16L << 20);
   if (full && g.vecC) {
     // one row of blocks (32 x WN_) per wave at a time through a wave-private LDS slice, read back row-wise: one
     // global_store_dwordx4 covers complete 256-byte row segments
@@ -256,7 +257,10 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
           const float4 old = *cp;
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
         }
-        *cp = v;
+        // an output too large to stay in the L2s (>= 64 MB) is streamed past them: -0.12 ms per train step, two same-box pairs
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        if (stream_c) __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_*>(cp));
+        else *cp = v;
       }
     }
   } else {
