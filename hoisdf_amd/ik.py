@@ -4,11 +4,13 @@
 Restates common/utils/inverse_kinematics.py:15-150 (global rotation = Kabsch/SVD fit of the five palm bones,
 then per finger and per joint the axis-angle that swings the template bone onto the target bone, expressed in the
 accumulated parent frame), batched, on whatever device the inputs live on (no host round trip, no per-call
-``ManoLayer`` construction).  **Partially pinned**: tests/golden/g12_ik.npz holds the outputs of the reference's own
-``ik_solver_mano`` on seeded joints (proper fits and reflected palms), generated with the ONE function the reference
-takes from kornia (``rotation_matrix_to_axis_angle``, kornia is not installed) supplied by scipy's SO(3) log map; poses
-(as rotations), joints and vertices agree to 2e-5 (tests/test_ik.py, CPU and on the device), next to the property the
-algorithm guarantees (MANO(pose from IK) reproduces the target joints)."""
+``ManoLayer`` construction).  **Pinned** (round 6): tests/golden/g12_ik.npz holds the outputs of the reference's own
+``ik_solver_mano`` on seeded joints (proper fits and reflected palms).  The ONE function the reference takes from the un-vendored
+kornia (``rotation_matrix_to_axis_angle``, :9 / :70) is supplied to it as a restatement of kornia's published algorithm
+(four-branch matrix -> quaternion with the 1e-8 guard, then 2 atan2 / sin: tests/golden/make_golden.py ik_golden) instead of
+round 5's scipy log map, so the fixture carries the reference's arithmetic; poses (as vectors and as rotations), joints and
+vertices agree to 2e-5 (tests/test_ik.py, CPU and on the device), next to the property the algorithm guarantees (MANO(pose from
+IK) reproduces the target joints)."""
 from __future__ import annotations
 
 from typing import Dict, Optional

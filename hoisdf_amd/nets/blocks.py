@@ -72,9 +72,11 @@ class SDFDecoder(nn.Module):
         self.linh2 = _WNLinear(dims[1], dims[2])
         self.linh3 = _WNLinear(dims[2], dims[3])
         self.use_classifier = bool(use_classifier)
+        # registration order = the reference's (common/nets/sdf_net.py:58-75: linh4 inside the layer loop, classifier_head after it):
+        # parameters() order is what optimizer state in a checkpoint is indexed by
+        self.linh4 = nn.Linear(dims[3], 1)
         if self.use_classifier:              # cfg.ClassifierBranch (common/nets/sdf_net.py:73-75): 6 class logits from the last hidden layer
             self.classifier_head = nn.Linear(dims[3], num_class)
-        self.linh4 = nn.Linear(dims[3], 1)
         self.dropout_prob = dropout_prob
 
     def hidden(self, x0):
@@ -175,9 +177,10 @@ class TransformerEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList(TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before)
                                     for _ in range(num_layers))
-        self.inter_norm = nn.LayerNorm(d_model)
-        # common/nets/transformer.py:86: the stack's closing norm exists only with normalize_before
+        # common/nets/transformer.py:86: the stack's closing norm exists only with normalize_before; registered BEFORE inter_norm as in
+        # the reference's TransformerEncoder.__init__ (:171-172) - parameters() order is what checkpointed optimizer state follows
         self.norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.inter_norm = nn.LayerNorm(d_model)
         self.normalize_before = bool(normalize_before)
         self.num_layers = num_layers
 
@@ -301,6 +304,16 @@ class TransformerDecoder(nn.Module):
 _MASK_CACHE = {}
 
 
+def _require_zero_pos(pos_embed):
+    """The reference adds ``pos`` to the QUERY and KEY inputs of every encoder layer and to the decoder's memory keys, never to
+    the values (common/nets/transformer.py:283-302,366-395); it only ever passes zeros (main/model.py:542,560), for which
+    that equals no embedding at all - the only case the fused layers implement.  Anything else is refused rather than
+    silently computed with other semantics (one device read, on the reference-signature entry only)."""
+    if pos_embed is not None and bool((pos_embed != 0).any()):
+        raise NotImplementedError("a non-zero pos_embed is not supported: the reference adds it to q and k of every layer "
+                                  "(common/nets/transformer.py:283-302) and always passes zeros (main/model.py:542,560)")
+
+
 def _mask_to_u8(mask: Optional[torch.Tensor], nq: int, device) -> torch.Tensor:
     """uint8 device copy of a (constant) boolean attention mask, uploaded once per (mask, device):
     a per-step host->device copy of pageable memory would synchronise the host with the stream."""
@@ -351,7 +364,8 @@ class Transformer(nn.Module):
 
     def forward(self, src, mask, query_embed, pos_embed, tgt_mask=None, src_mask=None, memory_mask=None):
         assert mask is None and src_mask is None, "padding / source masks are unused on this path"
-        x = src if pos_embed is None else src + pos_embed
+        _require_zero_pos(pos_embed)
+        x = src
         kv_len = _kv_len_from_memory_mask(memory_mask, src.shape[0])
         hs, memory, inter = self.forward_batch_first(x.permute(1, 0, 2).contiguous(), query_embed, tgt_mask,
                                                      kv_len)
@@ -376,6 +390,7 @@ class VoteTransformer(nn.Module):
 
     def forward(self, src, mask, pos_embed, src_mask=None):
         assert mask is None and src_mask is None
-        x = src if pos_embed is None else src + pos_embed
+        _require_zero_pos(pos_embed)
+        x = src
         memory, inter = self.encoder(x.permute(1, 0, 2).contiguous())
         return memory.permute(1, 0, 2), inter.permute(0, 2, 1, 3)

@@ -236,9 +236,13 @@ def lattice_bbox_mask(lattice: Tensor, center_b: Tensor, cam_intr_b: Tensor, bbo
 
 def sdf_infer(P: Params, cfg: OracleCfg, pyramid, center: Tensor, cam_intr: Tensor,
               bbox: Tensor, scale: float, num_points: int, kind: str,
-              return_debug: bool = False):
+              return_debug: bool = False, training: bool = False):
     """Dense-grid SDF evaluation + K smallest |sdf| per sample.  main/model.py:246-355.
-    Returns points (B,K,3) [scaled space], sdf (B,K,1) clamped, posenc (B,K,30)."""
+    Returns points (B,K,3) [scaled space], sdf (B,K,1) clamped, posenc (B,K,30).
+    ``training``: the reference calls this under ``torch.no_grad()`` but with the MODULE still in train mode during a
+    branch-B training step (main/model.py:462-481), so the SDF decoder's dropout (p = cfg.sdf_dropout after each of its four
+    hidden layers, common/nets/sdf_net.py:112-113) is live while the points are being ranked - the selected set of a
+    training step is a random function of the lattice.  ``linear_sdfin`` has no dropout."""
     B = center.shape[0]
     lattice = dense_lattice(cfg.bins_n)
     n = torch.tensor([cfg.input_img_shape[1] - 1, cfg.input_img_shape[0] - 1],
@@ -261,7 +265,7 @@ def sdf_infer(P: Params, cfg: OracleCfg, pyramid, center: Tensor, cam_intr: Tens
         fea = mlp(feats, P, "linear_sdfin", 2, True).squeeze(0)
         pe = posenc(samp)
         x0 = torch.cat([fea, pe, samp], 1).contiguous()
-        sdf = sdf_decoder(x0, P, f"{kind}_sdf_decoder", False).squeeze(1)
+        sdf = sdf_decoder(x0, P, f"{kind}_sdf_decoder", training, cfg.sdf_dropout).squeeze(1)
         order = torch.sort(sdf.abs())[1][:num_points]
         pts_o[b] = samp[order]
         sdf_o[b] = sdf[order].unsqueeze(-1)
@@ -594,9 +598,9 @@ def hot_path_forward(P: Params, cfg: OracleCfg, feature_pyramid: Dict[str, Tenso
     else:                                                                      # :462-481
         with torch.no_grad():
             hand_points, hand_sdf, hand_pe = sdf_infer(P, cfg, feature_pyramid, mano_root, K,
-                                                       meta_info["bbox_hand"], hs, nh, "hand")
+                                                       meta_info["bbox_hand"], hs, nh, "hand", training=training)
             obj_points, obj_sdf, obj_pe = sdf_infer(P, cfg, feature_pyramid, obj_center, K,
-                                                    meta_info["bbox_obj"], os_, no, "obj")
+                                                    meta_info["bbox_obj"], os_, no, "obj", training=training)
 
     sig_h = sdf_activation(hand_sdf.detach(), P["hand_sigmoid_beta"])         # :483-484
     sig_o = sdf_activation(obj_sdf.detach(), P["obj_sigmoid_beta"])

@@ -380,7 +380,7 @@ def option_goldens():
         cfg.pre_norm = True
         model, _ = build_reference("dexycb", nh, no, 16)
         model.eval()
-        keys_pre = sorted(k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net")))
+        keys_pre = [k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net"))]      # registration order
         with torch.no_grad():
             r = np.random.default_rng(7)
             S = nh + no
@@ -399,7 +399,7 @@ def option_goldens():
         cfg.ClassifierBranch = True
         model, _ = build_reference("dexycb", nh, no, 16)
         model.eval()
-        keys_cls = sorted(k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net")))
+        keys_cls = [k for k in model.state_dict() if not k.startswith(("backbone_net", "decoder_net"))]     # registration order
         with torch.no_grad():
             x = torch.from_numpy(np.random.default_rng(5).standard_normal((96, 289)).astype(np.float32))
             y, c = model.hand_sdf_decoder(x)
@@ -497,20 +497,59 @@ def metrics_golden():
 
 def ik_golden():
     """g12: the reference's closed-form IK post-process (common/utils/inverse_kinematics.py:15-150) run on seeded joints.
-    PARTIALLY PINNED: the reference imports ``kornia.geometry.conversions.rotation_matrix_to_axis_angle`` (kornia is not
-    installed); the harness provides that ONE function through scipy's ``Rotation.from_matrix(R).as_rotvec()`` (the same
-    SO(3) log map; kornia goes matrix -> quaternion -> axis-angle) - everything else in the fixture is the reference's own
-    code, with ``ManoLayer`` = the synthetic MANO-shaped asset (shim 4 above)."""
-    from scipy.spatial.transform import Rotation
+    The reference imports ``kornia.geometry.conversions.rotation_matrix_to_axis_angle`` (:9, used at :70 and in the finger
+    fits).  kornia is a third-party dependency absent from /root/reference and from this image (requirements.txt:7 names it
+    without a version); the harness supplies that ONE function as a restatement of kornia's published algorithm (0.6.9 - 0.7.x
+    ``kornia/geometry/conversions.py``): rotation matrix -> quaternion (w, x, y, z) by the four-branch trace method with
+    eps = 1e-8 under the square roots and divisions clamped at the dtype's tiny, then quaternion -> axis-angle through
+    2 atan2(+-sin, +-cos) / sin with the k = 2 small-angle branch - so the fixture carries the reference's arithmetic
+    (branch choices, the 1e-8 guard, float32 throughout), not scipy's SO(3) log map as in round 5.  Everything else in the
+    fixture is the reference's own code, with ``ManoLayer`` = the synthetic MANO-shaped asset (shim 4 above)."""
+
+    def rotation_matrix_to_quaternion(rotation_matrix, eps=1.0e-8):
+        def safe_zero_division(numerator, denominator):
+            return numerator / torch.clamp(denominator, min=torch.finfo(numerator.dtype).tiny)
+        v = rotation_matrix.reshape(*rotation_matrix.shape[:-2], 9)
+        m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.chunk(v, chunks=9, dim=-1)
+        trace = m00 + m11 + m22
+
+        def trace_positive_cond():
+            sq = torch.sqrt(trace + 1.0 + eps) * 2.0          # 4 qw
+            return torch.cat((0.25 * sq, safe_zero_division(m21 - m12, sq), safe_zero_division(m02 - m20, sq),
+                              safe_zero_division(m10 - m01, sq)), dim=-1)
+
+        def cond_1():
+            sq = torch.sqrt(1.0 + m00 - m11 - m22 + eps) * 2.0  # 4 qx
+            return torch.cat((safe_zero_division(m21 - m12, sq), 0.25 * sq, safe_zero_division(m01 + m10, sq),
+                              safe_zero_division(m02 + m20, sq)), dim=-1)
+
+        def cond_2():
+            sq = torch.sqrt(1.0 + m11 - m00 - m22 + eps) * 2.0  # 4 qy
+            return torch.cat((safe_zero_division(m02 - m20, sq), safe_zero_division(m01 + m10, sq), 0.25 * sq,
+                              safe_zero_division(m12 + m21, sq)), dim=-1)
+
+        def cond_3():
+            sq = torch.sqrt(1.0 + m22 - m00 - m11 + eps) * 2.0  # 4 qz
+            return torch.cat((safe_zero_division(m10 - m01, sq), safe_zero_division(m02 + m20, sq),
+                              safe_zero_division(m12 + m21, sq), 0.25 * sq), dim=-1)
+
+        where_2 = torch.where(m11 > m22, cond_2(), cond_3())
+        where_1 = torch.where((m00 > m11) & (m00 > m22), cond_1(), where_2)
+        return torch.where(trace > 0.0, trace_positive_cond(), where_1)
+
+    def quaternion_to_axis_angle(quaternion):
+        q1, q2, q3 = quaternion[..., 1], quaternion[..., 2], quaternion[..., 3]
+        cos_theta = quaternion[..., 0]
+        sin_squared_theta = q1 * q1 + q2 * q2 + q3 * q3
+        sin_theta = torch.sqrt(sin_squared_theta)
+        two_theta = 2.0 * torch.where(cos_theta < 0.0, torch.atan2(-sin_theta, -cos_theta), torch.atan2(sin_theta, cos_theta))
+        k = torch.where(sin_squared_theta > 0.0, two_theta / sin_theta, 2.0 * torch.ones_like(sin_theta))
+        return torch.stack((q1 * k, q2 * k, q3 * k), dim=-1)
 
     def rotation_matrix_to_axis_angle(R):
-        # the reference converts every fit, then keeps only the proper rotations (`[batch_id]`, :66-71): reflections
-        # (scipy refuses them) get a placeholder that is never read
-        Rn = R.detach().double().numpy()
-        out = np.zeros((Rn.shape[0], 3))
-        ok = np.linalg.det(Rn) > 0
-        out[ok] = Rotation.from_matrix(Rn[ok]).as_rotvec()
-        return torch.from_numpy(out).to(R.dtype)
+        # (a reflected palm fit goes through the same arithmetic - NaN or garbage, as in kornia; the reference keeps only the
+        # proper rotations, `[batch_id]`, :66-71)
+        return quaternion_to_axis_angle(rotation_matrix_to_quaternion(R))
 
     _stub_module("kornia")
     _stub_module("kornia.geometry")

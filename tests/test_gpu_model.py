@@ -113,6 +113,60 @@ def test_sdf_infer_selects_the_oracle_set():
         model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], tiny, 3.1, nh, "hand")
 
 
+def test_sdf_infer_in_train_mode_ranks_under_dropout_like_the_reference():
+    """Branch B of a TRAINING step (main/model.py:462-481): the reference runs sdf_infer under no_grad but with the module in train
+    mode, so the SDF decoder's dropout (p = 0.2, common/nets/sdf_net.py:112-113) is live while the lattice points are ranked - the
+    selected set is random (two oracle runs with independent masks share ~2 % of their 384 points on these weights).  The
+    device's mask stream is not torch's, so the check is statistical, against three oracle runs: the order statistics of the
+    NOISY |sdf| that ranked the points (mean and K-th smallest over ~29 000 candidates: tightly concentrated), the CLEAN |sdf| of
+    the selected points (how far from the surface the noise lets the selection drift: 0.11 against 0.0017 without dropout), the
+    overlaps between selections; eval mode returns the deterministic set again."""
+    from oracle import hoisdf_oracle as R
+    nh, no, bins, b = 384, 128, 64, 2
+    model, c = build("dexycb", nh, no, bins, train=True)
+    P = T.det_params(T.hot_path_param_shapes(992))
+    pyr_cpu = T.synthetic_pyramid(b, seed=8)
+    pyr, _ = nhwc_pyramid(pyr_cpu)
+    _, _, meta = T.synthetic_batch(b, nh, no, seed=81)
+    oc = oracle_cfg(c)
+    key = lambda r: tuple(round(float(x), 6) for x in r)
+
+    def oracle_run(training, seed):
+        torch.manual_seed(seed)
+        return R.sdf_infer(P, oc, pyr_cpu, meta["mano_root"], meta["cam_intr"], meta["bbox_hand"], 3.1, nh, "hand",
+                           return_debug=True, training=training)
+
+    pts_c, sdf_c, _, dbg_c = oracle_run(False, 0)
+    lattice = R.dense_lattice(bins)
+    clean_of = [{key(p): float(v) for p, v in zip(lattice[d["keep"]].tolist(), d["sdf"].abs().tolist())} for d in dbg_c]
+    noisy = [oracle_run(True, seed) for seed in (1, 2, 3)]
+    m = T.to_device(meta, DEV)
+    assert model.hand_sdf_decoder.training
+    runs = [model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand") for _ in range(2)]
+    for i in range(b):
+        o_sets = [{key(r) for r in n[0][i].tolist()} for n in noisy]
+        d_sets = [{key(r) for r in r_[0][i].cpu().tolist()} for r_ in runs]
+        o_mean = sum(float(n[1][i].abs().mean()) for n in noisy) / 3
+        o_kth = sum(float(n[1][i].abs().max()) for n in noisy) / 3
+        o_clean = sum(sum(clean_of[i][k] for k in st) / nh for st in o_sets) / 3
+        assert o_clean > 20 * float(sdf_c[i].abs().mean())                 # (the oracle itself: dropout moves the selection off the surface)
+        for r_, st in zip(runs, d_sets):
+            sdf = r_[1][i, :, 0].abs().cpu()
+            assert bool((sdf[1:] >= sdf[:-1] - 1e-7).all())                  # ranked by the noisy values it returns
+            assert abs(float(sdf.mean()) - o_mean) <= 0.15 * o_mean, (float(sdf.mean()), o_mean)
+            assert abs(float(sdf.max()) - o_kth) <= 0.15 * o_kth, (float(sdf.max()), o_kth)
+            d_clean = sum(clean_of[i][k] for k in st) / nh                   # (every selected point is a lattice survivor: KeyError otherwise)
+            assert abs(d_clean - o_clean) <= 0.12 * o_clean, (d_clean, o_clean)
+        ov = lambda x, y: len(x & y) / nh
+        oo = max(ov(o_sets[0], o_sets[1]), ov(o_sets[0], o_sets[2]), ov(o_sets[1], o_sets[2]))
+        assert ov(d_sets[0], d_sets[1]) <= oo + 0.05 and ov(d_sets[0], o_sets[0]) <= oo + 0.05, "selections as random as the oracle's"
+        assert d_sets[0] != d_sets[1], "two calls draw two masks"
+    model.eval()
+    pts_e, _, _, _ = model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand")
+    for i in range(b):
+        assert len({key(r) for r in pts_e[i].cpu().tolist()} ^ {key(r) for r in pts_c[i].tolist()}) <= 4
+
+
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
                                                   ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
 def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suffix):

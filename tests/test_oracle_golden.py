@@ -165,6 +165,17 @@ def test_option_state_dict_schemas_match_the_reference():
         ours = set(T.hot_path_param_shapes(992, **kw))
         theirs = {k for k in ref[key] if not k.startswith(skip)}
         assert ours == theirs, (key, sorted(ours ^ theirs)[:8])
+    # the product modules register their parameters in the reference's ORDER (the fixture lists are unsorted since round 6:
+    # optimizer state in a checkpoint is indexed by parameters() order - ClassifierBranch puts classifier_head behind linh4)
+    from hoisdf_amd.config import Config
+    from hoisdf_amd.model import get_model
+    for key, attr in (("pre_norm", "pre_norm"), ("classifier", "ClassifierBranch")):
+        c = Config()
+        c.resnet_type = 18
+        c.apply_setting("dexycb")
+        setattr(c, attr, True)
+        ours = [k for k in get_model("test", cfg=c).state_dict() if not k.startswith(("backbone_net", "decoder_net"))]
+        assert ours == ref[key], next((i, a, b) for i, (a, b) in enumerate(zip(ours, ref[key])) if a != b)
 
 
 def test_g6_vote(P):
