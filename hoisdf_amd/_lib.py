@@ -127,6 +127,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_linear_emu_prepare_batch": [_P, _I, _L, _P],
     "hoisdf_linear_fwd_emu": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P],
     "hoisdf_mag_measure": [_P, _L, _L, _I, _P, _P],
+    "hoisdf_head_mag_measure": [_P, _L, _L, _I, _I, _P, _P],
+    "hoisdf_linear_fwd_emu_heads": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _P],
+    "hoisdf_linear_bwd_input_emu_heads": [_P, _I, _P, _P, _I, _L, _I, _I, _P, _P, _P, _I, _P],
     "hoisdf_linear_fwd_emu_mag": [_P, _I, _P, _P, _P, _I, _L, _I, _I, _I, _F, _U64, _P, _P, _P, _P],
     "hoisdf_linear_bwd_input_emu": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P],
     "hoisdf_linear_bwd_input_emu_mag": [_P, _I, _P, _F, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P],
@@ -159,11 +162,11 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_attention_fwd_f16": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_bf16x2": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "hoisdf_attention_fwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P],
-    "hoisdf_attention_fwd_emu_mag": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P, _P, _P, _P],
+    "hoisdf_attention_fwd_emu_mag": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _L, _I, _P, _P, _P, _P, _P],
     "hoisdf_attention_bwd_emu": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
                                  _L, _P],
     "hoisdf_attention_bwd_emu_mag": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P,
-                                 _L, _P, _P, _P, _P, _P],
+                                 _L, _P, _P, _P, _P, _P, _P],
     "hoisdf_attention_small_fwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _U64, _P],
     "hoisdf_attention_small_bwd": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F,
                                    _U64, _P],
@@ -220,7 +223,8 @@ _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I]
           "hoisdf_linear_emu_supported": ([_P, _L, _I], C.c_int),
           "hoisdf_linear_emu_small_max_rows": ([], C.c_int),
           "hoisdf_linear_emu_pieces": ([], C.c_int),
-          "hoisdf_mag_words": ([], C.c_int),
+          "hoisdf_mag_words": ([_L], C.c_long),
+          "hoisdf_head_mag_words": ([_L, _I, _I], C.c_long),
           "hoisdf_linear_emu_small_supported": ([_P, _L, _P, _L, _L, _I, _I], C.c_int),
           "hoisdf_attention_f16_workspace": ([_I, _I, _I], C.c_long),
           "hoisdf_attention_bf16x2_workspace": ([_I, _I, _I, _I], C.c_long),

@@ -23,10 +23,11 @@ struct EmuAttn {
   float drop_p, inv_keep;
   uint32_t thresh;
   uint64_t seed;
-  const uint32_t* d_mag;           // f16x2 backward: magnitude words of dO
-  float* dq_scale;                 // f16x2 backward: one float the kernel leaves for the dQ reduce pass (0.125 / (sK sS))
-  const uint32_t *in_mag, *in_mag_kv;   // f16x2 form: magnitude words of the matrices the Q planes / the K and V planes were made from (their scales)
-  uint32_t* mag;                   // magnitude words (common.h) of what the kernel writes: out (forward), dk / dv (backward); null = none
+  // f16x2 form: head magnitudes (common.h) the planes of Q, K, V and dO were made with - ONE scale per (sample, head) and operand:
+  // word of (b, head) at x_hm[head * B + b] (each pointer is positioned at its operand's first head inside its matrix' array)
+  const uint32_t *q_hm, *k_hm, *v_hm, *d_hm;
+  float* dq_scale;                 // f16x2 backward: one float per (b, head) the kernel leaves for the dQ reduce pass (0.125 / (sK sS))
+  uint32_t* mag;                   // row magnitudes (common.h) of what the kernel writes: out (forward), [dq | dk | dv] rows (backward); null = none
 };
 
 __device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
@@ -42,6 +43,6 @@ __device__ __forceinline__ bool emu_block(int nx, int nbh, int& tile, int& bh) {
 // hoisdf_attention_bwd_emu); returns a HOISDF status
 // (chain: dQ through the ordered in-L2 running sum - a.dq_part one [bh][Lq][64] buffer, a.dq_flags zeroed - instead of partials)
 int attention_bwd4_emu_launch(const emu_attn::EmuAttn& a, bool chain, hipStream_t st);
-// attention_emu_bwd4h.hip: the f16x2 form (two f16 planes per operand in a.q / a.k / a.v / a.d, scales from a.in_mag / a.in_mag_kv / a.d_mag)
+// attention_emu_bwd4h.hip: the f16x2 form (two f16 planes per operand in a.q / a.k / a.v / a.d, per-(sample, head) scales from a.q_hm / k_hm / v_hm / d_hm)
 int attention_bwd4h_emu_launch(const emu_attn::EmuAttn& a, hipStream_t st);
 }  // namespace hoisdf

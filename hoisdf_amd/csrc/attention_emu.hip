@@ -99,7 +99,8 @@ __device__ __forceinline__ void split8(const f32x16& s, int jj, float mul, bf16x
 // [bh][64][Lp]; rows >= L are zero.  One block per (bh, 64-row tile): a thread owns 16 consecutive d of one row (4 threads per
 // row: 256-byte coalesced reads, 128-byte coalesced row-major writes); the transposed copies go through an LDS tile.
 // F16 (the f16x2 form of the attention, round 5): TWO planes of f16 bits - hi = f16(x scale s), lo = f16(x scale s - hi) with s the
-// power of two that the magnitude words `mag` (common.h) of the source matrix give; the third plane pointers are not touched.
+// power of two that the head magnitude of the block's (sample, head) gives (round 6; common.h: mag[head * B + b] - a sample's
+// planes do not depend on the other samples of the batch); the third plane pointers are not touched.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <bool F16>
@@ -110,11 +111,10 @@ __global__ __launch_bounds__(256) void emu_attn_convert_kernel(const float* __re
                                                                const uint32_t* __restrict__ mag) {
   constexpr int TP = 72;
   __shared__ __attribute__((aligned(16))) __bf16 tile[3][64 * TP];
-  __shared__ uint32_t red4[4];
   const int tid = threadIdx.x;
-  if (F16) scale *= mag_scale(mag_words_max(mag, MAG_WORDS, red4));
   const int nb = Lp / 64;
   const int kb = blockIdx.x % nb, bh = blockIdx.x / nb, b = bh / H, head = bh - b * H;
+  if (F16) { f16_saturate_on(); scale *= mag_scale(mag[head * B + b]); }
   const int r = tid >> 2, dc = (tid & 3) * 16;
   const int row = kb * 64 + r;
   const bool valid = row < L;
@@ -303,7 +303,10 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd_kernel(EmuAttn a) {
       }
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = m + log2f(ltot);       // log2 domain
   }
-  mag_publish_wave(a.mag, omax);
+  if (a.mag) {                               // row magnitudes of o (common.h): lanes c, c + 32 hold the two halves of the row's head slice
+    omax = max(omax, (uint32_t)__shfl_xor((int)omax, 32, 64));
+    if (h == 0 && qrow < a.Lq) atomicMax(a.mag + (size_t)b * a.Lq + qrow, omax);
+  }
 }
 
 
@@ -323,15 +326,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // NPL = planes per operand: 3 = fp32-equivalent (six products per product); 2 = bf16 hi + lo operands, three products - the 16-bit-operand
 // evaluation kernel of BASELINE configs[4] (hoisdf_attention_fwd_bf16x2; ~2^-17 relative operand error, f32 softmax and accumulation)
-// F16 (with NPL = 2): the f16x2 form - the planes hold f16 hi + lo pieces of Q s, K s, V s (s = the power of two from a.in_mag, the
-// magnitude words of the [q | k | v] matrix; emu_attn_convert_kernel<true>), the products run on v_mfma_f32_32x32x16_f16.  The scores
-// come out multiplied by s^2: the softmax works on them as they are (running maximum, rescale threshold and exponent argument carry
+// F16 (with NPL = 2): the f16x2 form - the planes hold f16 hi + lo pieces of Q sQ, K sK, V sV (the powers of two from the head
+// magnitudes of the block's (sample, head): a.q_hm / k_hm / v_hm; emu_attn_convert_kernel<true>), the products run on
+// v_mfma_f32_32x32x16_f16.  The scores come out multiplied by sQ sK: the softmax works on them as they are (running maximum, rescale threshold and exponent argument carry
 // the factor 1 / s^2 in one fused multiply-add); P is formed as 2^6 P (<= 2^14 at the lazy rescale's 2^8 head room) so that its f16
 // pieces keep 22 bits down to 2^-22 of the row's largest probability; the row sum carries the same 2^6 and O = acc / (l s).
 template <bool DROP, int NPL, bool F16>
 __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   static_assert(!F16 || NPL == 2, "the f16 form has two planes");
-  __shared__ uint32_t red4_[4];
   __shared__ __attribute__((aligned(16))) __bf16 Kb0[3 * ROWS_T];
   __shared__ __attribute__((aligned(16))) __bf16 Kb1[3 * ROWS_T];
   __shared__ __attribute__((aligned(16))) __bf16 Vb0[3 * TRN_T];
@@ -347,11 +349,10 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
   // f16 form: cs = 1 / s^2 takes the accumulated scores to the log2-domain scores, vinv = 1 / s takes the accumulated output back
   float cs = 1.f, vinv = 1.f;
   constexpr float PB = F16 ? 6.f : 0.f;                     // P is formed as 2^PB P
-  if (F16) {
-    const float iq_ = mag_inv_scale(mag_words_max(a.in_mag, MAG_WORDS, red4_));
-    __syncthreads();
-    const float ik_ = mag_inv_scale(mag_words_max(a.in_mag_kv, MAG_WORDS, red4_));
-    cs = fmaxf(iq_ * ik_, 0x1p-100f); vinv = ik_;           // (floored: operands below ~2^-37 have scores of exactly zero either way)
+  if (F16) {                                                // the (sample, head)'s own scales (common.h head magnitudes)
+    f16_saturate_on();
+    const float iq_ = mag_inv_scale(a.q_hm[head * a.B + b]), ik_ = mag_inv_scale(a.k_hm[head * a.B + b]);
+    cs = fmaxf(iq_ * ik_, 0x1p-100f); vinv = mag_inv_scale(a.v_hm[head * a.B + b]);      // (floored: operands below ~2^-37 have scores of exactly zero either way)
   }
   const float thr8 = F16 ? 8.f / cs : 8.f;                  // the lazy rescale's threshold in accumulator units
   float mneg = INFINITY;                                    // f16 form: PB - m cs (the exponent argument is fma(score, cs, mneg))
@@ -641,7 +642,10 @@ __global__ __launch_bounds__(256, 2) void emu_attn_fwd2_kernel(EmuAttn a) {
       }
     if (h == 0 && a.lse) a.lse[(size_t)bh * a.Lq + qrow] = (F16 ? m * cs - PB : m) + log2f(ltot);       // log2 domain
   }
-  mag_publish_wave(a.mag, omax);
+  if (a.mag) {                               // row magnitudes of o (common.h): lanes c, c + 32 hold the two halves of the row's head slice
+    omax = max(omax, (uint32_t)__shfl_xor((int)omax, 32, 64));
+    if (h == 0 && qrow < a.Lq) atomicMax(a.mag + (size_t)b * a.Lq + qrow, omax);
+  }
 }
 #pragma pop_macro("MB")
 
@@ -940,7 +944,11 @@ __global__ __launch_bounds__(512, 1) void emu_attn_bwd_stag_kernel(EmuAttn a) {
       gmax = max(gmax, max(mag_bits4(gk), mag_bits4(gv)));
     }
   }
-  mag_publish_wave(a.mag, gmax);
+  if (a.mag) {                               // row magnitudes of [dq | dk | dv] (common.h): the four k-groups of a key hold its row
+    gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, 16, 64));
+    gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, 32, 64));
+    if (g == 0 && key < a.Lk) atomicMax(a.mag + (size_t)b * a.Lk + key, gmax);
+  }
 }
 
 // delta[bh][q] = sum_d dO[q][d] * O[q][d]  (f32; 16 lanes per (q, head))
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(256) void emu_attn_delta_kernel(const float* __rest
 }
 
 // dq[b][q][head * 64 + d] = 0.125 * sum_kb part[kb][bh][q][d] in key-block order (one float4 per thread)
-// scale: null = 0.125 (the bf16x3 backward: Q pre-scaled by log2(e) / 8 ...); the f16x2 backward leaves 0.125 / (sK sS) there
+// scale: null = 0.125 (the bf16x3 backward: Q pre-scaled by log2(e) / 8 ...); the f16x2 backward leaves 0.125 / (sK sS) per (b, head) there
 __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __restrict__ part, int nkb, float* __restrict__ dq,
                                                                  int ldq, int B, int H, int Lq, uint32_t* __restrict__ mag,
                                                                  const float* __restrict__ scale) {
@@ -988,12 +996,15 @@ __global__ __launch_bounds__(256) void emu_attn_dq_reduce_kernel(const float* __
       for (int j = 0; j < 8; ++j)
         if (k0 + j < nkb) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
     }
-    const float sc = scale ? *scale : 0.125f;
+    const float sc = scale ? scale[bh] : 0.125f;
     const float4 r = make_float4(s.x * sc, s.y * sc, s.z * sc, s.w * sc);
     *reinterpret_cast<float4*>(dq + ((size_t)b * Lq + q) * ldq + head * D + d4 * 4) = r;
     qmax = mag_bits4(r);
+    if (mag) {                             // dq's share of the row magnitudes of [dq | dk | dv] (common.h): 16 lanes per row
+      qmax = group_max_u32<16>(qmax);
+      if (d4 == 0) atomicMax(mag + (size_t)b * Lq + q, qmax);
+    }
   }
-  mag_publish_wave(mag, qmax);             // dq's share of the magnitude words of [dq | dk | dv] (common.h), when wanted
 }
 
 }  // namespace hoisdf
@@ -1012,7 +1023,7 @@ inline Planes carve(__bf16*& w, size_t n, bool rows, bool trn) {
   for (int i = 0; i < 3; ++i) { p.t[i] = trn ? w : nullptr; if (trn) w += n; }
   return p;
 }
-// mag != null: the f16x2 planes of a matrix with those magnitude words (two planes, scaled); null: the bf16 planes
+// mag != null: the f16x2 planes (two planes, scaled per (sample, head) by the head magnitudes mag[head * B + b]); null: the bf16 planes
 int convert(const float* src, int ld, int L, int Lp, int B, int H, float scale, const Planes& p, hipStream_t st, const uint32_t* mag = nullptr) {
   const long nblk = (long)B * H * (Lp / 64);
   if (mag) hipLaunchKernelGGL(emu_attn_convert_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, st, src, ld, L, Lp, B, H, scale, p.r[0], p.r[1],
@@ -1045,9 +1056,10 @@ extern "C" long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int
 namespace {
 // the forward over planes that are in the workspace already (layout (kept form): [Q rows | K rows | V rows, V^T]; forward-only
 // form: [Q rows | K rows | V^T])
-// in_mag != null: the planes are the f16x2 ones (two planes, made with those magnitude words): the f16 kernel
+// q_hm != null: the planes are the f16x2 ones (two planes, made with those head magnitudes): the f16 kernel
 int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
-                    void* workspace, int keep, hipStream_t st, uint32_t* o_mag, const uint32_t* in_mag = nullptr, const uint32_t* in_mag_kv = nullptr) {
+                    void* workspace, int keep, hipStream_t st, uint32_t* o_mag, const uint32_t* q_hm = nullptr, const uint32_t* k_hm = nullptr,
+                    const uint32_t* v_hm = nullptr) {
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
   __bf16* w = reinterpret_cast<__bf16*>(workspace);
   const size_t nq = plane_elems(B, H, Lqp), nk = plane_elems(B, H, Lkp);
@@ -1056,13 +1068,15 @@ int fwd_over_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk,
   const Planes pv = carve(w, nk, keep != 0, true);
   EmuAttn a{};
   for (int i = 0; i < 3; ++i) { a.q[i] = pq.r[i]; a.k[i] = pk.r[i]; a.vt[i] = pv.t[i]; }
-  a.out = o; a.lse = lse; a.ldo = ldo; a.mag = o_mag; a.in_mag = in_mag; a.in_mag_kv = in_mag_kv ? in_mag_kv : in_mag;
+  a.out = o; a.lse = lse; a.ldo = ldo; a.mag = o_mag; a.q_hm = q_hm; a.k_hm = k_hm; a.v_hm = v_hm;
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   static int form = -1;                       // HOISDF_EMU_ATTN_FWD=1: the first (unpipelined) form (A/B runs)
   if (form < 0) { const char* e = getenv("HOISDF_EMU_ATTN_FWD"); form = (e && atoi(e) == 1) ? 1 : 2; }
   const dim3 fgrid(cdiv(Lq, 128) * 8 * cdiv(B * H, 8));
-  if (in_mag) {
+  if (q_hm) {
+    // (P is carried as 2^6 P up to 2^14 and the keep factor 1 / (1 - p) goes in before the f16 split: p < 0.75 keeps it below 65504)
+    HOISDF_REQUIRE(drop_p < 0.75f, HOISDF_ERR_INVALID, "attention_fwd_emu (f16x2 form): drop_p = %f, must be below 0.75", drop_p);
     if (drop_p > 0.f) hipLaunchKernelGGL((emu_attn_fwd2_kernel<true, 2, true>), fgrid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((emu_attn_fwd2_kernel<false, 2, true>), fgrid, dim3(256), 0, st, a);
   } else if (form == 1) hipLaunchKernelGGL(emu_attn_fwd_kernel, fgrid, dim3(256), 0, st, a);
@@ -1076,25 +1090,27 @@ extern "C" int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k,
                                         int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
                                         uint64_t seed, void* workspace, long workspace_bytes, int keep, void* stream) {
   return attention_fwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, workspace_bytes, keep,
-                               nullptr, stream, nullptr, nullptr);
+                               nullptr, stream, nullptr, nullptr, nullptr);
 }
-// the f16x2 form of the forward (qkv_mag = magnitude words of the matrix q, k, v are column slices of: one common power-of-two scale,
-// two f16 planes per operand, three products per product; include/hoisdf.h); o_mag receives o's words when given
+// the f16x2 form of the forward: q_mag / k_mag / v_mag = the head magnitudes (include/hoisdf.h) of q, k and v - one power-of-two scale
+// per (sample, head) and operand, two f16 planes per operand, three products per product; o_mag receives o's row magnitudes when given
 extern "C" int hoisdf_attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
                                             int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p,
-                                            uint64_t seed, void* workspace, long workspace_bytes, int keep, const uint32_t* qkv_mag,
-                                            const uint32_t* kv_mag, uint32_t* o_mag, void* stream) {
-  HOISDF_REQUIRE(qkv_mag, HOISDF_ERR_INVALID, "attention_fwd_emu_mag: the magnitude words of q / k / v are required (hoisdf_mag_measure)");
+                                            uint64_t seed, void* workspace, long workspace_bytes, int keep, const uint32_t* q_mag,
+                                            const uint32_t* k_mag, const uint32_t* v_mag, uint32_t* o_mag, void* stream) {
+  HOISDF_REQUIRE(q_mag && k_mag && v_mag, HOISDF_ERR_INVALID, "attention_fwd_emu_mag: the head magnitudes of q, k and v are required (hoisdf_head_mag_measure)");
   return attention_fwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, workspace_bytes, keep,
-                               o_mag, stream, qkv_mag, kv_mag);
+                               o_mag, stream, q_mag, k_mag, v_mag);
 }
-// (internal, common.h) + o_mag: the magnitude words of o (zero on entry; null = not wanted)
+// (internal, common.h) + o_mag: the row magnitudes of o (zero on entry; null = not wanted)
 int hoisdf::attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                                   int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
-                                  long workspace_bytes, int keep, uint32_t* o_mag, void* stream, const uint32_t* qkv_mag, const uint32_t* kv_mag) {
+                                  long workspace_bytes, int keep, uint32_t* o_mag, void* stream, const uint32_t* q_hm, const uint32_t* k_hm,
+                                  const uint32_t* v_hm) {
   if (int rc = check_emu(q, k, v, ldq, ldk, ldv, B, H, Lq, Lk, kv_len, drop_p, "attention_fwd_emu")) return rc;
   HOISDF_REQUIRE(o && workspace && ldo >= H * 64 && (ldo & 3) == 0 && (((uintptr_t)o | (uintptr_t)workspace) & 15) == 0,
                  HOISDF_ERR_INVALID, "attention_fwd_emu: bad output / workspace");
+  HOISDF_REQUIRE((!q_hm && !k_hm && !v_hm) || (q_hm && k_hm && v_hm), HOISDF_ERR_INVALID, "attention_fwd_emu: head magnitudes of all of q, k, v or of none");
   const long need = hoisdf_attention_emu_workspace(B, H, Lq, Lk, keep ? 2 : 0);
   HOISDF_REQUIRE(workspace_bytes >= need, HOISDF_ERR_WORKSPACE, "attention_fwd_emu: workspace %ld < %ld bytes", workspace_bytes, need);
   const int Lqp = (int)pad128(Lq), Lkp = (int)pad128(Lk);
@@ -1104,13 +1120,10 @@ int hoisdf::attention_fwd_emu_mag(const float* q, int ldq, const float* k, int l
   const Planes pq = carve(w, nq, true, false);
   const Planes pk = carve(w, nk, true, false);
   const Planes pv = carve(w, nk, keep != 0, true);
-  // qkv_mag: the magnitude words of the matrix q, k and v are column slices of - the f16x2 form (one scale for the three)
-  // (kv_mag: k and v come from another matrix than q - its words; null: the same)
-  if (qkv_mag && !kv_mag) kv_mag = qkv_mag;
-  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, qkv_mag)) return rc;
-  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, kv_mag)) return rc;
-  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, kv_mag)) return rc;
-  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st, o_mag, qkv_mag, kv_mag);
+  if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, q_hm)) return rc;
+  if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, k_hm)) return rc;
+  if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, v_hm)) return rc;
+  return fwd_over_planes(o, ldo, lse, B, H, Lq, Lk, kv_len, drop_p, seed, workspace, keep, st, o_mag, q_hm, k_hm, v_hm);
 }
 
 // ---- 16-bit-operand evaluation attention (BASELINE configs[4] "fp16 MFMA attention"): the pipelined forward over TWO bf16 planes per
@@ -1191,27 +1204,29 @@ extern "C" int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k,
                                         float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
                                         const void* fwd_workspace, void* workspace, long workspace_bytes, void* stream) {
   return attention_bwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, dk, dv, B, H, Lq, Lk, kv_len, drop_p, seed,
-                               fwd_workspace, workspace, workspace_bytes, nullptr, stream, nullptr, nullptr, nullptr);
+                               fwd_workspace, workspace, workspace_bytes, nullptr, stream, nullptr, nullptr, nullptr, nullptr);
 }
-// the backward in the f16x2 form (emu_attn_bwd4h_kernel): qkv_mag / kv_mag as in hoisdf_attention_fwd_emu_mag, do_mag = the magnitude
-// words of dout; fwd_workspace = the planes a forward OF THE SAME FORM kept (keep = 1), or NULL (q, k, v are converted here)
+// the backward in the f16x2 form (emu_attn_bwd4h_kernel): q_mag / k_mag / v_mag as in hoisdf_attention_fwd_emu_mag, do_mag = the head
+// magnitudes of dout; fwd_workspace = the planes a forward OF THE SAME FORM kept (keep = 1), or NULL (q, k, v are converted here)
 extern "C" int hoisdf_attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                                             int ldo, const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk,
                                             float* dv, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
-                                            const void* fwd_workspace, void* workspace, long workspace_bytes, const uint32_t* qkv_mag,
-                                            const uint32_t* kv_mag, const uint32_t* do_mag, uint32_t* g_mag, void* stream) {
-  HOISDF_REQUIRE(qkv_mag && do_mag, HOISDF_ERR_INVALID, "attention_bwd_emu_mag: the magnitude words of q / k / v and of dout are required");
+                                            const void* fwd_workspace, void* workspace, long workspace_bytes, const uint32_t* q_mag,
+                                            const uint32_t* k_mag, const uint32_t* v_mag, const uint32_t* do_mag, uint32_t* g_mag, void* stream) {
+  HOISDF_REQUIRE(q_mag && k_mag && v_mag && do_mag, HOISDF_ERR_INVALID, "attention_bwd_emu_mag: the head magnitudes of q, k, v and of dout are required");
   return attention_bwd_emu_mag(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, delta, dq, dk, dv, B, H, Lq, Lk, kv_len, drop_p, seed,
-                               fwd_workspace, workspace, workspace_bytes, g_mag, stream, qkv_mag, kv_mag, do_mag);
+                               fwd_workspace, workspace, workspace_bytes, g_mag, stream, q_mag, k_mag, v_mag, do_mag);
 }
-// (internal, common.h) + g_mag: ONE array of magnitude words for dq, dk and dv together (zero on entry; null = not wanted)
+// (internal, common.h) + g_mag: ONE array of row magnitudes for dq, dk and dv together (rows b L + s of a [dq | dk | dv] matrix: Lq == Lk;
+// zero on entry; null = not wanted)
 int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                                   const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                                   int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
-                                  void* workspace, long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* qkv_mag,
-                                  const uint32_t* kv_mag, const uint32_t* do_mag) {
-  const bool h2 = qkv_mag && do_mag;                 // the f16x2 form: two scaled f16 planes per operand (emu_attn_bwd4h_kernel)
-  if (h2 && !kv_mag) kv_mag = qkv_mag;
+                                  void* workspace, long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* q_hm,
+                                  const uint32_t* k_hm, const uint32_t* v_hm, const uint32_t* do_hm) {
+  const bool h2 = q_hm && k_hm && v_hm && do_hm;     // the f16x2 form: two scaled f16 planes per operand (emu_attn_bwd4h_kernel)
+  HOISDF_REQUIRE(h2 || (!q_hm && !k_hm && !v_hm && !do_hm), HOISDF_ERR_INVALID, "attention_bwd_emu: head magnitudes of all of q, k, v, dout or of none");
+  HOISDF_REQUIRE(!g_mag || Lq == Lk, HOISDF_ERR_INVALID, "attention_bwd_emu: one row-magnitude array for dq, dk, dv needs Lq == Lk");
   // with the forward's planes (fwd_workspace) q, k, v themselves are not read: they may be null; ldq / ldk / ldv still give the
   // layouts of dq / dk / dv
   if (int rc = check_emu(fwd_workspace && !q ? o : q, fwd_workspace && !k ? o : k, fwd_workspace && !v ? o : v, ldq, ldk, ldv, B, H, Lq,
@@ -1247,11 +1262,11 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
     pq = carve(f, nq, true, false); pk = carve(f, nk, true, false); pv = carve(f, nk, true, true);
   } else {
     pq = carve(w, nq, true, false); pk = carve(w, nk, true, false); pv = carve(w, nk, true, false);
-    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, h2 ? qkv_mag : nullptr)) return rc;
-    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, h2 ? kv_mag : nullptr)) return rc;
-    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, h2 ? kv_mag : nullptr)) return rc;
+    if (int rc = convert(q, ldq, Lq, Lqp, B, H, QS2, pq, st, q_hm)) return rc;
+    if (int rc = convert(k, ldk, Lk, Lkp, B, H, 1.f, pk, st, k_hm)) return rc;
+    if (int rc = convert(v, ldv, Lk, Lkp, B, H, 1.f, pv, st, v_hm)) return rc;
   }
-  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, pd, st, h2 ? do_mag : nullptr)) return rc;
+  if (int rc = convert(dout, lddo, Lq, Lqp, B, H, 1.f, pd, st, do_hm)) return rc;
   const long ng = (long)B * Lq * H;
   hipLaunchKernelGGL(emu_attn_delta_kernel, dim3((unsigned)((ng * 16 + 255) / 256)), dim3(256), 0, st, o, ldo, dout, lddo, delta, B, H, Lq);
   if (int rc = check_launch("attention_emu_delta")) return rc;
@@ -1263,8 +1278,8 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
   a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.kv_len = kv_len;
   a.drop_p = drop_p; a.inv_keep = 1.f / (1.f - drop_p); a.thresh = drop_threshold(drop_p); a.seed = seed;
   if (h2) {
-    a.in_mag = qkv_mag; a.in_mag_kv = kv_mag; a.d_mag = do_mag;
-    a.dq_scale = reinterpret_cast<float*>(pd.r[2]);          // (the third dO plane is free in this form: the reduce pass's factor lives there)
+    a.q_hm = q_hm; a.k_hm = k_hm; a.v_hm = v_hm; a.d_hm = do_hm;
+    a.dq_scale = reinterpret_cast<float*>(pd.r[2]);          // (the third dO plane is free in this form: the reduce pass's B H factors live there)
     if (int rc = attention_bwd4h_emu_launch(a, st)) return rc;
     const long n4h = (long)B * H * Lq * 16;
     hipLaunchKernelGGL(emu_attn_dq_reduce_kernel, dim3((unsigned)((n4h + 255) / 256)), dim3(256), 0, st, part, cdiv(kv_len, 128), dq, ldq,

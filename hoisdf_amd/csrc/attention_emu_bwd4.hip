@@ -580,7 +580,10 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4_kernel(EmuAttn a) {
         gmax = max(gmax, max(mag_bits4(gk), mag_bits4(gv)));
       }
   }
-  mag_publish_wave(a.mag, gmax);              // dk / dv's share of the magnitude words of [dq | dk | dv] (common.h), when wanted
+  if (a.mag) {                                // dk / dv's share of the row magnitudes of [dq | dk | dv] (common.h): lanes c, c + 32 hold a key's row
+    gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, 32, 64));
+    if (h == 0 && key < a.Lk) atomicMax(a.mag + (size_t)b * a.Lk + key, gmax);
+  }
 }
 
 int attention_bwd4_emu_launch(const EmuAttn& a, bool chain, hipStream_t st) {

@@ -82,21 +82,18 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
   const bool kvalid = key < a.kv_len;
   const int nq = ktile * 128 < a.kv_len ? (a.Lq + 31) / 32 : 0;
   const int dhalf = wave & 1, khalf = wave >> 1;             // this wave's dQ job: d half x key half
-  // ---- operand scales from the magnitude words (common.h): sQ of the matrix q came from, sK = sV of [k | v]'s, sD of dO's ---------------
-  __shared__ uint32_t red4_[4];
-  const uint32_t aq_ = mag_words_max(a.in_mag, MAG_WORDS, red4_);
-  __syncthreads();
-  const uint32_t ak_ = mag_words_max(a.in_mag_kv, MAG_WORDS, red4_);
-  __syncthreads();
-  const uint32_t ad_ = mag_words_max(a.d_mag, MAG_WORDS, red4_);
-  const float iq = mag_inv_scale(aq_), ik = mag_inv_scale(ak_), id = mag_inv_scale(ad_);
+  // ---- operand scales from the head magnitudes (common.h) of THIS (sample, head): sQ, sK, sV of the projected matrices, sD of dO's ----
+  f16_saturate_on();
+  const int hw_ = head * a.B + b;
+  const uint32_t aq_ = a.q_hm[hw_], ak_ = a.k_hm[hw_], av_ = a.v_hm[hw_], ad_ = a.d_hm[hw_];
+  const float iq = mag_inv_scale(aq_), ik = mag_inv_scale(ak_), iv = mag_inv_scale(av_), id = mag_inv_scale(ad_);
   const float cs = fmaxf(iq * ik, 0x1p-100f);                                // accumulated scores -> log2-domain scores
   constexpr float PBIAS = 13.f;                              // P is formed as 2^13 P
   constexpr float K1 = 0x1p-36f;                             // dS' = Pd' dP_acc 2^-36 - P' delta (sD sV 2^-36): dS sS with sS = sD sV 2^-23
-  const float k2a = mag_scale(ad_) * 0x1p-18f, k2b = mag_scale(ak_) * 0x1p-18f;      // (two factors: sD sV alone can leave the f32 range)
-  const float dk_scale = (LN2 * 0x1p23f * id) * (ik * iq);   // dK = dS'^T Q' ln 2 / (sS sQ)
+  const float k2a = mag_scale(ad_) * 0x1p-18f, k2b = mag_scale(av_) * 0x1p-18f;      // (two factors: sD sV alone can leave the f32 range)
+  const float dk_scale = (LN2 * 0x1p23f * id) * (iv * iq);   // dK = dS'^T Q' ln 2 / (sS sQ)
   const float dv_scale = 0x1p-13f * id;                      // dV = Pd'^T dO' / (2^13 sD)
-  if (blockIdx.x == 0 && tid == 0 && a.dq_scale) *a.dq_scale = (0.125f * 0x1p23f * id) * (ik * ik);      // dQ = K'^T dS' / (8 sK sS)
+  if (ktile == 0 && tid == 0 && a.dq_scale) a.dq_scale[bh] = (0.125f * 0x1p23f * id) * (ik * iv);      // dQ = K'^T dS' / (8 sK sS), per (b, head)
 
   // ---- resident operands ------------------------------------------------------------------------------------------------
   bf16x8 kf[4][2], vf[4][2], ktf[4][2];
@@ -478,7 +475,10 @@ __global__ __launch_bounds__(256, 1) void emu_attn_bwd4h_kernel(EmuAttn a) {
         gmax = max(gmax, max(mag_bits4(gk), mag_bits4(gv)));
       }
   }
-  mag_publish_wave(a.mag, gmax);              // dk / dv's share of the magnitude words of [dq | dk | dv] (common.h), when wanted
+  if (a.mag) {                                // dk / dv's share of the row magnitudes of [dq | dk | dv] (common.h): lanes c, c + 32 hold a key's row
+    gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, 32, 64));
+    if (h == 0 && key < a.Lk) atomicMax(a.mag + (size_t)b * a.Lk + key, gmax);
+  }
 }
 
 int attention_bwd4h_emu_launch(const EmuAttn& a, hipStream_t st) {

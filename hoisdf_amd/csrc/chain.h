@@ -64,15 +64,17 @@ const void* image_of(Ctx& c, const void* given, const float* W, int ldw, int N, 
 // K_pad >= K (default K): columns K .. K_pad - 1 of x are zero padding; the emulated form contracts over K_pad (they meet the zero
 // fill of the weight image, which is built from the K real columns) so that a ragged K (289) still takes the bf16 pipe
 void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const void* img, const float* b, float* y, int ldy, long M, int N,
-             int K, int act, float p, uint64_t seed, uint32_t* bits, int K_pad = 0, const uint32_t* x_mag = nullptr, uint32_t* y_mag = nullptr) {
-  // x_mag / y_mag: magnitude words of x (null: unknown) and for y (null: not wanted; zero on entry) - common.h; only the emulated
-  // tiled form reads / writes them: a caller that hands y_mag on must know that form ran (emu_rows of the same arguments)
+             int K, int act, float p, uint64_t seed, uint32_t* bits, int K_pad = 0, const uint32_t* x_mag = nullptr, uint32_t* y_mag = nullptr,
+             uint32_t* y_heads = nullptr, int head_L = 0) {
+  // x_mag / y_mag: row magnitudes of x (null: unknown) and for y (null: not wanted; zero on entry) - common.h; only the emulated
+  // tiled form reads / writes them: a caller that hands y_mag on must know that form ran (emu_rows of the same arguments);
+  // y_heads: head magnitudes of y (samples of head_L rows), the same way
   if (!c.ok()) return;
   if (K_pad < K || (K_pad + 15) / 16 != (K + 15) / 16) K_pad = K;
   if (emu_rows(c, M, x, ldx, K_pad)) {
     const void* im = image_of(c, img, W, ldw, N, K, 0);
     if (c.dry || !c.ok()) return;
-    c.rc = linear_fwd_emu_mag(x, ldx, im, b, y, ldy, M, N, K_pad, act, p, seed, bits, x_mag, y_mag, c.stream);
+    c.rc = linear_fwd_emu_mag(x, ldx, im, b, y, ldy, M, N, K_pad, act, p, seed, bits, x_mag, y_mag, c.stream, y_heads, head_L);
     return;
   }
   if (c.dry) return;
@@ -80,13 +82,15 @@ void lin_fwd(Ctx& c, const float* x, int ldx, const float* W, int ldw, const voi
   c.rc = hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, act, p, seed, bits, c.stream);
 }
 void lin_bwd_input(Ctx& c, const float* dy, int lddy, const uint32_t* bits, float p, const float* W, int ldw, const void* img_t, float* dx,
-                   int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag = nullptr, uint32_t* dx_mag = nullptr) {
+                   int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag = nullptr, uint32_t* dx_mag = nullptr,
+                   uint32_t* dx_heads = nullptr, int head_L = 0) {
   if (!c.ok()) return;
   if (!bits) p = 0.f;
   if (emu_rows(c, M, dy, lddy, N)) {
     const void* im = image_of(c, img_t, W, ldw, N, K, 1);
     if (c.dry || !c.ok()) return;
-    c.rc = linear_bwd_input_emu_mag(dy, lddy, bits, p, im, dx, lddx, M, N, K, accumulate, dy_mag, accumulate ? nullptr : dx_mag, c.stream);
+    c.rc = linear_bwd_input_emu_mag(dy, lddy, bits, p, im, dx, lddx, M, N, K, accumulate, dy_mag, accumulate ? nullptr : dx_mag, c.stream,
+                                    accumulate ? nullptr : dx_heads, head_L);
     return;
   }
   if (c.dry) return;

@@ -89,39 +89,63 @@ int linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, const float
 void attention_emu_plane_targets(void* workspace, int B, int H, int Lq, int Lk, int keep, QkvPlanes& q_part, QkvPlanes& kv_part);
 int attention_fwd_emu_planes(float* o, int ldo, float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed,
                              void* workspace, int keep, void* stream, uint32_t* o_mag = nullptr);
-// hoisdf_attention_fwd_emu / _bwd_emu with magnitude words (below) for o / for [dq | dk | dv] together
+// hoisdf_attention_fwd_emu / _bwd_emu with row magnitudes (below) for o / for [dq | dk | dv] together, and - the f16x2 form - the head
+// magnitudes (below) of q, k, v (and dout): all of them or none
 int attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse, int B,
                           int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace, long workspace_bytes, int keep,
-                          uint32_t* o_mag, void* stream, const uint32_t* qkv_mag = nullptr,       // qkv_mag: the f16x2 form of the forward
-                          const uint32_t* kv_mag = nullptr);                                     // (k, v from another matrix than q: its words)
+                          uint32_t* o_mag, void* stream, const uint32_t* q_hm = nullptr, const uint32_t* k_hm = nullptr,
+                          const uint32_t* v_hm = nullptr);
 int attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                           const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B, int H,
                           int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace, void* workspace,
-                          long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* qkv_mag = nullptr,
-                          const uint32_t* kv_mag = nullptr, const uint32_t* do_mag = nullptr);      // all three: the f16x2 form
+                          long workspace_bytes, uint32_t* g_mag, void* stream, const uint32_t* q_hm = nullptr,
+                          const uint32_t* k_hm = nullptr, const uint32_t* v_hm = nullptr, const uint32_t* do_hm = nullptr);
 
-// gemm_emu.hip, f16x2 form: is it on (HOISDF_EMU_FORM, process-wide); magnitude words of a row-major f32 matrix (emu_amax_words()
-// words, each the bits of a max |x| over a share of the matrix: the contraction's operand scale is derived from their maximum)
+// gemm_emu.hip, f16x2 form: is it on (HOISDF_EMU_FORM, process-wide); row magnitudes (below) of a row-major f32 matrix measured by
+// the library: M words, plain stores (no zeroing needed); head magnitudes of an attention operand (groups = columns / 64, L rows per sample)
 bool emu_form_h2();
-int emu_amax_words();
-int emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st);
-int emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st);      // into magnitude words (below)
+int emu_rowmag_launch(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st);
+int emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st);      // the same, traced as "a chain, once for all its readers"
+int emu_headmag_launch(const float* x, long ld, long M, int groups, int L, uint32_t* words, hipStream_t st);   // zeroes, then folds
+uint32_t* mag_scratch(hipStream_t st, long words);      // stream-ordered scratch for words the library measures itself (per device and stream)
 
-// ---- magnitude words (f16x2 form).  A kernel that writes a matrix which a later contraction reads as its row operand can leave
-// that matrix's largest magnitude behind while it still holds the values: MAG_WORDS u32 words, zero before the producer(s) run,
-// each wave folds the bits of its max |value| into one of them with an unsigned atomic max (|x| as IEEE bits orders like |x|;
-// several producers may share an array - dQ / dK / dV of one [dq | dk | dv] matrix).  The consumer reads the MAG_WORDS words.
-// An operand without words gets hoisdf's own magnitude pass (emu_amax_launch: one more read of the matrix).
-constexpr int MAG_WORDS = 256;
+// ---- row magnitudes (f16x2 form; round 6: one word per ROW instead of 256 words per matrix).  A kernel that writes a matrix which
+// a later contraction reads as its row operand leaves each row's largest magnitude behind while it still holds the values: one u32
+// per row, the IEEE bits of max |x[row][:]| (|x| as bits orders like |x|), ZERO before the producer(s) run, folded with an unsigned
+// atomic max - order-independent, hence deterministic; several producers may share an array (the column tiles of a GEMM, the heads
+// of an attention output, dQ / dK / dV of one [dq | dk | dv] matrix).  The forward / grad-input contraction scales EVERY ROW by its
+// own power of two (the scale leaves again in the epilogue, per output row): a row's rounding depends on that row alone - samples of
+// a batch do not see each other, and a row far below the matrix maximum keeps its 22 bits.  The grad-weight contracts OVER the rows:
+// each of its row slices takes the largest word of its own rows.  An operand without words gets hoisdf's own pass (emu_rowmag_launch:
+// one more read of the matrix).  A word smaller than the row's true maximum (a stale array) cannot produce Inf / NaN: the kernels that
+// split run with MODE.FP16_OVFL set, so an f16 piece saturates at +-65504 (4 x head room above the promised [2^13, 2^14), then clipping).
 __device__ __forceinline__ uint32_t mag_bits(float v) { return __builtin_bit_cast(uint32_t, v) & 0x7fffffffu; }
 __device__ __forceinline__ uint32_t mag_bits4(const float4& v) {
   return max(max(mag_bits(v.x), mag_bits(v.y)), max(mag_bits(v.z), mag_bits(v.w)));
 }
-__device__ __forceinline__ void mag_publish_wave(uint32_t* words, uint32_t m) {      // all 64 lanes of a wave; words may be null
+// f16 conversions of this wave saturate instead of overflowing to Inf (MODE.FP16_OVFL, hwreg(HW_REG_MODE, 23, 1)): once, at kernel entry
+__device__ __forceinline__ void f16_saturate_on() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+// all 64 lanes of a wave hold (part of) ONE row: fold the wave's maximum into that row's word; words may be null
+__device__ __forceinline__ void rowmag_publish_wave(uint32_t* words, long row, uint32_t m);
+// groups of G consecutive lanes (G = 4, 8, 16, 32, 64) each hold (part of) one row: every group's maximum ends in all of its lanes.
+// Within a 16-lane row the exchange is DPP (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: no LDS traffic).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int G>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t m) {
+  static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  m = max(m, dpp_u32<0xB1>(m));
+  m = max(m, dpp_u32<0x4E>(m));
+  if (G >= 8) m = max(m, dpp_u32<0x141>(m));
+  if (G >= 16) m = max(m, dpp_u32<0x140>(m));
+  if (G >= 32) m = max(m, (uint32_t)__shfl_xor((int)m, 16, 64));
+  if (G >= 64) m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));
+  return m;
+}
+__device__ __forceinline__ void rowmag_publish_wave(uint32_t* words, long row, uint32_t m) {
   if (!words) return;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(words + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (MAG_WORDS - 1)), m);
+  m = group_max_u32<64>(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(words + row, m);
 }
 // power-of-two operand scale from the largest magnitude (bits of |x|max): max |x| s in [2^13, 2^14); zero / denormal / huge maxima clamp
 __device__ __forceinline__ uint32_t mag_exp(uint32_t amax_bits) { return min(max((amax_bits >> 23) & 0xffu, 14u), 254u); }
@@ -134,17 +158,19 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* red4) { 
   __syncthreads();
   return max(max(red4[0], red4[1]), max(red4[2], red4[3]));
 }
-// the maximum over an array of magnitude words, by a 256-thread block (all threads call it)
-__device__ __forceinline__ uint32_t mag_words_max(const uint32_t* words, int n, uint32_t* red4) {
-  uint32_t m = 0u;
-  for (int i = threadIdx.x; i < n; i += 256) m = max(m, words[i]);
-  return block_max_u32(m, red4);
-}
+// ---- head magnitudes: the operands of the emulated attention (Q, K, V, dO: column slices of 64 per head, L rows per sample) take ONE
+// scale per (sample, head) - the softmax of a (sample, head) never sees another one's scale.  Layout of the words of a matrix with nc
+// 64-column groups and nb samples: word[group * nb + sample], zero before the producer runs (the GEMM whose epilogue writes the matrix
+// folds each wave tile's maximum into the word(s) of the samples its rows belong to; hoisdf_head_mag_measure for a matrix nobody described).
+__device__ __forceinline__ long head_words(long groups, long nb) { return groups * nb; }
 // the entries below with magnitude words (null = none): x_mag / dy_mag describe the row operand, y_mag / dx_mag receive the output's
+// (y_heads / dx_heads: head magnitudes of the output, samples of head_L rows; null = not wanted)
 int linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K, int act,
-                       float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag, uint32_t* y_mag, void* stream);
+                       float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag, uint32_t* y_mag, void* stream,
+                       uint32_t* y_heads = nullptr, int head_L = 0);
 int linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image, float* dx, int lddx,
-                             long M, int N, int K, int accumulate, const uint32_t* dy_mag, uint32_t* dx_mag, void* stream);
+                             long M, int N, int K, int accumulate, const uint32_t* dy_mag, uint32_t* dx_mag, void* stream,
+                             uint32_t* dx_heads = nullptr, int head_L = 0);
 int linear_bwd_weight_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const float* x, int ldx, float* dW, int lddw,
                               float* db, long M, int N, int K, float* workspace, long workspace_floats, const uint32_t* dy_mag,
                               const uint32_t* x_mag, void* stream);

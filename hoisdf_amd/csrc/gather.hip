@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, f
   const int lane = threadIdx.x & 63;
   long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long stride = (long)gridDim.x * 4;
-  uint32_t fmax = 0u;                               // feat's magnitude words (common.h), when wanted
   for (; r < a.n_rows; r += stride) {
+    uint32_t fmax = 0u;                             // feat's row magnitude (common.h), when wanted
     int b;
     float cam[3], uv[2], g[2];
     project_row(a, r, b, cam, uv, g);
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, f
       out[u] = acc;
       fmax = max(fmax, mag_bits4(acc));
     }
+    rowmag_publish_wave(feat_mag, r, fmax);
   }
-  mag_publish_wave(feat_mag, fmax);
 }
 
 __global__ __launch_bounds__(256) void gather_bwd_kernel(PyrDev P, ProjArgs a, const float* __restrict__ dfeat,

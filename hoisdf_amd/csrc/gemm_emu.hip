@@ -22,8 +22,10 @@
 // LDS-transposed 16-byte stores).
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
 
 #include "common.h"
 
@@ -31,6 +33,7 @@ namespace hoisdf {
 
 namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MFB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -66,9 +69,10 @@ struct EmuArgs {
   int act; float drop_p, inv_keep; uint32_t thresh; uint64_t seed;
   int tiles_m, tiles_n, vecC, beta;
   QkvPlanes qkv;                            // .on: the output tile goes into attention planes instead of C (common.h)
-  // f16x2 form: magnitude partials of A (max over a_amax_n words = max |A|, or an upper bound), the image's {scale, 1 / scale}
-  const uint32_t* a_amax; int a_amax_n; const float* b_scale;
-  uint32_t* amax_out;                       // magnitude words of C (common.h MAG_WORDS; any form; null = not wanted)
+  // f16x2 form: row magnitudes of A (common.h: one word per row, bits of max |A[row][:]| or an upper bound), the image's {scale, 1 / scale}
+  const uint32_t* a_amax; const float* b_scale;
+  uint32_t* amax_out;                       // row magnitudes of C (any form; zero on entry; null = not wanted)
+  uint32_t* head_out; int head_L, head_nb;  // head magnitudes of C (common.h: word[(col / 64) * head_nb + row / head_L]; null = not wanted)
 };
 }  // namespace
 
@@ -124,10 +128,21 @@ __global__ __launch_bounds__(256) void emu_prep_weight_batch_kernel(const hoisdf
 // sign map, accumulate-into, LDS-transposed 16-byte stores
 template <int TM_, int TN_, int NJ_>
 __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][NJ_], u32x4* lds, int m0, int n0, int wm, int wn, int wave,
-                                             int lane, int l31, int kh, float post_scale) {
+                                             int lane, int l31, int kh, float post_scale, const float* row_post = nullptr) {
   constexpr int WN_ = TN_ / 2;
   static_assert(WN_ == NJ_ * 32, "wave tile");
-  if (post_scale != 1.f) {                     // (grad-input, rotated form) 1 / keep of the forward's dropout, once per element; (f16x2) the operand scales
+  if (row_post) {                              // (f16x2) one factor per output ROW: the row's operand scale, the weight's, 1 / keep - from LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(row_post + wm * 128 + i * 32 + 8 * q + 4 * kh);
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] *= ps[e];
+      }
+  } else if (post_scale != 1.f) {                     // (grad-input, rotated form) 1 / keep of the forward's dropout, once per element; (f16x2) the operand scales
 #pragma unroll
     for (int j = 0; j < NJ_; ++j)
 #pragma unroll
@@ -163,17 +178,27 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
         for (int j = 0; j < NJ_; ++j) acc[i][j][r] *= drop_scale(rk, (uint32_t)(cbase + j * 32), g.thresh, g.inv_keep);
       }
   }
-  if (g.amax_out) {
-    // largest magnitude of the finished tile -> the output's magnitude words (common.h: the f16x2 form of the NEXT contraction scales
-    // its operand by it).  Rows / columns past M / N hold bias-only values: still a fair bound.
-    float m = 0.f;
+  if (g.head_out) {
+    // head magnitudes (common.h): each 64-column group of the wave's 128-row sub-tile -> the word(s) of the sample(s) its rows belong to
+    // (one sample when head_L % 128 == 0; otherwise every sample the 128 rows touch gets the whole sub-tile's maximum: an upper bound)
+    const int row0 = m0 + wm * 128;
+    if (row0 < g.M) {
+      const int b0 = row0 / g.head_L, b1 = (min(row0 + 127, g.M - 1)) / g.head_L;
 #pragma unroll
-    for (int j = 0; j < NJ_; ++j)
+      for (int hh = 0; hh < NJ_ / 2; ++hh) {
+        float m = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, __builtin_fabsf(acc[i][j][r]));
-    mag_publish_wave(g.amax_out, __builtin_bit_cast(uint32_t, m));
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, __builtin_fabsf(acc[i][2 * hh + j][r]));
+        uint32_t mb = group_max_u32<64>(__builtin_bit_cast(uint32_t, m));
+        const int grp = (n0 + wn * WN_ + hh * 64) >> 6;
+        if (lane == 0 && n0 + wn * WN_ + hh * 64 < g.N)
+          for (int b = b0; b <= b1; ++b) atomicMax(g.head_out + (size_t)grp * g.head_nb + b, mb);
+      }
+    }
   }
   if (g.qkv.on) {
     // attention-plane output (common.h QkvPlanes): every 128 x 64 part of the wave's sub-tile is 128 consecutive tokens of one sample x
@@ -253,6 +278,10 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
         const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
         float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
         float4* cp = reinterpret_cast<float4*>(g.C + (size_t)(m0 + wm * 128 + i * 32 + rr) * g.ldc + n0 + wn * WN_ + cc);
+        if (g.amax_out) {                     // row magnitudes of C (common.h): the LPR lanes of a row fold their share of it
+          const uint32_t mb = group_max_u32<LPR>(mag_bits4(v));
+          if (lane % LPR == 0) atomicMax(g.amax_out + (m0 + wm * 128 + i * 32 + rr), mb);
+        }
         if (g.beta) {
           const float4 old = *cp;
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
@@ -276,6 +305,19 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
             *cp = g.beta ? *cp + acc[i][j][r] : acc[i][j][r];
           }
         }
+    if (g.amax_out) {                         // (edge tiles / unaligned C: per row over the 32 lanes that hold its columns)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+          uint32_t mb = 0u;
+#pragma unroll
+          for (int j = 0; j < NJ_; ++j) if (cbase + j * 32 < g.N) mb = max(mb, mag_bits(acc[i][j][r]));
+          mb = group_max_u32<32>(mb);
+          if (l31 == 0 && row < g.M) atomicMax(g.amax_out + row, mb);
+        }
+    }
   }
   if (g.bits_out) {
     // lanes 0-31 hold 32 consecutive columns of one row, lanes 32-63 of the row 4 below: one ballot is two mask words.
@@ -673,7 +715,6 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int HTM = 256, HTN = 256;
 constexpr int HA_U4 = 2 * 2 * HTM, HB_U4 = 2 * 2 * HTN;      // 16-byte units of the activation stage / of one 256-row image block per slab
 constexpr int H_TRAILER = 128;
-constexpr int AMAX_BLOCKS = 512;
 
 // (the power-of-two operand scale from the magnitude words and the 256-thread block maximum live in common.h: the attention kernels use them too)
 __device__ __forceinline__ uint32_t h2_exp(uint32_t amax_bits) { return mag_exp(amax_bits); }
@@ -681,28 +722,52 @@ __device__ __forceinline__ float h2_scale(uint32_t amax_bits) { return mag_scale
 __device__ __forceinline__ float h2_inv_scale(uint32_t amax_bits) { return mag_inv_scale(amax_bits); }
 }  // namespace
 
-// magnitude words of a row-major f32 matrix: block b -> part[b] = bits of max |x| over its share (AMAX_BLOCKS blocks)
-template <bool WORDS>      // WORDS: folded into MAG_WORDS zero-filled magnitude words (common.h) instead of one plain word per block
-__global__ __launch_bounds__(256) void emu_amax_kernel(const float* __restrict__ x, long ld, long M, int K, uint32_t* __restrict__ part) {
-  __shared__ uint32_t red4[4];
+// row magnitudes (common.h) of a row-major f32 matrix measured by the library: one wave per row, eight rows in flight per wave, plain
+// stores (every row is written: no zeroing needed).  K % 4 == 0, rows 16-byte aligned.
+__global__ __launch_bounds__(256) void emu_rowmag_kernel(const float* __restrict__ x, long ld, long M, int K, uint32_t* __restrict__ words) {
+  constexpr int RPW = 8;
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   const int k4 = K >> 2;
-  const long n4 = M * k4;
-  uint32_t m = 0u;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256 * 4) {
-    uint32_t mm[4];
+  uint32_t m[RPW];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long j = i + (long)u * gridDim.x * 256;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (j < n4) { const long r = j / k4; v = *reinterpret_cast<const u32x4*>(x + r * ld + (j - r * k4) * 4); }
-      mm[u] = max(max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu));
-    }
-    m = max(m, max(max(mm[0], mm[1]), max(mm[2], mm[3])));
+  for (int r = 0; r < RPW; ++r) {
+    m[r] = 0u;
+    if (row0 + r < M)
+      for (int c = lane; c < k4; c += 64) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (row0 + r) * ld + 4 * c);
+        m[r] = max(m[r], max(max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu)));
+      }
   }
-  m = block_max_u32(m, red4);
-  if (threadIdx.x == 0) {
-    if (WORDS) atomicMax(part + (blockIdx.x & (MAG_WORDS - 1)), m);
-    else part[blockIdx.x] = m;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const uint32_t mm = group_max_u32<64>(m[r]);
+    if (lane == 0 && row0 + r < M) words[row0 + r] = mm;
+  }
+}
+// head magnitudes (common.h) of a row-major f32 matrix: groups of 64 columns x samples of L rows -> words[group * nb + sample] (zero on
+// entry).  One wave per 16 consecutive rows; a 16-lane group owns a column group (ncols = 64 groups: (groups + 3) / 4 sweeps).
+__global__ __launch_bounds__(256) void emu_headmag_kernel(const float* __restrict__ x, long ld, long M, int groups, int L, int nb,
+                                                          uint32_t* __restrict__ words) {
+  const int lane = threadIdx.x & 63;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  for (int g0 = 0; g0 < groups; g0 += 4) {
+    const int grp = g0 + (lane >> 4);
+    uint32_t m = 0u; long cur = -1;
+    for (int r = 0; r < 16; ++r) {
+      const long row = row0 + r;
+      if (row >= M) break;
+      const long b = row / L;
+      if (b != cur) {
+        if (cur >= 0 && grp < groups) { const uint32_t mm = group_max_u32<16>(m); if ((lane & 15) == 0) atomicMax(words + (size_t)grp * nb + cur, mm); }
+        cur = b; m = 0u;
+      }
+      if (grp < groups) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * ld + grp * 64 + 4 * (lane & 15));
+        m = max(m, max(max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu)));
+      }
+    }
+    if (cur >= 0 && grp < groups) { const uint32_t mm = group_max_u32<16>(m); if ((lane & 15) == 0) atomicMax(words + (size_t)grp * nb + cur, mm); }
   }
 }
 
@@ -791,7 +856,7 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
   constexpr int EPI = (4 * 32 * (TN_ / 2 + 4) * 4 + 64) / 16;         // the epilogue's four transposition slices + a few words
   __shared__ __attribute__((aligned(16))) u32x4 st0[EPI > STG ? EPI : STG];
   __shared__ __attribute__((aligned(16))) u32x4 st1[STG];
-  __shared__ uint32_t red4[4];
+  __shared__ __attribute__((aligned(16))) float rpost[HTM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -800,13 +865,22 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
   const int m0 = tm * HTM, n0 = tn * TN_;
   const int nslab = (g.K + KS - 1) / KS;
   const int last = nslab - 1;
+  const int rl = lane >> 2, qd = lane & 3, cq = qd >> 1;
 
-  // operand scales: A from its magnitude words, the weight's from the image trailer
-  uint32_t amb = 0u;
-  for (int i = tid; i < g.a_amax_n; i += NT) amb = max(amb, g.a_amax[i]);
-  amb = block_max_u32(amb, red4);
-  const float sA = h2_scale(amb);
-  const float post = h2_inv_scale(amb) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
+  // operand scales: ONE PER ROW of A from its row magnitudes (common.h; a row's rounding depends on that row alone), the weight's from
+  // the image trailer.  The staging thread keeps the scales of its four rows; every output row's factor (1 / row scale, 1 / weight
+  // scale, 1 / keep) waits in LDS for the epilogue.  f16 conversions saturate (a word below the row's true maximum clips, no Inf).
+  f16_saturate_on();
+  {
+    const int row = m0 + tid;
+    rpost[tid] = h2_inv_scale(row < g.M ? g.a_amax[row] : 0u) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
+  }
+  float sAr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + i * 64 + wave * 16 + rl;
+    sAr[i] = h2_scale(row < g.M ? g.a_amax[row] : 0u);
+  }
 
   f32x16 acc[4][NJ];
 #pragma unroll
@@ -817,7 +891,6 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // staging roles, descriptors and LDS slots: emu_kc2_kernel's (item i = row i * 64 + wave * 16 + lane / 4, quad lane % 4)
-  const int rl = lane >> 2, qd = lane & 3, cq = qd >> 1;
   const int rows_in = min(HTM, g.M - m0);
   __amdgpu_buffer_rsrc_t rsa[4], rsm[4];
 #pragma unroll
@@ -866,7 +939,7 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
       v_ = f32x2{xa_, xb_};                                                                                            \
     }                                                                                                                  \
     if (KTAIL) { if (!kin) v_ = f32x2{0.f, 0.f}; }                                                                     \
-    v_ *= sA;                                                                                                          \
+    v_ *= sAr[(p) >> 1];                                                                                               \
     const f16x2 h_ = __builtin_convertvector(v_, f16x2);                                                               \
     t0[p] = __builtin_bit_cast(uint32_t, h_); rp[p] = v_;                                                              \
     fu[p] = __builtin_convertvector(h_, f32x2);                                                                        \
@@ -943,7 +1016,7 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
 #undef SYNC
 #undef HSTAGE_ALL
 #undef HLOAD_ALL
-  emu_epilogue<HTM, TN_, NJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, post);
+  emu_epilogue<HTM, TN_, NJ>(g, acc, st0, m0, n0, wm, wn, wave, lane, l31, kh, 1.f, rpost);
 }
 
 
@@ -973,7 +1046,7 @@ struct DwArgs {
   float* colsum; long colsum_split_stride;   // partial bias gradients [split][N] (or db), may be null
   int M, N, K;
   int splitk, m_per_split, tiles_n, tiles_k;
-  const uint32_t* dy_amax; int dy_amax_n; const uint32_t* x_amax; int x_amax_n;      // f16x2 form: magnitude words of dy and x
+  const uint32_t* dy_amax; const uint32_t* x_amax;      // f16x2 form: row magnitudes (common.h) of dy and x, M words each
 };
 }  // namespace
 
@@ -1431,10 +1504,11 @@ __global__ __launch_bounds__(NT, 1) void emu_dw2h_kernel(DwArgs g) {
   const int mbeg = split * g.m_per_split;
   const int mend = min(g.M, mbeg + g.m_per_split);
   const int nslab = (mend - mbeg + KS - 1) / KS;
-  // operand scales from the magnitude words (common.h): dy s_dy and x s_x in [2^13, 2^14) at their largest element
+  // operand scales from the row magnitudes (common.h) of THIS slice's rows (the contraction runs over them, so one scale per operand
+  // and slice; the partial tile leaves unscaled): dy s_dy and x s_x in [2^13, 2^14) at the slice's largest element
+  f16_saturate_on();
   uint32_t am_dy = 0u, am_x = 0u;
-  for (int i = threadIdx.x; i < g.dy_amax_n; i += NT) am_dy = max(am_dy, g.dy_amax[i]);
-  for (int i = threadIdx.x; i < g.x_amax_n; i += NT) am_x = max(am_x, g.x_amax[i]);
+  for (int i = mbeg + (int)threadIdx.x; i < mend; i += NT) { am_dy = max(am_dy, g.dy_amax[i]); am_x = max(am_x, g.x_amax[i]); }
   am_dy = block_max_u32(am_dy, red4);
   __syncthreads();
   am_x = block_max_u32(am_x, red4);
@@ -1682,21 +1756,33 @@ bool form_h2() {
   return f == 1;
 }
 
-// magnitude words for an operand nobody measured: a ring of word arrays per stream (stream order makes the reuse safe)
-uint32_t* amax_ring_slot(hipStream_t st) {
-  struct Ring { uint32_t* base; unsigned next; };
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, Ring> rings;
-  constexpr unsigned SLOTS = 64;
-  std::lock_guard<std::mutex> lk(mu);
-  Ring& r = rings[st];
-  if (!r.base) {
-    if (hipMalloc(reinterpret_cast<void**>(&r.base), (size_t)SLOTS * AMAX_BLOCKS * 4) != hipSuccess) { r.base = nullptr; return nullptr; }
-    r.next = 0;
-  }
-  return r.base + (size_t)(r.next++ % SLOTS) * AMAX_BLOCKS;
-}
 }  // namespace
+
+// row / head magnitudes for an operand nobody described: stream-ordered scratch from one arena per (device, stream) - the stream
+// handle alone is not a key (torch's default stream is handle 0 on every device).  Everything that reads a slot runs on the slot's
+// stream behind the pass that filled it, so wrapping around is safe whatever the arena's size; an arena that is too small for a
+// request is replaced by a larger one (the old one stays allocated: launches in flight may still read it).  The first use on a
+// stream allocates (hipMalloc synchronises and is illegal under graph capture: hosts that capture pass their own words).
+uint32_t* mag_scratch(hipStream_t st, long words) {
+  struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Arena> arenas;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const size_t bytes = ((size_t)(words > 0 ? words : 1) * 4 + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> lk(mu);
+  Arena& a = arenas[std::make_pair(dev, st)];
+  if (!a.base || bytes * 4 > a.cap) {
+    const size_t cap = bytes * 8 > ((size_t)32 << 20) ? bytes * 8 : ((size_t)32 << 20);
+    char* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), cap) != hipSuccess) return nullptr;
+    a.base = p; a.cap = cap; a.off = 0;
+  }
+  if (a.off + bytes > a.cap) a.off = 0;
+  uint32_t* r = reinterpret_cast<uint32_t*>(a.base + a.off);
+  a.off += bytes;
+  return r;
+}
 
 // HOISDF_MAG_TRACE=1: every operand the library had to measure itself, on stderr (who asked, rows x columns) - which producers to teach
 static void mag_trace(const char* who, long M, int K) {
@@ -1704,18 +1790,25 @@ static void mag_trace(const char* who, long M, int K) {
   if (on < 0) { const char* e = getenv("HOISDF_MAG_TRACE"); on = (e && atoi(e) != 0) ? 1 : 0; }
   if (on) fprintf(stderr, "[hoisdf mag] measured by the library: %s operand %ld x %d\n", who, M, K);
 }
-// magnitude words of a row-major matrix into `part` (AMAX_BLOCKS words)
-int emu_amax_launch(const float* x, long ld, long M, int K, uint32_t* part, hipStream_t st) {
-  hipLaunchKernelGGL(emu_amax_kernel<false>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, part);
-  return check_launch("emu_amax");
+// row magnitudes of a row-major matrix into `words` (M words, every one written)
+int emu_rowmag_launch(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st) {
+  if (M <= 0) return HOISDF_OK;
+  hipLaunchKernelGGL(emu_rowmag_kernel, dim3((unsigned)cdiv(M, 32)), dim3(256), 0, st, x, ld, M, K, words);
+  return check_launch("emu_rowmag");
 }
-// the same pass into magnitude words (MAG_WORDS, zero on entry): for an operand several contractions will read
+// the same pass for an operand several contractions will read
 int emu_mag_measure(const float* x, long ld, long M, int K, uint32_t* words, hipStream_t st) {
   mag_trace("a chain, once for all its readers:", M, K);
-  hipLaunchKernelGGL(emu_amax_kernel<true>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ld, M, K, words);
-  return check_launch("emu_amax (words)");
+  return emu_rowmag_launch(x, ld, M, K, words, st);
 }
-int emu_amax_words() { return AMAX_BLOCKS; }
+// head magnitudes (common.h) of x[M][groups * 64 ...]: words[group * nb + row / L], nb = ceil(M / L); cleared here
+int emu_headmag_launch(const float* x, long ld, long M, int groups, int L, uint32_t* words, hipStream_t st) {
+  const int nb = cdiv(M, L);
+  if (hipMemsetAsync(words, 0, (size_t)groups * nb * 4, st) != hipSuccess) { set_error("head magnitudes: memset failed"); return HOISDF_ERR_LAUNCH; }
+  if (M <= 0) return HOISDF_OK;
+  hipLaunchKernelGGL(emu_headmag_kernel, dim3((unsigned)cdiv(M, 64)), dim3(256), 0, st, x, ld, M, groups, L, nb, words);
+  return check_launch("emu_headmag");
+}
 bool emu_form_h2() { return form_h2(); }
 
 namespace {
@@ -1748,11 +1841,11 @@ int launch_emu(EmuArgs g, hipStream_t st) {
     g.tiles_n = cdiv(g.N, tw);
     g.b_scale = reinterpret_cast<const float*>(h2_trailer(const_cast<u32x4*>(g.Bimg), g.N, g.K)) + 16;
     if (!g.a_amax) {
-      uint32_t* part = amax_ring_slot(st);
-      if (!part) { set_error("linear_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      uint32_t* part = mag_scratch(st, g.M);
+      if (!part) { set_error("linear_emu: cannot allocate the row magnitudes"); return HOISDF_ERR_LAUNCH; }
       mag_trace(g.beta ? "grad-input (+=)" : g.abits ? "grad-input (masked)" : g.qkv.on ? "in-projection" : "forward / grad-input", g.M, g.K);
-      if (int rc = emu_amax_launch(g.A, g.lda, g.M, g.K, part, st)) return rc;
-      g.a_amax = part; g.a_amax_n = AMAX_BLOCKS;
+      if (int rc = emu_rowmag_launch(g.A, g.lda, g.M, g.K, part, st)) return rc;
+      g.a_amax = part;
     }
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(NT);
     const bool kt = g.K % KS != 0 || (cdiv(g.K, KS) & 1);
@@ -1845,23 +1938,28 @@ extern "C" int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_
                                          uint32_t* y_mag, void* stream) {
   return linear_fwd_emu_mag(x, ldx, w_image, bias, y, ldy, M, N, K, act, drop_p, seed, relu_bits, x_mag, y_mag, stream);
 }
-extern "C" int hoisdf_mag_words(void) { return MAG_WORDS; }
-// the magnitude words of a matrix nobody left words for: one read of x (hosts that chain the *_mag entries themselves call this once per
-// operand instead of letting every consumer measure it again)
+// row magnitudes (include/hoisdf.h): u32 words a matrix of `rows` rows takes
+extern "C" long hoisdf_mag_words(long rows) { return rows > 0 ? rows : 0; }
+// the row magnitudes of a matrix nobody left words for: one read of x (hosts that chain the *_mag entries themselves call this once per
+// operand instead of letting every contraction measure it again); every word is written, no clearing needed
 extern "C" int hoisdf_mag_measure(const float* x, long ldx, long M, int K, uint32_t* words, void* stream) {
   HOISDF_REQUIRE(words && (M == 0 || x) && M >= 0 && K > 0 && ldx >= K, HOISDF_ERR_INVALID, "mag_measure: bad arguments");
   HOISDF_REQUIRE(M == 0 || hoisdf_linear_emu_supported(x, ldx, K), HOISDF_ERR_INVALID, "mag_measure: x must be 16-byte aligned with ldx and K multiples of 4");
-  hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(words, 0, MAG_WORDS * sizeof(uint32_t), st) != hipSuccess) { set_error("mag_measure: memset failed"); return HOISDF_ERR_LAUNCH; }
-  if (M == 0) return HOISDF_OK;
-  hipLaunchKernelGGL(emu_amax_kernel<true>, dim3(AMAX_BLOCKS), dim3(256), 0, st, x, ldx, M, K, words);
-  return check_launch("mag_measure");
+  return emu_rowmag_launch(x, ldx, M, K, words, as_stream(stream));
+}
+// head magnitudes (include/hoisdf.h) of an attention operand matrix x[M][>= groups * 64], samples of L rows: words a host must provide,
+// and the pass that fills them (clears first)
+extern "C" long hoisdf_head_mag_words(long M, int groups, int L) { return (M > 0 && groups > 0 && L > 0) ? (long)groups * cdiv(M, L) : 0; }
+extern "C" int hoisdf_head_mag_measure(const float* x, long ldx, long M, int groups, int L, uint32_t* words, void* stream) {
+  HOISDF_REQUIRE(words && (M == 0 || x) && M >= 0 && groups > 0 && L > 0 && ldx >= (long)groups * 64 && ldx % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0, HOISDF_ERR_INVALID, "head_mag_measure: bad arguments");
+  return emu_headmag_launch(x, ldx, M, groups, L, words, as_stream(stream));
 }
 extern "C" int hoisdf_linear_emu_pieces(void) { return form_h2() ? 2 : 3; }
 
 int hoisdf::linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N, int K,
                                int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag, uint32_t* y_mag,
-                               void* stream) {
+                               void* stream, uint32_t* y_heads, int head_L) {
   HOISDF_REQUIRE(M == 0 || (x && w_image && y), HOISDF_ERR_INVALID, "linear_fwd_emu: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && M < (1L << 31), HOISDF_ERR_INVALID,
                  "linear_fwd_emu: bad sizes M=%ld N=%d K=%d ldx=%d ldy=%d", M, N, K, ldx, ldy);
@@ -1874,7 +1972,11 @@ int hoisdf::linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, con
   g.C = y; g.ldc = ldy; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.act = act; g.drop_p = drop_p; g.inv_keep = 1.f / (1.f - drop_p); g.thresh = drop_threshold(drop_p); g.seed = seed;
   g.bits_out = relu_bits; g.ldbits_out = (N + 31) / 32;
-  g.a_amax = x_mag; g.a_amax_n = x_mag ? MAG_WORDS : 0; g.amax_out = y_mag;
+  g.a_amax = x_mag; g.amax_out = y_mag;
+  if (y_heads) {
+    HOISDF_REQUIRE(head_L > 0 && N % 64 == 0, HOISDF_ERR_INVALID, "linear_fwd_emu: head magnitudes need N %% 64 == 0 and the rows per sample");
+    g.head_out = y_heads; g.head_L = head_L; g.head_nb = cdiv(M, head_L);
+  }
   return launch_emu(g, as_stream(stream));
 }
 
@@ -1890,10 +1992,20 @@ int hoisdf::linear_fwd_emu_qkv(const float* x, int ldx, const void* w_image, con
   g.A = x; g.lda = ldx; g.Bimg = static_cast<const u32x4*>(w_image);
   g.C = nullptr; g.ldc = N; g.bias = bias; g.M = (int)M; g.N = N; g.K = K;
   g.inv_keep = 1.f; g.qkv = pl;
-  g.a_amax = x_mag; g.a_amax_n = x_mag ? MAG_WORDS : 0;
+  g.a_amax = x_mag;
   return launch_emu(g, as_stream(stream));
 }
 
+extern "C" int hoisdf_linear_fwd_emu_heads(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
+                                           int K, const uint32_t* x_mag, uint32_t* y_mag, uint32_t* y_heads, int L, void* stream) {
+  HOISDF_REQUIRE(y_heads, HOISDF_ERR_INVALID, "linear_fwd_emu_heads: y_heads is required");
+  return linear_fwd_emu_mag(x, ldx, w_image, bias, y, ldy, M, N, K, 0, 0.f, 0, nullptr, x_mag, y_mag, stream, y_heads, L);
+}
+extern "C" int hoisdf_linear_bwd_input_emu_heads(const float* dy, int lddy, const void* wt_image, float* dx, int lddx, long M, int N, int K,
+                                                 const uint32_t* dy_mag, uint32_t* dx_mag, uint32_t* dx_heads, int L, void* stream) {
+  HOISDF_REQUIRE(dx_heads, HOISDF_ERR_INVALID, "linear_bwd_input_emu_heads: dx_heads is required");
+  return linear_bwd_input_emu_mag(dy, lddy, nullptr, 0.f, wt_image, dx, lddx, M, N, K, 0, dy_mag, dx_mag, stream, dx_heads, L);
+}
 extern "C" int hoisdf_linear_bwd_input_emu(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p,
                                            const void* wt_image, float* dx, int lddx, long M, int N, int K, int accumulate,
                                            void* stream) {
@@ -1907,7 +2019,7 @@ extern "C" int hoisdf_linear_bwd_input_emu_mag(const float* dy, int lddy, const 
 
 int hoisdf::linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* relu_bits, float drop_p, const void* wt_image, float* dx,
                                      int lddx, long M, int N, int K, int accumulate, const uint32_t* dy_mag, uint32_t* dx_mag,
-                                     void* stream) {
+                                     void* stream, uint32_t* dx_heads, int head_L) {
   HOISDF_REQUIRE(M == 0 || (dy && wt_image && dx), HOISDF_ERR_INVALID, "linear_bwd_input_emu: null pointer");
   HOISDF_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && lddx >= K && M < (1L << 31) && drop_p >= 0.f && drop_p < 1.f,
                  HOISDF_ERR_INVALID, "linear_bwd_input_emu: bad sizes");
@@ -1921,7 +2033,11 @@ int hoisdf::linear_bwd_input_emu_mag(const float* dy, int lddy, const uint32_t* 
   g.C = dx; g.ldc = lddx; g.M = (int)M; g.N = K; g.K = N;
   g.inv_keep = 1.f;
   g.beta = accumulate ? 1 : 0;
-  g.a_amax = dy_mag; g.a_amax_n = dy_mag ? MAG_WORDS : 0; g.amax_out = dx_mag;
+  g.a_amax = dy_mag; g.amax_out = dx_mag;
+  if (dx_heads) {
+    HOISDF_REQUIRE(head_L > 0 && K % 64 == 0 && !accumulate, HOISDF_ERR_INVALID, "linear_bwd_input_emu: head magnitudes need K %% 64 == 0, the rows per sample, no accumulation");
+    g.head_out = dx_heads; g.head_L = head_L; g.head_nb = cdiv(M, head_L);
+  }
   return launch_emu(g, as_stream(stream));
 }
 
@@ -2032,20 +2148,20 @@ int bwd_weight_emu(const float* dy, int lddy, const uint32_t* relu_bits, float d
   const unsigned lb = 2u * (3 * 2 * DT + 3 * 2 * dtk) * 16u;
   const int form = dw_old_form() ? 1 : 2;     // HOISDF_EMU_DW=1: the first main-loop form for the 256-wide tiles (A/B runs)
   if (dtk == 256 && form == 2 && h2) {
-    g.dy_amax = dy_mag; g.dy_amax_n = MAG_WORDS; g.x_amax = x_mag; g.x_amax_n = MAG_WORDS;
+    g.dy_amax = dy_mag; g.x_amax = x_mag;
     if (!dy_mag) {
-      uint32_t* part = amax_ring_slot(st);
-      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      uint32_t* part = mag_scratch(st, M);
+      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the row magnitudes"); return HOISDF_ERR_LAUNCH; }
       mag_trace("grad-weight dy", M, N);
-      if (int rc = emu_amax_launch(dy, lddy, M, N, part, st)) return rc;
-      g.dy_amax = part; g.dy_amax_n = AMAX_BLOCKS;
+      if (int rc = emu_rowmag_launch(dy, lddy, M, N, part, st)) return rc;
+      g.dy_amax = part;
     }
     if (!x_mag) {
-      uint32_t* part = amax_ring_slot(st);
-      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the magnitude words"); return HOISDF_ERR_LAUNCH; }
+      uint32_t* part = mag_scratch(st, M);
+      if (!part) { set_error("linear_bwd_weight_emu: cannot allocate the row magnitudes"); return HOISDF_ERR_LAUNCH; }
       mag_trace("grad-weight x", M, K);
-      if (int rc = emu_amax_launch(x, ldx, M, K, part, st)) return rc;
-      g.x_amax = part; g.x_amax_n = AMAX_BLOCKS;
+      if (int rc = emu_rowmag_launch(x, ldx, M, K, part, st)) return rc;
+      g.x_amax = part;
     }
     const bool hasdb = g.colsum != nullptr;
     if (relu_bits && hasdb) hipLaunchKernelGGL((emu_dw2h_kernel<true, true>), grid, block, 0, st, g);

@@ -32,15 +32,15 @@ void mlp_carve(const hoisdf_mlp* m, long M, Bump& b, MlpSaved& s) {
     const bool act = i < last || m->act_last;
     s.bits[i] = act ? static_cast<uint32_t*>(b.take(M * bits_words(m->dims[i + 1]) * 4)) : nullptr;
   }
-  s.mag = static_cast<uint32_t*>(b.take((long)m->n_layers * MAG_WORDS * 4));
+  s.mag = static_cast<uint32_t*>(b.take((long)m->n_layers * M * 4));       // (row magnitudes: M words per array)
 }
 inline bool chain_mags_on(const Ctx& c, long M) { return c.emu && emu_form_h2() && M >= EMU_MIN_ROWS; }
-// n zero-filled magnitude-word arrays from the workspace (null: not in the f16x2 form; a measuring pass only reserves the bytes)
+// n zero-filled row-magnitude arrays (M words each) from the workspace (null: not in the f16x2 form; a measuring pass only reserves the bytes)
 uint32_t* chain_mags(Ctx& c, long M, int n) {
   if (!chain_mags_on(c, M)) return nullptr;
-  uint32_t* p = static_cast<uint32_t*>(c.ws->take((long)n * MAG_WORDS * 4));
+  uint32_t* p = static_cast<uint32_t*>(c.ws->take((long)n * M * 4));
   if (c.dry || !p || !c.ok()) return nullptr;
-  if (hipMemsetAsync(p, 0, (size_t)n * MAG_WORDS * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return nullptr; }
+  if (hipMemsetAsync(p, 0, (size_t)n * M * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return nullptr; }
   return p;
 }
 // x_mag: the caller's magnitude words of x; null = measured here ONCE (array 0 of s.mag) for the layer-0 contraction and, in the
@@ -49,7 +49,7 @@ void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, c
   const int last = m->n_layers - 1;
   const float* in = x; int ldin = ldx;
   uint32_t* mg = chain_mags_on(c, M) && !c.dry && s.mag && c.ok() ? s.mag : nullptr;
-  if (mg && hipMemsetAsync(mg, 0, (size_t)m->n_layers * MAG_WORDS * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return; }
+  if (mg && hipMemsetAsync(mg, 0, (size_t)m->n_layers * M * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return; }
   const uint32_t* in_mag = mg ? x_mag : nullptr;
   if (mg && !in_mag && emu_rows(c, M, x, ldx, m->dims[0])) {
     if ((c.rc = emu_mag_measure(x, ldx, M, m->dims[0], mg, c.st)) != HOISDF_OK) return;
@@ -59,7 +59,7 @@ void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, c
     float* out = i < last ? s.h[i] : y;
     const int ldo = i < last ? m->dims[i + 1] : ldy;
     // (the tiled emulated form is the one that writes the words: the same test lin_fwd makes)
-    uint32_t* out_mag = mg && i < last && emu_rows(c, M, in, ldin, m->dims[i]) ? mg + (i + 1) * MAG_WORDS : nullptr;
+    uint32_t* out_mag = mg && i < last && emu_rows(c, M, in, ldin, m->dims[i]) ? mg + (long)(i + 1) * M : nullptr;
     lin_fwd(c, in, ldin, m->w[i], m->dims[i], m->img[i], m->b[i], out, ldo, M, m->dims[i + 1], m->dims[i], s.bits[i] ? 1 : 0, 0.f, 0, s.bits[i], 0,
             in_mag, out_mag);
     in = out; ldin = ldo; in_mag = out_mag;
@@ -74,21 +74,21 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
   const bool fwd_mags = mg && s.mag;
   const uint32_t* g_mag = nullptr;
   if (mg && emu_rows(c, M, dy, lddy, m->dims[last + 1])) {   // dy feeds two contractions: measured once
-    if ((c.rc = emu_mag_measure(dy, lddy, M, m->dims[last + 1], mg + (last + 1) * MAG_WORDS, c.st)) != HOISDF_OK) return;
-    g_mag = mg + (last + 1) * MAG_WORDS;
+    if ((c.rc = emu_mag_measure(dy, lddy, M, m->dims[last + 1], mg + (long)(last + 1) * M, c.st)) != HOISDF_OK) return;
+    g_mag = mg + (long)(last + 1) * M;
   }
   for (int i = last; i >= 0; --i) {
     const float* in = i > 0 ? s.h[i - 1] : x;
     const int ldin = i > 0 ? m->dims[i] : ldx;
     // the words of the layer's input: h[i - 1]'s from the forward's epilogue; x's from the caller or from the forward's own pass
-    const uint32_t* in_mag = !fwd_mags ? nullptr : i > 0 ? (emu_rows(c, M, i > 1 ? s.h[i - 2] : x, i > 1 ? m->dims[i - 1] : ldx, m->dims[i - 1]) ? s.mag + i * MAG_WORDS : nullptr)
+    const uint32_t* in_mag = !fwd_mags ? nullptr : i > 0 ? (emu_rows(c, M, i > 1 ? s.h[i - 2] : x, i > 1 ? m->dims[i - 1] : ldx, m->dims[i - 1]) ? s.mag + (long)i * M : nullptr)
                                                          : (x_mag ? x_mag : (emu_rows(c, M, x, ldx, m->dims[0]) ? s.mag : nullptr));
     lin_bwd_weight(c, g, ldg, s.bits[i], 0.f, in, ldin, G->dw[i], G->db[i], M, m->dims[i + 1], m->dims[i], 0, g_mag, g_mag ? in_mag : nullptr);
     if (i == 0 && !dx) break;
     float* gin = i > 0 ? c.ws->floats(M * m->dims[i]) : dx;
     const int ldgin = i > 0 ? m->dims[i] : lddx;
     if (!c.dry && c.ok() && !gin) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-    uint32_t* gin_mag = mg && i > 0 && emu_rows(c, M, g, ldg, m->dims[i + 1]) ? mg + i * MAG_WORDS : nullptr;
+    uint32_t* gin_mag = mg && i > 0 && emu_rows(c, M, g, ldg, m->dims[i + 1]) ? mg + (long)i * M : nullptr;
     lin_bwd_input(c, g, ldg, s.bits[i], 0.f, m->w[i], m->dims[i], m->img_t[i], gin, ldgin, M, m->dims[i + 1], m->dims[i], i == 0 ? accumulate_dx : 0,
                   g_mag, gin_mag);
     g = gin; ldg = ldgin; g_mag = gin_mag;

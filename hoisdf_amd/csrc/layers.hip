@@ -98,9 +98,11 @@ int geometry(const hoisdf_encoder_layer_desc* d, Geo& g) {
 struct Saved {
   float* qkv; float* qbuf; float* kvbuf; float* xq; float* o; float* lse; float* a; float* x1; float* h; uint32_t* bits; float* f; float* st;
   void* planes; long planes_bytes;
-  uint32_t* mag;       // magnitude words (common.h) of o, x1, h, x_out: 4 x MAG_WORDS, zeroed by the forward before its first launch
+  // row magnitudes (common.h) of o, x1, h, x_out (M words each) and the head magnitudes of the projected q, k, v (3 H B words: the
+  // groups of [q | k | v], or of q followed by those of [k | v]) - one region, zeroed by the forward before its first launch
+  uint32_t* mag; long mag_bytes;
 };
-enum { MAG_O = 0, MAG_X1 = 1, MAG_H = 2, MAG_XOUT = 3, MAG_QKV = 4, MAG_KV = 5, MAG_FWD = 6 };   // (QKV: [q | k | v], or q alone next to KV = [k | v])
+enum { MAG_O = 0, MAG_X1 = 1, MAG_H = 2, MAG_XOUT = 3, MAG_ROWS = 4 };
 void carve_saved(const Geo& g, Bump& b, Saved& s) {
   const int E = g.E;
   s.qkv = s.qbuf = s.kvbuf = s.xq = nullptr;
@@ -114,8 +116,13 @@ void carve_saved(const Geo& g, Bump& b, Saved& s) {
   s.st = b.floats(6 * g.M);
   s.planes_bytes = g.att_bwd_emu ? hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 2) : 0;     // (bf16x3 or, with att_h2, f16x2 planes: the backward runs in the forward's form)
   s.planes = s.planes_bytes ? b.take(s.planes_bytes) : nullptr;
-  s.mag = static_cast<uint32_t*>(b.take((long)MAG_FWD * MAG_WORDS * 4));
+  s.mag_bytes = ((long)MAG_ROWS * g.M + 3L * g.H * g.B) * 4;
+  s.mag = static_cast<uint32_t*>(b.take(s.mag_bytes));
 }
+// the head magnitudes inside Saved::mag: q's groups, then k's, then v's (H B words each)
+uint32_t* head_q(const Geo& g, uint32_t* mag) { return mag ? mag + (long)MAG_ROWS * g.M : nullptr; }
+uint32_t* head_k(const Geo& g, uint32_t* mag) { return mag ? head_q(g, mag) + (long)g.H * g.B : nullptr; }
+uint32_t* head_v(const Geo& g, uint32_t* mag) { return mag ? head_q(g, mag) + 2L * g.H * g.B : nullptr; }
 // magnitude words travel between the kernels of a layer when its contractions run in the f16x2 form (every row count of a layer's
 // contractions is M or Ms >= M: one test covers them all)
 bool layer_mags(const Ctx& c, const Geo& g) { return c.emu && emu_form_h2() && g.M >= EMU_MIN_ROWS; }
@@ -131,9 +138,10 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
   void* aw = s.planes; long ab = s.planes_bytes;
   if (g.att == 2 && !aw) { ab = hoisdf_attention_emu_workspace(g.B, g.H, g.nq, g.S, 0); aw = ws.take(ab); }
   const bool mags = layer_mags(c, g) && (dry || s.mag);
-  auto mg = [&](int i) -> uint32_t* { return mags && s.mag ? s.mag + i * MAG_WORDS : nullptr; };
-  const uint32_t* xm = mags ? d->x_mag : nullptr;             // the caller's words for x (null: the in-projection measures it)
-  if (mags && !dry && c.ok() && hipMemsetAsync(s.mag, 0, (size_t)MAG_FWD * MAG_WORDS * 4, c.st) != hipSuccess) c.rc = HOISDF_ERR_LAUNCH;
+  auto mg = [&](int i) -> uint32_t* { return mags && s.mag ? s.mag + (long)i * g.M : nullptr; };
+  uint32_t* const smag = mags ? s.mag : nullptr;
+  const uint32_t* xm = mags ? d->x_mag : nullptr;             // the caller's row magnitudes of x (B S words; null: the in-projection measures it)
+  if (mags && !dry && c.ok() && hipMemsetAsync(s.mag, 0, (size_t)s.mag_bytes, c.st) != hipSuccess) c.rc = HOISDF_ERR_LAUNCH;
   if (g.fused_qkv) {
     // in-projection straight into the attention planes (same values as the f32 matrix + conversion pass: bit-identical planes)
     QkvPlanes pq{}, pkv{};
@@ -151,20 +159,23 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
         attention_emu_plane_targets(aw, g.B, g.H, g.nq, g.S, s.planes ? 1 : 0, pq, pkv);
         if (g.full) c.rc = linear_fwd_emu_qkv(x, E, im, w->b_in, g.Ms, 3 * E, E, pq, stream, xm);
         else {
-          c.rc = linear_fwd_emu_qkv(s.xq, E, im_q, w->b_in, g.M, E, E, pq, stream, xm);       // (rows of x: its words bound them)
+          c.rc = linear_fwd_emu_qkv(s.xq, E, im_q, w->b_in, g.M, E, E, pq, stream, nullptr);  // (a row subset of x: measured)
           pkv.col0 = E;
           if (c.ok()) c.rc = linear_fwd_emu_qkv(x, E, im_kv, w->b_in ? w->b_in + E : nullptr, g.Ms, 2 * E, E, pkv, stream, xm);
         }
       }
     }
   } else if (g.full) {
-    lin_fwd(c, x, E, w->w_in, E, w->img_in, w->b_in, s.qkv, 3 * E, g.Ms, 3 * E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_QKV) : nullptr);
+    lin_fwd(c, x, E, w->w_in, E, w->img_in, w->b_in, s.qkv, 3 * E, g.Ms, 3 * E, E, 0, 0.f, 0, nullptr, 0, xm, nullptr,
+            g.att_h2 ? head_q(g, smag) : nullptr, g.S);
     q = s.qkv; k = s.qkv + E; v = s.qkv + 2 * E; ldq = ldkv = 3 * E;
   } else {
     if (!dry && c.ok()) c.rc = rows_copy_add(s.xq, (long)g.nq * E, x, (long)g.S * E, g.B, g.nq, E, 0, c.st);
     xq2 = s.xq;
-    lin_fwd(c, s.xq, E, w->w_in, E, w->img_in_q, w->b_in, s.qbuf, E, g.M, E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_QKV) : nullptr);
-    lin_fwd(c, x, E, w->w_in + (size_t)E * E, E, w->img_in_kv, w->b_in ? w->b_in + E : nullptr, s.kvbuf, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr, 0, xm, g.att_h2 ? mg(MAG_KV) : nullptr);
+    lin_fwd(c, s.xq, E, w->w_in, E, w->img_in_q, w->b_in, s.qbuf, E, g.M, E, E, 0, 0.f, 0, nullptr, 0, nullptr, nullptr,
+            g.att_h2 ? head_q(g, smag) : nullptr, g.nq);
+    lin_fwd(c, x, E, w->w_in + (size_t)E * E, E, w->img_in_kv, w->b_in ? w->b_in + E : nullptr, s.kvbuf, 2 * E, g.Ms, 2 * E, E, 0, 0.f, 0, nullptr, 0, xm, nullptr,
+            g.att_h2 ? head_k(g, smag) : nullptr, g.S);
     q = s.qbuf; k = s.kvbuf; v = s.kvbuf + E; ldq = E; ldkv = 2 * E;
   }
   const uint32_t* o_mag = g.att == 2 ? mg(MAG_O) : nullptr;        // (the exact-f32 attention leaves none: the out-projection measures o itself)
@@ -175,9 +186,10 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
     if (!dry && c.ok()) {
       if (!aw) c.rc = HOISDF_ERR_WORKSPACE;
       else {
-        const uint32_t* qm = g.att_h2 ? mg(MAG_QKV) : nullptr;              // (null without the words: the bf16x3 form)
+        const bool hm = g.att_h2 && smag;                                   // (without the head magnitudes: the bf16x3 form)
         c.rc = attention_fwd_emu_mag(q, ldq, k, ldkv, v, ldkv, s.o, E, s.lse, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], aw, ab,
-                                     s.planes ? 1 : 0, mg(MAG_O), stream, qm, qm && !g.full ? mg(MAG_KV) : nullptr);
+                                     s.planes ? 1 : 0, mg(MAG_O), stream, hm ? head_q(g, smag) : nullptr, hm ? head_k(g, smag) : nullptr,
+                                     hm ? head_v(g, smag) : nullptr);
       }
     }
   } else if (!dry && c.ok()) {
@@ -223,13 +235,18 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   float* delta = ws.floats((long)g.B * g.H * g.nq);
   if (!dry && (!dx1 || !df || !dh || !dxq || !da || !dO || !delta)) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
   if (!dry && !dx2) { set_error("encoder_layer_bwd: no upstream gradient (g_x_out and g_y both null)"); return HOISDF_ERR_INVALID; }
-  // magnitude words of df, dh, da, [dq | dk | dv] (or dq and [dk | dv]) (common.h): written by the kernel that produces the matrix, read by the contraction that consumes it
-  enum { MAG_DF = 0, MAG_DH = 1, MAG_DA = 2, MAG_DQKV = 3, MAG_DKV = 4, MAG_DO = 5, MAG_BWD = 6 };
-  uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)MAG_BWD * MAG_WORDS * 4));
+  // row magnitudes of df, dh, da (M words each), of [dq | dk | dv] (Ms words) and the head magnitudes of dO (H B words) (common.h): written
+  // by the kernel that produces the matrix, read by the contraction that consumes it
+  enum { MAG_DF = 0, MAG_DH = 1, MAG_DA = 2, MAG_BROWS = 3 };
+  const long bmag_bytes = ((long)MAG_BROWS * M + Ms + (long)g.H * g.B) * 4;
+  uint32_t* bmag = static_cast<uint32_t*>(ws.take(bmag_bytes));
   const bool mags = layer_mags(c, g) && (dry || bmag);
-  auto mg = [&](int i) -> uint32_t* { return mags && bmag ? bmag + i * MAG_WORDS : nullptr; };
-  auto fm = [&](int i) -> const uint32_t* { return mags && s.mag ? s.mag + i * MAG_WORDS : nullptr; };       // the forward's (o, x1, h, x_out)
-  if (mags && !dry && c.ok() && hipMemsetAsync(bmag, 0, (size_t)MAG_BWD * MAG_WORDS * 4, c.st) != hipSuccess) c.rc = HOISDF_ERR_LAUNCH;
+  auto mg = [&](int i) -> uint32_t* { return mags && bmag ? bmag + (long)i * M : nullptr; };
+  uint32_t* const mag_dqkv = mags && bmag ? bmag + (long)MAG_BROWS * M : nullptr;
+  uint32_t* const head_do = mags && bmag ? bmag + (long)MAG_BROWS * M + Ms : nullptr;
+  auto fm = [&](int i) -> const uint32_t* { return mags && s.mag ? s.mag + (long)i * M : nullptr; };       // the forward's (o, x1, h, x_out)
+  uint32_t* const smag = mags ? s.mag : nullptr;
+  if (mags && !dry && c.ok() && hipMemsetAsync(bmag, 0, (size_t)bmag_bytes, c.st) != hipSuccess) c.rc = HOISDF_ERR_LAUNCH;
   if (!dry && c.ok()) c.rc = add_layernorm_bwd_mag(dx2, s.x1, s.f, w->g2, st + 2 * M, st + 3 * M, nullptr, dx1, df, G->dg2, G->dbe2, M, E, g.p, d->seed[3], nullptr, mg(MAG_DF), stream);
   lin_bwd_input(c, df, E, nullptr, 0.f, w->w2, F, w->img_t_2, dh, F, M, E, F, 0, mg(MAG_DF), mg(MAG_DH));
   lin_bwd_weight(c, df, E, nullptr, 0.f, s.h, F, G->dw2, G->db2, M, E, F, 0, mg(MAG_DF), fm(MAG_H));
@@ -237,7 +254,7 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   lin_bwd_weight(c, dh, F, s.bits, g.p, s.x1, E, G->dw1, G->db1, M, F, E, 0, mg(MAG_DH), fm(MAG_X1));
   const float* xq2 = g.full ? x : s.xq;
   if (!dry && c.ok()) c.rc = add_layernorm_bwd_mag(dx1, xq2, s.a, w->g1, st, st + M, nullptr, dxq, da, G->dg1, G->dbe1, M, E, g.p, d->seed[1], nullptr, mg(MAG_DA), stream);
-  lin_bwd_input(c, da, E, nullptr, 0.f, w->w_out, E, w->img_t_out, dO, E, M, E, E, 0, mg(MAG_DA), g.att_h2 ? mg(MAG_DO) : nullptr);
+  lin_bwd_input(c, da, E, nullptr, 0.f, w->w_out, E, w->img_t_out, dO, E, M, E, E, 0, mg(MAG_DA), nullptr, g.att_h2 ? head_do : nullptr, g.nq);
   lin_bwd_weight(c, da, E, nullptr, 0.f, s.o, E, G->dw_out, G->db_out, M, E, E, 0, mg(MAG_DA), g.att == 2 ? fm(MAG_O) : nullptr);
   const bool amag = mags && g.att_bwd_emu && g.full;       // (separate q / kv matrices: the two kernels' words would have to be told apart)
   auto attn_bwd = [&](const float* q, int ldq, const float* k, const float* v, int ldkv, float* dq, float* dk, float* dv) {
@@ -246,12 +263,12 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
       void* aw = ws.take(ab);
       if (dry || !c.ok()) return;
       if (!aw) { c.rc = HOISDF_ERR_WORKSPACE; return; }
-      // (f16x2 form: the words of the projected matrices from the forward, dO's from the out-projection's grad-input)
-      const uint32_t* qm = g.att_h2 && mags ? fm(MAG_QKV) : nullptr;
-      if (g.att_h2 && !qm) { set_error("encoder_layer_bwd: the forward ran the f16x2 attention but the magnitude words are not available"); c.rc = HOISDF_ERR_INVALID; return; }
+      // (f16x2 form: the head magnitudes of the projected matrices from the forward, dO's from the out-projection's grad-input)
+      const bool hm = g.att_h2 && smag && head_do;
+      if (g.att_h2 && !hm) { set_error("encoder_layer_bwd: the forward ran the f16x2 attention but the head magnitudes are not available"); c.rc = HOISDF_ERR_INVALID; return; }
       c.rc = attention_bwd_emu_mag(q, ldq, k, ldkv, v, ldkv, s.o, E, dO, E, s.lse, delta, dq, dk, dv, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0],
-                                   s.planes, aw, ab, amag ? mg(MAG_DQKV) : nullptr, stream, qm, qm && !g.full ? fm(MAG_KV) : nullptr,
-                                   qm ? mg(MAG_DO) : nullptr);
+                                   s.planes, aw, ab, amag ? mag_dqkv : nullptr, stream, hm ? head_q(g, smag) : nullptr,
+                                   hm ? head_k(g, smag) : nullptr, hm ? head_v(g, smag) : nullptr, hm ? head_do : nullptr);
     } else if (!dry && c.ok()) {
       c.rc = hoisdf_attention_bwd(q, ldq, k, ldkv, v, ldkv, s.o, E, dO, E, s.lse, delta, dq, dk, dv, g.B, g.H, g.nq, g.S, g.S, g.p, d->seed[0], stream);
     }
@@ -261,8 +278,8 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
     if (!dry && !dqkv) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
     if (g.fused_qkv) attn_bwd(nullptr, 3 * E, nullptr, nullptr, 3 * E, dqkv, dqkv + E, dqkv + 2 * E);       // (the kept planes are the operands)
     else attn_bwd(s.qkv, 3 * E, s.qkv + E, s.qkv + 2 * E, 3 * E, dqkv, dqkv + E, dqkv + 2 * E);
-    lin_bwd_input(c, dqkv, 3 * E, nullptr, 0.f, w->w_in, E, w->img_t_in, dxq, E, Ms, 3 * E, E, 1, amag ? mg(MAG_DQKV) : nullptr, nullptr);   // += : attention branch joins the residual
-    lin_bwd_weight(c, dqkv, 3 * E, nullptr, 0.f, x, E, G->dw_in, G->db_in, Ms, 3 * E, E, 0, amag ? mg(MAG_DQKV) : nullptr, amag ? d->x_mag : nullptr);
+    lin_bwd_input(c, dqkv, 3 * E, nullptr, 0.f, w->w_in, E, w->img_t_in, dxq, E, Ms, 3 * E, E, 1, amag ? mag_dqkv : nullptr, nullptr);   // += : attention branch joins the residual
+    lin_bwd_weight(c, dqkv, 3 * E, nullptr, 0.f, x, E, G->dw_in, G->db_in, Ms, 3 * E, E, 0, amag ? mag_dqkv : nullptr, amag ? d->x_mag : nullptr);
   } else {
     float* dq = ws.floats(M * E); float* dkv = ws.floats(Ms * 2 * E);
     if (!dry && (!dq || !dkv)) { set_error("encoder_layer_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
@@ -298,7 +315,7 @@ extern "C" const uint32_t* hoisdf_encoder_layer_out_mag(const hoisdf_encoder_lay
   if (!layer_mags(c, g)) return nullptr;
   Bump b(const_cast<void*>(saved), 1L << 62); Saved s;
   carve_saved(g, b, s);
-  return s.mag ? s.mag + MAG_XOUT * MAG_WORDS : nullptr;
+  return s.mag ? s.mag + (long)MAG_XOUT * g.M : nullptr;
 }
 
 extern "C" long hoisdf_encoder_layer_workspace_bytes(const hoisdf_encoder_layer_desc* d, int backward_pass) {

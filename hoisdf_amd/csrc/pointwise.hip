@@ -17,7 +17,6 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ p
                                                      float* __restrict__ pe, uint32_t* __restrict__ x0_mag) {
   long idx = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per (row, slot<36)
   const long total = n_rows * 36;
-  uint32_t vmax = 0u;                                    // magnitude words (common.h) of what goes into x0, when wanted
   for (; idx < total; idx += (long)gridDim.x * 256) {
     const long r = idx / 36;
     const int s = (int)(idx - r * 36);
@@ -32,9 +31,11 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ p
       val = pts[r * 3 + (s - 30)];
     }
     if (x0 && col0 + s < ldx0) x0[(size_t)r * ldx0 + col0 + s] = val;   // s in [33,36) zero-fills the pad
-    vmax = max(vmax, mag_bits(val));
+    // row magnitudes (common.h) of what goes into x0, when wanted: an upper bound per row - the sines / cosines are <= 1, the three
+    // coordinates as they are (one atomic per row instead of 36)
+    if (x0_mag && s == 0)
+      atomicMax(x0_mag + r, max(max(mag_bits(1.f), mag_bits(pts[r * 3])), max(mag_bits(pts[r * 3 + 1]), mag_bits(pts[r * 3 + 2]))));
   }
-  mag_publish_wave(x0_mag, vmax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -113,7 +114,6 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dwa[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};   // K <= 512: 2 float4 per lane
   float dba = 0.f;
-  uint32_t hmax = 0u;                                    // dh's magnitude words (common.h), when wanted
   const long stride = (long)gridDim.x * 4;
   for (long r0 = (long)blockIdx.x * 4 + wave; r0 < n_rows; r0 += 2 * stride) {
     const long r1 = r0 + stride;
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
     const float g1 = (two && t1 >= -clampv && t1 <= clampv) ? dsdf[r1] * (1.f - t1 * t1) : 0.f;
     const float* h0 = h + (size_t)r0 * ldh;
     const float* h1 = h + (size_t)(two ? r1 : r0) * ldh;
+    uint32_t hmax0 = 0u, hmax1 = 0u;                     // dh's row magnitudes (common.h), when wanted
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = lane * 4 + i * 256;
@@ -134,14 +135,15 @@ __global__ __launch_bounds__(256) void sdf_head_bwd_kernel(const float* __restri
         const float4 d0 = make_float4(g0 * ww.x, g0 * ww.y, g0 * ww.z, g0 * ww.w), d1 = make_float4(g1 * ww.x, g1 * ww.y, g1 * ww.z, g1 * ww.w);
         *reinterpret_cast<float4*>(dh + (size_t)r0 * lddh + c) = d0;
         if (two) *reinterpret_cast<float4*>(dh + (size_t)r1 * lddh + c) = d1;
-        hmax = max(hmax, max(mag_bits4(d0), mag_bits4(d1)));          // (g1 = 0 without a second row)
+        hmax0 = max(hmax0, mag_bits4(d0)); hmax1 = max(hmax1, mag_bits4(d1));
         dwa[i].x += g0 * a0.x + g1 * a1.x; dwa[i].y += g0 * a0.y + g1 * a1.y;
         dwa[i].z += g0 * a0.z + g1 * a1.z; dwa[i].w += g0 * a0.w + g1 * a1.w;
       }
     }
     dba += g0 + g1;
+    rowmag_publish_wave(dh_mag, r0, hmax0);
+    if (two) rowmag_publish_wave(dh_mag, r1, hmax1);
   }
-  mag_publish_wave(dh_mag, hmax);
 #pragma unroll
   for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&red[wave][lane * 4 + i * 256]) = dwa[i];
   if (lane == 0) red[wave][512] = dba;
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  uint32_t ymax = 0u;                               // y's magnitude words (common.h), when wanted
   for (; orow < M; orow += (long)gridDim.x * 4) {
+    uint32_t ymax = 0u;                             // y's row magnitude (common.h), when wanted
     const long row = rpg > 0 ? (orow / take) * rpg + orow % take : orow;       // input row
     float4 v[4];
     float s = 0.f;
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
       if (mean) mean[orow] = mu;
       if (rstd) rstd[orow] = rs;
     }
+    rowmag_publish_wave(y_mag, orow, ymax);
   }
-  mag_publish_wave(y_mag, ymax);
 }
 
 // backward: dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dr = dx * mask/(1-p).
@@ -331,8 +333,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 4; ++i) { dg[i] = make_float4(0, 0, 0, 0); db[i] = make_float4(0, 0, 0, 0); }
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  uint32_t xmax = 0u, rmax = 0u;            // magnitude words of dx / dr (common.h), when wanted
   for (; row < M; row += (long)gridDim.x * 4) {
+    uint32_t xmax = 0u, rmax = 0u;          // row magnitudes of dx / dr (common.h), when wanted
     long crow = row;                        // row of dy / mean / rstd
     if (rpg > 0) {
       const long grp = row / rpg;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
             xmax = max(xmax, mag_bits4(e));
           }
         }
+        rowmag_publish_wave(dx_mag, row, xmax);
         continue;
       }
       crow = grp * take + t;
@@ -412,9 +415,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         }
       }
     }
+    rowmag_publish_wave(dx_mag, row, xmax);
+    rowmag_publish_wave(dr_mag, row, rmax);
   }
-  mag_publish_wave(dx_mag, xmax);
-  mag_publish_wave(dr_mag, rmax);
   // reduce the 4 waves of the block through LDS, then one atomic per column per block
   __shared__ float red[2][4][1024];
   const int w = threadIdx.x >> 6;

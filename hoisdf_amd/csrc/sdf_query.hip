@@ -44,14 +44,14 @@ int layer(const float* x, int ldx, const float* W, int ldw, const float* b, floa
   }
   return hoisdf_linear_fwd(x, ldx, W, ldw, b, y, ldy, M, N, K, 1, drop_p, seed, nullptr, stream);
 }
-constexpr long QMAG_BYTES = 5L * MAG_WORDS * 4;       // magnitude words of feat, ha, cat, h0, h2 behind the image scratch
+inline long qmag_bytes(long n_rows) { return align64(5L * n_rows) * 4; }       // row magnitudes (common.h) of feat, ha, cat, h0, h2 behind the image scratch
 }  // namespace
 
 extern "C" long hoisdf_sdf_query_workspace(long n_rows, int C, int need_feat) {
   if (n_rows <= 0 || C <= 0) return 0;
   long fl = align64(n_rows * HID0) * 2 + align64(n_rows * CAT_LD);
   if (need_feat) fl += align64(n_rows * (long)C);
-  return fl * (long)sizeof(float) + emu_scratch_bytes(C) + QMAG_BYTES;
+  return fl * (long)sizeof(float) + emu_scratch_bytes(C) + qmag_bytes(n_rows);
 }
 
 extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* points, const int32_t* sample_idx, long n_rows,
@@ -76,12 +76,12 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   float* hb = ha + align64(n_rows * HID0);
   float* cat = hb + align64(n_rows * HID0);
   float* feat_ws = cat + align64(n_rows * CAT_LD);
-  void* img = gemm_emu_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - emu_scratch_bytes(C) - QMAG_BYTES))
+  void* img = gemm_emu_mode() ? static_cast<void*>(static_cast<char*>(workspace) + (need - emu_scratch_bytes(C) - qmag_bytes(n_rows)))
                                                       : nullptr;
-  // magnitude words (f16x2 form) handed from each kernel to the contraction that reads its output
-  uint32_t* qm = (img && emu_form_h2()) ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (need - QMAG_BYTES)) : nullptr;
-  auto mg = [&](int i) -> uint32_t* { return qm ? qm + i * MAG_WORDS : nullptr; };
-  if (qm && hipMemsetAsync(qm, 0, QMAG_BYTES, as_stream(stream)) != hipSuccess) { set_error("sdf_query_fwd: memset failed"); return HOISDF_ERR_LAUNCH; }
+  // row magnitudes (f16x2 form) handed from each kernel to the contraction that reads its output
+  uint32_t* qm = (img && emu_form_h2()) ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (need - qmag_bytes(n_rows))) : nullptr;
+  auto mg = [&](int i) -> uint32_t* { return qm ? qm + (long)i * n_rows : nullptr; };
+  if (qm && hipMemsetAsync(qm, 0, (size_t)qmag_bytes(n_rows), as_stream(stream)) != hipSuccess) { set_error("sdf_query_fwd: memset failed"); return HOISDF_ERR_LAUNCH; }
   const uint32_t* m_feat = nullptr; bool has = false;
   int rc;
   // K1 (unless the caller shares its gathered rows)
@@ -253,7 +253,7 @@ void train_carve(long n, int C, Bump& b, TrainSaved& s) {
   s.ba = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.bf = static_cast<uint32_t*>(b.take(n * bits_words(LAT) * 4));
   s.b0 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b1 = static_cast<uint32_t*>(b.take(n * bits_words(H1 + 1) * 4));
   s.b2 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4)); s.b3 = static_cast<uint32_t*>(b.take(n * bits_words(HID0) * 4));
-  s.mag = static_cast<uint32_t*>(b.take((long)TM_N * MAG_WORDS * 4));
+  s.mag = static_cast<uint32_t*>(b.take((long)TM_N * n * 4));
 }
 }  // namespace
 
@@ -272,9 +272,9 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   const int C = w ? w->C : 1;
   train_carve(n, C, saved, s);
   const bool mags = train_mags(c, n) && !dry && s.mag;
-  auto mg = [&](int i) -> uint32_t* { return mags ? s.mag + i * MAG_WORDS : nullptr; };
+  auto mg = [&](int i) -> uint32_t* { return mags ? s.mag + (long)i * n : nullptr; };
   if (!dry) {
-    if (mags) c.rc = hipMemsetAsync(s.mag, 0, (size_t)TM_N * MAG_WORDS * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
+    if (mags) c.rc = hipMemsetAsync(s.mag, 0, (size_t)TM_N * n * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
     if (c.ok()) c.rc = project_gather_fwd_mag(pyr, points, sample_idx, n, rps, center, cam_intr, scale, img_h, img_w, s.feat, C, cam_out, nullptr, mg(TM_FEAT), stream);
     if (c.ok()) c.rc = hipMemsetAsync(s.cat, 0, sizeof(float) * n * CAT_LD, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;   // pad columns
   }
@@ -305,11 +305,11 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   if (!dry && (!dh3 || !dh2 || !dcat || !dh0 || !dha || !dfeat)) { set_error("sdf_query_bwd: workspace too small"); return HOISDF_ERR_WORKSPACE; }
   // magnitude words of the gradients that feed contractions: dh3, dh2, dcat, dh0, dha (dx0 is accumulated into: measured by its consumers)
   enum { BM_DH3 = 0, BM_DH2 = 1, BM_DCAT = 2, BM_DH0 = 3, BM_DHA = 4, BM_N = 5 };
-  uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)BM_N * MAG_WORDS * 4));
+  uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)BM_N * n * 4));
   const bool mags = train_mags(c, n) && !dry && bmag && s.mag;
-  auto mg = [&](int i) -> uint32_t* { return mags ? bmag + i * MAG_WORDS : nullptr; };
-  auto fm = [&](int i) -> const uint32_t* { return mags ? s.mag + i * MAG_WORDS : nullptr; };
-  if (mags) c.rc = hipMemsetAsync(bmag, 0, (size_t)BM_N * MAG_WORDS * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
+  auto mg = [&](int i) -> uint32_t* { return mags ? bmag + (long)i * n : nullptr; };
+  auto fm = [&](int i) -> const uint32_t* { return mags ? s.mag + (long)i * n : nullptr; };
+  if (mags) c.rc = hipMemsetAsync(bmag, 0, (size_t)BM_N * n * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
   if (!dry && c.ok()) c.rc = sdf_head_bwd_mag(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, mg(BM_DH3), stream);
   lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0, mg(BM_DH3), mg(BM_DH2));
   lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0, 0, mg(BM_DH3), fm(TM_H2));

@@ -459,15 +459,23 @@ def _h2() -> bool:
 
 
 def _mag_measure(a2, lda, M, K):
-    """magnitude words (f16x2 form) of an operand whose producer left none: one read of it (hoisdf_mag_measure), so that the
-    contractions that consume it - forward and grad-weight of a layer, grad-input and grad-weight of its backward - do not each
-    measure it again.  None outside the f16x2 form."""
+    """row magnitudes (f16x2 form, include/hoisdf.h: one word per row) of an operand whose producer left none: one read of it
+    (hoisdf_mag_measure), so that the contractions that consume it - forward and grad-weight of a layer, grad-input and
+    grad-weight of its backward - do not each measure it again.  None outside the f16x2 form."""
     if not _h2():
         return None
-    from ._lib import lib
-    words = torch.empty(lib().hoisdf_mag_words(), device=a2.device, dtype=torch.int32)
+    words = torch.empty(max(int(M), 1), device=a2.device, dtype=torch.int32)
     call("hoisdf_mag_measure", _p(a2), lda, M, K, _p(words), _st())
     a2._hoisdf_words = (words, a2._version, a2.data_ptr(), lda, M, K)
+    return words
+
+
+def _head_measure(a2, lda, M, groups, L):
+    """head magnitudes (include/hoisdf.h) of an attention operand matrix: one word per (64-column group, sample of L rows) ->
+    int32 tensor [groups][M / L] (the attention entries take one scale per (sample, head) from it)"""
+    nb = (M + L - 1) // L
+    words = torch.empty(groups * nb, device=a2.device, dtype=torch.int32)
+    call("hoisdf_head_mag_measure", _p(a2), lda, M, groups, L, _p(words), _st())
     return words
 
 
@@ -1130,9 +1138,9 @@ def _attn_h2(rows: int) -> bool:
     return _ATTN_FORM_H2 and _GEMM_EMU and _h2() and rows >= _GEMM_EMU_MIN_ROWS
 
 
-def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv_mag=None):
+def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False, heads=None):
     """keep: a backward will follow - convert Q, K, V once into every plane it needs and park the workspace for it.
-    qkv_mag: magnitude words of the matrix q, k, v are slices of -> the f16x2 form of the forward (no planes kept)"""
+    heads = (q, k, v head magnitudes: one scale per (sample, head) and operand) -> the f16x2 form of the forward (no planes kept)"""
     from ._lib import lib
     B, Lq, E = q.shape
     Lk = k.shape[1]
@@ -1143,9 +1151,9 @@ def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv
     ws = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     o = torch.empty(B, Lq, E, device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    if qkv_mag is not None:
+    if heads is not None:
         call("hoisdf_attention_fwd_emu_mag", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk,
-             kv_len, float(drop_p), seed, _p(ws), nbytes, 0, _p(qkv_mag), _p(kv_mag), None, _st())
+             kv_len, float(drop_p), seed, _p(ws), nbytes, 0, _p(heads[0]), _p(heads[1]), _p(heads[2]), None, _st())
         return o, lse
     call("hoisdf_attention_fwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(lse), B, H, Lq, Lk,
          kv_len, float(drop_p), seed, _p(ws), nbytes, int(keep), _st())
@@ -1156,8 +1164,8 @@ def _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv
     return o, lse
 
 
-def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed, qkv_mag=None, kv_mag=None):
-    """qkv_mag (and kv_mag when k, v come from another matrix than q): the f16x2 form of the backward (the words the forward used)"""
+def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed, heads=None):
+    """heads: the (q, k, v) head magnitudes the forward used -> the f16x2 form of the backward"""
     from ._lib import lib
     B, Lq, E = q.shape
     Lk = k.shape[1]
@@ -1168,11 +1176,11 @@ def _attn_bwd_emu(q, k, v, o, lse, do, dq, dk, dv, H, kv_len, drop_p, seed, qkv_
     delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
     if kept is not None:
         kept.record_stream(torch.cuda.current_stream(q.device))
-    if qkv_mag is not None:
-        do_mag = _mag_measure(do, E, B * Lq, E)
+    if heads is not None:
+        do_hm = _head_measure(do, E, B * Lq, H, Lq)
         call("hoisdf_attention_bwd_emu_mag", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E, _p(lse),
-             _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _p(qkv_mag),
-             _p(kv_mag), _p(do_mag), None, _st())
+             _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _p(heads[0]),
+             _p(heads[1]), _p(heads[2]), _p(do_hm), None, _st())
         return
     call("hoisdf_attention_bwd_emu", _p(q), q.stride(1), _p(k), k.stride(1), _p(v), v.stride(1), _p(o), E, _p(do), E, _p(lse),
          _p(delta), _p(dq), _p(dk), _p(dv), B, H, Lq, Lk, kv_len, float(drop_p), seed, _p(kept), _p(ws), nbytes, _st())
@@ -1189,17 +1197,17 @@ def _emu_bwd() -> bool:
     return _ATTN_BWD_EMU or deterministic()
 
 
-def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False, qkv_mag=None, kv_mag=None):
-    if mode == 2 and qkv_mag is not None:
-        return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, qkv_mag=qkv_mag, kv_mag=kv_mag)
+def _attn_fwd_mode(mode, q, k, v, H, kv_len, drop_p, seed, keep=False, heads=None):
+    if mode == 2 and heads is not None:
+        return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, heads=heads)
     if mode == 2:
         return _attn_fwd_emu(q, k, v, H, kv_len, drop_p, seed, keep=keep and _emu_bwd())
     return _attn_fwd(q, k, v, H, kv_len, drop_p, seed)
 
 
-def _attn_bwd_mode(mode, *a, qkv_mag=None, kv_mag=None):
+def _attn_bwd_mode(mode, *a, heads=None):
     if mode == 2 and _emu_bwd():
-        return _attn_bwd_emu(*a, qkv_mag=qkv_mag, kv_mag=kv_mag)
+        return _attn_bwd_emu(*a, heads=heads)
     return _attn_bwd(*a)
 
 
@@ -1475,18 +1483,20 @@ class _EncoderLayer(torch.autograd.Function):
             q = qbuf.view(B, nq, E)
             kv3 = kvbuf.view(B, S, 2 * E)
             k, v = kv3[:, :, :E], kv3[:, :, E:]
-        qm = kvm = None
+        heads = None
         if _use_f16(p, x, w_in, w_out, w1, w2):
             # gradient-free eval with cfg.attention_f16_eval: the f16-operand kernel (no LSE: nothing is saved for a backward)
             o, lse = _attn_fwd_f16(q, k, v, H, S), None
         else:
             if split == 2 and _attn_h2(B * nq) and E == 64 * H:
-                # the f16x2 form of the forward, as the coarse entry runs it: the scales from the magnitudes of the projected matrices
+                # the f16x2 form of the forward, as the coarse entry runs it: one scale per (sample, head) from the projected matrices
                 if full:
-                    qm = _mag_measure(qkv, 3 * E, B * S, 3 * E)
+                    hm = _head_measure(qkv, 3 * E, B * S, 3 * H, S)
+                    heads = (hm, hm[H * B:], hm[2 * H * B:])
                 else:
-                    qm, kvm = _mag_measure(qbuf, E, B * nq, E), _mag_measure(kvbuf, 2 * E, B * S, 2 * E)
-            o, lse = _attn_fwd_mode(split, q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad), qkv_mag=qm, kv_mag=kvm)
+                    hq, hkv = _head_measure(qbuf, E, B * nq, H, nq), _head_measure(kvbuf, 2 * E, B * S, 2 * H, S)
+                    heads = (hq, hkv, hkv[H * B:])
+            o, lse = _attn_fwd_mode(split, q, k, v, H, S, p, s_attn, keep=any(ctx.needs_input_grad), heads=heads)
         M = B * nq
         a, _ = _lin_fwd(o.view(M, E), w_out, b_out, False, 0.0, 0, False)
         xq2 = xq.view(M, E)
@@ -1511,7 +1521,7 @@ class _EncoderLayer(torch.autograd.Function):
         ctx.save_for_backward(x, qkv if full else qbuf, qkv if full else kvbuf, o, lse, a, x1, h, bits, f, x2, st, w_in,
                               w_out, w1, w2, g1, g2, g3)
         ctx.meta = (B, S, E, nq, full, float(p), H, (s_attn, s_ln1, s_ffn, s_ln2), split, ni)
-        ctx.attn_mags = (qm, kvm)
+        ctx.attn_heads = heads
         return x2.view(B, nq, E), y.view(B, ni, E)
 
     @staticmethod
@@ -1558,8 +1568,8 @@ class _EncoderLayer(torch.autograd.Function):
         do = torch.empty(M, E, device=dev)
         _lin_bwd_input(da, None, 0.0, w_out, do, False)
         _lin_bwd_weight(da, None, 0.0, o.view(M, E), dw_out, db_out)
-        qm, kvm = ctx.attn_mags                                       # (the f16x2 forward's words: the backward runs in the same form)
-        bwd = lambda *a_: _attn_bwd_mode(split, *a_, qkv_mag=qm, kv_mag=kvm)
+        heads = ctx.attn_heads                                        # (the f16x2 forward's head magnitudes: the backward runs in the same form)
+        bwd = lambda *a_: _attn_bwd_mode(split, *a_, heads=heads)
         do3 = do.view(B, nq, E)
         if full:
             qkv3 = qs.view(B, S, 3 * E)

@@ -149,22 +149,43 @@ int hoisdf_linear_emu_supported(const float* a, long lda, int contraction);
  * "b3"  bf16x3: the exact three-piece split described above, six products per product, any operand range.
  * "h2"  f16x2 (default since round 5): every operand is scaled by a power of two s that puts its largest magnitude in
  *       [2^13, 2^14) and split into TWO f16 pieces, x s = hi + lo + r with |r| <= max(2^-22 |x s|, 2^-25): 22 significant bits
- *       (on average 2^-24 relative, the rounding of an f32 operation) for every element within 2^-16 of the matrix's largest, an
- *       ABSOLUTE error of 2^-38 max |x| below that (the low piece is an f16 subnormal there); each product is accumulated in f32 from
- *       THREE f16 MFMA products (lo hi + hi lo + hi hi; the dropped lo lo term is <= 2^-22 of the product) and the result is scaled
- *       back.  Half the matrix-pipe work of b3.  Error against fp64 on the model's operands: that of b3 and of the exact-f32 entries
- *       (tests/test_gpu_emu.py, test_gpu_bench_geometry.py); what it gives up is RELATIVE accuracy of elements more than 2^16 below
- *       the largest one of the same operand matrix (their error stays 2^-38 of that largest one).
- *       The scale needs the operand's largest magnitude at launch time: weights carry theirs in the image; for the row operand
- *       the caller may pass "magnitude words" that the producing kernel left behind (hoisdf_mag_words() u32 words, zero-filled
- *       before the producer(s) ran; every wave of a producer folds the IEEE bits of its max |value| into one word with an unsigned
- *       atomic max: the *_mag entries below do that for their output when y_mag / dx_mag is given - not with accumulate = 1).
- *       Without words (x_mag = NULL, and in the plain entries) the library measures the operand itself: one more read of it.
+ *       (on average 2^-24 relative, the rounding of an f32 operation) for every element within 2^-16 of the largest one sharing its
+ *       scale, an ABSOLUTE error of 2^-38 of that largest one below (the low piece is an f16 subnormal there); each product is
+ *       accumulated in f32 from THREE f16 MFMA products (lo hi + hi lo + hi hi; the dropped lo lo term is <= 2^-22 of the product) and
+ *       the result is scaled back.  Half the matrix-pipe work of b3.  Error against fp64 on the model's operands: that of b3 and of
+ *       the exact-f32 entries (tests/test_gpu_emu.py, test_gpu_bench_geometry.py).
+ *       WHO SHARES A SCALE (round 6): a weight matrix has one scale (kept in its image).  The row operand of a forward / grad-input
+ *       contraction has ONE SCALE PER ROW (token): a row's rounding depends on that row alone, so the samples of a batch do not
+ *       influence each other's results (sample 0 of a batch is bit-identical whatever the other samples are) and a row far below
+ *       the matrix maximum keeps its 22 bits.  The grad-weight contracts over the rows: each of its row slices takes the largest
+ *       magnitude of its own rows.  The attention operands (Q, K, V, dO) have one scale per (sample, head).
+ *       The scales need the magnitudes at launch time.  ROW MAGNITUDES of a matrix of M rows: hoisdf_mag_words(M) = M u32 words, word
+ *       r = the IEEE bits of max |x[r][:]| (or of an upper bound), ZERO-FILLED before the producer(s) run: the *_mag entries below
+ *       fold their output's into y_mag / dx_mag with an unsigned atomic max per row and column tile (not with accumulate = 1), so do
+ *       the LayerNorm, gather, positional-encoding, SDF-head and attention entries of the composite calls.  Without words (x_mag =
+ *       NULL, and in the plain entries) the library measures the operand itself: one more read of it (hoisdf_mag_measure does the
+ *       same once for several consumers).  HEAD MAGNITUDES of an attention operand matrix (rows = B samples x L tokens, groups of 64
+ *       columns = heads): hoisdf_head_mag_words(M, groups, L) words, word[group * B + sample]; zero-filled, then folded by
+ *       hoisdf_linear_fwd_emu_heads / the composite entries, or made by hoisdf_head_mag_measure.
+ *       A word SMALLER than the true maximum (a stale array) cannot make Inf / NaN: the splitting kernels run with f16 saturation
+ *       on (MODE.FP16_OVFL) - up to 4x too small is harmless (head room of the [2^13, 2^14) target), beyond that the row's largest
+ *       elements clip at 65504 / scale.
  * hoisdf_linear_emu_pieces() = 2 (h2) or 3 (b3).  The image format follows the form: images are built and consumed in one process. */
 int hoisdf_linear_emu_pieces(void);
-int hoisdf_mag_words(void);
-/* the words of a matrix whose producer left none: zero-fills `words` and folds max |x| of the M x K matrix into them (one read of x) */
+long hoisdf_mag_words(long rows);
+/* the row magnitudes of a matrix whose producer left none: every word is written (no clearing needed); one read of x */
 int hoisdf_mag_measure(const float* x, long ldx, long M, int K, uint32_t* words, void* stream);
+long hoisdf_head_mag_words(long M, int groups, int L);
+/* the head magnitudes of x[M][>= groups * 64] (samples of L consecutive rows): clears `words`, then one read of x */
+int hoisdf_head_mag_measure(const float* x, long ldx, long M, int groups, int L, uint32_t* words, void* stream);
+/* hoisdf_linear_fwd_emu_mag that also folds the head magnitudes of y (N % 64 == 0; zero-filled `y_heads`, samples of L rows) - what an
+ * attention in-projection leaves for hoisdf_attention_fwd_emu_mag; y_mag may be NULL */
+int hoisdf_linear_fwd_emu_heads(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
+                                int K, const uint32_t* x_mag, uint32_t* y_mag, uint32_t* y_heads, int L, void* stream);
+/* the same for a grad-input (no sign bitmap, no accumulation): what an out-projection's backward leaves for the dO operand of
+ * hoisdf_attention_bwd_emu_mag (K % 64 == 0: the heads are the columns of dx) */
+int hoisdf_linear_bwd_input_emu_heads(const float* dy, int lddy, const void* wt_image, float* dx, int lddx, long M, int N, int K,
+                                      const uint32_t* dy_mag, uint32_t* dx_mag, uint32_t* dx_heads, int L, void* stream);
 int hoisdf_linear_fwd_emu_mag(const float* x, int ldx, const void* w_image, const float* bias, float* y, int ldy, long M, int N,
                               int K, int act, float drop_p, uint64_t seed, uint32_t* relu_bits, const uint32_t* x_mag,
                               uint32_t* y_mag, void* stream);
@@ -429,18 +450,19 @@ long hoisdf_attention_emu_workspace(int B, int H, int Lq, int Lk, int mode);
 int hoisdf_attention_fwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                              float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
                              long workspace_bytes, int keep, void* stream);
-/* the forward in the f16x2 form (round 5; see "the two arithmetic forms" at hoisdf_linear_fwd_emu_mag): qkv_mag = the magnitude
- * words of the matrix q (and, with kv_mag = NULL, k and v) are column slices of, kv_mag = those of the matrix k and v come from when
- * that is another one (hoisdf_mag_measure, or the y_mag of the in-projection): one power-of-two scale per matrix; two f16 planes per
+/* the forward in the f16x2 form (round 5; see "the two arithmetic forms" at hoisdf_linear_fwd_emu_mag): q_mag / k_mag / v_mag = the head
+ * magnitudes of q, k and v (each pointer positioned at ITS operand's first head: for q, k, v that are column slices 0 / E / 2E of one
+ * [q | k | v] matrix with words w = hoisdf_head_mag_words(B L, 3 H, L): w, w + H B, w + 2 H B) - one power-of-two scale per (sample,
+ * head) and operand (round 6; round 5 had one per matrix: a sample's rounding depended on its batch companions); two f16 planes per
  * operand, three v_mfma_f32_32x32x16_f16 products per product, P carried as 2^6 P.  Same contracts, LSE convention and dropout mask
- * as hoisdf_attention_fwd_emu.  Accuracy: the operand pieces keep 22 bits, so a score s (log2 domain) carries an absolute error of
- * ~2^-22 |s| where the bf16x3 form has f32 rounding only - indistinguishable at the |s| <~ 100 of trained attention, 4x the bf16x3
- * form's output error at |s| ~ 2000.  The planes it keeps (keep = 1) are f16x2 planes - only a backward of the same form reads them.
- * o_mag (optional) receives the words of o. */
+ * as hoisdf_attention_fwd_emu; drop_p < 0.75.  Accuracy: the operand pieces keep 22 bits, so a score s (log2 domain) carries an
+ * absolute error of ~2^-22 |s| where the bf16x3 form has f32 rounding only - indistinguishable at the |s| <~ 100 of trained attention,
+ * 4x the bf16x3 form's output error at |s| ~ 2000.  The planes it keeps (keep = 1) are f16x2 planes - only a backward of the same form
+ * reads them.  o_mag (optional, zero-filled, B Lq words) receives the row magnitudes of o. */
 int hoisdf_attention_fwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                                  float* lse, int B, int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, void* workspace,
-                                 long workspace_bytes, int keep, const uint32_t* qkv_mag, const uint32_t* kv_mag, uint32_t* o_mag,
-                                 void* stream);
+                                 long workspace_bytes, int keep, const uint32_t* q_mag, const uint32_t* k_mag, const uint32_t* v_mag,
+                                 uint32_t* o_mag, void* stream);
 long hoisdf_attention_bwd_emu_workspace(int B, int H, int Lq, int Lk, int kept);
 int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                              const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
@@ -448,13 +470,14 @@ int hoisdf_attention_bwd_emu(const float* q, int ldq, const float* k, int ldk, c
                              void* workspace, long workspace_bytes, void* stream);
 /* the backward in the f16x2 form (emu_attn_bwd4h_kernel, round 5): Q, K, V, dO and P as two scaled f16 pieces (three products per
  * product), dS as three (its magnitude follows P: five products in dQ and dK) - 76 instead of 120 MFMAs per query tile; one pass, no
- * atomics, run-to-run identical like hoisdf_attention_bwd_emu.  qkv_mag / kv_mag: as hoisdf_attention_fwd_emu_mag; do_mag: the
- * magnitude words of dout (all required; hoisdf_mag_measure).  fwd_workspace: the planes a forward OF THIS FORM kept, or NULL. */
+ * atomics, run-to-run identical like hoisdf_attention_bwd_emu.  q_mag / k_mag / v_mag: as hoisdf_attention_fwd_emu_mag; do_mag: the
+ * head magnitudes of dout (all required; hoisdf_head_mag_measure, or hoisdf_linear_bwd_input_emu_heads).  fwd_workspace: the planes a
+ * forward OF THIS FORM kept, or NULL.  g_mag (optional, zero-filled, B L words; needs Lq == Lk): the row magnitudes of a [dq | dk | dv] matrix. */
 int hoisdf_attention_bwd_emu_mag(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, int ldo,
                                  const float* dout, int lddo, const float* lse, float* delta, float* dq, float* dk, float* dv, int B,
                                  int H, int Lq, int Lk, int kv_len, float drop_p, uint64_t seed, const void* fwd_workspace,
-                                 void* workspace, long workspace_bytes, const uint32_t* qkv_mag, const uint32_t* kv_mag,
-                                 const uint32_t* do_mag, uint32_t* g_mag, void* stream);
+                                 void* workspace, long workspace_bytes, const uint32_t* q_mag, const uint32_t* k_mag,
+                                 const uint32_t* v_mag, const uint32_t* do_mag, uint32_t* g_mag, void* stream);
 /* Small masked attention (17 MANO queries, tgt_mask of common/utils/misc.py:11-31):
  * mask [Lq][Lk] uint8, 1 = masked; Lq, Lk <= 64. probs [B][H][Lq][Lk] saved for backward. */
 int hoisdf_attention_small_fwd(const float* q, int ldq, const float* k, int ldk, const float* v,

@@ -158,9 +158,9 @@ def test_f16x2_grad_weight_matches_fp64(M, N, K, masked):
         scale = keep.to(DEV).double() / (1 - p)
     dye = gy.double() * scale
     outs = []
-    nw_ = lib().hoisdf_mag_words()
-    ymag = torch.zeros(nw_, dtype=torch.int32, device=DEV); ymag[3] = gy.abs().max().view(torch.int32)
-    xmag = torch.zeros(nw_, dtype=torch.int32, device=DEV); xmag[200] = x.abs().max().view(torch.int32)
+    assert lib().hoisdf_mag_words(M) == M
+    ymag = gy.abs().amax(1).contiguous().view(torch.int32)       # row magnitudes (include/hoisdf.h): one word per row
+    xmag = x.abs().amax(1).contiguous().view(torch.int32)
     for kw in (dict(form="h2"), dict(form="h2"), dict(dy_mag=ymag, x_mag=xmag), dict(dy_mag=ymag)):
         dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
         O._gemm_bwd_weight(gy, N, bits, p, x, K, dW, db, M, N, K, **kw)
@@ -364,9 +364,8 @@ def test_f16x2_form_at_the_ends_of_the_f32_range():
 
 
 def test_magnitude_words_travel_from_producer_to_consumer():
-    """hoisdf_linear_fwd_emu_mag / _bwd_input_emu_mag: the words a contraction leaves for its output hold max |y| (never less, and
-    within the padding rows' bias-only values of it); a consumer given those words computes bit-identically to one that measures
-    the operand itself whenever both find the same power of two."""
+    """hoisdf_linear_fwd_emu_mag / _bwd_input_emu_mag: the row magnitudes a contraction leaves for its output hold max |y[row][:]| of
+    every row, exactly; a consumer given them computes bit-identically to one that measures the operand itself."""
     if pieces() != 2:
         pytest.skip("f16x2 form only")
     O = ops()
@@ -376,30 +375,130 @@ def test_magnitude_words_travel_from_producer_to_consumer():
     x = torch.randn(M, K, generator=g).to(DEV)
     W1 = (torch.randn(N, K, generator=g) / 16).to(DEV)
     W2 = (torch.randn(K, N, generator=g) / 16).to(DEV)
-    nw = lib().hoisdf_mag_words()
-    ymag = torch.zeros(nw, dtype=torch.int32, device=DEV)
-    zmag = torch.zeros(nw, dtype=torch.int32, device=DEV)
+    ymag = torch.zeros(M, dtype=torch.int32, device=DEV)          # row magnitudes: one word per row, zero before the producer runs
+    zmag = torch.zeros(M, dtype=torch.int32, device=DEV)
     y = torch.empty(M, N, device=DEV); z = torch.empty(M, K, device=DEV); z0 = torch.empty(M, K, device=DEV)
     st = O._st()
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     call("hoisdf_linear_fwd_emu_mag", p(x), K, p(O._emu_image(W1, False)), None, p(y), N, M, N, K, 1, 0.0, 0, None, None, p(ymag), st)
-    got = float(ymag.view(torch.float32).max())
-    assert got == float(y.abs().max()), (got, float(y.abs().max()))
+    assert torch.equal(ymag.view(torch.float32), y.abs().amax(1))        # every row's own maximum, exactly
     call("hoisdf_linear_fwd_emu_mag", p(y), N, p(O._emu_image(W2, False)), None, p(z), K, M, K, N, 0, 0.0, 0, None, p(ymag), p(zmag), st)
     call("hoisdf_linear_fwd_emu", p(y), N, p(O._emu_image(W2, False)), None, p(z0), K, M, K, N, 0, 0.0, 0, None, st)
     assert torch.equal(z, z0)
-    assert float(zmag.view(torch.float32).max()) == float(z.abs().max())
+    assert torch.equal(zmag.view(torch.float32), z.abs().amax(1))
     assert_close(z, torch.relu(x.double() @ W1.double().t()) @ W2.double().t(), rel=2e-6, what="two chained contractions")
     # grad-input with the words of dy; accumulate = 1 leaves dx_mag alone
     dx = torch.empty(M, K, device=DEV); dx0 = torch.empty(M, K, device=DEV)
-    dmag = torch.zeros(nw, dtype=torch.int32, device=DEV)
+    dmag = torch.zeros(M, dtype=torch.int32, device=DEV)
     call("hoisdf_linear_bwd_input_emu_mag", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx), K, M, N, K, 0, p(ymag), p(dmag), st)
     call("hoisdf_linear_bwd_input_emu", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx0), K, M, N, K, 0, st)
-    assert torch.equal(dx, dx0) and float(dmag.view(torch.float32).max()) == float(dx.abs().max())
+    assert torch.equal(dx, dx0) and torch.equal(dmag.view(torch.float32), dx.abs().amax(1))
     dmag.zero_()
     call("hoisdf_linear_bwd_input_emu_mag", p(y), N, None, 0.0, p(O._emu_image(W1, True)), p(dx), K, M, N, K, 1, p(ymag), p(dmag), st)
     assert int(dmag.abs().max()) == 0
     assert_close(dx, 2 * dx0.double(), rel=1e-6, what="accumulate")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 256), (2500, 224, 292), (65536, 256, 1024)])
+def test_f16x2_rows_are_scaled_one_by_one(M, N, K):
+    """Round 6: the row operand of a forward / grad-input contraction has one power-of-two scale PER ROW (include/hoisdf.h).
+    (a) rows whose magnitudes span 60 decades each come back at the form's accuracy relative to THEIR OWN largest output (one scale per
+    matrix left every row more than 2^16 below the largest with an absolute error instead); (b) a row's result does not depend on the
+    other rows of the matrix: the first 2048 rows are bit-identical next to quiet and next to x 1e6 louder companions - forward,
+    masked grad-input and the magnitudes the epilogue leaves."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    g = torch.Generator().manual_seed(M + N)
+    mags = torch.pow(10.0, 60.0 * torch.rand(M, 1, generator=g) - 30.0)
+    x = (torch.randn(M, K, generator=g) * mags).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    y = torch.empty(M, N, device=DEV)
+    O._gemm_fwd(x, K, W, None, y, N, M, N, K, 0, 0.0, 0, None)
+    ref = x.double() @ W.double().t()
+    rowmax = ref.abs().amax(1, keepdim=True).clamp_min(1e-300)
+    assert float(((y.double() - ref).abs() / rowmax).max()) <= 2e-6
+    dx = torch.empty(M, K, device=DEV)
+    gy = (torch.randn(M, N, generator=g) * mags).to(DEV)
+    O._gemm_bwd_input(gy, N, None, 0.0, W, dx, K, M, N, K, False)
+    refd = gy.double() @ W.double()
+    assert float(((dx.double() - refd).abs() / refd.abs().amax(1, keepdim=True).clamp_min(1e-300)).max()) <= 2e-6
+    # (b) companions
+    R = 2048
+    x2 = x.clone(); x2[R:] = torch.randn(M - R, K, generator=g).to(DEV) * 1e6
+    y2 = torch.empty(M, N, device=DEV)
+    O._gemm_fwd(x2, K, W, None, y2, N, M, N, K, 0, 0.0, 0, None)
+    assert torch.equal(y2[:R], y[:R]) and not torch.equal(y2[R:], y[R:])
+    gy2 = gy.clone(); gy2[R:] = torch.randn(M - R, N, generator=g).to(DEV) * 1e-9
+    dx2 = torch.empty(M, K, device=DEV)
+    O._gemm_bwd_input(gy2, N, None, 0.0, W, dx2, K, M, N, K, False)
+    assert torch.equal(dx2[:R], dx[:R])
+
+
+def test_attention_f16x2_samples_do_not_see_each_other():
+    """one scale per (sample, head) for Q, K, V and dO (round 6; round 5: one per projected matrix): sample 0's attention output, LSE
+    and gradients are bit-identical whatever the other samples of the batch hold - here samples 300 x louder."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    B, L, E, H = 4, 1024, 256, 4
+    g = torch.Generator().manual_seed(3)
+    res = []
+    base = torch.randn(B, L, 3 * E, generator=g)
+    go0 = torch.randn(B, L, E, generator=g)
+    for loud in (1.0, 300.0):
+        qkv = base.clone(); qkv[1:] *= loud
+        go = go0.clone(); go[1:] *= loud
+        qkv, go = qkv.to(DEV), go.to(DEV)
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+        hm = O._head_measure(qkv, 3 * E, B * L, 3 * H, L)
+        heads = (hm, hm[H * B:], hm[2 * H * B:])
+        o, lse = O._attn_fwd_emu(q, k, v, H, L, 0.1, 5, heads=heads)
+        dqkv = torch.empty_like(qkv)
+        O._attn_bwd_emu(q, k, v, o, lse, go, dqkv[..., :E], dqkv[..., E:2 * E], dqkv[..., 2 * E:], H, L, 0.1, 5, heads=heads)
+        res.append((o, lse, dqkv))
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_[0], b_[0]) and not torch.equal(a_[1], b_[1])
+
+
+def test_a_stale_row_magnitude_clips_instead_of_overflowing():
+    """what a wrong (too small) magnitude does.  The splitting kernels run with f16 saturation on (MODE.FP16_OVFL):
+    a word up to 4 x below the row's true maximum is inside the head room of the [2^13, 2^14) target - results unchanged to rounding;
+    a word 2^12 below it clips the row's largest elements at 65504 / scale - wrong for that row, but finite (no Inf / NaN reaches the
+    next layer) and the OTHER rows are untouched; a correct word next to it keeps its row exact."""
+    if pieces() != 2:
+        pytest.skip("f16x2 form only")
+    O = ops()
+    from hoisdf_amd._lib import call
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 8448, 256, 256
+    x = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / 16).to(DEV)
+    img = O._emu_image(W, False)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    good = x.abs().amax(1).contiguous().view(torch.int32)
+    def fwd(words):
+        y = torch.empty(M, N, device=DEV)
+        call("hoisdf_linear_fwd_emu_mag", p(x), K, p(img), None, p(y), N, M, N, K, 0, 0.0, 0, None, p(words), None, O._st())
+        return y
+    y0 = fwd(good)
+    ref = x.double() @ W.double().t()
+    assert_close(y0, ref, rel=2e-6, what="correct words")
+    stale4 = (x.abs().amax(1) / 4).contiguous().view(torch.int32)
+    assert_close(fwd(stale4), ref, rel=2e-6, what="4 x stale: inside the head room")
+    bad = good.clone()
+    bad[7] = (x[7].abs().max() / 4096).view(torch.int32)               # row 7: 2^12 too small; a zero word for row 9 (an all-zero row's word on data)
+    bad[9] = 0
+    yb = fwd(bad)
+    assert bool(torch.isfinite(yb).all())
+    keep = torch.ones(M, dtype=torch.bool, device=DEV); keep[7] = keep[9] = False
+    assert torch.equal(yb[keep], y0[keep])
+    assert float((yb[7] - y0[7]).abs().max()) > 0                     # (clipped: wrong, finite)
+    # the same through the grad-weight (its row slices take the largest word of their rows): finite
+    dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    gy = torch.randn(M, N, generator=g).to(DEV)
+    O._gemm_bwd_weight(gy, N, None, 0.0, x, K, dW, db, M, N, K, dy_mag=gy.abs().amax(1).contiguous().view(torch.int32), x_mag=bad)
+    assert bool(torch.isfinite(dW).all())
 
 
 def test_the_bf16x3_form_meets_the_same_bars():
@@ -554,13 +653,14 @@ def test_f16x2_attention_forward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv,
     kvm[..., :E] *= 0.5
     k, v = kvm[..., :E], kvm[..., E:]
     ref = _ref_attn64(q.double().cpu().contiguous(), k.double().cpu().contiguous(), v.double().cpu().contiguous(), H, kv)
-    # the words of "the matrix q, k, v are slices of": measured (hoisdf_mag_measure) for [k | v], folded with q's maximum by hand
-    mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=DEV)
-    call("hoisdf_mag_measure", C.c_void_p(kvm.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
-    mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
+    # head magnitudes (include/hoisdf.h): one scale per (sample, head) and operand - measured for q and for the [k | v] matrix
+    hq = O._head_measure(q, E, B * Lq, H, Lq)
+    hkv = O._head_measure(kvm, 2 * E, B * Lk, 2 * H, Lk)
+    assert torch.equal(hq.view(torch.float32).view(H, B), q.abs().view(B, Lq, H, 64).amax((1, 3)).t())
+    heads = (hq, hkv, hkv[H * B:])
     ob, lb = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0)
-    oh, lh = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, qkv_mag=mag)
-    oh2, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, qkv_mag=mag)
+    oh, lh = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, heads=heads)
+    oh2, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.0, 0, heads=heads)
     assert torch.equal(oh, oh2) and not torch.equal(oh, ob)
     assert_close(oh, ref, rel=2e-5, what="f16x2 out")
     mx = float(ref.abs().max())
@@ -570,7 +670,7 @@ def test_f16x2_attention_forward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv,
     assert float((lh - lb).abs().max()) <= 2e-5 * max(1.0, float(lb.abs().max()))
     # dropout: the same keep decisions as the bf16x3 kernel (same seed): outputs agree to rounding
     od, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.1, 4321)
-    oe, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.1, 4321, qkv_mag=mag)
+    oe, _ = O._attn_fwd_emu(q, k, v, H, kv, 0.1, 4321, heads=heads)
     assert_close(oe, od.double(), rel=2e-5, what="f16x2 out with dropout")
 
 
@@ -592,17 +692,17 @@ def test_f16x2_attention_backward_is_as_accurate_as_the_bf16x3_one(B, Lq, Lk, kv
     kvm = torch.randn(B, Lk, 2 * E, generator=g).to(DEV)
     go = (torch.randn(B, Lq, E, generator=g) * gamp).to(DEV)          # (gamp: output gradients at both ends of the f32 range too)
     k, v = kvm[..., :E], kvm[..., E:]
-    mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=DEV)
-    call("hoisdf_mag_measure", C.c_void_p(kvm.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
-    mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
+    hq = O._head_measure(q, E, B * Lq, H, Lq)
+    hkv = O._head_measure(kvm, 2 * E, B * Lk, 2 * H, Lk)
+    heads = (hq, hkv, hkv[H * B:])
 
     def run(h2, seed=99):
         if h2:
-            o, lse = O._attn_fwd_emu(q, k, v, H, kv, p, seed, qkv_mag=mag)
+            o, lse = O._attn_fwd_emu(q, k, v, H, kv, p, seed, heads=heads)
         else:
             o, lse = O._attn_fwd_emu(q, k, v, H, kv, p, seed)
         dq = torch.empty_like(q); dkv = torch.empty_like(kvm)
-        O._attn_bwd_emu(q, k, v, o, lse, go, dq, dkv[..., :E], dkv[..., E:], H, kv, p, seed, **(dict(qkv_mag=mag) if h2 else {}))
+        O._attn_bwd_emu(q, k, v, o, lse, go, dq, dkv[..., :E], dkv[..., E:], H, kv, p, seed, **(dict(heads=heads) if h2 else {}))
         return dq, dkv
     dqh, dkvh = run(True)
     dqh2, dkvh2 = run(True)

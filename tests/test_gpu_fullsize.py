@@ -64,6 +64,32 @@ def test_batch_permutation_equivariance(setup):
         assert err <= 2e-6, f"{k}: {err:.3e}"                        # same arithmetic per sample; only launch geometry differs
 
 
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_a_samples_outputs_do_not_depend_on_its_batch_companions(setup, mode):
+    """True of the reference (every op is per sample); true here since round 6 gave every row of a contraction's row operand and every
+    (sample, head) of the attention operands its OWN f16x2 scale: sample 0's outputs are BIT-IDENTICAL whatever samples 1 .. 31
+    are - other pyramids, other points, other cameras, and a x 300 louder batch (a sigma-gate / activation outlier next door used
+    to coarsen everybody's rounding: one scale per matrix in round 5).  "train" = branch A on the given points (dropout off),
+    "eval" = the dense-lattice sdf_infer path (ragged survivor counts per sample: rows of different samples share GEMM tiles)."""
+    from hoisdf_amd import ops
+    model, c, pyr, batch = setup
+    ref = run(model, pyr, batch, mode)
+    other = tuple(T.to_device(x, DEV) for x in T.synthetic_batch(B, NH, NO, seed=977))
+    pyr_o = [v.to(DEV).permute(0, 2, 3, 1).contiguous() for v in T.synthetic_pyramid(B, seed=55).values()]
+    for loud in (1.0, 300.0):
+        levels = [torch.cat([l[:1], lo[1:] * loud]) for l, lo in zip(pyr.levels, pyr_o)]
+        mixed = tuple({k: (torch.cat([v[:1], other[i][k][1:]]) if torch.is_tensor(v) and v.shape[:1] == (B,) else v) for k, v in d.items()}
+                      for i, d in enumerate(batch))
+        got = run(model, ops.PyramidNHWC(levels), mixed, mode)
+        n = 0
+        for k, v in ref.items():
+            if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B and k.endswith("_out"):
+                assert float((got[k][1] - v[1]).abs().max()) > 0, k                        # the companions really changed
+                assert torch.equal(got[k][0], v[0]), (mode, loud, k, float((got[k][0] - v[0]).abs().max()))
+                n += 1
+        assert n >= 3
+
+
 def test_point_permutation_invariance(setup):
     model, c, pyr, batch = setup
     inputs, targets, meta = batch

@@ -46,15 +46,14 @@ if __name__ == "__main__":
         if "_h2_" in case:
             import ctypes as C
             from hoisdf_amd._lib import call, lib
-            mag = torch.empty(lib().hoisdf_mag_words(), dtype=torch.int32, device=dev)
-            call("hoisdf_mag_measure", C.c_void_p(kv.data_ptr()), 2 * E, B * Lk, 2 * E, C.c_void_p(mag.data_ptr()), O._st())
-            mag[5] = torch.maximum(mag[5], q.abs().max().view(torch.int32))
-            o, lse = O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, qkv_mag=mag)
+            hq_, hkv_ = O._head_measure(q, E, B * Lq, H, Lq), O._head_measure(kv, 2 * E, B * Lk, 2 * H, Lk)
+            heads = (hq_, hkv_, hkv_[H * B:])
+            o, lse = O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, heads=heads)
             for _ in range(3):
                 if entry == "hoisdf_attention_fwd_emu_mag":
-                    O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, qkv_mag=mag)
+                    O._attn_fwd_emu(q, k, v, H, Lk, p, 1234, heads=heads)
                 else:
-                    O._attn_bwd_emu(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, Lk, p, 1234, qkv_mag=mag)
+                    O._attn_bwd_emu(q, k, v, o, lse, do, dq, dkv[:, :, :E], dkv[:, :, E:], H, Lk, p, 1234, heads=heads)
             torch.cuda.synchronize()
             sys.exit(0)
         o, lse = O._attn_fwd(q, k, v, H, Lk, p, 1234)
