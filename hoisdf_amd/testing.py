@@ -141,17 +141,27 @@ def det_params(shapes: Dict[str, Tuple[int, ...]], seed: int = 0) -> "OrderedDic
     return OrderedDict((k, det_param(k, s, seed)) for k, s in shapes.items())
 
 
+OUTLIER_CHANNELS = (3, 17, 40)          # (modulo a level's channel count)
+
+
 def synthetic_pyramid(B: int, big: bool = False, seed: int = 0, scale: float = 1.0,
-                      nonneg: bool = True) -> "OrderedDict[str, torch.Tensor]":
-    """Random NCHW feature maps shaped like the CNN decoder's pyramid (post-ReLU => >= 0)."""
+                      nonneg: bool = True, outliers: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+    """Random NCHW feature maps shaped like the CNN decoder's pyramid (post-ReLU => >= 0).
+    outliers != 1: channels OUTLIER_CHANNELS of every level are that many times louder (trained CNN features have such channels;
+    the "_smallbeta" fixtures use x 100)."""
     spec = PYRAMID_BIG if big else PYRAMID_SMALL
     out = OrderedDict()
     for name, (c, hw) in spec.items():
         a = _rng("pyr." + name, seed).standard_normal((B, c, hw, hw)).astype(np.float32) * scale
         if nonneg:
             a = np.maximum(a, 0)
+        if outliers != 1.0:
+            a[:, [ch % c for ch in OUTLIER_CHANNELS]] *= np.float32(outliers)
         out[name] = torch.from_numpy(a)
     return out
+
+
+SMALL_BETA = {"hand_sigmoid_beta": 2e-3, "obj_sigmoid_beta": 1e-2}     # a trained model's gates: sigma up to 500 (main/model.py:123-126)
 
 
 def synthetic_batch(B: int, n_hand: int, n_obj: int, seed: int = 1234):

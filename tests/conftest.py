@@ -44,12 +44,13 @@ def pyramid_gradient_close(got, golden_fp32, suffix):
     got = got.double().cpu()
     mx = float(golden_fp32.abs().max())
     err_ref = float((got - golden_fp32.double()).abs().max())
-    assert err_ref <= 2.2e-3 * mx, ("vs the reference's fp32 gradient", err_ref / mx)
     name = "g8_train_dexycb" + suffix + "_fp64"
     if os.path.exists(os.path.join(GOLDEN, name + ".npz")):
         g64 = load_golden(name)["grad.pyr.stride32"].double()
         err64 = float((got - g64).abs().max())
         ref64 = float((golden_fp32.double() - g64).abs().max())
+        # (the trained-like "_smallbeta" fixture: the reference's own fp32 sits 4.6e-3 of the max from fp64)
+        assert err_ref <= max(2.2e-3 * mx, 2.2 * ref64), ("vs the reference's fp32 gradient", err_ref / mx, ref64 / mx)
         assert err64 <= max(1.2e-3 * mx, 1.2 * ref64), ("vs fp64", err64 / mx, "reference fp32 vs fp64", ref64 / mx)
     else:
         assert err_ref <= 1.0e-3 * mx, err_ref / mx

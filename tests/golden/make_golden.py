@@ -219,9 +219,11 @@ def train_branch_b_golden():
     _train_goldens(2, 48, 16, "_branchB", ("dexycb",), epoch_cnt=10 ** 8)
 
 
-def _train_goldens(B, nh, no, suffix, settings, epoch_cnt=0):
+def _train_goldens(B, nh, no, suffix, settings, epoch_cnt=0, prepare=None, pyramid_kw=None):
     for setting in settings:
         model, cfg = build_reference(setting, nh, no, 16)
+        if prepare:
+            prepare(model)
         model.train()
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout):
@@ -230,7 +232,7 @@ def _train_goldens(B, nh, no, suffix, settings, epoch_cnt=0):
                 m.dropout = 0.0
             if hasattr(m, "dropout_prob"):
                 m.dropout_prob = 0.0
-        pyr = T.synthetic_pyramid(B, big=setting == "ho3d", seed=3)      # "ho3d" = the big decoder: C = 3968
+        pyr = T.synthetic_pyramid(B, big=setting == "ho3d", seed=3, **(pyramid_kw or {}))      # "ho3d" = the big decoder: C = 3968
         pyr = {k: v.clone().requires_grad_(True) for k, v in pyr.items()}
         model.backbone_net, model.decoder_net = _Backbone(), _Decoder(pyr)
         inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=31)
@@ -283,6 +285,38 @@ def big_goldens():
                 keep[k + "_mean"] = keep.pop(k).mean(1)
         save(f"g7_e2e_{setting}_n{nh + no}", **keep)
     train_goldens(sizes=((2, 1536, 512, "_n2048"),), settings=("dexycb",))
+
+
+def smallbeta_goldens():
+    """Round 6: trained-like statistics at BASELINE configs[1]'s points.  Every other fixture runs det_param's
+    beta = 0.08 / 0.12 (sigma <= 12.5); a trained model's betas sit near the 2e-3 floor (main/model.py:123-126): here hand 2e-3 (the
+    floor itself: sigma = 500 outside the surface, ~1e-30 inside) and obj 1e-2, on a pyramid whose channels 3 / 17 / 40 are x 100
+    louder than the rest (testing.synthetic_pyramid(outliers=100)).  Token rows then span ~30 decades inside one matrix and the
+    pyramid-fed MLPs see outlier columns - what the f16x2 form's shared scales had never been shown.
+    g7_e2e_dexycb_n2048_smallbeta: eval through the 64^3-lattice sdf_infer (B = 2); g8_train_dexycb_n2048_smallbeta: train fwd + bwd."""
+    nh, no, B = 1536, 512, 2
+
+    def set_beta(model):
+        with torch.no_grad():
+            for k, v in T.SMALL_BETA.items():
+                getattr(model, k).fill_(v)
+
+    model, cfg = build_reference("dexycb", nh, no, 64)
+    set_beta(model)
+    model.eval()
+    pyr = T.synthetic_pyramid(B, big=False, seed=2, outliers=100.0)
+    model.backbone_net, model.decoder_net = _Backbone(), _Decoder(pyr)
+    inputs, targets, meta = T.synthetic_batch(B, nh, no, seed=21)
+    with torch.no_grad():
+        out = model(inputs, targets, meta, "eval")
+    keep = {k: v for k, v in out.items() if torch.is_tensor(v) and v.numel() < 200000
+            and k not in ("hand_seg_gt_out", "obj_seg_gt_out", "hand_seg_pred_out", "obj_seg_pred_out", "joint_heatmap_out",
+                          "joint_heatmap", "obj_seg", "hand_seg")}
+    for k in ("obj_rot_out", "obj_trans_out"):
+        if k in keep:
+            keep[k + "_mean"] = keep.pop(k).mean(1)
+    save("g7_e2e_dexycb_n2048_smallbeta", **keep)
+    _train_goldens(B, nh, no, "_n2048_smallbeta", ("dexycb",), prepare=set_beta, pyramid_kw=dict(outliers=100.0))
 
 
 def aux_loss_golden():
@@ -590,7 +624,7 @@ def schema_golden():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik", "aux", "sampler", "options"]
+    which = sys.argv[1:] or ["stage", "e2e", "train", "trainB", "mano", "schema", "big", "metrics", "ik", "aux", "sampler", "options", "smallbeta"]
     if "schema" in which:
         schema_golden()
     if "mano" in which:
@@ -615,3 +649,5 @@ if __name__ == "__main__":
         sampler_golden()
     if "options" in which:
         option_goldens()
+    if "smallbeta" in which:
+        smallbeta_goldens()

@@ -48,14 +48,22 @@ def oracle_cfg(c, **kw):
 E2E = [("dexycb", False, 48, 16, 16, 2), ("ho3d", True, 48, 16, 16, 2), ("ho3d_render", False, 48, 16, 16, 2),
        ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1), ("ho3d", True, 384, 128, 64, 1),
        # BASELINE.json sizes: configs[1] points, configs[3] (IK variant, 4096 points), configs[4] (8192 points)
-       ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1), ("dexycb", False, 6144, 2048, 64, 1)]
+       ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1), ("dexycb", False, 6144, 2048, 64, 1),
+       # round 6: trained-like statistics (betas 2e-3 / 1e-2: sigma gates up to 500; x 100 outlier channels in the pyramid)
+       ("dexycb", False, 1536, 512, 64, 2, "_smallbeta")]
 
 
-@pytest.mark.parametrize("setting,big,nh,no,bins,b", E2E)
-def test_eval_forward_matches_reference_goldens(setting, big, nh, no, bins, b):
-    g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
+@pytest.mark.parametrize("case", E2E)
+def test_eval_forward_matches_reference_goldens(case):
+    setting, big, nh, no, bins, b = case[:6]
+    sfx = case[6] if len(case) > 6 else ""
+    g = load_golden(f"g7_e2e_{setting}_n{nh + no}{sfx}")
     model, c = build(setting, nh, no, bins)
-    pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=big, seed=2))
+    if sfx == "_smallbeta":
+        with torch.no_grad():
+            for k_, v_ in T.SMALL_BETA.items():
+                getattr(model, k_).fill_(v_)
+    pyr, _ = nhwc_pyramid(T.synthetic_pyramid(b, big=big, seed=2, outliers=100.0 if sfx == "_smallbeta" else 1.0))
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=21)
     if bins == 16:
         meta["bbox_hand"] = torch.tensor([0.0, 0, 256, 256]).repeat(b, 1)
@@ -168,22 +176,33 @@ def test_sdf_infer_in_train_mode_ranks_under_dropout_like_the_reference():
 
 
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
-                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
+                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB"),
+                                                  ("dexycb", 1536, 512, "_n2048_smallbeta")])
 def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suffix):
     """branch A (pre-points + jitter), every dropout p = 0: losses and gradients vs g8 goldens (the _n2048 fixture is the
     reference's own fwd+bwd at BASELINE configs[1]'s 1536+512 points).  _branchB: the training step after
-    cfg.point_sampling_epoch with the draw p >= 0.4 - query points from the dense-lattice sdf_infer (main/model.py:470-481)."""
+    cfg.point_sampling_epoch with the draw p >= 0.4 - query points from the dense-lattice sdf_infer (main/model.py:470-481).
+    _n2048_smallbeta (round 6): trained-like statistics - betas 2e-3 / 1e-2 (sigma up to 500: token rows spanning ~30 decades inside
+    one matrix) and x 100 outlier channels in the pyramid.  There fp32 ITSELF is ill-conditioned: the reference's own fp32 gradient
+    norms sit up to 1.3e-3 (hand_sigmoid_beta: 11.7 %) away from the fp64 values of the pinned oracle (tools/fp64_truth_smallbeta.py),
+    so gradient norms are held two-sided: within 1e-3 of the fp64 truth, or no further from it than 1.5 x the reference's own fp32."""
     g = load_golden(f"g8_train_{setting}{suffix}")
+    small = suffix.endswith("_smallbeta")
+    g64 = load_golden(f"g8_train_{setting}{suffix}_fp64") if small else None
     epoch_cnt = 10 ** 8 if suffix == "_branchB" else 0
     b = 2
     model, c = build(setting, nh, no, 16, train=True)
+    if small:
+        with torch.no_grad():
+            for k_, v_ in T.SMALL_BETA.items():
+                getattr(model, k_).fill_(v_)
     c.dropout = 0.0
     for m in model.modules():
         if hasattr(m, "p"):
             m.p = 0.0
         if hasattr(m, "dropout_prob"):
             m.dropout_prob = 0.0
-    pyr, levels = nhwc_pyramid(T.synthetic_pyramid(b, big=setting == "ho3d", seed=3), requires_grad=True)   # "ho3d": C = 3968
+    pyr, levels = nhwc_pyramid(T.synthetic_pyramid(b, big=setting == "ho3d", seed=3, outliers=100.0 if small else 1.0), requires_grad=True)   # "ho3d": C = 3968
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=31)
     # reproduce the reference's CPU jitter stream (torch.manual_seed(1234): hand first, then obj)
     torch.manual_seed(1234)
@@ -210,7 +229,11 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
             # orders on the CPU already differ by 1.3e-3 there, tests/test_oracle_golden.py); since round 4 the device sums
             # them in a fixed block order (hoisdf_token_build_bwd_ordered) - the bar is the CPU's own order noise, 3e-3
             rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 1e-3
-            assert abs(gn - float(g[key])) <= rt * float(g[key]) + 1e-6, (name, gn, float(g[key]))
+            if small:
+                t64, ref = float(g64[key]), float(g[key])
+                assert abs(gn - t64) <= max(rt * abs(t64), 1.5 * abs(ref - t64)) + 1e-6, (name, gn, t64, ref)
+            else:
+                assert abs(gn - float(g[key])) <= rt * float(g[key]) + 1e-6, (name, gn, float(g[key]))
             n += 1
         elif not name.startswith(("backbone", "decoder_net")):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
@@ -221,13 +244,15 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
         assert err <= rel * float(ref.abs().max()) + 1e-9, err
 
     brel = 3e-3 if suffix == "_branchB" else 1e-3
-    gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"], brel)
-    gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
+    if not small:                   # (small betas: the two scalars are covered by the two-sided gradient-norm rule above)
+        gclose(model.hand_sigmoid_beta.grad, g["grad.hand_sigmoid_beta"], brel)
+        gclose(model.obj_sigmoid_beta.grad, g["grad.obj_sigmoid_beta"], brel)
     gclose(model.linear_handcls.layers[2].weight.grad, g["grad.linear_handcls.layers.2.weight"])
     gclose(model.hand_sdf_decoder.linh0.weight_g.grad, g["grad.hand_sdf_decoder.linh0.weight_g"])
     pyramid_gradient_close(levels[4].grad.permute(0, 3, 1, 2)[:, ::16], g["grad.pyr.stride32"], suffix)
     gn2 = levels[0].grad.double().norm().item()
-    assert abs(gn2 - float(g["grad.pyr.stride2_norm"])) <= 1e-3 * float(g["grad.pyr.stride2_norm"])
+    t2 = float(g64["grad.pyr.stride2_norm"]) if small else float(g["grad.pyr.stride2_norm"])
+    assert abs(gn2 - t2) <= max(1e-3 * t2, 1.5 * abs(float(g["grad.pyr.stride2_norm"]) - t2)), (gn2, t2)
 
 
 def test_transformer_seq_first_surface_matches_golden():

@@ -206,17 +206,28 @@ def test_g9_mano_and_rotations():
 E2E = [("dexycb", False, 48, 16, 16, 2), ("ho3d", True, 48, 16, 16, 2), ("ho3d_render", False, 48, 16, 16, 2),
        ("dexycb", False, 384, 128, 64, 1), ("ho3d_render", False, 384, 128, 64, 1), ("ho3d", True, 384, 128, 64, 1),
        # the sizes BASELINE.json's configs[1] / configs[3] name (configs[4]'s 6144+2048 fixture is checked on the GPU only)
-       ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1)]
+       ("dexycb", False, 1536, 512, 64, 2), ("ho3d_render", False, 3072, 1024, 64, 1),
+       # round 6: trained-like statistics (betas 2e-3 / 1e-2, x 100 outlier channels in the pyramid: make_golden.py smallbeta_goldens)
+       ("dexycb", False, 1536, 512, 64, 2, "_smallbeta")]
 
 
-@pytest.mark.parametrize("setting,big,nh,no,bins,b", E2E)
-def test_g7_e2e(setting, big, nh, no, bins, b):
-    g = load_golden(f"g7_e2e_{setting}_n{nh + no}")
+def _smallbeta(Pm):
+    for k, v in T.SMALL_BETA.items():
+        Pm[k] = torch.full_like(Pm[k], v)
+
+
+@pytest.mark.parametrize("case", E2E)
+def test_g7_e2e(case):
+    setting, big, nh, no, bins, b = case[:6]
+    sfx = case[6] if len(case) > 6 else ""
+    g = load_golden(f"g7_e2e_{setting}_n{nh + no}{sfx}")
     ik = setting == "ho3d_render"
     Pm = T.det_params(T.hot_path_param_shapes(3968 if big else 992, ik=ik))
+    if sfx == "_smallbeta":
+        _smallbeta(Pm)
     cfg = O.OracleCfg(num_samp_hand=nh, num_samp_obj=no, bins_n=bins, use_inverse_kinematics=ik,
                       dataset="ho3d" if "ho3d" in setting else "dexycb")
-    pyr = T.synthetic_pyramid(b, big=big, seed=2)
+    pyr = T.synthetic_pyramid(b, big=big, seed=2, outliers=100.0 if sfx == "_smallbeta" else 1.0)
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=21)
     if bins == 16:
         meta["bbox_hand"] = torch.tensor([0.0, 0, 256, 256]).repeat(b, 1)
@@ -243,7 +254,8 @@ def test_g7_e2e(setting, big, nh, no, bins, b):
 
 
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
-                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB")])
+                                                  ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB"),
+                                                  ("dexycb", 1536, 512, "_n2048_smallbeta")])
 def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     """_branchB: epoch >= cfg.point_sampling_epoch and the draw p = 0.844 >= 0.4 -> the query points come from the
     dense-lattice sdf_infer (main/model.py:470-481), the rest of the step trains on them."""
@@ -253,11 +265,15 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     big = setting == "ho3d"                              # the big decoder: C = 3968 (main/config.py:96,101-108)
     b = 2
     Pm = T.det_params(T.hot_path_param_shapes(3968 if big else 992, ik=ik))
+    small = suffix.endswith("_smallbeta")
+    g64 = load_golden(f"g8_train_{setting}{suffix}_fp64") if small else None
+    if small:
+        _smallbeta(Pm)
     for v in Pm.values():
         v.requires_grad_(True)
     cfg = O.OracleCfg(num_samp_hand=nh, num_samp_obj=no, bins_n=16, use_inverse_kinematics=ik,
                       dataset="ho3d" if "ho3d" in setting else "dexycb", dropout=0.0, sdf_dropout=0.0)
-    pyr = {k: v.requires_grad_(True) for k, v in T.synthetic_pyramid(b, big=big, seed=3).items()}
+    pyr = {k: v.requires_grad_(True) for k, v in T.synthetic_pyramid(b, big=big, seed=3, outliers=100.0 if small else 1.0).items()}
     inputs, targets, meta = T.synthetic_batch(b, nh, no, seed=31)
     layer = MANO.ManoLayer(MANO.synthetic_assets(0))
     random.seed(0)
@@ -278,7 +294,13 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
             # branch B samples the points closest to the surface: d sigma / d beta is large there and the scalar beta
             # gradient is a heavily cancelling sum (observed 1.3e-3 between two fp32 summation orders)
             rt = 3e-3 if (suffix == "_branchB" and name.endswith("sigmoid_beta")) else 2e-4
-            close(p.grad.double().norm().float(), g[key], rtol=rt, atol=1e-6)
+            if small:
+                # fp32 itself is ill-conditioned at trained-like statistics: the REFERENCE's fp32 norms sit up to 1.3e-3 (hand beta:
+                # 11.7 %) from the fp64 values (tools/fp64_truth_smallbeta.py) - the restatement is held to the same distance
+                t64, ref, got = float(g64[key]), float(g[key]), float(p.grad.double().norm())
+                assert abs(got - t64) <= max(1e-3 * abs(t64), 1.5 * abs(ref - t64)) + 1e-6, (name, got, t64, ref)
+            else:
+                close(p.grad.double().norm().float(), g[key], rtol=rt, atol=1e-6)
             n += 1
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, name   # unused params
@@ -288,8 +310,18 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     def gclose(a, b, rel=3e-4 if nh < 1000 else 1e-3):
         close(a, b, rtol=0, atol=rel * float(b.abs().max()) + 1e-9)
 
-    gclose(Pm["hand_sigmoid_beta"].grad, g["grad.hand_sigmoid_beta"], **({"rel": 3e-3} if suffix == "_branchB" else {}))
+    if not small:
+        gclose(Pm["hand_sigmoid_beta"].grad, g["grad.hand_sigmoid_beta"], **({"rel": 3e-3} if suffix == "_branchB" else {}))
     gclose(Pm["linear_handcls.layers.2.weight"].grad, g["grad.linear_handcls.layers.2.weight"])
+    if small:                         # two-sided against the fp64 run, like the gradient norms above
+        t64 = g64["grad.pyr.stride32"].double()
+        mx = float(t64.abs().max())
+        d_ref = float((g["grad.pyr.stride32"].double() - t64).abs().max())
+        d_got = float((pyr["stride32"].grad[:, ::16].double() - t64).abs().max())
+        assert d_got <= max(1.2e-3 * mx, 1.5 * d_ref), (d_got / mx, d_ref / mx)
+        t2, r2 = float(g64["grad.pyr.stride2_norm"]), float(g["grad.pyr.stride2_norm"])
+        assert abs(float(pyr["stride2"].grad.double().norm()) - t2) <= max(1e-3 * t2, 1.5 * abs(r2 - t2))
+        return
     gclose(pyr["stride32"].grad[:, ::16], g["grad.pyr.stride32"])
     close(pyr["stride2"].grad.double().norm().float(), g["grad.pyr.stride2_norm"], rtol=1e-4)
 
