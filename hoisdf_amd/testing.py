@@ -162,6 +162,19 @@ def synthetic_pyramid(B: int, big: bool = False, seed: int = 0, scale: float = 1
 
 
 SMALL_BETA = {"hand_sigmoid_beta": 2e-3, "obj_sigmoid_beta": 1e-2}     # a trained model's gates: sigma up to 500 (main/model.py:123-126)
+# "_trainedlike" fixtures: SMALL_BETA + outlier channels + the FIRST encoder layer's query / key projections scaled down to the token
+# magnitudes they then see (sigma-gated rows up to ~5e3 / 2.4e4), as a network trained on such inputs would have them: attention scores
+# of O(10-100).  With det_param's unit-gain q / k weights the same tokens give scores of 7e6 (hand) / 2.4e8 (object) in the log2 domain:
+# one fp32 ulp of such a score is 0.5 / 16 - softmax is then decided by rounding, in any fp32 implementation
+TRAINED_LIKE_QK = {"hand_transformer.encoder.layers.0.self_attn": 3e-3, "obj_transformer.encoder.layers.0.self_attn": 7e-4}
+
+
+def apply_trained_like(get, E: int = 256):
+    """scale rows [0, 2E) (q and k) of the two first-layer in-projections in place; ``get(name)`` returns the tensor of a parameter name"""
+    with torch.no_grad():
+        for prefix, f in TRAINED_LIKE_QK.items():
+            get(prefix + ".in_proj_weight")[:2 * E].mul_(f)
+            get(prefix + ".in_proj_bias")[:2 * E].mul_(f)
 
 
 def synthetic_batch(B: int, n_hand: int, n_obj: int, seed: int = 1234):

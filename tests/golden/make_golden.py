@@ -318,6 +318,14 @@ def smallbeta_goldens():
     save("g7_e2e_dexycb_n2048_smallbeta", **keep)
     _train_goldens(B, nh, no, "_n2048_smallbeta", ("dexycb",), prepare=set_beta, pyramid_kw=dict(outliers=100.0))
 
+    # "_trainedlike": the same + the first encoder layers' q / k projections at the scale a trained network would have them for such
+    # tokens (testing.TRAINED_LIKE_QK: scores of O(10-100) instead of 7e6 / 2.4e8, where fp32 softmax is decided by rounding)
+    def trained_like(model):
+        set_beta(model)
+        sd = dict(model.named_parameters())
+        T.apply_trained_like(lambda n: sd[n])
+    _train_goldens(B, nh, no, "_n2048_trainedlike", ("dexycb",), prepare=trained_like, pyramid_kw=dict(outliers=100.0))
+
 
 def aux_loss_golden():
     """g13 (f4): the encoder-side auxiliary image losses as the reference's own forward computes them

@@ -216,7 +216,7 @@ def _smallbeta(Pm):
         Pm[k] = torch.full_like(Pm[k], v)
 
 
-@pytest.mark.parametrize("case", E2E)
+@pytest.mark.parametrize("case", E2E, ids=lambda c: "-".join(str(x) for x in c))
 def test_g7_e2e(case):
     setting, big, nh, no, bins, b = case[:6]
     sfx = case[6] if len(case) > 6 else ""
@@ -255,7 +255,7 @@ def test_g7_e2e(case):
 
 @pytest.mark.parametrize("setting,nh,no,suffix", [("dexycb", 48, 16, ""), ("ho3d_render", 48, 16, ""), ("ho3d", 48, 16, ""),
                                                   ("dexycb", 1536, 512, "_n2048"), ("dexycb", 48, 16, "_branchB"),
-                                                  ("dexycb", 1536, 512, "_n2048_smallbeta")])
+                                                  ("dexycb", 1536, 512, "_n2048_smallbeta"), ("dexycb", 1536, 512, "_n2048_trainedlike")])
 def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     """_branchB: epoch >= cfg.point_sampling_epoch and the draw p = 0.844 >= 0.4 -> the query points come from the
     dense-lattice sdf_infer (main/model.py:470-481), the rest of the step trains on them."""
@@ -265,10 +265,12 @@ def test_g8_train_fwd_bwd(setting, nh, no, suffix):
     big = setting == "ho3d"                              # the big decoder: C = 3968 (main/config.py:96,101-108)
     b = 2
     Pm = T.det_params(T.hot_path_param_shapes(3968 if big else 992, ik=ik))
-    small = suffix.endswith("_smallbeta")
+    small = suffix.endswith(("_smallbeta", "_trainedlike"))        # trained-like statistics (make_golden.py smallbeta_goldens)
     g64 = load_golden(f"g8_train_{setting}{suffix}_fp64") if small else None
     if small:
         _smallbeta(Pm)
+    if suffix.endswith("_trainedlike"):
+        T.apply_trained_like(lambda n_: Pm[n_])
     for v in Pm.values():
         v.requires_grad_(True)
     cfg = O.OracleCfg(num_samp_hand=nh, num_samp_obj=no, bins_n=16, use_inverse_kinematics=ik,

@@ -11,12 +11,15 @@ from hoisdf_amd import testing as T
 from hoisdf_amd.nets import mano as MANO
 from oracle import hoisdf_oracle as O
 torch.set_num_threads(8)
-g = dict(np.load("tests/golden/g8_train_dexycb_n2048_smallbeta.npz"))
+VAR = sys.argv[1] if len(sys.argv) > 1 else "smallbeta"            # or "trainedlike" (testing.TRAINED_LIKE_QK on top)
+g = dict(np.load(f"tests/golden/g8_train_dexycb_n2048_{VAR}.npz"))
 nh, no, b = 1536, 512, 2
 def run(dt):
     P0 = T.det_params(T.hot_path_param_shapes(992, ik=False))
     for k, v in T.SMALL_BETA.items():
         P0[k] = torch.full_like(P0[k], v)
+    if VAR == "trainedlike":
+        T.apply_trained_like(lambda n: P0[n])
     Pm = {k: v.to(dt).requires_grad_(True) for k, v in P0.items()}
     cfg = O.OracleCfg(num_samp_hand=nh, num_samp_obj=no, bins_n=16, use_inverse_kinematics=False, dataset="dexycb", dropout=0.0, sdf_dropout=0.0)
     pyr = {k: v.to(dt).requires_grad_(True) for k, v in T.synthetic_pyramid(b, big=False, seed=3, outliers=100.0).items()}
@@ -53,4 +56,4 @@ rows.sort(reverse=True)
 print("largest distances from fp64 (relative): reference fp32 | oracle fp32 | key | fp64 | oracle fp32 | reference fp32")
 for r in rows[:12]:
     print("  %.2e  %.2e  %-60s %.7g %.7g %.7g" % r)
-np.savez_compressed("tests/golden/g8_train_dexycb_n2048_smallbeta_fp64.npz", **{k: np.asarray(v, np.float64) for k, v in r64.items()})
+np.savez_compressed(f"tests/golden/g8_train_dexycb_n2048_{VAR}_fp64.npz", **{k: np.asarray(v, np.float64) for k, v in r64.items()})

@@ -16,6 +16,10 @@ the windows their data allows.
 import os
 import sys
 P2 = [(1, 0), (0, 1), (0, 0)]                                    # (A plane, B plane) of two-piece operands: small terms first
+# S = Q . K^T is accumulated in the FORWARD's order (attn_fwd2_phase.py FWD2_S2: K lo Q hi, K hi Q lo, K hi Q hi per k-step - here with
+# A = Q, B = K: (Q hi, K lo) first): the recomputed scores are then BIT-IDENTICAL to the ones the forward's LSE was made from, so
+# P = exp2(S - lse) cannot be thrown off by a last-bit difference of S where |S| is large (at |S| ~ 2^21 one ulp is a factor 1.19 of P)
+P2S = [(0, 1), (1, 0), (0, 0)]
 P23 = [(1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]                   # A two pieces, B (dS) three pieces
 N = 76
 CAP = int(os.environ.get("BWD4H_CAP", "34"))          # (A/B runs: the committed schedule is CAP = 34, look-ahead 4)
@@ -47,7 +51,7 @@ def main():
 
     for m in range(12):                                   # S
         j, k = divmod(m, 3)
-        x, y = P2[k]
+        x, y = P2S[k]
         mf.append("%s(s, fr[%d][%d], kf[%d][%d])" % ("MFMA_SP" if m else "MFMA_SP0", j & 1, x, j, y))
     for m in range(12):                                   # dP
         j, k = divmod(m, 3)
