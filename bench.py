@@ -39,8 +39,9 @@ DTYPE_F32 = "f32"                  # every contraction on the exact-f32 MFMA (--
 DTYPE_EMU = "f32 (bf16x3-emulated contractions, f32 accumulate)"   # HOISDF_EMU_FORM=b3: 3-way exact bf16 split, 6 products, f32 accumulation
 # the default since round 5: linear layers AND the encoder attention in the f16x2 form (two scaled f16 pieces per operand, 3 products:
 # include/hoisdf.h); HOISDF_EMU_FORM=b3 brings the bf16x3 arithmetic back for both
-DTYPE_EMU_H2 = "f32 (emulated contractions, f32 accumulate, f16x2 form: operands as scaled hi + lo f16 pieces x 3 products; the attention backward's dS as three pieces x 5)"
-PMC_FILE = "r05_pmc.json"
+DTYPE_EMU_H2 = ("f32 (emulated contractions, f32 accumulate, f16x2 form: operands as scaled hi + lo f16 pieces x 3 products - 22 operand bits, one power-of-two "
+                "scale per ROW of a linear layer's row operand, per (sample, head) of the attention operands, per weight matrix; the attention backward's dS as three pieces x 5)")
+PMC_FILE = "r06_pmc.json"
 # what a BARE v_mfma_f32_32x32x16_bf16 stream (registers only, one wave per SIMD) sustains on this power-capped board (1400 W) when the
 # operands are the bf16x3 pieces of N(0,1) values / uniform random values: 1542-1568 TF of the 2500 TF datasheet peak (2044-2100 TF on
 # zero / constant operands) - tools/ubench/mfma_data.hip, profiles/r05_mfma_rate_vs_operand_data.txt
@@ -48,7 +49,7 @@ MEASURED_MFMA_CEILING_TFLOPS = 1555.0
 # the same probe with v_mfma_f32_32x32x16_f16 on the hi / lo f16 pieces of N(0,1) values: 1345-1380 TF (tools/ubench/mfma_data_f16.hip,
 # profiles/r05_mfma_rate_vs_operand_data_f16.txt)
 MEASURED_MFMA_CEILING_F16_TFLOPS = 1365.0
-STEP_TRACE = "r05_bench_kernel_stats.csv"      # rocprofv3 kernel trace of this bench restricted to the timed steps (tools/trace_stats.py)
+STEP_TRACE = "r06_bench_kernel_stats.csv"      # rocprofv3 kernel trace of this bench restricted to the timed steps (tools/trace_stats.py)
 LOSS_WEIGHTS = dict(sdfhand_loss=50, sdfobj_loss=25, joint_heatmap=100 / 100000, obj_seg=1, hand_seg=1,
                     obj_rot=0.7, obj_trans=100.0, loss_joint_3d=0.1, loss_joint_cls=1.0, loss_all_joint_3d=0.1)
 
@@ -497,11 +498,12 @@ def main():
     }
     res["config"]["arithmetic"] = {
         "linear_layers": {"emu": ("fp32 emulated on the f16 MFMA pipe (f16x2 form, HOISDF_EMU_FORM=h2): both f32 operands scaled by a power of two "
-                                  "(largest magnitude -> [2^13, 2^14)) and split into hi + lo f16 pieces, 3 products, f32 accumulate; the scale's "
-                                  "magnitudes travel from the producing kernel's epilogue to the consuming contraction" if h2_form else
+                                  "(largest magnitude of each ROW of the activation / gradient operand, of the weight matrix -> [2^13, 2^14)) and split into hi + lo f16 pieces, "
+                                  "3 products, f32 accumulate; the row magnitudes travel from the producing kernel's epilogue to the consuming contraction "
+                                  "(round 6: a sample's result no longer depends on its batch companions)" if h2_form else
                                   "fp32 emulated on the bf16 MFMA pipe: exact 3-way bf16 split of both f32 operands, 6 products, f32 accumulate"),
                           "f32": "exact-f32 MFMA"}[args.gemm],
-        "attention": {"emu": ("forward and backward emulated fp32 in the f16x2 form (scaled hi + lo f16 planes of Q, K, V, dO, P: 3 products; dS three pieces: 5 products; "
+        "attention": {"emu": ("forward and backward emulated fp32 in the f16x2 form (hi + lo f16 planes of Q, K, V, dO scaled per (sample, head), P: 3 products; dS three pieces: 5 products; "
                               "HOISDF_ATTN_FORM=b3: the bf16x3 kernels; the 17-query decoder attention exact-f32)" if (h2_form and os.environ.get("HOISDF_ATTN_FORM", "h2")[:1].lower() != "b") else
                               "forward and backward emulated fp32 in the bf16x3 form (exact 3-way bf16 split, 6 products; the 17-query decoder attention exact-f32)")
                              if os.environ.get("HOISDF_ATTN_BWD", "emu") != "f32" else
@@ -594,9 +596,17 @@ def main():
                                                          "launch_us_this_run": round(us, 1)}
                     res["roofline"]["hbm_gbps"] = round(r0["hbm_bytes_per_launch"] / (us * 1e-6) / 1e9, 1)
                     res["roofline"]["hbm_peak_gbps"] = 8000.0
-                    if "mfma_busy" in r0:
-                        res["roofline"]["mfma_busy"] = r0["mfma_busy"]
-                        res["roofline"]["effective_clock_ghz"] = r0["effective_clock_ghz"]
+                    # algorithmic bytes of that launch: the row operand read once, the output written once (f32),
+                    # the weight image read once (4 bytes per weight: two f16 planes) - what `traffic` is to be compared with
+                    if "linear" in m and len(shape) == 3:
+                        Mr, a1, a2 = shape
+                        res["roofline"]["algorithmic_bytes"] = int(4 * (Mr * a1 + Mr * a2 + a1 * a2))
+                        res["roofline"]["traffic_over_algorithmic"] = round(r0["hbm_bytes_per_launch"] / res["roofline"]["algorithmic_bytes"], 3)
+                    for k_ in ("mfma_busy", "mfma_busy_ghz", "mfma_busy_of_peak_clock", "clock_note"):
+                        if k_ in r0:
+                            res["roofline"][k_] = r0[k_]
+                    clk = r0.get("effective_clock_ghz")
+                    res["roofline"]["effective_clock_ghz"] = clk if (clk is not None and clk <= 2.45) else None     # (never above the part's 2.4 GHz)
                     break
         except Exception as ex:                 # the PMC file is evidence, not a dependency of the measurement
             res["roofline"]["traffic_note"] = f"no PMC record: {ex}"
