@@ -4,6 +4,9 @@
 #pragma once
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -28,6 +31,18 @@ struct Bump {
   }
   float* floats(long n) { return static_cast<float*>(take(n * 4)); }
 };
+
+// Whether a forward call left row magnitudes in its saved block depends on process-wide switches (hoisdf_set_gemm_emu, the form): the
+// forward RECORDS what it did per block (keyed by the address of the block's magnitude region) and the backward of that block asks
+// here instead of re-reading the switches - one flipped in between (bench.py and the cfg setters do flip them at run time) would
+// otherwise make the backward trust words nobody wrote.  -1: no record (a host that never ran the forward through this library).
+struct SavedMags {
+  std::mutex mu;
+  std::unordered_map<const void*, int> on;
+  void put(const void* key, bool v) { if (!key) return; std::lock_guard<std::mutex> l(mu); if (on.size() > 8192) on.clear(); on[key] = v ? 1 : 0; }
+  int get(const void* key) { std::lock_guard<std::mutex> l(mu); auto it = on.find(key); return it == on.end() ? -1 : it->second; }
+};
+inline SavedMags& saved_mags() { static SavedMags s; return s; }
 
 struct Ctx {
   hipStream_t st; void* stream;

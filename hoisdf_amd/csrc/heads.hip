@@ -49,6 +49,7 @@ void mlp_forward(Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, c
   const int last = m->n_layers - 1;
   const float* in = x; int ldin = ldx;
   uint32_t* mg = chain_mags_on(c, M) && !c.dry && s.mag && c.ok() ? s.mag : nullptr;
+  if (!c.dry) saved_mags().put(s.mag, mg != nullptr);            // (what the backward of this block may rely on: chain.h)
   if (mg && hipMemsetAsync(mg, 0, (size_t)m->n_layers * M * 4, c.st) != hipSuccess) { c.rc = HOISDF_ERR_LAUNCH; return; }
   const uint32_t* in_mag = mg ? x_mag : nullptr;
   if (mg && !in_mag && emu_rows(c, M, x, ldx, m->dims[0])) {
@@ -71,7 +72,7 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
   const float* g = dy; int ldg = lddy;
   const int last = m->n_layers - 1;
   uint32_t* mg = chain_mags(c, M, m->n_layers + 1);         // array i = the gradient entering layer i (i = n_layers: dy)
-  const bool fwd_mags = mg && s.mag;
+  const bool fwd_mags = mg && s.mag && saved_mags().get(s.mag) != 0;      // (0: the forward of this block ran without them)
   const uint32_t* g_mag = nullptr;
   if (mg && emu_rows(c, M, dy, lddy, m->dims[last + 1])) {   // dy feeds two contractions: measured once
     if ((c.rc = emu_mag_measure(dy, lddy, M, m->dims[last + 1], mg + (long)(last + 1) * M, c.st)) != HOISDF_OK) return;
@@ -96,7 +97,7 @@ void mlp_backward(Ctx& c, const hoisdf_mlp* m, const hoisdf_mlp_grads* G, const 
 }
 // the words mlp_forward(m, x) left for x in its saved block (null when it did not measure)
 const uint32_t* enc_mag(const Ctx& c, const hoisdf_mlp* m, const float* x, int ldx, long M, const MlpSaved& s) {
-  return chain_mags_on(c, M) && !c.dry && s.mag && emu_rows(c, M, x, ldx, m->dims[0]) ? s.mag : nullptr;
+  return chain_mags_on(c, M) && !c.dry && s.mag && saved_mags().get(s.mag) != 0 && emu_rows(c, M, x, ldx, m->dims[0]) ? s.mag : nullptr;
 }
 bool grads_ok(const hoisdf_mlp* m, const hoisdf_mlp_grads* G) {
   if (!G) return false;

@@ -211,7 +211,7 @@ int forward(const float* x, const hoisdf_encoder_layer_weights* w, const hoisdf_
 
 int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weights* w, const hoisdf_encoder_layer_desc* d, const Geo& g,
              Bump& saved, const float* g_x_out, const float* g_y, float* dx, const hoisdf_encoder_layer_grads* G, Bump& ws, bool dry,
-             void* stream) {
+             void* stream, bool fwd_mags = true) {
   Ctx c{as_stream(stream), stream, &ws, dry, gemm_emu_mode()};
   Saved s;
   carve_saved(g, saved, s);
@@ -244,8 +244,8 @@ int backward(const float* x, const float* x_out, const hoisdf_encoder_layer_weig
   auto mg = [&](int i) -> uint32_t* { return mags && bmag ? bmag + (long)i * M : nullptr; };
   uint32_t* const mag_dqkv = mags && bmag ? bmag + (long)MAG_BROWS * M : nullptr;
   uint32_t* const head_do = mags && bmag ? bmag + (long)MAG_BROWS * M + Ms : nullptr;
-  auto fm = [&](int i) -> const uint32_t* { return mags && s.mag ? s.mag + (long)i * M : nullptr; };       // the forward's (o, x1, h, x_out)
-  uint32_t* const smag = mags ? s.mag : nullptr;
+  auto fm = [&](int i) -> const uint32_t* { return mags && fwd_mags && s.mag ? s.mag + (long)i * M : nullptr; };       // the forward's (o, x1, h, x_out)
+  uint32_t* const smag = mags && fwd_mags ? s.mag : nullptr;
   if (mags && !dry && c.ok() && hipMemsetAsync(bmag, 0, (size_t)bmag_bytes, c.st) != hipSuccess) c.rc = HOISDF_ERR_LAUNCH;
   if (!dry && c.ok()) c.rc = add_layernorm_bwd_mag(dx2, s.x1, s.f, w->g2, st + 2 * M, st + 3 * M, nullptr, dx1, df, G->dg2, G->dbe2, M, E, g.p, d->seed[3], nullptr, mg(MAG_DF), stream);
   lin_bwd_input(c, df, E, nullptr, 0.f, w->w2, F, w->img_t_2, dh, F, M, E, F, 0, mg(MAG_DF), mg(MAG_DH));
@@ -346,7 +346,10 @@ extern "C" int hoisdf_encoder_layer_fwd(const float* x, const hoisdf_encoder_lay
   static char none;                                  // (a real pass never measures: a null buffer is an empty one)
   if (!sv.base) { sv.base = &none; sv.cap = 0; }
   if (!ws.base) { ws.base = &none; ws.cap = 0; }
-  if (d->training) saved_forms().put(saved, (g.fused_qkv ? 1 : 0) | (g.att_h2 ? 2 : 0));
+  if (d->training) {
+    Ctx c0{nullptr, nullptr, nullptr, false, gemm_emu_mode()};
+    saved_forms().put(saved, (g.fused_qkv ? 1 : 0) | (g.att_h2 ? 2 : 0) | (layer_mags(c0, g) ? 4 : 0));     // (4: row / head magnitudes were left in `saved`)
+  }
   const int rc = forward(x, w, d, g, x_out, y_out, sv, ws, false, stream);
   if (rc == HOISDF_ERR_WORKSPACE) set_error("encoder_layer_fwd: workspace (%ld bytes) or saved buffer (%ld bytes) too small", workspace_bytes, saved_bytes);
   return rc;
@@ -365,8 +368,9 @@ extern "C" int hoisdf_encoder_layer_bwd(const float* x, const float* x_out, cons
   HOISDF_REQUIRE(al16(x) && al16(dx) && al16(saved) && al16(workspace), HOISDF_ERR_INVALID, "encoder_layer_bwd: buffers must be 16-byte aligned");
   const int recorded = saved_forms().take(saved);              // what the forward of THIS saved buffer decided (-1: unknown host, recompute)
   if (recorded >= 0) { g.fused_qkv = (recorded & 1) != 0; g.att_h2 = (recorded & 2) != 0; }
+  const bool fwd_mags = recorded < 0 || (recorded & 4) != 0;   // (a forward that ran with the emulation off left no magnitudes to trust)
   Bump sv(const_cast<void*>(saved), saved_bytes), ws(workspace, workspace_bytes);
-  const int rc = backward(x, x_out, w, d, g, sv, g_x_out, g_y, dx, grads, ws, false, stream);
+  const int rc = backward(x, x_out, w, d, g, sv, g_x_out, g_y, dx, grads, ws, false, stream, fwd_mags);
   if (rc == HOISDF_OK && sv.overflow) { set_error("encoder_layer_bwd: saved buffer too small"); return HOISDF_ERR_WORKSPACE; }
   if (rc == HOISDF_ERR_WORKSPACE) set_error("encoder_layer_bwd: workspace (%ld bytes) too small", workspace_bytes);
   return rc;

@@ -272,6 +272,7 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   const int C = w ? w->C : 1;
   train_carve(n, C, saved, s);
   const bool mags = train_mags(c, n) && !dry && s.mag;
+  if (!dry) saved_mags().put(s.mag, mags);                       // (what the backward of this block may rely on: chain.h)
   auto mg = [&](int i) -> uint32_t* { return mags ? s.mag + (long)i * n : nullptr; };
   if (!dry) {
     if (mags) c.rc = hipMemsetAsync(s.mag, 0, (size_t)TM_N * n * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
@@ -307,8 +308,9 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   enum { BM_DH3 = 0, BM_DH2 = 1, BM_DCAT = 2, BM_DH0 = 3, BM_DHA = 4, BM_N = 5 };
   uint32_t* bmag = static_cast<uint32_t*>(ws.take((long)BM_N * n * 4));
   const bool mags = train_mags(c, n) && !dry && bmag && s.mag;
+  const bool fmags = mags && saved_mags().get(s.mag) != 0;       // (0: the forward of this block ran without them)
   auto mg = [&](int i) -> uint32_t* { return mags ? bmag + (long)i * n : nullptr; };
-  auto fm = [&](int i) -> const uint32_t* { return mags ? s.mag + (long)i * n : nullptr; };
+  auto fm = [&](int i) -> const uint32_t* { return fmags ? s.mag + (long)i * n : nullptr; };
   if (mags) c.rc = hipMemsetAsync(bmag, 0, (size_t)BM_N * n * 4, c.st) == hipSuccess ? HOISDF_OK : HOISDF_ERR_LAUNCH;
   if (!dry && c.ok()) c.rc = sdf_head_bwd_mag(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, mg(BM_DH3), stream);
   lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0, mg(BM_DH3), mg(BM_DH2));

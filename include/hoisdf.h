@@ -539,11 +539,11 @@ typedef struct hoisdf_encoder_layer_desc {
   int attention;                /* 0: exact-f32 kernels; 2: emulated-fp32 forward (hoisdf_attention_fwd_emu) */
   int attention_bwd_emulated;   /* with attention == 2: the order-fixed emulated backward instead of the f32 fused one */
   int training;                 /* 0: nothing is saved (saved may be NULL), hoisdf_encoder_layer_bwd cannot follow */
-  const uint32_t* x_mag;        /* optional: magnitude words of x (f16x2 form, see hoisdf_linear_fwd_emu_mag; NULL = the layer measures
-                                 * x itself), e.g. hoisdf_encoder_layer_out_mag of the layer below; must stay valid until the backward */
+  const uint32_t* x_mag;        /* optional: row magnitudes of x (B S words; f16x2 form, see hoisdf_linear_fwd_emu_mag; NULL = the layer
+                                 * measures x itself), e.g. hoisdf_encoder_layer_out_mag of the layer below; must stay valid until the backward */
 } hoisdf_encoder_layer_desc;
-/* where a training forward left the magnitude words of x_out inside `saved` (NULL when the layer's contractions do not run in the
- * f16x2 form): the x_mag of the next layer's descriptor */
+/* where a training forward left the row magnitudes of x_out (B n_query words) inside `saved` (NULL when the layer's contractions do
+ * not run in the f16x2 form): the x_mag of the next layer's descriptor */
 const uint32_t* hoisdf_encoder_layer_out_mag(const hoisdf_encoder_layer_desc* d, const void* saved);
 typedef struct hoisdf_encoder_layer_weights {
   const float *w_in, *b_in;     /* [3E][E], [3E]: packed q | k | v in-projection */
