@@ -489,14 +489,15 @@ def _mag_known(a2, lda, M, K):
     return None
 
 
-def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits, x_mag=None):
-    """-> the magnitude words of x2 that the emulated f16x2 contraction used (given or measured here; None otherwise)"""
+def _gemm_fwd(x2, ldx, W, b, y, ldy, M, N, K, act, drop_p, seed, bits, x_mag=None, y_mag=None):
+    """-> the row magnitudes of x2 that the emulated f16x2 contraction used (given or measured here; None otherwise);
+    y_mag (zero-filled int32 [M]): receives y's row magnitudes from the epilogue (f16x2 form)"""
     if _emu_ok(M, x2, ldx, K):
         if _h2():
             if x_mag is None:
                 x_mag = _mag_measure(x2, ldx, M, K)
             call("hoisdf_linear_fwd_emu_mag", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
-                 float(drop_p), seed, _p(bits), _p(x_mag), None, _st())
+                 float(drop_p), seed, _p(bits), _p(x_mag), _p(y_mag), _st())
             return x_mag
         call("hoisdf_linear_fwd_emu", _p(x2), ldx, _p(_emu_image(W, False)), _p(b), _p(y), ldy, M, N, K, int(act),
              float(drop_p), seed, _p(bits), _st())

@@ -72,9 +72,11 @@ if __name__ == "__main__":
         bits = torch.empty(M, (N + 31) // 32, dtype=torch.int32, device=dev)
         O.set_gemm_emu("_emu" in case or "_b3_" in case)
         O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.0, 0, bits)
+        ymag = torch.zeros(M, dtype=torch.int32, device=dev) if "_emu" in case else None      # (as in the step: the epilogue leaves y's row magnitudes)
+        xmag = O._mag_measure(x, K, M, K) if "_emu" in case else None
         for _ in range(3):
             if "linear_fwd" in case:
-                O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.0, 0, bits)
+                O._gemm_fwd(x, K, W, b, y, N, M, N, K, 1, 0.1 if "_emu" in case else 0.0, 7, bits, x_mag=xmag, y_mag=ymag)
             elif "bwd_input" in case:
                 O._gemm_bwd_input(dy, N, bits, 0.0, W, dx, K, M, N, K, 0)
             else:
