@@ -1227,6 +1227,7 @@ int hoisdf::attention_bwd_emu_mag(const float* q, int ldq, const float* k, int l
   const bool h2 = q_hm && k_hm && v_hm && do_hm;     // the f16x2 form: two scaled f16 planes per operand (emu_attn_bwd4h_kernel)
   HOISDF_REQUIRE(h2 || (!q_hm && !k_hm && !v_hm && !do_hm), HOISDF_ERR_INVALID, "attention_bwd_emu: head magnitudes of all of q, k, v, dout or of none");
   HOISDF_REQUIRE(!g_mag || Lq == Lk, HOISDF_ERR_INVALID, "attention_bwd_emu: one row-magnitude array for dq, dk, dv needs Lq == Lk");
+  HOISDF_REQUIRE(!h2 || drop_p < 0.75f, HOISDF_ERR_INVALID, "attention_bwd_emu (f16x2 form): drop_p = %f, must be below 0.75 (as in the forward)", drop_p);
   // with the forward's planes (fwd_workspace) q, k, v themselves are not read: they may be null; ldq / ldk / ldv still give the
   // layouts of dq / dk / dv
   if (int rc = check_emu(fwd_workspace && !q ? o : q, fwd_workspace && !k ? o : k, fwd_workspace && !v ? o : v, ldq, ldk, ldv, B, H, Lq,
