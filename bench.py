@@ -586,7 +586,12 @@ def main():
                     a0 = by_shape.setdefault((m, shape), [0, 0.0])
                     a0[0] += 1
                     a0[1] += s0.elapsed_time(e0)
-            for (m, shape), (cnt, ms) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+            # the family's DOMINANT entry first (the C entry with the most time: for the f16x2 linear family the forward,
+            # emu_h2_kernel<false, false, 2>), within it the shape with the most time
+            per_entry = {}
+            for (m, shape), (cnt, ms) in by_shape.items():
+                per_entry[m] = per_entry.get(m, 0.0) + ms
+            for (m, shape), (cnt, ms) in sorted(by_shape.items(), key=lambda kv: (-per_entry[kv[0][0]], -kv[1][1])):
                 rec = [r for r in pmc if r["entry"] == m and tuple(r["shape"]) == tuple(shape) and "hbm_bytes_per_launch" in r]
                 if rec:
                     r0 = rec[0]

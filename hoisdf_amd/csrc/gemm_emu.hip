@@ -870,17 +870,16 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
   // operand scales: ONE PER ROW of A from its row magnitudes (common.h; a row's rounding depends on that row alone), the weight's from
   // the image trailer.  The staging thread keeps the scales of its four rows; every output row's factor (1 / row scale, 1 / weight
   // scale, 1 / keep) waits in LDS for the epilogue.  f16 conversions saturate (a word below the row's true maximum clips, no Inf).
+  // (the five words are REQUESTED here, ahead of the first slab's loads, and used behind them: no load round trip of its own per tile)
   f16_saturate_on();
-  {
-    const int row = m0 + tid;
-    rpost[tid] = h2_inv_scale(row < g.M ? g.a_amax[row] : 0u) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
-  }
-  float sAr[4];
+  const uint32_t wpost = m0 + tid < g.M ? g.a_amax[m0 + tid] : 0u;
+  uint32_t wrow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + i * 64 + wave * 16 + rl;
-    sAr[i] = h2_scale(row < g.M ? g.a_amax[row] : 0u);
+    wrow[i] = row < g.M ? g.a_amax[row] : 0u;
   }
+  float sAr[4];
 
   f32x16 acc[4][NJ];
 #pragma unroll
@@ -974,8 +973,11 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
   const int nslab2 = (nslab + 1) & ~1;
   f16x8 aH[4], aL[4], bP[NJ], bQ[NJ], bL[NJ];
   HLOAD_ALL(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sAr[i] = h2_scale(wrow[i]);
   HSTAGE_ALL(st0, 0);
   HLOAD_ALL(1);
+  rpost[tid] = h2_inv_scale(wpost) * g.b_scale[1] * (MASK ? g.ascale : 1.f);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) { aL[i] = HLA(st0, 1, i); aH[i] = HLA(st0, 0, i); }
