@@ -273,15 +273,26 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
       for (int j = 0; j < NJ_; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2) + 4 * kh) * ES + j * 32 + l31] = acc[i][j][r];
+      if (g.amax_out) {
+        // row magnitudes of C (common.h): lane l folds the (l >> 5) half of row l & 31 of the 32-row block parked in its wave's LDS slice
+        // (WN_ / 8 16-byte reads + as many v_max3 with |.| operands), the two halves meet through one exchange, lanes 0-31 publish
+        // (the first form - 4 DPP steps per stored 16-byte piece - cost 700 issue slots per wave tile, this one ~120)
+        const float* rp = w + l31 * ES + kh * (WN_ / 2);
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < WN_ / 8; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+          m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.x)), __builtin_fmaxf(__builtin_fabsf(t.y), __builtin_fmaxf(__builtin_fabsf(t.z), __builtin_fabsf(t.w))));
+        }
+        uint32_t mb = __builtin_bit_cast(uint32_t, m);
+        mb = max(mb, (uint32_t)__shfl_xor((int)mb, 32, 64));
+        if (kh == 0) atomicMax(g.amax_out + (m0 + wm * 128 + i * 32 + l31), mb);
+      }
 #pragma unroll
       for (int p = 0; p < 32 / RPI; ++p) {
         const int rr = p * RPI + lane / LPR, cc = (lane % LPR) * 4;
         float4 v = *reinterpret_cast<const float4*>(w + rr * ES + cc);
         float4* cp = reinterpret_cast<float4*>(g.C + (size_t)(m0 + wm * 128 + i * 32 + rr) * g.ldc + n0 + wn * WN_ + cc);
-        if (g.amax_out) {                     // row magnitudes of C (common.h): the LPR lanes of a row fold their share of it
-          const uint32_t mb = group_max_u32<LPR>(mag_bits4(v));
-          if (lane % LPR == 0) atomicMax(g.amax_out + (m0 + wm * 128 + i * 32 + rr), mb);
-        }
         if (g.beta) {
           const float4 old = *cp;
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
