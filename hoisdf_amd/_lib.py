@@ -153,6 +153,9 @@ SIGNATURES: Dict[str, List] = {
     "hoisdf_adamw_step": [_P, _I, _D, _D, _D, _D, _D, _L, _F, _P],
     "hoisdf_aux_image_losses_fwd": [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "hoisdf_aux_image_losses_bwd": [_P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "hoisdf_bn_stats": [_P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _P, _L, _P],
+    "hoisdf_bn_apply_fwd": [_P, _L, _P, _L, _P, _P, _I, _F, _P, _P, _I, _P, _P, _L, _I, _P],
+    "hoisdf_bn_bwd": [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "hoisdf_token_build_fwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd": [_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "hoisdf_token_build_bwd_ordered": [_P, _P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -202,6 +205,7 @@ _RET = {"hoisdf_version": C.c_char_p, "hoisdf_last_error": C.c_char_p}
 _OTHER = {"hoisdf_set_deterministic": ([_I], None), "hoisdf_set_gemm_emu": ([_I], None), "hoisdf_get_gemm_emu": ([], C.c_int), "hoisdf_get_deterministic": ([], C.c_int),
           "hoisdf_mano_dirs_image_floats": ([], C.c_long),
           "hoisdf_point_loss_blocks": ([_L], C.c_int),
+          "hoisdf_bn_workspace_floats": ([_L, _I], C.c_long),
           "hoisdf_token_build_bwd_partials": ([], C.c_int),
           "hoisdf_tokens_saved_bytes": ([_P, _L, _I], C.c_long),
           "hoisdf_tokens_workspace_bytes": ([_P, _L, _I], C.c_long),

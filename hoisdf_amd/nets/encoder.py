@@ -21,8 +21,29 @@ import torch.nn.functional as F
 _PENDING_NBT = []          # num_batches_tracked buffers touched in this forward: bumped with ONE multi-tensor add
 
 
+# HOISDF_BN=torch: BatchNorm / add / ReLU stay the library sequence (MIOpen BatchNorm + ATen add + clamp, seven passes over the map
+# forward, eight backward); default: the fused two-pass-per-direction HIP kernels (ops.bn_act, csrc/bnact.hip)
+_BN_FUSED = [os.environ.get("HOISDF_BN", "hip") != "torch"]
+
+
+def set_bn_fused(on: bool) -> None:
+    _BN_FUSED[0] = bool(on)
+
+
 def bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual=None) -> torch.Tensor:
-    """relu?(bn(x) (+ residual)) with the plain torch (MIOpen) BatchNorm"""
+    """relu?(bn(x) (+ residual)): the fused HIP passes on a CUDA map (training: batch statistics; evaluation without a gradient
+    path: running statistics), otherwise the plain torch (MIOpen) BatchNorm + add + relu"""
+    if _BN_FUSED[0] and x.is_cuda:
+        from .. import ops
+        train = bn.training or bn.running_mean is None
+        grad = torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad) or
+                                            (residual is not None and residual.requires_grad))
+        if ops.bn_act_supported(x) and (train or not grad) and (not train or bn.momentum is not None or not bn.track_running_stats):
+            track = train and bn.track_running_stats and bn.running_mean is not None
+            if track:
+                _PENDING_NBT.append(bn.num_batches_tracked)
+            return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if (track or not train) else None,
+                              bn.running_var if (track or not train) else None, train, bn.momentum, bn.eps, relu, residual)
     if bn.training and bn.track_running_stats and bn.momentum is not None and x.is_cuda:
         # what nn.BatchNorm2d.forward does, minus its per-module `num_batches_tracked += 1` kernel (69 tiny launches per
         # step for ResNet-50 + decoder): the counters are bumped together by flush_bn_counters()

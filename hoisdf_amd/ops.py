@@ -2185,3 +2185,80 @@ def aux_image_losses(decoder_out, joint_coord, hand_seg, obj_seg, sigma: float):
     return _AuxImageLosses.apply(decoder_out, joint_coord, hand_seg, obj_seg, sigma)
 
 
+
+
+# ---------------------------------------------------------------------------------------------
+# (f4) BatchNorm2d (+ residual) (+ ReLU) of a channels_last encoder map
+# ---------------------------------------------------------------------------------------------
+def _rows_cl(t: torch.Tensor):
+    """a (N, C, H, W) map whose memory is channels_last rows -> (t, row stride) with t usable as [N H W][C] (a channel slice of a
+    concatenation keeps its parent's row stride); anything else is made channels_last-dense first"""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    ld = sw if w > 1 else sh if h > 1 else sn if n > 1 else c          # (the stride of a size-1 dimension says nothing)
+    ok = ((sc == 1 or c == 1) and ld >= c and ld % 4 == 0 and t.data_ptr() % 16 == 0 and (w == 1 or sw == ld)
+          and (h == 1 or sh == w * ld) and (n == 1 or sn == h * w * ld))
+    if not ok:
+        t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        ld = c
+    return t, ld
+
+
+def bn_act_supported(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 8 == 0 and 8 <= x.shape[1] <= 2048 and x.numel() > 0
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+        _chk(x, weight, bias, residual)
+        n, c, h, w = x.shape
+        M = n * h * w
+        x, ldx = _rows_cl(x)
+        ldr = 0
+        if residual is not None:
+            assert residual.shape == x.shape, (residual.shape, x.shape)
+            residual, ldr = _rows_cl(residual)
+        y = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)      # channels_last, dense rows
+        need_grad = training and (x.requires_grad or (weight is not None and weight.requires_grad) or
+                                  (residual is not None and residual.requires_grad))
+        if training:
+            from ._lib import lib
+            nws = lib().hoisdf_bn_workspace_floats(M, c)
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+            stats = torch.empty(2, c, device=x.device, dtype=torch.float32)
+            mean, invstd = stats[0], stats[1]
+            call("hoisdf_bn_stats", _p(x), ldx, M, c, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                 float(momentum if momentum is not None else 0.0), float(eps), _p(ws), nws, _st())
+            bits = torch.empty(M, c // 8, device=x.device, dtype=torch.uint8) if (relu and need_grad) else None
+            call("hoisdf_bn_apply_fwd", _p(x), ldx, _p(residual), ldr, _p(mean), _p(invstd), 0, float(eps), _p(weight), _p(bias), int(relu),
+                 _p(y), _p(bits), M, c, _st())
+            ctx.save_for_backward(x, weight, mean, invstd, bits)
+            ctx.meta = (M, c, ldx, residual is not None, bool(relu), weight is not None, bias is not None)
+        else:
+            call("hoisdf_bn_apply_fwd", _p(x), ldx, _p(residual), ldr, _p(running_mean), _p(running_var), 1, float(eps), _p(weight), _p(bias),
+                 int(relu), _p(y), None, M, c, _st())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, invstd, bits = ctx.saved_tensors
+        M, c, ldx, has_res, relu, has_w, has_b = ctx.meta
+        dy, lddy = _rows_cl(dy)
+        n, _, h, w = x.shape
+        dx = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        dres = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2) if has_res else None
+        dwb = torch.empty(2, c, device=x.device, dtype=torch.float32)
+        from ._lib import lib
+        nws = lib().hoisdf_bn_workspace_floats(M, c)
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        call("hoisdf_bn_bwd", _p(dy), lddy, _p(x), ldx, _p(bits if relu else None), _p(mean), _p(invstd), _p(weight), _p(dx), _p(dres),
+             _p(dwb[0]), _p(dwb[1]), M, c, _p(ws), nws, _st())
+        return dx, (dwb[0] if has_w else None), (dwb[1] if has_b else None), dres, None, None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean, running_var, training: bool, momentum, eps: float, relu: bool, residual=None):
+    """(f4) relu?(batch_norm(x) (+ residual)) of a channels_last map in two HBM passes per direction (csrc/bnact.hip);
+    training: batch statistics, running statistics updated in place as torch.nn.functional.batch_norm does;
+    otherwise the running statistics normalise (no gradient path: evaluation)."""
+    return _BnAct.apply(x, weight, bias, residual, running_mean, running_var, bool(training), momentum, float(eps), bool(relu))

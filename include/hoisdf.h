@@ -758,6 +758,29 @@ int hoisdf_aux_image_losses_bwd(const float* dec, long sb, long sc, long sh, lon
                                 const float* g_obj_seg, const float* g_hand_seg, int B, int H, int W, float* ddec,
                                 void* stream);
 
+/* ---- (f4) BatchNorm2d (+ residual add) (+ ReLU) of a channels_last encoder map -------------------------------------
+ * reference: the BatchNorm2d -> ReLU pairs and the `out += identity; relu(out)` block tails of common/nets/resnet.py (the
+ * torchvision ResNet blocks it wraps) and common/nets/layer.py:23-63 (Conv / ConvTranspose -> BatchNorm2d -> ReLU), i.e.
+ * torch.nn.functional.batch_norm(training) [+ add] + relu and its autograd backward.  The convolutions stay MIOpen's.
+ * A channels_last (N, C, H, W) map is the row-major matrix [M = N H W][C] (row stride ld >= C, ld % 4 == 0; C % 8 == 0,
+ * C <= 2048).  hoisdf_bn_stats: batch mean and 1 / sqrt(biased variance + eps) per channel (shifted f32 sums per block, f64
+ * combination in block order by the last block: bit-reproducible), running statistics updated as torch does (unbiased
+ * variance, momentum; NULL = not tracked).  hoisdf_bn_apply_fwd: y [M][C] dense = relu?((x - mean) gamma invstd + beta
+ * (+ residual)); second_is_variance = 1: the fourth argument holds variances (evaluation mode: the running statistics);
+ * sign_bits [M][C / 8] bytes (bit j of byte (row, c / 8) = y[row][c + j] > 0; NULL = not wanted).  hoisdf_bn_bwd: dx [M][C]
+ * dense, d_residual (NULL = no residual) = dy masked by the sign bits (NULL = no ReLU), dgamma / dbeta [C] overwritten.
+ * workspace: hoisdf_bn_workspace_floats(M, C) floats. */
+long hoisdf_bn_workspace_floats(long M, int C);
+int hoisdf_bn_stats(const float* x, long ldx, long M, int C, float* mean, float* invstd, float* running_mean,
+                    float* running_var, float momentum, float eps, float* workspace, long workspace_floats,
+                    void* stream);
+int hoisdf_bn_apply_fwd(const float* x, long ldx, const float* residual, long ldr, const float* mean,
+                        const float* invstd_or_var, int second_is_variance, float eps, const float* gamma,
+                        const float* beta, int relu, float* y, uint8_t* sign_bits, long M, int C, void* stream);
+int hoisdf_bn_bwd(const float* dy, long lddy, const float* x, long ldx, const uint8_t* sign_bits, const float* mean,
+                  const float* invstd, const float* gamma, float* dx, float* d_residual, float* dgamma, float* dbeta,
+                  long M, int C, float* workspace, long workspace_floats, void* stream);
+
 /* ---- optimizer step of the training loop ------------------------------------------------------------------
  * reference: torch.optim.AdamW(model.parameters(), lr=cfg.lr) (common/base.py:64-73; betas (0.9, 0.999), eps 1e-8,
  * weight_decay 1e-2 = torch defaults), stepped once per iteration (main/train.py:139).
