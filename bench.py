@@ -640,18 +640,20 @@ def main():
         # the committed rocprofv3 trace of this same command (single stream, 5 timed steps) - evidence quoted, not measured in this run
         try:
             import csv
-            split = {"hip_hot_path": 0.0, "encoder_libraries": 0.0, "aten_glue": 0.0}
+            split = {"hip_hot_path": 0.0, "hip_encoder_side": 0.0, "encoder_libraries": 0.0, "aten_glue": 0.0}
             with open(os.path.join(REPO, "profiles", STEP_TRACE), newline="") as f:
                 for r in csv.DictReader(f):
                     n, ms = r["Name"], float(r["TotalNsPerStep"]) * 1e-6
-                    k = "hip_hot_path" if "hoisdf" in n else ("aten_glue" if ("at::native" in n or "rocclr" in n) else "encoder_libraries")
+                    # (hip_encoder_side: this library's (f4) kernels inside the image encoder - BatchNorm + residual + ReLU, csrc/bnact.hip)
+                    k = (("hip_encoder_side" if "::bn_" in n else "hip_hot_path") if "hoisdf" in n else
+                         ("aten_glue" if ("at::native" in n or "rocclr" in n) else "encoder_libraries"))
                     split[k] += ms
             res["hot_path"]["kernel_ms_per_step_by_owner"] = {k: round(v, 2) for k, v in split.items()}
             res["hot_path"]["kernel_ms_per_step_by_owner"]["file"] = f"profiles/{STEP_TRACE}"
-            res["hot_path"]["amdahl_note"] = ("the image encoder (MIOpen / CK / ATen; out of the hot path by north_star) is %.0f %% of the step's "
-                                              "kernel time: hot-path work can still buy at most %.2fx" %
-                                              (100 * (split["encoder_libraries"] + split["aten_glue"]) / max(sum(split.values()), 1e-9),
-                                               sum(split.values()) / max(split["encoder_libraries"] + split["aten_glue"], 1e-9)))
+            enc_ms = split["encoder_libraries"] + split["aten_glue"] + split["hip_encoder_side"]
+            res["hot_path"]["amdahl_note"] = ("the image encoder (MIOpen / CK convolutions, ATen, this library's fused BatchNorm passes; out of the hot path by "
+                                              "north_star) is %.0f %% of the step's kernel time: hot-path work can still buy at most %.2fx" %
+                                              (100 * enc_ms / max(sum(split.values()), 1e-9), sum(split.values()) / max(enc_ms, 1e-9)))
         except Exception as ex:
             res["hot_path"]["kernel_ms_per_step_by_owner"] = f"no trace file: {ex}"
         res["kernels"] = {n: {"ms_per_step": round(v["total_ms"] / timed_steps, 3), "tflops": round(v["tflops"], 2),

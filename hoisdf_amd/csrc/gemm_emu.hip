@@ -299,6 +299,9 @@ __device__ __forceinline__ void emu_epilogue(const EmuArgs& g, f32x16 (&acc)[4][
         }
         // an output too large to stay in the L2s (>= 64 MB) is streamed past them: -0.12 ms per train step, two same-box pairs
         typedef float v4f_ __attribute__((ext_vector_type(4)));
+#ifdef H2_ABL_NOSTORE                 /* (tools/ablate_h2.sh: how much of the kernel is the output's way to HBM?  never true at run time) */
+        if (g.seed != 0x5eed5eed5eedull) continue;
+#endif
         if (stream_c) __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_*>(cp));
         else *cp = v;
       }
@@ -527,8 +530,13 @@ __global__ __launch_bounds__(NT, 2) void emu_kc2_kernel(EmuArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rows_q = max(min(rows_in - i * 64, 64), 0);     // valid rows of this quarter
+#ifdef H2_ABL_NOLOADA                 /* (tools/ablate_h2.sh: every tile reads the FIRST tile's rows - the same loads, served by the caches) */
+    rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)i * 64) * g.lda), 0,
+                                               rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+#else
     rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)m0 + i * 64) * g.lda), 0,
                                                rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+#endif
     rsm[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(MASK ? g.abits + ((size_t)m0 + i * 64) * g.ldbits : nullptr), 0,
                                                MASK ? (int)((long)rows_q * g.ldbits * 4) : 0, 0x00020000);
   }
@@ -906,8 +914,13 @@ __global__ __launch_bounds__(NT, NJ == 4 ? 1 : 2) void emu_h2_kernel(EmuArgs g) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rows_q = max(min(rows_in - i * 64, 64), 0);
+#ifdef H2_ABL_NOLOADA                 /* (tools/ablate_h2.sh: every tile reads the FIRST tile's rows - the same loads, served by the caches) */
+    rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)i * 64) * g.lda), 0,
+                                               rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+#else
     rsa[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A + ((size_t)m0 + i * 64) * g.lda), 0,
                                                rows_q > 0 ? (int)((((long)rows_q - 1) * g.lda + g.K) * 4) : 0, 0x00020000);
+#endif
     rsm[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(MASK ? g.abits + ((size_t)m0 + i * 64) * g.ldbits : nullptr), 0,
                                                MASK ? (int)((long)rows_q * g.ldbits * 4) : 0, 0x00020000);
   }
