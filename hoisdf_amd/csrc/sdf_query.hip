@@ -5,7 +5,7 @@
 //   * the gathered 992 / 3968-wide feature rows can be handed in (shared by the callers that query the same camera
 //     points: the reference gathers the same pixels three times, main/model.py:445/486/499) or out;
 //   * linear_sdfin's second layer, the positional encoding and xyz are written straight into the decoder-input row
-//     x0 = [feat256 | pe30 | xyz3 | 0 0 0], which sits at column 224 of a 516-wide row [h1 (223) | 0 | x0 (292)]; decoder
+//     x0 = [feat256 | pe30 | xyz3 | 0 0 0], which sits at column 224 of a 516-wide row [h1 (223) | 0 | x0 (292)] (row stride 544); decoder
 //     layer 1 writes its 223 outputs (+ one zero column: a padded weight row) at column 0, so the skip-concatenation
 //     [h1 | x0] of common/nets/sdf_net.py:104-106 is the row itself - layer 2 contracts all 516 columns with a
 //     column-padded weight matrix (zeros under the pad columns);
@@ -19,13 +19,17 @@
 using namespace hoisdf;
 
 namespace {
-constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, CAT_LD = 516, X0_COL = 224;
+constexpr int HID0 = 512, LAT = 256, PF = 33, H1 = 223, X0 = LAT + PF, CAT_K = 516, X0_COL = 224;
+// row stride of the concatenated row in the workspaces: 544 floats = 17 x 128 bytes (the 516-float stride of round 5 left every row
+// and every 64-byte slab segment of the K = 292 / 516 contractions at a 16-byte alignment: -7 ... -10 % on those two layers,
+// tools/mb_ld_emu.py); the weights keep their [512][516] layout (include/hoisdf.h), columns 516 .. 543 are never read
+constexpr int CAT_LD = 544;
 inline long align64(long v) { return (v + 63) / 64 * 64; }
 constexpr long EMU_MIN_ROWS_Q = 2048;
 
 // scratch of the emulated form (hoisdf_set_gemm_emu): the bf16x3 slab image of the layer's weight, built right before the layer
 inline long emu_scratch_bytes(int C) {
-  const long a = hoisdf_linear_emu_image_bytes(HID0, C), b = hoisdf_linear_emu_image_bytes(HID0, CAT_LD);
+  const long a = hoisdf_linear_emu_image_bytes(HID0, C), b = hoisdf_linear_emu_image_bytes(HID0, CAT_K);
   return ((a > b ? a : b) + 255) / 256 * 256;
 }
 
@@ -113,7 +117,7 @@ extern "C" int hoisdf_sdf_query_fwd(const hoisdf_pyramid* pyr, const float* poin
   bool has1 = false;
   rc = layer(ha, HID0, w->dec_w1, HID0, w->dec_b1, cat, CAT_LD, n_rows, H1 + 1, HID0, HID0, drop_p, seed + 1, img, w->emu_img[3], stream, has ? mg(3) : nullptr, has_cat ? mg(2) : nullptr, &has1);
   if (rc) return rc;
-  rc = layer(cat, CAT_LD, w->dec_w2, CAT_LD, w->dec_b2, ha, HID0, n_rows, HID0, CAT_LD, CAT_LD, drop_p, seed + 2, img, w->emu_img[4], stream, has_cat && has1 ? mg(2) : nullptr, mg(4), &has);
+  rc = layer(cat, CAT_LD, w->dec_w2, CAT_K, w->dec_b2, ha, HID0, n_rows, HID0, CAT_K, CAT_K, drop_p, seed + 2, img, w->emu_img[4], stream, has_cat && has1 ? mg(2) : nullptr, mg(4), &has);
   if (rc) return rc;
   rc = layer(ha, HID0, w->dec_w3, HID0, w->dec_b3, hb, HID0, n_rows, HID0, HID0, HID0, drop_p, seed + 3, img, w->emu_img[5], stream, has ? mg(4) : nullptr, nullptr, nullptr);
   if (rc) return rc;
@@ -288,7 +292,7 @@ static int sdf_train_forward(const hoisdf_pyramid* pyr, const float* points, con
   // (the words of cat: x0's columns are complete here; layer 1 adds its own columns' before layer 2 reads the whole row)
   lin_fwd(c, x0, CAT_LD, w->dec_w0, w->dec_ld0, w->emu_img[2], w->dec_b0, s.h0, HID0, n, HID0, X0, 1, drop_p, seed, s.b0, X0 + 3, mg(TM_CAT), mg(TM_H0));   // as hoisdf_sdf_query_fwd: the three pad columns of x0 are zero
   lin_fwd(c, s.h0, HID0, w->dec_w1, HID0, w->emu_img[3], w->dec_b1, s.cat, CAT_LD, n, H1 + 1, HID0, 1, drop_p, seed + 1, s.b1, 0, mg(TM_H0), mg(TM_CAT));
-  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_LD, w->emu_img[4], w->dec_b2, s.h2, HID0, n, HID0, CAT_LD, 1, drop_p, seed + 2, s.b2, 0, mg(TM_CAT), mg(TM_H2));
+  lin_fwd(c, s.cat, CAT_LD, w->dec_w2, CAT_K, w->emu_img[4], w->dec_b2, s.h2, HID0, n, HID0, CAT_K, 1, drop_p, seed + 2, s.b2, 0, mg(TM_CAT), mg(TM_H2));
   lin_fwd(c, s.h2, HID0, w->dec_w3, HID0, w->emu_img[5], w->dec_b3, s.h3, HID0, n, HID0, HID0, 1, drop_p, seed + 3, s.b3, 0, mg(TM_H2), nullptr);
   if (!dry && c.ok()) c.rc = hoisdf_sdf_head_fwd(s.h3, HID0, w->dec_w4, w->dec_b4, s.raw, sdf, n, HID0, clamp, stream);
   return c.rc;
@@ -315,8 +319,8 @@ static int sdf_train_backward(const hoisdf_pyramid_grad* dpyr, const float* poin
   if (!dry && c.ok()) c.rc = sdf_head_bwd_mag(d_sdf, s.raw, s.h3, HID0, w->dec_w4, dh3, HID0, G->d_dec_w4, G->d_dec_b4, n, HID0, clamp, mg(BM_DH3), stream);
   lin_bwd_input(c, dh3, HID0, s.b3, drop_p, w->dec_w3, HID0, w->emu_img_t[5], dh2, HID0, n, HID0, HID0, 0, mg(BM_DH3), mg(BM_DH2));
   lin_bwd_weight(c, dh3, HID0, s.b3, drop_p, s.h2, HID0, G->d_dec_w3, G->d_dec_b3, n, HID0, HID0, 0, mg(BM_DH3), fm(TM_H2));
-  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_LD, w->emu_img_t[4], dcat, CAT_LD, n, HID0, CAT_LD, 0, mg(BM_DH2), mg(BM_DCAT));
-  lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_LD, 0, mg(BM_DH2), fm(TM_CAT));
+  lin_bwd_input(c, dh2, HID0, s.b2, drop_p, w->dec_w2, CAT_K, w->emu_img_t[4], dcat, CAT_LD, n, HID0, CAT_K, 0, mg(BM_DH2), mg(BM_DCAT));
+  lin_bwd_weight(c, dh2, HID0, s.b2, drop_p, s.cat, CAT_LD, G->d_dec_w2, G->d_dec_b2, n, HID0, CAT_K, 0, mg(BM_DH2), fm(TM_CAT));
   lin_bwd_input(c, dcat, CAT_LD, s.b1, drop_p, w->dec_w1, HID0, w->emu_img_t[3], dh0, HID0, n, H1 + 1, HID0, 0, mg(BM_DCAT), mg(BM_DH0));
   lin_bwd_weight(c, dcat, CAT_LD, s.b1, drop_p, s.h0, HID0, G->d_dec_w1, G->d_dec_b1, n, H1 + 1, HID0, 0, mg(BM_DCAT), fm(TM_H0));
   // layer 0 reads x0 = cat[:, 224:513]: its input gradient joins the skip connection's (accumulate), its weight gradient is [512][292]
