@@ -339,12 +339,12 @@ def test_token_build_and_vote():
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("bins", [16, 64])
+@pytest.mark.parametrize("bins", [16, 20, 64])          # (one chunk of 4096 lattice indices per block: 1, 2 with a ragged tail, 64)
 def test_lattice_candidates_match_oracle(bins):
     O, R = ops(), oracle()
     B = 3
     _, _, meta = T.synthetic_batch(B, 8, 8, seed=60)
-    if bins == 16:
+    if bins <= 20:
         meta["bbox_hand"] = torch.tensor([30.0, 20, 230, 240]).repeat(B, 1)
     pts, sidx, lidx, counts, offsets, _ = O.lattice_candidates(meta["mano_root"].to(DEV), meta["cam_intr"].to(DEV),
                                                                meta["bbox_hand"].to(DEV), 3.1, bins)
