@@ -31,5 +31,14 @@ python bench.py --config 4 --no-cpu-baseline --exact-f32 0 --bf16x3-leg 0 > $O/b
 python bench.py --branch-mix --no-cpu-baseline --exact-f32 0 --bf16x3-leg 0 > $O/bench_branch_mix.json 2> /dev/null
 # the round-5 tree on the same box (ab/r5tree: git archive of 811360c + its own library), interleaved quick lines
 [ -d ab/r5tree ] && bash ab/ab_r5.sh > $O/same_box_ab_vs_round5.txt 2>&1
+# this round's encoder-side / inference-side changes against their switches, same box, alternating
+Q="--steps 10 --warmup 5 --no-cpu-baseline --exact-f32 0 --bf16x3-leg 0"
+val() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
+{
+  echo "# bench.py $Q (configs[1]): HOISDF_BN=torch (MIOpen BatchNorm + ATen add / relu) vs the fused BatchNorm passes, alternating"
+  for i in 1 2 3; do echo "torch $(HOISDF_BN=torch python bench.py $Q 2>/dev/null | val)"; echo "hip   $(python bench.py $Q 2>/dev/null | val)"; done
+  echo "# bench.py --config 3 $Q: round-1 lattice kernels + round-1 gather loop (HOISDF_LATTICE=1 HOISDF_GATHER_FWD=1) vs the chunked lattice passes + gather_fwd4"
+  for i in 1 2; do echo "old   $(HOISDF_LATTICE=1 HOISDF_GATHER_FWD=1 python bench.py --config 3 $Q 2>/dev/null | val)"; echo "new   $(python bench.py --config 3 $Q 2>/dev/null | val)"; done
+} > $O/same_box_ab_this_round.txt 2>&1
 HOISDF_MAG_TRACE=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --bf16x3-leg 0 --exact-f32 0 --no-kernel-timing 2>&1 >/dev/null | grep "hoisdf mag" | sort | uniq -c | sort -rn > $O/library_side_magnitude_passes_3_steps.txt
 ls -la $O

@@ -21,6 +21,14 @@ CASES = {
     # the bf16x3 grad-weight (no magnitudes needed: what runs where no words are at hand)
     "linear_bwd_weight_b3_65536x1024x256": ("hoisdf_linear_bwd_weight_emu", "emu_dw2_kernel<true, true>", (65536, 1024, 256)),
     "linear_fwd_f32_65536x1024x256": ("hoisdf_linear_fwd", "gemm_f32_kernel<true, true, false, false>", (65536, 1024, 256)),
+    # round 6, HBM-bound passes: (f4) BatchNorm + residual + ReLU of a 32 x 256 x 64 x 64 channels_last map (ResNet-50 layer1's block tail:
+    # 131072 rows x 256 channels = 134 MB per map); shape = (rows, channels, 1 = with residual)
+    "bn_stats_131072x256": ("hoisdf_bn_stats", "bn_stats_kernel", (131072, 256, 1)),
+    "bn_apply_fwd_131072x256": ("hoisdf_bn_apply_fwd", "bn_apply_fwd_kernel<true, true>", (131072, 256, 1)),
+    "bn_bwd_reduce_131072x256": ("hoisdf_bn_bwd", "bn_bwd_reduce_kernel<true>", (131072, 256, 1)),
+    "bn_bwd_dx_131072x256": ("hoisdf_bn_bwd", "bn_bwd_dx_kernel<true, true>", (131072, 256, 1)),
+    # K1 at the lattice survivors of one configs[3] sdf_infer call: 320 000 points x 992 channels (shape = rows, channels, 0)
+    "gather_fwd_320000x992": ("hoisdf_project_gather_fwd", "gather_fwd4_kernel", (320000, 992, 0)),
 }
 if __name__ == "__main__":
     if sys.argv[1] == "--list":
@@ -30,6 +38,39 @@ if __name__ == "__main__":
     case = sys.argv[1]
     entry, _, shape = CASES[case]
     dev = "cuda"
+    if case.startswith("bn_"):
+        M, Cc, _ = shape
+        x = torch.randn(32, Cc, 64, M // (32 * 64), device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        res = torch.randn_like(x).requires_grad_(True)
+        w, b = torch.rand(Cc, device=dev).requires_grad_(True), torch.randn(Cc, device=dev).requires_grad_(True)
+        rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        gy = torch.randn_like(x)
+        for _ in range(3):
+            x.grad = res.grad = w.grad = b.grad = None
+            y = O.bn_act(x, w, b, rm, rv, True, 0.1, 1e-5, True, res)
+            y.backward(gy)
+        torch.cuda.synchronize()
+        sys.exit(0)
+    if case.startswith("gather_"):
+        from hoisdf_amd import testing as T
+        n, Cc, _ = shape
+        B = 16
+        g = torch.Generator(device=dev).manual_seed(0)
+        levels = [torch.randn(B, h, h, c, device=dev, generator=g) for h, c in ((128, 32), (64, 64), (32, 128), (16, 256), (8, 512))]
+        pyr = O.PyramidNHWC(levels)
+        per = n // B
+        # a 64^3-like lattice slab in front of the camera: consecutive points are depth neighbours, as sdf_infer's survivors are
+        zz = torch.linspace(-1, 1, 64, device=dev)
+        idx = torch.arange(per, device=dev)
+        pts = torch.stack([((idx // 4096) % 64).float() / 31.5 - 1, ((idx // 64) % 64).float() / 31.5 - 1, zz[idx % 64]], 1)
+        pts = pts.unsqueeze(0).repeat(B, 1, 1).contiguous()
+        center = torch.tensor([0.0, 0.0, 0.7], device=dev).repeat(B, 1)
+        K = torch.tensor([[250.0, 0, 128], [0, 250.0, 128], [0, 0, 1]], device=dev).repeat(B, 1, 1)
+        with torch.no_grad():
+            for _ in range(3):
+                O.project_gather(pyr, pts, center, K, 3.1)
+        torch.cuda.synchronize()
+        sys.exit(0)
     if "attn" in case:
         B, Lq, Lk = shape
         E, H, p = 256, 4, 0.1
