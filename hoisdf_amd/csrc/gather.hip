@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(PyrDev P, ProjArgs a, f
 // memory-level parallelism written out: a lane's (up to) four float4 columns belong to fixed levels (constants hoisted out of the row
 // loop), all SIXTEEN tap loads of a row are issued before the first is used (a border tap re-reads the nw pixel and is not added - the
 // sums are those of gather_fwd_kernel bit for bit), and the next row's point and sample index are requested while this row's taps are
-// in flight.  Lattice points of one sdf_infer call (320 000 rows): 948 -> @@ us.
+// in flight.  Lattice points of one sdf_infer call (320 000 rows): 948 -> 691 us in configs[3]'s trace (3.2 TB/s, profiles/r06_pmc.json).
 __global__ __launch_bounds__(256) void gather_fwd4_kernel(PyrDev P, ProjArgs a, float* __restrict__ feat, int ldf, float* __restrict__ cam_out,
                                                           float* __restrict__ uv_out, uint32_t* __restrict__ feat_mag) {
   const int lane = threadIdx.x & 63;
