@@ -390,10 +390,11 @@ def test_errors_are_reported_not_swallowed():
         O.linear(torch.zeros(4, 4), torch.zeros(4, 4))               # CPU tensors: no fallback
 
 
-def test_vote_loss_fused_matches_reference_loss():
+@pytest.mark.parametrize("P", [130, 1700])          # (1700 points: four segments of 425 in separate blocks + the ordered merge)
+def test_vote_loss_fused_matches_reference_loss(P):
     """K12 + JointvoteLoss reductions (common/nets/loss.py:31-56) vs the oracle's joint_vote, fwd + bwd."""
     O, R = ops(), oracle()
-    L, B, P, J = 3, 2, 130, 20
+    L, B, J = 3, 2, 20
     pts = rnd(B, P, 3, seed=70) * 0.05
     gt = pts[:, :J] * 1000 + rnd(B, J, 3, seed=71) * 15            # some points fall inside the 40 mm radius
     off = (rnd(L, B, P, J * 3, seed=72) * 0.02).requires_grad_(True)
