@@ -16,6 +16,8 @@
 // LDS tiles are row-major with a 68-float pitch: ds_read_b128 of 4 consecutive d for 16 keys
 // of a lane group lands on 16 distinct 4-bank slots; b32 column reads are lane-consecutive.
 #include <cstdlib>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hoisdf {
@@ -220,8 +222,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // (max, sum, O) states are merged through LDS at the end.  Same dropout hash / lse convention as attn_fwd_kernel,
 // so the fused backward applies unchanged.
 // ============================================================================================
+// Round 6: with few (b, head) pairs and many keys (configs[3]: 64 blocks x 96 key tiles, 105 us) the key tiles are also cut over
+// `nsplit` blocks per (b, head) (blockIdx.y); each leaves its merged (max, sum, O) state in `part` ([bh][split][64 + 2][32] floats) and
+// attn_fewq_merge_kernel folds the splits in order.  nsplit = 1: the block writes the output itself, as before.
 constexpr int FEWQ_WAVES = 8;
-__global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs a, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float Os[FEWQ_WAVES][DH][33];   // O^T partials [d][q]
   __shared__ float Ms[FEWQ_WAVES][32], Lsum[FEWQ_WAVES][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,8 +256,10 @@ __global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
 
-  const int ntiles = (a.kv_len + 31) / 32;
-  for (int kt = wave; kt < ntiles; kt += FEWQ_WAVES) {
+  const int ntiles_all = (a.kv_len + 31) / 32;
+  const int nsplit = gridDim.y, per_split = (ntiles_all + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * per_split, ntiles = min(ntiles_all, kt0 + per_split);
+  for (int kt = kt0 + wave; kt < ntiles; kt += FEWQ_WAVES) {
     const int key = kt * 32 + c;                       // this lane's K row (A operand of S^T = K.Q^T)
     f32x16 s;
 #pragma unroll
@@ -329,6 +336,32 @@ __global__ __launch_bounds__(64 * FEWQ_WAVES) void attn_fwd_fewq_kernel(AttnArgs
       const float sc = Ms[w][q] == -INFINITY ? 0.f : EXP2(Ms[w][q] - M);
       L += Lsum[w][q] * sc;
       acc += Os[w][d][q] * sc;
+    }
+    if (nsplit == 1) {
+      a.out[((size_t)b * a.Lq + q) * a.ldo + head * DH + d] = acc / L;
+      if (d == 0 && a.lse) a.lse[(size_t)bh * a.Lq + q] = M + log2f(L);
+    } else {
+      float* ps = part + ((size_t)bh * nsplit + blockIdx.y) * (DH + 2) * 32;
+      ps[d * 32 + q] = acc;
+      if (d == 0) { ps[DH * 32 + q] = M; ps[(DH + 1) * 32 + q] = L; }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void attn_fewq_merge_kernel(AttnArgs a, const float* __restrict__ part, int nsplit) {
+  const int bh = blockIdx.x, b = bh / a.H, head = bh - b * a.H;
+  const float* ps = part + (size_t)bh * nsplit * (DH + 2) * 32;
+  for (int e = threadIdx.x; e < DH * 32; e += 256) {
+    const int d = e >> 5, q = e & 31;
+    if (q >= a.Lq) continue;
+    float M = -INFINITY;
+    for (int g = 0; g < nsplit; ++g) M = fmaxf(M, ps[(size_t)g * (DH + 2) * 32 + DH * 32 + q]);
+    float L = 0.f, acc = 0.f;
+    for (int g = 0; g < nsplit; ++g) {
+      const float* pg = ps + (size_t)g * (DH + 2) * 32;
+      const float mg = pg[DH * 32 + q];
+      const float sc = mg == -INFINITY ? 0.f : EXP2(mg - M);
+      L += pg[(DH + 1) * 32 + q] * sc;
+      acc += pg[d * 32 + q] * sc;
     }
     a.out[((size_t)b * a.Lq + q) * a.ldo + head * DH + d] = acc / L;
     if (d == 0 && a.lse) a.lse[(size_t)bh * a.Lq + q] = M + log2f(L);
@@ -876,7 +909,15 @@ extern "C" int hoisdf_attention_fwd(const float* q, int ldq, const float* k, int
   HOISDF_REQUIRE(o && ldo >= H * DH && (ldo & 3) == 0 && ((uintptr_t)o & 15) == 0, HOISDF_ERR_INVALID,
                  "attention_fwd: bad output");
   if (Lq <= 32) {
-    hipLaunchKernelGGL(attn_fwd_fewq_kernel, dim3(B * H), dim3(64 * FEWQ_WAVES), 0, as_stream(stream), a);
+    // (b, head) pairs x key splits ~ 256 blocks, a split = at least 16 key tiles (two per wave); HOISDF_FEWQ_SPLIT=0: never split
+    static int split_on = -1;
+    if (split_on < 0) { const char* e = getenv("HOISDF_FEWQ_SPLIT"); split_on = (e && atoi(e) == 0) ? 0 : 1; }
+    const int ntiles = cdiv(kv_len, 32);
+    int nsplit = split_on ? min(max(1, 256 / (B * H)), max(1, ntiles / 16)) : 1;
+    float* part = nsplit > 1 ? reinterpret_cast<float*>(mag_scratch(as_stream(stream), (long)B * H * nsplit * (DH + 2) * 32)) : nullptr;
+    if (!part) nsplit = 1;
+    hipLaunchKernelGGL(attn_fwd_fewq_kernel, dim3(B * H, nsplit), dim3(64 * FEWQ_WAVES), 0, as_stream(stream), a, part);
+    if (nsplit > 1) hipLaunchKernelGGL(attn_fewq_merge_kernel, dim3(B * H), dim3(256), 0, as_stream(stream), a, part, nsplit);
     return check_launch("attention_fwd_fewq");
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(Lq, 128) * 8 * cdiv(B * H, 8)), dim3(256), 0, as_stream(stream), a);

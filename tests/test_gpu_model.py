@@ -151,7 +151,12 @@ def test_sdf_infer_in_train_mode_ranks_under_dropout_like_the_reference():
     noisy = [oracle_run(True, seed) for seed in (1, 2, 3)]
     m = T.to_device(meta, DEV)
     assert model.hand_sdf_decoder.training
-    runs = [model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand") for _ in range(2)]
+    # (the three statistics of ONE draw scatter by +-10 % around their expectation, the oracle's as much as the device's - measured over
+    # 12 device seeds and 6 oracle seeds, tools/dbg_branchb_spread.py: single draws are held to a gross-error band, the AVERAGE of six
+    # draws to the oracle's average; the device's mask stream is seeded here so that the test does not depend on what ran before it)
+    from hoisdf_amd import ops as _ops
+    _ops.manual_seed(20260930)
+    runs = [model.sdf_infer(pyr, m["mano_root"], m["cam_intr"], m["bbox_hand"], 3.1, nh, "hand") for _ in range(6)]
     for i in range(b):
         o_sets = [{key(r) for r in n[0][i].tolist()} for n in noisy]
         d_sets = [{key(r) for r in r_[0][i].cpu().tolist()} for r_ in runs]
@@ -159,13 +164,18 @@ def test_sdf_infer_in_train_mode_ranks_under_dropout_like_the_reference():
         o_kth = sum(float(n[1][i].abs().max()) for n in noisy) / 3
         o_clean = sum(sum(clean_of[i][k] for k in st) / nh for st in o_sets) / 3
         assert o_clean > 20 * float(sdf_c[i].abs().mean())                 # (the oracle itself: dropout moves the selection off the surface)
+        d_mean, d_kth, d_clean = [], [], []
         for r_, st in zip(runs, d_sets):
             sdf = r_[1][i, :, 0].abs().cpu()
             assert bool((sdf[1:] >= sdf[:-1] - 1e-7).all())                  # ranked by the noisy values it returns
-            assert abs(float(sdf.mean()) - o_mean) <= 0.15 * o_mean, (float(sdf.mean()), o_mean)
-            assert abs(float(sdf.max()) - o_kth) <= 0.15 * o_kth, (float(sdf.max()), o_kth)
-            d_clean = sum(clean_of[i][k] for k in st) / nh                   # (every selected point is a lattice survivor: KeyError otherwise)
-            assert abs(d_clean - o_clean) <= 0.12 * o_clean, (d_clean, o_clean)
+            d_mean.append(float(sdf.mean())); d_kth.append(float(sdf.max()))
+            d_clean.append(sum(clean_of[i][k] for k in st) / nh)             # (every selected point is a lattice survivor: KeyError otherwise)
+            assert abs(d_mean[-1] - o_mean) <= 0.35 * o_mean and abs(d_kth[-1] - o_kth) <= 0.35 * o_kth, (d_mean[-1], o_mean, d_kth[-1], o_kth)
+            assert abs(d_clean[-1] - o_clean) <= 0.35 * o_clean, (d_clean[-1], o_clean)
+        avg = lambda xs: sum(xs) / len(xs)
+        assert abs(avg(d_mean) - o_mean) <= 0.10 * o_mean, (avg(d_mean), o_mean)
+        assert abs(avg(d_kth) - o_kth) <= 0.10 * o_kth, (avg(d_kth), o_kth)
+        assert abs(avg(d_clean) - o_clean) <= 0.10 * o_clean, (avg(d_clean), o_clean)
         ov = lambda x, y: len(x & y) / nh
         oo = max(ov(o_sets[0], o_sets[1]), ov(o_sets[0], o_sets[2]), ov(o_sets[1], o_sets[2]))
         assert ov(d_sets[0], d_sets[1]) <= oo + 0.05 and ov(d_sets[0], o_sets[0]) <= oo + 0.05, "selections as random as the oracle's"
