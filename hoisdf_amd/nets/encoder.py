@@ -38,7 +38,9 @@ def bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual=None) -> to
         train = bn.training or bn.running_mean is None
         grad = torch.is_grad_enabled() and (x.requires_grad or (bn.weight is not None and bn.weight.requires_grad) or
                                             (residual is not None and residual.requires_grad))
-        if ops.bn_act_supported(x) and (train or not grad) and (not train or bn.momentum is not None or not bn.track_running_stats):
+        # (a map that is not channels_last-dense - an NCHW encoder - would be transposed on the way in and handed on in another layout: torch's path)
+        if (ops.bn_act_supported(x) and x.is_contiguous(memory_format=torch.channels_last) and (train or not grad)
+                and (not train or bn.momentum is not None or not bn.track_running_stats)):
             track = train and bn.track_running_stats and bn.running_mean is not None
             if track:
                 _PENDING_NBT.append(bn.num_batches_tracked)
