@@ -578,7 +578,8 @@ def test_attention_few_queries_kernel_incl_dropout():
     O = ops()
     import hoisdf_amd.ops as OO
     E, H = 256, 4
-    for B, Lq, Lk, kv in [(2, 17, 1536, 1536), (1, 1, 40, 33), (3, 32, 700, 650), (2, 5, 96, 96)]:
+    # (1536 keys: three key splits of 16 tiles over separate blocks + the merge kernel; 3000 of 3100: five splits, the last one ragged)
+    for B, Lq, Lk, kv in [(2, 17, 1536, 1536), (1, 1, 40, 33), (3, 32, 700, 650), (2, 5, 96, 96), (1, 17, 3100, 3000)]:
         q = rnd(B, Lq, E, seed=50)
         kvt = rnd(B, Lk, 2 * E, seed=51)
         ref = _ref_attention(q.double(), kvt[..., :E].double(), kvt[..., E:].double(), H, kv)
