@@ -339,14 +339,19 @@ def main():
     timed_steps = 0
     model.branch_log = []
     t0 = time.perf_counter()
+    marks = []                                  # host clock after each step's launches were queued (no synchronisation: diagnostics only)
     for i in range(args.steps):
         sample = timer is not None and i % args.time_every == 0
         _lib.set_timer(timer if sample else None)
         cfg.overlap_streams = not sample        # event-bracketed steps run single-stream: with the object stack on a second
         timed_steps += int(sample)              # stream a kernel's events would also span the other stream's kernels
         last = step()
+        marks.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("HOISDF_BENCH_STEP_LOG") and rank == 0:
+        print("host clock per step (ms, launches queued, no sync):", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)],
+              "drain %.1f" % (1e3 * (t0 + dt - marks[-1])), file=sys.stderr)
     _lib.set_timer(None)
     for bname in getattr(model, "branch_log", []):
         branches[bname] += 1
