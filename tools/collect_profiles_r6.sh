@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 cd /tmp
 for cfg in default config3 config4; do
   extra=""; marker=""
-  [ $cfg = config3 ] && extra="--config 3" && marker="vote_loss_fwd_kernel"
-  [ $cfg = config4 ] && extra="--config 4" && marker="vote_loss_fwd_kernel"
+  [ $cfg = config3 ] && extra="--config 3" && marker="vote_loss_fwd_kernel vote_loss_merge_kernel"
+  [ $cfg = config4 ] && extra="--config 4" && marker="vote_loss_fwd_kernel vote_loss_merge_kernel"
   HOISDF_TWO_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- \
       python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --exact-f32 0 --bf16x3-leg 0 --no-kernel-timing $extra > $O/bench_${cfg}_under_rocprof.json 2> /dev/null
   T=$(find $O/trace -name "*kernel_trace.csv" | head -1)
