@@ -19,6 +19,10 @@ Units of one family are ordered STAGE-major over element quads so that neighbour
     python tools/gen/attn_bwd4_phase.py > hoisdf_amd/csrc/attn_bwd4_phase.inc"""
 import sys
 PROD = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]          # (A plane, B plane): small terms first
+# S = Q . K^T is accumulated in the FORWARD's order (attn_fwd2_phase.py FWD2_S: PROD over (K plane, Q plane) with A = K; here A = Q, so
+# the pairs are swapped): the recomputed scores are then bit-identical to the ones the forward's LSE was made from - where |S| is large
+# (a saturated first-layer attention: 2^21) a last-bit difference of S is a factor 1.19 of P (round 6, as in attn_bwd4h_phase.py)
+PRODS = [(y, x) for x, y in PROD]
 CAP = 22
 COST = {"FR": 6, "TR": 9, "HA": 14, "HB": 18, "HC": 22, "LQ": 6, "DL": 6, "PA": 34, "PB": 20, "PC": 14, "PD": 14, "PE": 10,
         "QA": 22, "QB": 14, "QC": 14, "QD": 10, "TW": 22, "STQ": 8, "STS": 10, "LDG": 8, "LDS_": 6, "XOL": 14, "XOS": 12, "XW": 10, "XOP": 20, "XOW": 4, "XSIG": 8}
@@ -47,7 +51,7 @@ def main():
     # ---- the MFMA stream and its fragment reads (group g + 1 is read behind MFMAs 1..3 of group g) ----
     for m in range(24):                                   # S
         j, k = divmod(m, 6)
-        x, y = PROD[k]
+        x, y = PRODS[k]
         mf.append("%s(s, fr[%d][%d], kf[%d][%d])" % ("MFMA_SP" if m else "MFMA_SP0", j & 1, x, j, y))
     for m in range(24):                                   # dP
         j, k = divmod(m, 6)
