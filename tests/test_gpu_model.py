@@ -34,6 +34,17 @@ def build(setting, nh, no, bins, train=False):
     return model, c
 
 
+def _needs_the_emulated_attention():
+    """The saturated-attention fixtures (_smallbeta: first-layer scores of ~2^21 in the log2 domain, where one f32 ulp of a score is a
+    factor 1.19 of P) pin the DEFAULT arithmetic, whose backward re-accumulates the scores bit-identically to its forward.  The exact-f32
+    MFMA attention (HOISDF_ATTENTION=f32 / HOISDF_ATTN_BWD=f32, the round-2 kernels kept for A/B runs) sums them in another order
+    forward and backward: joints 1.5e-4 off and first-layer gradients without meaning on this fixture (measured, round 6)."""
+    import os
+    from hoisdf_amd import ops
+    if not (ops.gemm_emu() and ops.attention_emu()) or os.environ.get("HOISDF_ATTN_BWD") == "f32":
+        pytest.skip("saturated-attention fixture: holds for the emulated (default) attention, not for the exact-f32 MFMA kernels")
+
+
 def nhwc_pyramid(pyr, requires_grad=False):
     from hoisdf_amd import ops
     lv = [v.to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(requires_grad) for v in pyr.values()]
@@ -61,6 +72,7 @@ def test_eval_forward_matches_reference_goldens(case):
     g = load_golden(f"g7_e2e_{setting}_n{nh + no}{sfx}")
     model, c = build(setting, nh, no, bins)
     if sfx == "_smallbeta":
+        _needs_the_emulated_attention()
         with torch.no_grad():
             for k_, v_ in T.SMALL_BETA.items():
                 getattr(model, k_).fill_(v_)
@@ -208,6 +220,8 @@ def test_train_fwd_bwd_matches_reference_goldens_and_oracle(setting, nh, no, suf
     g = load_golden(f"g8_train_{setting}{suffix}")
     small = suffix.endswith(("_smallbeta", "_trainedlike"))
     saturated = suffix.endswith("_smallbeta")
+    if saturated:
+        _needs_the_emulated_attention()
     upstream = ("linear_transformerin.", "hand_sigmoid_beta", "obj_sigmoid_beta", "hand_transformer.encoder.layers.0.self_attn.in_proj",
                 "obj_transformer.encoder.layers.0.self_attn.in_proj")
     g64 = load_golden(f"g8_train_{setting}{suffix}_fp64") if small else None
