@@ -182,6 +182,8 @@ def test_second_stream_overlaps_the_compute_stream_next_to_a_rccl_process_group(
     kernels, one per stream, must take the time of one."""
     if not hasattr(torch.cuda, "_sleep"):
         pytest.skip("torch.cuda._sleep not available")
+    if os.environ.get("HOISDF_TWO_STREAMS") == "0" or os.environ.get("HOISDF_DETERMINISTIC") == "1":
+        pytest.skip("the model runs single-stream in this process (HOISDF_TWO_STREAMS=0 / deterministic mode): no second stream to test")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_overlap_worker, args=(_free_port(), q))
