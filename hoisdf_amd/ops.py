@@ -2204,6 +2204,17 @@ def _rows_cl(t: torch.Tensor):
     return t, ld
 
 
+_BN_WS = {}
+
+
+def _bn_workspace_floats(M: int, c: int) -> int:
+    n = _BN_WS.get((M, c))
+    if n is None:
+        from ._lib import lib
+        n = _BN_WS[(M, c)] = lib().hoisdf_bn_workspace_floats(M, c)
+    return n
+
+
 def bn_act_supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 8 == 0 and 8 <= x.shape[1] <= 2048 and x.numel() > 0
 
@@ -2223,8 +2234,7 @@ class _BnAct(torch.autograd.Function):
         need_grad = training and (x.requires_grad or (weight is not None and weight.requires_grad) or
                                   (residual is not None and residual.requires_grad))
         if training:
-            from ._lib import lib
-            nws = lib().hoisdf_bn_workspace_floats(M, c)
+            nws = _bn_workspace_floats(M, c)
             ws = torch.empty(nws, device=x.device, dtype=torch.float32)
             stats = torch.empty(2, c, device=x.device, dtype=torch.float32)
             mean, invstd = stats[0], stats[1]
@@ -2249,8 +2259,7 @@ class _BnAct(torch.autograd.Function):
         dx = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2)
         dres = torch.empty((n, h, w, c), device=x.device, dtype=torch.float32).permute(0, 3, 1, 2) if has_res else None
         dwb = torch.empty(2, c, device=x.device, dtype=torch.float32)
-        from ._lib import lib
-        nws = lib().hoisdf_bn_workspace_floats(M, c)
+        nws = _bn_workspace_floats(M, c)
         ws = torch.empty(nws, device=x.device, dtype=torch.float32)
         call("hoisdf_bn_bwd", _p(dy), lddy, _p(x), ldx, _p(bits if relu else None), _p(mean), _p(invstd), _p(weight), _p(dx), _p(dres),
              _p(dwb[0]), _p(dwb[1]), M, c, _p(ws), nws, _st())
