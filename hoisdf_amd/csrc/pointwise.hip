@@ -447,6 +447,192 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 6: the two kernels above for D <= 256 (one float4 per lane: every LayerNorm of the model, E = 256) with FOUR rows of a wave in
+// flight - the row loop above is a chain (loads -> two wave reductions -> stores) that the next row's loads wait behind: the largest
+// launches ran at 3.8 - 4.1 TB/s where the BatchNorm passes reach 5.7.  Per row the arithmetic is the same, expression by expression.
+constexpr int LN_NR = 4;
+__device__ __forceinline__ void ln_drop4(float4& b, uint64_t seed, long row, int lane, uint32_t thresh, float inv_keep) {
+  const uint32_t rk = drop_rowkey(seed, (uint32_t)row), e = (uint32_t)(lane * 4);
+  b.x *= drop_scale(rk, e + 0, thresh, inv_keep);
+  b.y *= drop_scale(rk, e + 1, thresh, inv_keep);
+  b.z *= drop_scale(rk, e + 2, thresh, inv_keep);
+  b.w *= drop_scale(rk, e + 3, thresh, inv_keep);
+}
+__global__ __launch_bounds__(256) void add_ln_fwd256_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long M,
+                                                            int D, float eps, float drop_p, float inv_keep, uint64_t seed, uint32_t thresh,
+                                                            uint32_t* __restrict__ y_mag) {
+  const int lane = threadIdx.x & 63;
+  const int nu = D >> 2;
+  const bool act = lane < nu;
+  float4 g = make_float4(0, 0, 0, 0), bb = make_float4(0, 0, 0, 0);
+  if (act) { g = *reinterpret_cast<const float4*>(gamma + lane * 4); bb = *reinterpret_cast<const float4*>(beta + lane * 4); }
+  long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
+  const long stride = (long)gridDim.x * 4 * LN_NR;
+  for (; base < M; base += stride) {
+    float4 v[LN_NR], b[LN_NR];
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      v[k] = make_float4(0, 0, 0, 0); b[k] = make_float4(0, 0, 0, 0);
+      if (act && row < M) {
+        v[k] = *reinterpret_cast<const float4*>(x + (size_t)row * D + lane * 4);
+        if (r) b[k] = *reinterpret_cast<const float4*>(r + (size_t)row * D + lane * 4);
+      }
+    }
+    float s[LN_NR], q[LN_NR], mu[LN_NR], rs[LN_NR];
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      s[k] = 0.f;
+      if (act && row < M) {
+        float4 a = v[k];
+        if (r) {
+          float4 t = b[k];
+          if (drop_p > 0.f) ln_drop4(t, seed, row, lane, thresh, inv_keep);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        v[k] = a;
+        s[k] += a.x + a.y + a.z + a.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) mu[k] = wave_sum(s[k]) / (float)D;
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      q[k] = 0.f;
+      if (act && base + k < M) {
+        const float a = v[k].x - mu[k], b_ = v[k].y - mu[k], c = v[k].z - mu[k], d = v[k].w - mu[k];
+        q[k] += a * a + b_ * b_ + c * c + d * d;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) rs[k] = rsqrtf(wave_sum(q[k]) / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      if (row >= M) break;
+      uint32_t ymax = 0u;
+      if (act) {
+        float4 o;
+        o.x = (v[k].x - mu[k]) * rs[k] * g.x + bb.x;
+        o.y = (v[k].y - mu[k]) * rs[k] * g.y + bb.y;
+        o.z = (v[k].z - mu[k]) * rs[k] * g.z + bb.z;
+        o.w = (v[k].w - mu[k]) * rs[k] * g.w + bb.w;
+        *reinterpret_cast<float4*>(y + (size_t)row * D + lane * 4) = o;
+        ymax = mag_bits4(o);
+      }
+      if (lane == 0) {
+        if (mean) mean[row] = mu[k];
+        if (rstd) rstd[row] = rs[k];
+      }
+      rowmag_publish_wave(y_mag, row, ymax);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_ln_bwd256_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ r,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dr,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int D, float drop_p,
+                                                            float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds,
+                                                            const float* __restrict__ dx_add, uint32_t* __restrict__ dx_mag,
+                                                            uint32_t* __restrict__ dr_mag) {
+  const int lane = threadIdx.x & 63;
+  const int nu = D >> 2;
+  const bool act = lane < nu;
+  float4 dg = make_float4(0, 0, 0, 0), db = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
+  if (act) g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
+  const long stride = (long)gridDim.x * 4 * LN_NR;
+  for (; base < M; base += stride) {
+    float4 a[LN_NR], b[LN_NR], d[LN_NR], e[LN_NR];
+    float mu[LN_NR], rs[LN_NR];
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      a[k] = b[k] = d[k] = e[k] = make_float4(0, 0, 0, 0);
+      mu[k] = 0.f; rs[k] = 0.f;
+      if (row < M) {
+        mu[k] = mean[row]; rs[k] = rstd[row];
+        if (act) {
+          a[k] = *reinterpret_cast<const float4*>(x + (size_t)row * D + lane * 4);
+          if (r) b[k] = *reinterpret_cast<const float4*>(r + (size_t)row * D + lane * 4);
+          d[k] = *reinterpret_cast<const float4*>(dy + (size_t)row * D + lane * 4);
+          if (dx_add) e[k] = *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + lane * 4);
+        }
+      }
+    }
+    float4 xh[LN_NR], gd[LN_NR];
+    float s1[LN_NR], s2[LN_NR];
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      xh[k] = gd[k] = make_float4(0, 0, 0, 0);
+      s1[k] = 0.f; s2[k] = 0.f;
+      if (act && row < M) {
+        float4 aa = a[k];
+        if (r) {
+          float4 t = b[k];
+          if (drop_p > 0.f) ln_drop4(t, seed, row, lane, thresh, inv_keep);
+          aa.x += t.x; aa.y += t.y; aa.z += t.z; aa.w += t.w;
+        }
+        xh[k] = make_float4((aa.x - mu[k]) * rs[k], (aa.y - mu[k]) * rs[k], (aa.z - mu[k]) * rs[k], (aa.w - mu[k]) * rs[k]);
+        gd[k] = make_float4(d[k].x * g.x, d[k].y * g.y, d[k].z * g.z, d[k].w * g.w);
+        dg.x += d[k].x * xh[k].x; dg.y += d[k].y * xh[k].y; dg.z += d[k].z * xh[k].z; dg.w += d[k].w * xh[k].w;
+        db.x += d[k].x; db.y += d[k].y; db.z += d[k].z; db.w += d[k].w;
+        s1[k] += gd[k].x + gd[k].y + gd[k].z + gd[k].w;
+        s2[k] += gd[k].x * xh[k].x + gd[k].y * xh[k].y + gd[k].z * xh[k].z + gd[k].w * xh[k].w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) { s1[k] = wave_sum(s1[k]) / (float)D; s2[k] = wave_sum(s2[k]) / (float)D; }
+#pragma unroll
+    for (int k = 0; k < LN_NR; ++k) {
+      const long row = base + k;
+      if (row >= M) break;
+      uint32_t xmax = 0u, rmax = 0u;
+      if (act) {
+        float4 o;
+        o.x = rs[k] * (gd[k].x - s1[k] - xh[k].x * s2[k]);
+        o.y = rs[k] * (gd[k].y - s1[k] - xh[k].y * s2[k]);
+        o.z = rs[k] * (gd[k].z - s1[k] - xh[k].z * s2[k]);
+        o.w = rs[k] * (gd[k].w - s1[k] - xh[k].w * s2[k]);
+        float4 ox = o;
+        if (dx_add) { ox.x += e[k].x; ox.y += e[k].y; ox.z += e[k].z; ox.w += e[k].w; }
+        *reinterpret_cast<float4*>(dx + (size_t)row * D + lane * 4) = ox;
+        xmax = mag_bits4(ox);
+        if (dr) {
+          if (drop_p > 0.f) ln_drop4(o, seed, row, lane, thresh, inv_keep);
+          *reinterpret_cast<float4*>(dr + (size_t)row * D + lane * 4) = o;
+          rmax = mag_bits4(o);
+        }
+      }
+      rowmag_publish_wave(dx_mag, row, xmax);
+      rowmag_publish_wave(dr_mag, row, rmax);
+    }
+  }
+  // the block's column sums as in add_ln_bwd_kernel: the four waves through LDS, then one atomic per column per block (or the ordered fold)
+  __shared__ float red[2][4][256];
+  __shared__ float flat[512];
+  const int w = threadIdx.x >> 6;
+  if (act) {
+    *reinterpret_cast<float4*>(&red[0][w][lane * 4]) = dg;
+    *reinterpret_cast<float4*>(&red[1][w][lane * 4]) = db;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < D) {
+    const int c = threadIdx.x;
+    flat[c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    flat[D + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  }
+  __syncthreads();
+  __shared__ unsigned s_last;
+  block_column_sum(dgamma, D, dbeta, D, flat, &s_last, ds);
+}
+
+// ------------------------------------------------------------------------------------------
 // y = x + dropout(r)  (x == nullptr: y = dropout(r), the backward's dr = dy * mask / keep): the residual of a PRE-norm layer
 // (common/nets/transformer.py:304-331,397-437; the post-norm layers fuse this into add_ln_*).  Same (seed, row, column) mask
 // function as add_ln_fwd_kernel.  One float4 per thread.
@@ -474,6 +660,12 @@ __global__ __launch_bounds__(256) void residual_dropout_kernel(const float* __re
 
 using namespace hoisdf;
 
+// HOISDF_LN_ROWS=1: add + LayerNorm with one row per wave in flight for every width (the round-1 kernels; A/B runs)
+static bool ln_one_row_form() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("HOISDF_LN_ROWS"); v = (e && atoi(e) == 1) ? 1 : 0; }
+  return v == 1;
+}
 static int row_grid(long n_rows) {
   long blocks = (n_rows + 3) / 4;
   if (blocks > 256L * 8) blocks = 256L * 8;
@@ -601,6 +793,13 @@ int hoisdf::add_layernorm_fwd_mag(const float* x, const float* r, const float* g
   HOISDF_REQUIRE(D > 0 && D <= 1024 && (D & 3) == 0 && drop_p >= 0.f && drop_p < 1.f, HOISDF_ERR_INVALID,
                  "add_layernorm_fwd: D=%d must be a multiple of 4 and <= 1024", D);
   if (M == 0) return HOISDF_OK;
+  if (D <= 256 && !ln_one_row_form()) {
+    int blocks = cdiv(M, 4 * LN_NR);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_ln_fwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y, mean, rstd, M, D, eps, drop_p,
+                       1.f / (1.f - drop_p), seed, drop_threshold(drop_p), y_mag);
+    return check_launch("add_layernorm_fwd");
+  }
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
                      mean, rstd, M, D, eps, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0, y_mag);
   return check_launch("add_layernorm_fwd");
@@ -649,6 +848,13 @@ int hoisdf::add_layernorm_bwd_mag(const float* dy, const float* x, const float* 
   static int cap = -1;                          // HOISDF_LN_BWD_BLOCKS: blocks of the backward (A/B runs; default 1024 = 4 per CU)
   if (cap < 0) { const char* e = getenv("HOISDF_LN_BWD_BLOCKS"); cap = e && atoi(e) > 0 ? atoi(e) : 1024; }
   if (blocks > cap) blocks = cap;
+  if (D <= 256 && !ln_one_row_form()) {
+    blocks = cdiv(M, 4 * LN_NR);
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(add_ln_bwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd, dx, dr, dgamma, dbeta, M, D,
+                       drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), det_scratch((size_t)blocks * 2 * D), dx_add, dx_mag, dr_mag);
+    return check_launch("add_layernorm_bwd");
+  }
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
                      dx, dr, dgamma, dbeta, M, D, drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p),
                      det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0, dx_mag, dr_mag);

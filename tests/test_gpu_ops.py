@@ -284,9 +284,9 @@ def test_attention_dropout_is_consistent_between_fwd_and_bwd():
 
 
 # ---------------------------------------------------------------------------------------------
-def test_add_layernorm_and_plain():
+@pytest.mark.parametrize("M,D", [(1500, 256), (1501, 256), (3, 256), (37, 64), (1500, 512)])      # (D <= 256: four rows of a wave in flight, ragged tails)
+def test_add_layernorm_and_plain(M, D):
     O = ops()
-    M, D = 1500, 256
     x, r = rnd(M, D, seed=40).double().requires_grad_(True), rnd(M, D, seed=41).double().requires_grad_(True)
     g, b = (1 + 0.1 * rnd(D, seed=42)).double().requires_grad_(True), rnd(D, seed=43).double().requires_grad_(True)
     ref = F.layer_norm(x + r, (D,), g, b, 1e-5)
