@@ -27,6 +27,9 @@ CASES = {
     "bn_apply_fwd_131072x256": ("hoisdf_bn_apply_fwd", "bn_apply_fwd_kernel<true, true>", (131072, 256, 1)),
     "bn_bwd_reduce_131072x256": ("hoisdf_bn_bwd", "bn_bwd_reduce_kernel<true>", (131072, 256, 1)),
     "bn_bwd_dx_131072x256": ("hoisdf_bn_bwd", "bn_bwd_dx_kernel<true, true>", (131072, 256, 1)),
+    # add + LayerNorm of one encoder layer's 65536 x 256 rows (dropout on the residual branch, dx_add and dr as in the layer's backward)
+    "add_ln_fwd_65536x256": ("hoisdf_add_layernorm_fwd", "add_ln_fwd256_kernel", (65536, 256, 0)),
+    "add_ln_bwd_65536x256": ("hoisdf_add_layernorm_bwd", "add_ln_bwd256_kernel", (65536, 256, 0)),
     # K1 at the lattice survivors of one configs[3] sdf_infer call: 320 000 points x 992 channels (shape = rows, channels, 0)
     "gather_fwd_320000x992": ("hoisdf_project_gather_fwd", "gather_fwd4_kernel", (320000, 992, 0)),
 }
@@ -48,6 +51,17 @@ if __name__ == "__main__":
         for _ in range(3):
             x.grad = res.grad = w.grad = b.grad = None
             y = O.bn_act(x, w, b, rm, rv, True, 0.1, 1e-5, True, res)
+            y.backward(gy)
+        torch.cuda.synchronize()
+        sys.exit(0)
+    if case.startswith("add_ln_"):
+        M, D, _ = shape
+        x = torch.randn(M, D, device=dev, requires_grad=True); r = torch.randn(M, D, device=dev, requires_grad=True)
+        g = torch.rand(D, device=dev, requires_grad=True); b = torch.randn(D, device=dev, requires_grad=True)
+        gy = torch.randn(M, D, device=dev)
+        for _ in range(3):
+            x.grad = r.grad = g.grad = b.grad = None
+            y = O.add_layernorm(x, r, g, b, 1e-5, 0.1)
             y.backward(gy)
         torch.cuda.synchronize()
         sys.exit(0)
