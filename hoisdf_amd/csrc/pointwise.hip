@@ -462,10 +462,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd256_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long M,
                                                             int D, float eps, float drop_p, float inv_keep, uint64_t seed, uint32_t thresh,
-                                                            uint32_t* __restrict__ y_mag) {
+                                                            int rpg, int take, uint32_t* __restrict__ y_mag) {
+  // rpg > 0 (hoisdf_layernorm_rows_fwd): as add_ln_fwd_kernel - M counts the compact output rows, input row = in_row(output row)
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   const bool act = lane < nu;
+  auto in_row = [&](long orow) -> long { return rpg > 0 ? (orow / take) * rpg + orow % take : orow; };
   float4 g = make_float4(0, 0, 0, 0), bb = make_float4(0, 0, 0, 0);
   if (act) { g = *reinterpret_cast<const float4*>(gamma + lane * 4); bb = *reinterpret_cast<const float4*>(beta + lane * 4); }
   long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_NR;
@@ -474,9 +476,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd256_kernel(const float* __restr
     float4 v[LN_NR], b[LN_NR];
 #pragma unroll
     for (int k = 0; k < LN_NR; ++k) {
-      const long row = base + k;
+      const long row = in_row(base + k);
       v[k] = make_float4(0, 0, 0, 0); b[k] = make_float4(0, 0, 0, 0);
-      if (act && row < M) {
+      if (act && base + k < M) {
         v[k] = *reinterpret_cast<const float4*>(x + (size_t)row * D + lane * 4);
         if (r) b[k] = *reinterpret_cast<const float4*>(r + (size_t)row * D + lane * 4);
       }
@@ -484,13 +486,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd256_kernel(const float* __restr
     float s[LN_NR], q[LN_NR], mu[LN_NR], rs[LN_NR];
 #pragma unroll
     for (int k = 0; k < LN_NR; ++k) {
-      const long row = base + k;
       s[k] = 0.f;
-      if (act && row < M) {
+      if (act && base + k < M) {
         float4 a = v[k];
         if (r) {
           float4 t = b[k];
-          if (drop_p > 0.f) ln_drop4(t, seed, row, lane, thresh, inv_keep);
+          if (drop_p > 0.f) ln_drop4(t, seed, in_row(base + k), lane, thresh, inv_keep);
           a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
         v[k] = a;
@@ -537,8 +538,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd256_kernel(const float* __restr
                                                             const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dr,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, long M, int D, float drop_p,
                                                             float inv_keep, uint64_t seed, uint32_t thresh, DetScratch ds,
-                                                            const float* __restrict__ dx_add, uint32_t* __restrict__ dx_mag,
-                                                            uint32_t* __restrict__ dr_mag) {
+                                                            const float* __restrict__ dx_add, int rpg, int take,
+                                                            uint32_t* __restrict__ dx_mag, uint32_t* __restrict__ dr_mag) {
+  // rpg > 0 (hoisdf_layernorm_rows_bwd): as add_ln_bwd_kernel - M counts ALL input rows; dy / mean / rstd are compact: only rows
+  // t < take of a group carry a gradient, the others pass dx_add through (or get 0)
   const int lane = threadIdx.x & 63;
   const int nu = D >> 2;
   const bool act = lane < nu;
@@ -549,17 +552,29 @@ __global__ __launch_bounds__(256) void add_ln_bwd256_kernel(const float* __restr
   for (; base < M; base += stride) {
     float4 a[LN_NR], b[LN_NR], d[LN_NR], e[LN_NR];
     float mu[LN_NR], rs[LN_NR];
+    bool live[LN_NR];                           // the row carries a gradient through the LayerNorm (wave-uniform)
 #pragma unroll
     for (int k = 0; k < LN_NR; ++k) {
       const long row = base + k;
       a[k] = b[k] = d[k] = e[k] = make_float4(0, 0, 0, 0);
       mu[k] = 0.f; rs[k] = 0.f;
+      live[k] = false;
       if (row < M) {
-        mu[k] = mean[row]; rs[k] = rstd[row];
+        long crow = row;
+        live[k] = true;
+        if (rpg > 0) {
+          const long grp = row / rpg;
+          const int t = (int)(row - grp * rpg);
+          live[k] = t < take;
+          crow = grp * take + t;
+        }
+        if (live[k]) { mu[k] = mean[crow]; rs[k] = rstd[crow]; }
         if (act) {
-          a[k] = *reinterpret_cast<const float4*>(x + (size_t)row * D + lane * 4);
-          if (r) b[k] = *reinterpret_cast<const float4*>(r + (size_t)row * D + lane * 4);
-          d[k] = *reinterpret_cast<const float4*>(dy + (size_t)row * D + lane * 4);
+          if (live[k]) {
+            a[k] = *reinterpret_cast<const float4*>(x + (size_t)row * D + lane * 4);
+            if (r) b[k] = *reinterpret_cast<const float4*>(r + (size_t)row * D + lane * 4);
+            d[k] = *reinterpret_cast<const float4*>(dy + (size_t)crow * D + lane * 4);
+          }
           if (dx_add) e[k] = *reinterpret_cast<const float4*>(dx_add + (size_t)row * D + lane * 4);
         }
       }
@@ -571,7 +586,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd256_kernel(const float* __restr
       const long row = base + k;
       xh[k] = gd[k] = make_float4(0, 0, 0, 0);
       s1[k] = 0.f; s2[k] = 0.f;
-      if (act && row < M) {
+      if (act && live[k]) {
         float4 aa = a[k];
         if (r) {
           float4 t = b[k];
@@ -593,6 +608,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd256_kernel(const float* __restr
       const long row = base + k;
       if (row >= M) break;
       uint32_t xmax = 0u, rmax = 0u;
+      if (!live[k]) {                         // (no gradient through this row: dx = what arrives from the other consumer, or 0)
+        if (act) { *reinterpret_cast<float4*>(dx + (size_t)row * D + lane * 4) = e[k]; xmax = mag_bits4(e[k]); }
+        rowmag_publish_wave(dx_mag, row, xmax);
+        continue;
+      }
       if (act) {
         float4 o;
         o.x = rs[k] * (gd[k].x - s1[k] - xh[k].x * s2[k]);
@@ -797,7 +817,7 @@ int hoisdf::add_layernorm_fwd_mag(const float* x, const float* r, const float* g
     int blocks = cdiv(M, 4 * LN_NR);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(add_ln_fwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y, mean, rstd, M, D, eps, drop_p,
-                       1.f / (1.f - drop_p), seed, drop_threshold(drop_p), y_mag);
+                       1.f / (1.f - drop_p), seed, drop_threshold(drop_p), 0, 0, y_mag);
     return check_launch("add_layernorm_fwd");
   }
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, r, gamma, beta, y,
@@ -825,6 +845,13 @@ extern "C" int hoisdf_layernorm_rows_fwd(const float* x, const float* gamma, con
                  HOISDF_ERR_INVALID, "layernorm_rows_fwd: D=%d rows_per_group=%d take=%d", D, rows_per_group, take);
   const long M = groups * take;
   if (M == 0) return HOISDF_OK;
+  if (D <= 256 && !ln_one_row_form()) {
+    int blocks = cdiv(M, 4 * LN_NR);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_ln_fwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, (const float*)nullptr, gamma, beta, y, mean, rstd, M, D,
+                       eps, 0.f, 1.f, (uint64_t)0, 0u, rows_per_group, take, (uint32_t*)nullptr);
+    return check_launch("layernorm_rows_fwd");
+  }
   hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(row_grid(M)), dim3(256), 0, as_stream(stream), x, (const float*)nullptr, gamma,
                      beta, y, mean, rstd, M, D, eps, 0.f, 1.f, (uint64_t)0, 0u, rows_per_group, take, (uint32_t*)nullptr);
   return check_launch("layernorm_rows_fwd");
@@ -852,7 +879,7 @@ int hoisdf::add_layernorm_bwd_mag(const float* dy, const float* x, const float* 
     blocks = cdiv(M, 4 * LN_NR);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(add_ln_bwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd, dx, dr, dgamma, dbeta, M, D,
-                       drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), det_scratch((size_t)blocks * 2 * D), dx_add, dx_mag, dr_mag);
+                       drop_p, 1.f / (1.f - drop_p), seed, drop_threshold(drop_p), det_scratch((size_t)blocks * 2 * D), dx_add, 0, 0, dx_mag, dr_mag);
     return check_launch("add_layernorm_bwd");
   }
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, r, gamma, mean, rstd,
@@ -872,6 +899,14 @@ extern "C" int hoisdf_layernorm_rows_bwd(const float* dy, const float* x, const 
   if (M == 0) return HOISDF_OK;
   int blocks = row_grid(M);
   if (blocks > 512) blocks = 512;
+  if (D <= 256 && !ln_one_row_form()) {
+    blocks = cdiv(M, 4 * LN_NR);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(add_ln_bwd256_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, (const float*)nullptr, gamma, mean, rstd, dx,
+                       (float*)nullptr, dgamma, dbeta, M, D, 0.f, 1.f, (uint64_t)0, 0u, det_scratch((size_t)blocks * 2 * D), dx_add, rows_per_group,
+                       take, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    return check_launch("layernorm_rows_bwd");
+  }
   hipLaunchKernelGGL(add_ln_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, x, (const float*)nullptr, gamma,
                      mean, rstd, dx, (float*)nullptr, dgamma, dbeta, M, D, 0.f, 1.f, (uint64_t)0, 0u,
                      det_scratch((size_t)blocks * 2 * D), dx_add, rows_per_group, take, (uint32_t*)nullptr, (uint32_t*)nullptr);
