@@ -108,6 +108,34 @@ class SyntheticDataset(torch.utils.data.Dataset):
         return sq(ins), sq(tg), sq(mt)
 
 
+def reserve_hbm_pool(model: torch.nn.Module, fraction: float = 0.5, device=None) -> int:
+    """After the first steps: hand PyTorch's caching allocator `fraction` of the peak it has seen so far as FREE cached blocks, one per
+    stream the model launches on (blocks are owned by the stream they were freed on).  The step's allocation pattern is not exactly
+    repeatable - two streams race, a training step after `cfg.point_sampling_epoch` draws its point branch - and a request the cache
+    cannot serve costs a hipMalloc: synchronous, 50-250 ms for the multi-GB workspaces of `sdf_infer` (measured: the first branch-B
+    step of a run took 383 ms instead of 90).  288 GB of HBM per GPU is there to be laid out once.  Returns the bytes reserved."""
+    if not torch.cuda.is_available():
+        return 0
+    dev = torch.device(device) if device is not None else next(model.parameters()).device
+    if dev.type != "cuda":
+        return 0
+    peak = torch.cuda.max_memory_allocated(dev)
+    free, _ = torch.cuda.mem_get_info(dev)
+    extra = min(int(fraction * peak), int(0.25 * free))
+    streams = [torch.cuda.current_stream(dev)]
+    side = getattr(model, "_side_stream", None) or getattr(getattr(model, "module", None), "_side_stream", None)
+    if side is not None:
+        streams.append(side)
+    per = extra // len(streams) // (1 << 20) * (1 << 20)
+    if per <= 0:
+        return 0
+    for st in streams:
+        with torch.cuda.stream(st):
+            t = torch.empty(per, dtype=torch.uint8, device=dev)
+            del t
+    return per * len(streams)
+
+
 def snapshot_path(model_dir: str, epoch: int, itr: int) -> str:
     return osp.join(model_dir, f"snapshot_{epoch}_{itr}.pth.tar")
 
