@@ -240,6 +240,11 @@ class Trainer:
         total.backward()
         self.reducer.finish()
         self.optimizer.step()
+        self._steps_done = getattr(self, "_steps_done", 0) + 1
+        if self._steps_done == 3 and dev.type == "cuda":
+            # the allocator has seen the step's pattern: leave it free cached blocks on both streams, so that a later step that
+            # allocates differently (the other point branch, the two streams racing) does not stall in a hipMalloc
+            self.hbm_pool_bytes = reserve_hbm_pool(self.model, float(getattr(self.cfg, "hbm_pool_fraction", 0.5)), dev)
         return total.detach(), {k: v.detach() for k, v in loss.items()}
 
     def save_model(self, epoch: int, itr: int) -> Optional[str]:
